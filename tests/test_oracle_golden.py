@@ -1,0 +1,143 @@
+"""Pin oracle/ref_port.py against the fixtures captured from the real reference
+(tests/golden/make_golden.py).  CPU only."""
+
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_port as R
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name), allow_pickle=False)
+
+
+def _dict_from(keys, lens):
+    return {tuple(int(x) for x in keys[i, :lens[i]]): i for i in range(len(lens))}
+
+
+def test_match_python_port_bit_exact(golden_dir):
+    z = _load(golden_dir, "match.npz")
+    for c in z["cases"]:
+        keys, lens, max_n = z[f"{c}_keys"], z[f"{c}_lens"], int(z[f"{c}_max_n"])
+        d = _dict_from(keys, lens)
+        for si in range(int(z["n_streams"])):
+            tok = z[f"{c}_s{si}_tok"].tolist()
+            off, ids = R.match_csr_python(d, max_n, tok)
+            assert np.array_equal(off, z[f"{c}_s{si}_off"]), (c, si)
+            assert np.array_equal(ids, z[f"{c}_s{si}_ids"]), (c, si)
+
+
+def test_match_numpy_port_bit_exact(golden_dir):
+    z = _load(golden_dir, "match.npz")
+    for c in z["cases"]:
+        keys, lens, max_n = z[f"{c}_keys"], z[f"{c}_lens"], int(z[f"{c}_max_n"])
+        for si in range(int(z["n_streams"])):
+            tok = z[f"{c}_s{si}_tok"][None, :]
+            hits = R.match_hits(keys, lens, tok, max_n)
+            off, ids = R.hits_to_csr(hits)
+            assert np.array_equal(off, z[f"{c}_s{si}_off"]), (c, si)
+            assert np.array_equal(ids, z[f"{c}_s{si}_ids"]), (c, si)
+
+
+def test_multiplicity_case(golden_dir):
+    """[7,7,7,7] vs {(7,),(7,7),(7,7,7)} gives position 1 ids [0,1,1,2,2]."""
+    d = {(7,): 0, (7, 7): 1, (7, 7, 7): 2}
+    off, ids = R.match_csr_python(d, 3, [7, 7, 7, 7])
+    assert ids[off[1]:off[2]].tolist() == [0, 1, 1, 2, 2]
+    assert ids[off[0]:off[1]].tolist() == [0, 1, 2]
+
+
+def test_fit_order_matches_reference(golden_dir):
+    z = _load(golden_dir, "match.npz")
+    for c in z["cases"]:
+        flat, cl = z[f"{c}_corpus_flat"], z[f"{c}_corpus_lens"]
+        min_freq, max_f = (int(x) for x in z[f"{c}_fit_args"])
+        corpus, p = [], 0
+        for n in cl:
+            corpus.append(flat[p:p + n].tolist())
+            p += n
+        grams = R.fit(corpus, int(z[f"{c}_max_n"]), min_freq, max_f)
+        keys, lens = z[f"{c}_keys"], z[f"{c}_lens"]
+        assert len(grams) == len(lens)
+        for i, g in enumerate(grams):
+            assert tuple(int(x) for x in keys[i, :lens[i]]) == g
+
+
+@pytest.mark.parametrize("use_mm", [False, True])
+def test_lookup_port_bit_exact(golden_dir, use_mm):
+    z = _load(golden_dir, "lookup.npz")
+    for c in z["cases"]:
+        keys, lens, max_n = z[f"{c}_keys"], z[f"{c}_lens"], int(z[f"{c}_max_n"])
+        table = z[f"{c}_table"]
+        n, d = table.shape
+        cache = R.RefCache(_dict_from(keys, lens), max_n, d, use_memory_map=use_mm)
+        cache.cache_embeddings(list(range(n)), torch.from_numpy(table))
+        # a4
+        g = cache.get_embeddings(z[f"{c}_gather_ids"].tolist())
+        assert np.array_equal(g.numpy(), z[f"{c}_gather_out"])
+        # a5
+        te = cache.get_token_embeddings(z[f"{c}_tok"].tolist())
+        assert sorted(te.keys()) == z[f"{c}_te_positions"].tolist()
+        p = 0
+        for pos, rows in zip(z[f"{c}_te_positions"], z[f"{c}_te_rows"]):
+            assert np.array_equal(te[int(pos)].numpy(), z[f"{c}_te_stacks"][p:p + rows])
+            p += rows
+        # a6
+        agg = R.aggregate(cache, z[f"{c}_tok"].tolist(), d)
+        assert np.array_equal(agg.numpy(), z[f"{c}_agg_f32"]), c
+        agg16 = R.aggregate(cache, z[f"{c}_tok"].tolist(), d, half=True)
+        assert np.array_equal(agg16.numpy().view(np.uint16), z[f"{c}_agg_f16"].view(np.uint16)), c
+
+
+def test_embed_numpy_matches_reference_aggregate(golden_dir):
+    """The vectorised oracle (sequential fp32 sum in list order, / K) against engine.py:250."""
+    z = _load(golden_dir, "lookup.npz")
+    for c in z["cases"]:
+        keys, lens, max_n = z[f"{c}_keys"], z[f"{c}_lens"], int(z[f"{c}_max_n"])
+        hits = R.match_hits(keys, lens, z[f"{c}_tok"][None, :], max_n)
+        off, ids = R.hits_to_csr(hits)
+        assert np.array_equal(off, z[f"{c}_off"]) and np.array_equal(ids, z[f"{c}_ids"])
+        out = R.embed_numpy(z[f"{c}_table"], off, ids, "mean")
+        ref = z[f"{c}_agg_f32"][0]
+        # torch.mean may divide or multiply by 1/K; allow 1 ulp, report exactness
+        np.testing.assert_allclose(out, ref, rtol=3e-7, atol=1e-7)
+
+
+def test_combine_port_matches_reference(golden_dir):
+    z = _load(golden_dir, "combine.npz")
+    for c in z["cases"]:
+        pos = z[f"{c}_pos"]
+        x = R.combine(torch.from_numpy(z[f"{c}_input_ids"]), torch.from_numpy(z[f"{c}_fg"]),
+                      torch.from_numpy(z[f"{c}_wte"]), torch.from_numpy(z[f"{c}_wpe"]),
+                      torch.from_numpy(z[f"{c}_proj"]),
+                      torch.from_numpy(pos) if pos.size else None)
+        assert np.array_equal(x.numpy(), z[f"{c}_embeds"]), c
+
+
+def test_quantizers_round_trip():
+    rng = np.random.default_rng(5)
+    rows = rng.standard_normal((37, 256)).astype(np.float32)
+    rows[3] = 0.0
+    q, s = R.quantize_i8(rows)
+    dq = R.dequantize_i8(q, s)
+    assert np.all(q[3] == 0) and np.all(np.abs(q) <= 127)
+    assert np.max(np.abs(dq - rows)) <= 0.51 * float(s.astype(np.float32).max()) + 1e-6
+    p, s4 = R.quantize_i4(rows)
+    dq4 = R.dequantize_i4(p, s4)
+    assert p.shape == (37, 128) and s4.shape == (37, 2)
+    assert np.max(np.abs(dq4 - rows)) <= 0.51 * float(s4.astype(np.float32).max()) + 1e-6
+    # idempotence: re-quantising a dequantised table reproduces the codes
+    q2, s2 = R.quantize_i8(dq)
+    assert np.array_equal(R.dequantize_i8(q2, s2), dq)
+
+
+def test_synth_generators_are_deterministic():
+    a = R.synth_rows_i8(7, np.array([0, 1, 2**33 + 5], dtype=np.uint64), 64)
+    b = R.synth_rows_i8(7, np.array([0, 1, 2**33 + 5], dtype=np.uint64), 64)
+    assert a.dtype == np.int8 and a.shape == (3, 64) and np.array_equal(a, b)
+    assert not np.array_equal(a[0], a[1])
+    s = R.synth_scale_f16(7, np.arange(100), 0.02 / 127)
+    assert s.dtype == np.float16 and np.all(s > 0)

@@ -1,0 +1,181 @@
+/*
+ * scone_hip.h -- C ABI of libscone_hip.so: the MI355X (gfx950) f-gram embedding
+ * lookup / aggregation path.
+ *
+ * The reference (llmsresearch/scone) is pure Python and has no FFI of its own.
+ * Each entry point below names the reference code it replaces (file:line under
+ * the reference checkout); INTEGRATION.md shows the ctypes stub a maintainer
+ * would add on the reference side.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no C++ or torch types cross this boundary
+ *   - every function returns 0 (SCONE_OK) or a negative errno-style code and
+ *     never throws; scone_last_error(h) holds a human-readable message
+ *   - the caller owns every buffer it passes; the library owns the index, the
+ *     table and its workspaces
+ *   - "d_" pointers are device pointers on the handle's device, "h_" pointers
+ *     are host pointers; all device work is enqueued on the given stream
+ *     (hipStream_t passed as void*; NULL = the default stream) and the call
+ *     returns without synchronising unless documented otherwise
+ *   - a handle is immutable on the lookup path: lookups from several host
+ *     threads on different streams are safe as long as each thread uses its
+ *     own workspace (see scone_embed's workspace note)
+ */
+#ifndef SCONE_HIP_H
+#define SCONE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SCONE_ABI_VERSION 1
+
+typedef struct scone_handle scone_handle;
+typedef void *scone_stream_t; /* hipStream_t */
+
+/* table row formats (defined by this library; the reference's cache is always
+ * fp32, scone/inference/embedding_cache.py:86,134,139) */
+enum {
+  SCONE_FMT_F32 = 0, /* [N,d] float                                     row_bytes 4d      */
+  SCONE_FMT_F16 = 1, /* [N,d] IEEE half                                 row_bytes 2d      */
+  SCONE_FMT_I8 = 2,  /* [N,d] int8 + scales[N] half (per row)           row_bytes d+2     */
+  SCONE_FMT_I4 = 3   /* [N,d/2] offset-binary nibbles (elem 2k = low)   row_bytes d/2+2*d/128
+                        + scales[N,d/128] half (per 128-group)                            */
+};
+enum { SCONE_PLACE_HBM = 0, SCONE_PLACE_PINNED_HOST = 1 };
+enum { SCONE_REDUCE_MEAN = 0, SCONE_REDUCE_SUM = 1 };
+enum { SCONE_DT_F32 = 0, SCONE_DT_F16 = 1, SCONE_DT_BF16 = 2 };
+
+enum {
+  SCONE_OK = 0,
+  SCONE_ESTATE = -1,  /* call order / missing index or table            */
+  SCONE_EHIP = -5,    /* a HIP runtime call failed                      */
+  SCONE_ENOMEM = -12, /* allocation failed / index full                 */
+  SCONE_ENODEV = -19, /* no usable GPU                                  */
+  SCONE_EINVAL = -22, /* bad argument                                   */
+  SCONE_ERANGE = -34  /* id / token / row outside the configured range  */
+};
+
+typedef struct scone_cfg {
+  uint32_t struct_size;    /* = sizeof(scone_cfg)                                          */
+  int32_t device;          /* HIP device ordinal                                           */
+  int32_t max_n;           /* longest f-gram, 1..4 (NGramExtractor.max_n,
+                              scone/tokenization/n_gram_extractor.py:39)                    */
+  int32_t dim;             /* embedding_dim d (EmbeddingCache.embedding_dim, :45);
+                              multiple of 4 (F32), 8 (F16), 16 (I8), 128 (I4); 0 = index only */
+  int32_t table_fmt;       /* SCONE_FMT_*                                                  */
+  int32_t placement;       /* SCONE_PLACE_*                                                */
+  uint64_t n_rows;         /* N = number of f-grams (global)                               */
+  uint64_t row_begin;      /* rows owned by this handle: [row_begin, row_end); the whole   */
+  uint64_t row_end;        /* table is 0..N (row_end = 0 means N)                          */
+  uint64_t index_capacity; /* hash slots; 0 = smallest power of two >= 2*N                 */
+} scone_cfg;
+
+/* ---- lifecycle ----------------------------------------------------------- */
+int scone_abi_version(void);
+const char *scone_strerror(int code);
+/* Allocates the (empty) index and, when cfg->dim > 0, the table storage. */
+int scone_create(const scone_cfg *cfg, scone_handle **out);
+void scone_destroy(scone_handle *h);
+const char *scone_last_error(const scone_handle *h);
+/* Sticky device-side status bits raised by kernels (bit 0: token outside the
+ * base-embedding vocabulary, bit 1: f-gram id outside the table, bit 2: index
+ * full); synchronises the stream, returns the bits in *bits and clears them. */
+int scone_status(scone_handle *h, uint32_t *bits, scone_stream_t stream);
+
+/* ---- index: f-gram -> id (replaces NGramExtractor.f_grams / f_gram_to_id,
+ *      n_gram_extractor.py:42-44, and the id map of embedding_cache.py:173) --- */
+/* keys[n, max_n] uint32 token ids (first lens[i] used), lens[n] in 1..max_n;
+ * key i gets id = id0 + i.  May be called repeatedly.  On a duplicate key the
+ * smallest id wins.  Host-pointer variant copies through a staging buffer and
+ * synchronises; the device variant is stream-ordered. */
+int scone_index_build(scone_handle *h, const uint32_t *h_keys, const uint8_t *h_lens,
+                      uint64_t n, uint64_t id0);
+int scone_index_build_device(scone_handle *h, const uint32_t *d_keys, const uint8_t *d_lens,
+                             uint64_t n, uint64_t id0, scone_stream_t stream);
+/* Synchronises.  n_keys = distinct keys stored, n_dups = duplicate insertions seen. */
+int scone_index_stats(scone_handle *h, uint64_t *n_keys, uint64_t *capacity, uint64_t *n_dups);
+
+/* ---- table: rows (replaces EmbeddingCache.cache_embeddings storage,
+ *      embedding_cache.py:56-111) ------------------------------------------- */
+/* Raw rows already in the handle's format.  rows: nrows * payload bytes
+ * (4d / 2d / d / d/2); scales: NULL (F32,F16), half[nrows] (I8), half[nrows, d/128] (I4).
+ * src_is_device selects host or device source pointers.  Rows are global ids and must
+ * lie inside [row_begin,row_end). */
+int scone_table_upload(scone_handle *h, const void *rows, const void *scales, uint64_t row0,
+                       uint64_t nrows, int src_is_device, scone_stream_t stream);
+/* fp32 rows on the device -> the handle's format (quantised on the GPU). */
+int scone_table_store_f32(scone_handle *h, const float *d_rows_f32, uint64_t row0, uint64_t nrows,
+                          scone_stream_t stream);
+/* Scattered variant: row i of d_rows_f32 goes to global row d_ids[i]
+ * (cache_embeddings(f_gram_ids, embeddings), embedding_cache.py:98-99,110-111). */
+int scone_table_store_f32_ids(scone_handle *h, const float *d_rows_f32, const int64_t *d_ids,
+                              uint64_t nrows, scone_stream_t stream);
+/* Counter-based synthetic rows (bench / full-size tests); any row can be
+ * recomputed on the host (oracle/ref_port.py synth_*). */
+int scone_table_fill_synthetic(scone_handle *h, uint32_t seed, float base_scale,
+                               scone_stream_t stream);
+/* Row gather: out[i,:] = dequantised row d_ids[i] as fp32
+ * (EmbeddingCache.get_embeddings, embedding_cache.py:113-147). */
+int scone_table_gather_rows(scone_handle *h, const int64_t *d_ids, uint64_t n, float *d_out,
+                            scone_stream_t stream);
+
+/* ---- hot path ------------------------------------------------------------ */
+/* Per-window membership + id (NGramExtractor.get_token_f_grams,
+ * n_gram_extractor.py:106-126, one entry per (n, start)):
+ * d_hits[(n-1)*B*T + b*T + i] = id of tok[b, i:i+n] or -1. */
+int scone_match(scone_handle *h, const int32_t *d_tok, int32_t B, int32_t T, int32_t *d_hits,
+                scone_stream_t stream);
+/* Per-position id lists in the reference's order (n ascending, start ascending,
+ * duplicates kept) as CSR over the B*T positions: d_offsets[B*T+1] (int32),
+ * d_ids[ids_cap] (int32).  Writes the total to *h_total after synchronising the
+ * stream; returns SCONE_ERANGE (and a valid *h_total) if ids_cap is too small. */
+int scone_match_csr(scone_handle *h, const int32_t *d_tok, int32_t B, int32_t T,
+                    int32_t *d_offsets, int32_t *d_ids, int64_t ids_cap, int64_t *h_total,
+                    scone_stream_t stream);
+/* Aggregate precomputed id lists: out[t,:] = reduce_k dequant(row ids[offsets[t]+k])
+ * (+ base[t,:] when d_base != NULL, same dtype as out); zeros where the list is
+ * empty (engine.py:247-259). */
+int scone_gather_reduce(scone_handle *h, const int32_t *d_offsets, const int32_t *d_ids,
+                        int64_t ntok, const void *d_base, int32_t reduce, void *d_out,
+                        int32_t out_dtype, scone_stream_t stream);
+/* Fused match + gather + dequantise + reduce + combine
+ * (n_gram_extractor.py:106-126 -> embedding_cache.py:113-181 -> engine.py:234-266 ->
+ *  language_model.py:239-254 with the projection folded into the table):
+ *   out[b,i,:] = cast( (wte[tok[b,i]] + reduce_k row_k) + wpe[pos[b,i]] )
+ * d_wte / d_wpe: [vocab,d] / [n_pos,d] in out_dtype, or NULL (term omitted);
+ * d_pos: int32 [B,T] or NULL (= arange(T), language_model.py:248-251).
+ * Uses the handle's internal hit workspace (grown on first use / by scone_reserve),
+ * so concurrent calls on one handle must be stream-ordered. */
+int scone_embed(scone_handle *h, const int32_t *d_tok, int32_t B, int32_t T, const void *d_wte,
+                int64_t vocab, const void *d_wpe, int64_t n_pos, const int32_t *d_pos,
+                int32_t reduce, void *d_out, int32_t out_dtype, scone_stream_t stream);
+int scone_reserve(scone_handle *h, int64_t max_tokens);
+/* Optional timing of the gather/reduce kernel launched by scone_embed: while enabled, every
+ * call brackets that kernel with HIP events on the launch stream (a ring of 1024 pairs).
+ * scone_profile_read synchronises the device, returns the number of timed launches and
+ * their summed duration in milliseconds since the last reset, and optionally resets. */
+int scone_profile_enable(scone_handle *h, int enable);
+int scone_profile_read(scone_handle *h, uint64_t *n_launches, double *total_ms, int reset);
+
+/* ---- row-sharded tables (one handle per GPU; RCCL exchange is done by the
+ *      caller between the two calls) ---------------------------------------- */
+/* fp32 partial sums over the rows this handle owns + the full per-position hit
+ * count (the index is replicated, so every rank knows K). */
+int scone_embed_partial(scone_handle *h, const int32_t *d_tok, int32_t B, int32_t T,
+                        float *d_partial, int32_t *d_counts, scone_stream_t stream);
+/* out[t,:] = cast( (wte[tok[t]] + sum[t,:] / K_t) + wpe[pos[t]] ) for t in
+ * [tok_begin, tok_end) of the flattened B*T positions; d_sum / d_counts / d_out
+ * are indexed from tok_begin (slice-local), d_tok / d_pos are the full [B,T]. */
+int scone_finalize(scone_handle *h, const float *d_sum, const int32_t *d_counts,
+                   const int32_t *d_tok, int32_t B, int32_t T, int64_t tok_begin, int64_t tok_end,
+                   const void *d_wte, int64_t vocab, const void *d_wpe, int64_t n_pos,
+                   const int32_t *d_pos, int32_t reduce, void *d_out, int32_t out_dtype,
+                   scone_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SCONE_HIP_H */

@@ -1,0 +1,269 @@
+// Handle lifecycle, error reporting and workspaces of libscone_hip.so.
+#include "scone_common.h"
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+int scone_fail(scone_handle *h, int code, const char *what) {
+  if (h) h->err = what ? what : "";
+  return code;
+}
+
+int scone_hip_fail(scone_handle *h, hipError_t e, const char *what) {
+  if (h) {
+    h->err = std::string(what ? what : "HIP call") + ": " + hipGetErrorString(e);
+  }
+  (void)hipGetLastError();  // clear the sticky error
+  return e == hipErrorOutOfMemory ? SCONE_ENOMEM : SCONE_EHIP;
+}
+
+int scone_ensure_hits(scone_handle *h, int64_t ntok) {
+  if (ntok <= h->hits_cap_tokens) return SCONE_OK;
+  if (h->d_hits) SCONE_HIP(h, hipFree(h->d_hits));
+  h->d_hits = nullptr;
+  h->hits_cap_tokens = 0;
+  SCONE_HIP(h, hipMalloc(&h->d_hits, (size_t)ntok * h->cfg.max_n * sizeof(int32_t)));
+  h->hits_cap_tokens = ntok;
+  return SCONE_OK;
+}
+
+extern "C" int scone_abi_version(void) { return SCONE_ABI_VERSION; }
+
+extern "C" const char *scone_strerror(int code) {
+  switch (code) {
+    case SCONE_OK: return "ok";
+    case SCONE_ESTATE: return "invalid state or call order";
+    case SCONE_EHIP: return "HIP runtime error";
+    case SCONE_ENOMEM: return "out of memory or index full";
+    case SCONE_ENODEV: return "no usable GPU";
+    case SCONE_EINVAL: return "invalid argument";
+    case SCONE_ERANGE: return "value out of range";
+    default: return "unknown error";
+  }
+}
+
+static thread_local std::string g_create_err;
+
+extern "C" const char *scone_last_error(const scone_handle *h) {
+  return h ? h->err.c_str() : g_create_err.c_str();
+}
+
+static bool payload_geometry(const scone_cfg &c, size_t *payload, size_t *scale_bytes) {
+  const size_t d = (size_t)c.dim;
+  switch (c.table_fmt) {
+    case SCONE_FMT_F32:
+      if (d % 4) return false;
+      *payload = 4 * d, *scale_bytes = 0;
+      return true;
+    case SCONE_FMT_F16:
+      if (d % 8) return false;
+      *payload = 2 * d, *scale_bytes = 0;
+      return true;
+    case SCONE_FMT_I8:
+      if (d % 16) return false;
+      *payload = d, *scale_bytes = 2;
+      return true;
+    case SCONE_FMT_I4:
+      if (d % SCONE_I4_GROUP) return false;
+      *payload = d / 2, *scale_bytes = 2 * (d / SCONE_I4_GROUP);
+      return true;
+    default: return false;
+  }
+}
+
+extern "C" int scone_create(const scone_cfg *cfg, scone_handle **out) {
+  if (!cfg || !out) return SCONE_EINVAL;
+  *out = nullptr;
+  if (cfg->struct_size != sizeof(scone_cfg)) {
+    g_create_err = "scone_create: struct_size mismatch (ABI)";
+    return SCONE_EINVAL;
+  }
+  if (cfg->max_n < 1 || cfg->max_n > SCONE_MAX_N || cfg->dim < 0) {
+    g_create_err = "scone_create: max_n must be 1..4 and dim >= 0";
+    return SCONE_EINVAL;
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    (void)hipGetLastError();
+    g_create_err = "scone_create: no HIP device visible";
+    return SCONE_ENODEV;
+  }
+  if (cfg->device < 0 || cfg->device >= ndev) {
+    g_create_err = "scone_create: device ordinal out of range";
+    return SCONE_EINVAL;
+  }
+  scone_handle *h = new (std::nothrow) scone_handle();
+  if (!h) return SCONE_ENOMEM;
+  h->cfg = *cfg;
+  h->device = cfg->device;
+  if (h->cfg.row_end == 0) h->cfg.row_end = h->cfg.n_rows;
+  if (h->cfg.row_begin > h->cfg.row_end || h->cfg.row_end > h->cfg.n_rows) {
+    g_create_err = "scone_create: need row_begin <= row_end <= n_rows";
+    delete h;
+    return SCONE_EINVAL;
+  }
+  h->local_rows = h->cfg.row_end - h->cfg.row_begin;
+  h->slots = nullptr, h->d_counters = nullptr, h->d_status = nullptr;
+  h->rows = nullptr, h->scales = nullptr, h->rows_pinned_host = false;
+  h->d_hits = nullptr, h->hits_cap_tokens = 0, h->d_block_sums = nullptr, h->block_sums_cap = 0;
+  h->d_total = nullptr, h->staging = nullptr, h->staging_bytes = 0;
+  h->row_payload_bytes = 0, h->scale_bytes_per_row = 0;
+  h->prof_on = false, h->prof_ev = nullptr, h->prof_head = 0, h->prof_n = 0, h->prof_ms = 0.0;
+
+  uint64_t cap = cfg->index_capacity;
+  if (cap == 0) {
+    cap = 64;
+    while (cap < 2 * cfg->n_rows) cap <<= 1;
+  }
+  if (cap & (cap - 1)) {
+    g_create_err = "scone_create: index_capacity must be a power of two";
+    delete h;
+    return SCONE_EINVAL;
+  }
+  h->cap = cap;
+
+  int rc = SCONE_OK;
+  hipError_t e;
+#define CREATE_HIP(call)                         \
+  do {                                           \
+    e = (call);                                  \
+    if (e != hipSuccess) {                       \
+      rc = scone_hip_fail(h, e, #call);          \
+      goto fail;                                 \
+    }                                            \
+  } while (0)
+  CREATE_HIP(hipSetDevice(h->device));
+  CREATE_HIP(hipMalloc(&h->slots, cap * sizeof(scone_slot)));
+  CREATE_HIP(hipMemset(h->slots, 0, cap * sizeof(scone_slot)));
+  CREATE_HIP(hipMalloc(&h->d_counters, 2 * sizeof(unsigned long long)));
+  CREATE_HIP(hipMemset(h->d_counters, 0, 2 * sizeof(unsigned long long)));
+  CREATE_HIP(hipMalloc(&h->d_status, sizeof(uint32_t)));
+  CREATE_HIP(hipMemset(h->d_status, 0, sizeof(uint32_t)));
+  CREATE_HIP(hipMalloc(&h->d_total, sizeof(int64_t)));
+  if (cfg->dim > 0) {
+    if (!payload_geometry(h->cfg, &h->row_payload_bytes, &h->scale_bytes_per_row)) {
+      h->err = "scone_create: dim not compatible with table_fmt (F32 %4, F16 %8, I8 %16, I4 %128)";
+      rc = SCONE_EINVAL;
+      goto fail;
+    }
+    size_t rows_bytes = (size_t)h->local_rows * h->row_payload_bytes;
+    size_t scales_bytes = (size_t)h->local_rows * h->scale_bytes_per_row;
+    if (rows_bytes == 0) rows_bytes = 16;
+    if (cfg->placement == SCONE_PLACE_PINNED_HOST) {
+      // rows stay in host DRAM, mapped into the GPU's address space; scales stay in HBM
+      CREATE_HIP(hipHostMalloc(&h->rows, rows_bytes, hipHostMallocMapped | hipHostMallocPortable));
+      h->rows_pinned_host = true;
+    } else if (cfg->placement == SCONE_PLACE_HBM) {
+      CREATE_HIP(hipMalloc(&h->rows, rows_bytes));
+    } else {
+      h->err = "scone_create: unknown placement";
+      rc = SCONE_EINVAL;
+      goto fail;
+    }
+    if (scales_bytes) CREATE_HIP(hipMalloc(&h->scales, scales_bytes));
+  }
+#undef CREATE_HIP
+  *out = h;
+  return SCONE_OK;
+fail:
+  g_create_err = h->err;
+  scone_destroy(h);
+  return rc;
+}
+
+extern "C" void scone_destroy(scone_handle *h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  if (h->slots) (void)hipFree(h->slots);
+  if (h->d_counters) (void)hipFree(h->d_counters);
+  if (h->d_status) (void)hipFree(h->d_status);
+  if (h->d_total) (void)hipFree(h->d_total);
+  if (h->rows) {
+    if (h->rows_pinned_host) (void)hipHostFree(h->rows);
+    else (void)hipFree(h->rows);
+  }
+  if (h->scales) (void)hipFree(h->scales);
+  if (h->d_hits) (void)hipFree(h->d_hits);
+  if (h->d_block_sums) (void)hipFree(h->d_block_sums);
+  if (h->staging) (void)hipFree(h->staging);
+  if (h->prof_ev) {
+    for (int i = 0; i < 2 * SCONE_PROF_RING; ++i) (void)hipEventDestroy(h->prof_ev[i]);
+    delete[] h->prof_ev;
+  }
+  delete h;
+}
+
+extern "C" int scone_status(scone_handle *h, uint32_t *bits, scone_stream_t stream) {
+  if (!h || !bits) return SCONE_EINVAL;
+  SCONE_HIP(h, hipSetDevice(h->device));
+  hipStream_t s = (hipStream_t)stream;
+  SCONE_HIP(h, hipMemcpyAsync(bits, h->d_status, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+  SCONE_HIP(h, hipMemsetAsync(h->d_status, 0, sizeof(uint32_t), s));
+  SCONE_HIP(h, hipStreamSynchronize(s));
+  return SCONE_OK;
+}
+
+extern "C" int scone_reserve(scone_handle *h, int64_t max_tokens) {
+  if (!h || max_tokens < 0) return SCONE_EINVAL;
+  SCONE_HIP(h, hipSetDevice(h->device));
+  return scone_ensure_hits(h, max_tokens);
+}
+
+// ---------------------------------------------------------------- kernel timing
+static int prof_drain(scone_handle *h) {
+  if (h->prof_head == 0) return SCONE_OK;
+  SCONE_HIP(h, hipDeviceSynchronize());
+  for (uint64_t i = 0; i < h->prof_head; ++i) {
+    float ms = 0.f;
+    SCONE_HIP(h, hipEventElapsedTime(&ms, h->prof_ev[2 * i], h->prof_ev[2 * i + 1]));
+    h->prof_ms += ms;
+    h->prof_n += 1;
+  }
+  h->prof_head = 0;
+  return SCONE_OK;
+}
+
+int scone_prof_begin(scone_handle *h, hipStream_t s) {
+  if (!h->prof_on) return SCONE_OK;
+  if (h->prof_head == SCONE_PROF_RING) {
+    int rc = prof_drain(h);
+    if (rc) return rc;
+  }
+  SCONE_HIP(h, hipEventRecord(h->prof_ev[2 * h->prof_head], s));
+  return SCONE_OK;
+}
+
+int scone_prof_end(scone_handle *h, hipStream_t s) {
+  if (!h->prof_on) return SCONE_OK;
+  SCONE_HIP(h, hipEventRecord(h->prof_ev[2 * h->prof_head + 1], s));
+  h->prof_head += 1;
+  return SCONE_OK;
+}
+
+extern "C" int scone_profile_enable(scone_handle *h, int enable) {
+  if (!h) return SCONE_EINVAL;
+  SCONE_HIP(h, hipSetDevice(h->device));
+  if (enable && !h->prof_ev) {
+    h->prof_ev = new (std::nothrow) hipEvent_t[2 * SCONE_PROF_RING];
+    if (!h->prof_ev) return scone_fail(h, SCONE_ENOMEM, "scone_profile_enable: out of memory");
+    for (int i = 0; i < 2 * SCONE_PROF_RING; ++i) SCONE_HIP(h, hipEventCreate(&h->prof_ev[i]));
+  }
+  if (!enable) {
+    int rc = prof_drain(h);
+    if (rc) return rc;
+  }
+  h->prof_on = enable != 0;
+  return SCONE_OK;
+}
+
+extern "C" int scone_profile_read(scone_handle *h, uint64_t *n_launches, double *total_ms, int reset) {
+  if (!h) return SCONE_EINVAL;
+  SCONE_HIP(h, hipSetDevice(h->device));
+  int rc = prof_drain(h);
+  if (rc) return rc;
+  if (n_launches) *n_launches = h->prof_n;
+  if (total_ms) *total_ms = h->prof_ms;
+  if (reset) h->prof_n = 0, h->prof_ms = 0.0;
+  return SCONE_OK;
+}

@@ -1,0 +1,130 @@
+// Internal declarations shared by the .hip translation units of libscone_hip.so.
+// gfx950 only: 64-lane wavefronts are assumed throughout.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <hip/hip_bf16.h>
+#include <stdint.h>
+
+#include <string>
+
+#include "../../include/scone_hip.h"
+
+#define SCONE_WAVE 64
+#define SCONE_I4_GROUP 128
+#define SCONE_MAX_N 4
+#define SCONE_PROF_RING 1024
+#define SCONE_MAX_CAND 10  // max_n (max_n + 1) / 2 at max_n = 4
+
+#define SCONE_ST_BAD_TOKEN 1u
+#define SCONE_ST_BAD_ID 2u
+#define SCONE_ST_INDEX_FULL 4u
+
+// ---------------------------------------------------------------- hash index
+// 16-byte slot.  lo/ext hold the exact packed key (no fingerprints, so a probe
+// never returns a wrong id):  hi = (ext << 32) | (id + 1).  Empty: lo == 0.
+struct __attribute__((aligned(16))) scone_slot {
+  unsigned long long lo;
+  unsigned long long hi;
+};
+
+struct scone_key {
+  unsigned long long lo;
+  uint32_t ext;
+  bool ok;  // false: some token cannot be represented -> cannot be in the index
+};
+
+// Tokens are stored +1 so that an absent position is 0 and no valid key is all-zero.
+// max_n <= 3: 32 bits per token (96-bit key).  max_n == 4: 24 bits per token.
+__host__ __device__ inline scone_key scone_pack_key(const uint32_t *t, int n, int max_n) {
+  scone_key k;
+  k.ok = true;
+  if (max_n <= 3) {
+    unsigned long long v0 = (unsigned long long)t[0] + 1ull;
+    unsigned long long v1 = n > 1 ? (unsigned long long)t[1] + 1ull : 0ull;
+    unsigned long long v2 = n > 2 ? (unsigned long long)t[2] + 1ull : 0ull;
+    k.ok = (v0 >> 32) == 0 && (v1 >> 32) == 0 && (v2 >> 32) == 0;
+    k.lo = v0 | (v1 << 32);
+    k.ext = (uint32_t)v2;
+  } else {
+    uint32_t v[4];
+    for (int i = 0; i < 4; ++i) {
+      v[i] = i < n ? t[i] + 1u : 0u;
+      if (i < n && t[i] >= 0xFFFFFFu) k.ok = false;
+    }
+    k.lo = (unsigned long long)v[0] | ((unsigned long long)v[1] << 24) |
+           ((unsigned long long)(v[2] & 0xFFFFu) << 48);
+    k.ext = (v[2] >> 16) | (v[3] << 8);
+  }
+  return k;
+}
+
+__host__ __device__ inline unsigned long long scone_hash_key(unsigned long long lo, uint32_t ext) {
+  unsigned long long x = lo ^ ((unsigned long long)ext * 0x9E3779B97F4A7C15ull);
+  x ^= x >> 30;
+  x *= 0xBF58476D1CE4E5B9ull;
+  x ^= x >> 27;
+  x *= 0x94D049BB133111EBull;
+  x ^= x >> 31;
+  return x;
+}
+
+// lowbias32 finaliser; numpy twin: oracle/ref_port.py hash32
+__host__ __device__ inline uint32_t scone_hash32(uint32_t x) {
+  x ^= x >> 16;
+  x *= 0x7FEB352Du;
+  x ^= x >> 15;
+  x *= 0x846CA68Bu;
+  x ^= x >> 16;
+  return x;
+}
+
+// ---------------------------------------------------------------- handle
+struct scone_handle {
+  scone_cfg cfg;
+  int device;
+  // index
+  scone_slot *slots;
+  uint64_t cap;  // power of two
+  unsigned long long *d_counters;  // [0] inserted, [1] duplicates
+  uint32_t *d_status;              // sticky status bits
+  // table
+  void *rows;        // payload rows, local row r = global id - row_begin
+  void *scales;      // I8: half[rows]; I4: half[rows, d/128]
+  size_t row_payload_bytes;
+  size_t scale_bytes_per_row;
+  uint64_t local_rows;
+  bool rows_pinned_host;
+  // workspaces
+  int32_t *d_hits;
+  int64_t hits_cap_tokens;
+  int32_t *d_block_sums;
+  int64_t block_sums_cap;
+  int64_t *d_total;
+  void *staging;
+  size_t staging_bytes;
+  // optional kernel timing (scone_profile_*)
+  bool prof_on;
+  hipEvent_t *prof_ev;  // [2 * SCONE_PROF_RING]
+  uint64_t prof_head;   // pairs recorded since the last drain
+  uint64_t prof_n;      // launches accumulated
+  double prof_ms;
+  std::string err;
+};
+
+int scone_fail(scone_handle *h, int code, const char *what);
+int scone_hip_fail(scone_handle *h, hipError_t e, const char *what);
+int scone_ensure_hits(scone_handle *h, int64_t ntok);
+int scone_prof_begin(scone_handle *h, hipStream_t s);  // no-ops unless profiling is enabled
+int scone_prof_end(scone_handle *h, hipStream_t s);
+
+#define SCONE_HIP(h, call)                                       \
+  do {                                                           \
+    hipError_t e__ = (call);                                     \
+    if (e__ != hipSuccess) return scone_hip_fail((h), e__, #call); \
+  } while (0)
+
+// launchers implemented in the kernel translation units
+int scone_launch_match(scone_handle *h, const int32_t *d_tok, int32_t B, int32_t T, int32_t *d_hits,
+                       hipStream_t s);

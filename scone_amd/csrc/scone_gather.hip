@@ -1,0 +1,149 @@
+// The bandwidth-bound core: sparse row gather + dequantise + ordered fp32 reduce +
+// combine with the base token / position embeddings.  No MFMA: every byte fetched
+// is used once; the kernel is priced against the HBM roofline.
+//
+// Replaces, on the GPU:
+//   EmbeddingCache.get_token_embeddings / get_embeddings  scone/inference/embedding_cache.py:113-181
+//   embeddings.mean(dim=0), zero-fill, .half()            scone/inference/engine.py:247-266
+//   wte(input_ids) + f_gram_embeddings + wpe(position_ids) scone/models/language_model.py:239-254
+//
+// Work decomposition (gfx950, 64-lane waves): a *group* of LPT lanes owns one
+// token; a wave therefore carries 64/LPT tokens.  Each lane owns 16-byte vectors
+// v = lane, lane+LPT, ... of every row (VEC elements each), so one wave
+// instruction reads LPT*16 contiguous bytes of 64/LPT different rows.  For every
+// token all K_t row vectors are requested before the first one is consumed
+// (K_t <= 10 independent 16-byte loads per lane per vector column); accumulation
+// is sequential in the reference's list order in fp32, so results do not depend
+// on the launch geometry.
+#include "scone_gather_impl.h"
+
+using namespace scone_gather;
+
+namespace {
+
+int launch_fmt(scone_handle *h, const embed_args &a, int src, int mode, int out_dtype, hipStream_t s) {
+  if (mode == MODE_FINALIZE) return launch_f32(h, a, src, mode, out_dtype, s);
+  switch (h->cfg.table_fmt) {
+    case SCONE_FMT_F32: return launch_f32(h, a, src, mode, out_dtype, s);
+    case SCONE_FMT_F16: return launch_f16(h, a, src, mode, out_dtype, s);
+    case SCONE_FMT_I8: return launch_i8(h, a, src, mode, out_dtype, s);
+    case SCONE_FMT_I4: return launch_i4(h, a, src, mode, out_dtype, s);
+    default: return scone_fail(h, SCONE_EINVAL, "unknown table_fmt");
+  }
+}
+void fill_table_view(const scone_handle *h, table_view &tv) {
+  tv.rows = reinterpret_cast<const uint8_t *>(h->rows);
+  tv.scales = reinterpret_cast<const __half *>(h->scales);
+  tv.row_begin = (long long)h->cfg.row_begin;
+  tv.row_end = (long long)h->cfg.row_end;
+  tv.n_rows = (long long)h->cfg.n_rows;
+  tv.row_bytes = (int)h->row_payload_bytes;
+  tv.d = h->cfg.dim;
+}
+
+int need_table(scone_handle *h, const char *who) {
+  if (!h) return SCONE_EINVAL;
+  if (h->cfg.dim <= 0 || !h->rows) return scone_fail(h, SCONE_ESTATE, who);
+  return SCONE_OK;
+}
+
+}  // namespace
+
+extern "C" int scone_gather_reduce(scone_handle *h, const int32_t *d_offsets, const int32_t *d_ids, int64_t ntok,
+                                   const void *d_base, int32_t reduce, void *d_out, int32_t out_dtype,
+                                   scone_stream_t stream) {
+  int rc = need_table(h, "scone_gather_reduce: handle has no table (dim == 0)");
+  if (rc) return rc;
+  if (ntok < 0) return scone_fail(h, SCONE_EINVAL, "scone_gather_reduce: negative ntok");
+  if (ntok == 0) return SCONE_OK;
+  if (!d_offsets || !d_out) return scone_fail(h, SCONE_EINVAL, "scone_gather_reduce: null pointer");
+  if (reduce != SCONE_REDUCE_MEAN && reduce != SCONE_REDUCE_SUM)
+    return scone_fail(h, SCONE_EINVAL, "scone_gather_reduce: bad reduce");
+  SCONE_HIP(h, hipSetDevice(h->device));
+  embed_args a = {};
+  fill_table_view(h, a.tv);
+  a.offsets = d_offsets, a.ids = d_ids;
+  a.BT = ntok, a.T = (int)(ntok > 0x7FFFFFFF ? 0x7FFFFFFF : ntok), a.max_n = h->cfg.max_n;
+  a.tok_begin = 0, a.ntok = ntok;
+  a.base = d_base, a.reduce = reduce, a.out = d_out, a.status = h->d_status;
+  return launch_fmt(h, a, SRC_CSR, MODE_FULL, out_dtype, (hipStream_t)stream);
+}
+
+extern "C" int scone_embed(scone_handle *h, const int32_t *d_tok, int32_t B, int32_t T, const void *d_wte,
+                           int64_t vocab, const void *d_wpe, int64_t n_pos, const int32_t *d_pos, int32_t reduce,
+                           void *d_out, int32_t out_dtype, scone_stream_t stream) {
+  int rc = need_table(h, "scone_embed: handle has no table (dim == 0)");
+  if (rc) return rc;
+  if (B < 0 || T < 0) return scone_fail(h, SCONE_EINVAL, "scone_embed: negative B or T");
+  const long long BT = (long long)B * T;
+  if (BT == 0) return SCONE_OK;
+  if (!d_tok || !d_out) return scone_fail(h, SCONE_EINVAL, "scone_embed: null pointer");
+  if (reduce != SCONE_REDUCE_MEAN && reduce != SCONE_REDUCE_SUM)
+    return scone_fail(h, SCONE_EINVAL, "scone_embed: bad reduce");
+  if ((d_wte && vocab <= 0) || (d_wpe && n_pos <= 0))
+    return scone_fail(h, SCONE_EINVAL, "scone_embed: wte/wpe given without vocab/n_pos");
+  SCONE_HIP(h, hipSetDevice(h->device));
+  hipStream_t s = (hipStream_t)stream;
+  rc = scone_ensure_hits(h, BT);
+  if (rc) return rc;
+  rc = scone_launch_match(h, d_tok, B, T, h->d_hits, s);
+  if (rc) return rc;
+  embed_args a = {};
+  fill_table_view(h, a.tv);
+  a.hits = h->d_hits, a.BT = BT, a.T = T, a.max_n = h->cfg.max_n;
+  a.tok_begin = 0, a.ntok = BT;
+  a.tok = d_tok, a.pos = d_pos, a.wte = d_wte, a.vocab = vocab, a.wpe = d_wpe, a.n_pos = n_pos;
+  a.reduce = reduce, a.out = d_out, a.status = h->d_status;
+  rc = scone_prof_begin(h, s);
+  if (rc) return rc;
+  rc = launch_fmt(h, a, SRC_HITS, MODE_FULL, out_dtype, s);
+  if (rc) return rc;
+  return scone_prof_end(h, s);
+}
+
+extern "C" int scone_embed_partial(scone_handle *h, const int32_t *d_tok, int32_t B, int32_t T, float *d_partial,
+                                   int32_t *d_counts, scone_stream_t stream) {
+  int rc = need_table(h, "scone_embed_partial: handle has no table (dim == 0)");
+  if (rc) return rc;
+  if (B < 0 || T < 0) return scone_fail(h, SCONE_EINVAL, "scone_embed_partial: negative B or T");
+  const long long BT = (long long)B * T;
+  if (BT == 0) return SCONE_OK;
+  if (!d_tok || !d_partial || !d_counts) return scone_fail(h, SCONE_EINVAL, "scone_embed_partial: null pointer");
+  SCONE_HIP(h, hipSetDevice(h->device));
+  hipStream_t s = (hipStream_t)stream;
+  rc = scone_ensure_hits(h, BT);
+  if (rc) return rc;
+  rc = scone_launch_match(h, d_tok, B, T, h->d_hits, s);
+  if (rc) return rc;
+  embed_args a = {};
+  fill_table_view(h, a.tv);
+  a.hits = h->d_hits, a.BT = BT, a.T = T, a.max_n = h->cfg.max_n;
+  a.tok_begin = 0, a.ntok = BT;
+  a.reduce = SCONE_REDUCE_SUM, a.partial = d_partial, a.counts = d_counts, a.status = h->d_status;
+  return launch_fmt(h, a, SRC_HITS, MODE_PARTIAL, SCONE_DT_F32, s);
+}
+
+extern "C" int scone_finalize(scone_handle *h, const float *d_sum, const int32_t *d_counts, const int32_t *d_tok,
+                              int32_t B, int32_t T, int64_t tok_begin, int64_t tok_end, const void *d_wte,
+                              int64_t vocab, const void *d_wpe, int64_t n_pos, const int32_t *d_pos, int32_t reduce,
+                              void *d_out, int32_t out_dtype, scone_stream_t stream) {
+  if (!h) return SCONE_EINVAL;
+  if (h->cfg.dim <= 0) return scone_fail(h, SCONE_ESTATE, "scone_finalize: handle has no table (dim == 0)");
+  const long long BT = (long long)B * T;
+  if (B < 0 || T < 0 || tok_begin < 0 || tok_end < tok_begin || tok_end > BT)
+    return scone_fail(h, SCONE_EINVAL, "scone_finalize: bad token range");
+  if (tok_end == tok_begin) return SCONE_OK;
+  if (!d_sum || !d_counts || !d_out || ((d_wte || d_wpe) && !d_tok))
+    return scone_fail(h, SCONE_EINVAL, "scone_finalize: null pointer");
+  if (reduce != SCONE_REDUCE_MEAN && reduce != SCONE_REDUCE_SUM)
+    return scone_fail(h, SCONE_EINVAL, "scone_finalize: bad reduce");
+  SCONE_HIP(h, hipSetDevice(h->device));
+  embed_args a = {};
+  fill_table_view(h, a.tv);
+  a.BT = BT, a.T = T, a.max_n = h->cfg.max_n;
+  a.tok_begin = tok_begin, a.ntok = tok_end - tok_begin;
+  a.tok = d_tok, a.pos = d_pos, a.wte = d_wte, a.vocab = vocab, a.wpe = d_wpe, a.n_pos = n_pos;
+  a.reduce = reduce, a.out = d_out, a.sums = d_sum, a.counts = const_cast<int32_t *>(d_counts);
+  a.status = h->d_status;
+  return launch_fmt(h, a, SRC_HITS, MODE_FINALIZE, out_dtype, (hipStream_t)stream);
+}

@@ -1,0 +1,8 @@
+// k_embed instantiations for table format SCONE_FMT_I8 (see scone_gather_impl.h).
+#include "scone_gather_impl.h"
+
+namespace scone_gather {
+int launch_i8(scone_handle *h, const embed_args &a, int src, int mode, int out_dtype, hipStream_t s) {
+  return launch_table_fmt<SCONE_FMT_I8>(h, a, src, mode, out_dtype, s);
+}
+}  // namespace scone_gather

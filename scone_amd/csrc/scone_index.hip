@@ -1,0 +1,358 @@
+// f-gram index (exact-key open-addressing hash table in HBM), the per-window match
+// kernel and the CSR expansion of the reference's per-position id lists.
+//
+// Replaces, on the GPU:
+//   NGramExtractor.f_grams / f_gram_to_id            scone/tokenization/n_gram_extractor.py:42-44
+//   NGramExtractor.get_token_f_grams                 scone/tokenization/n_gram_extractor.py:106-126
+//   [f_gram_to_id[g] for g in f_grams]               scone/inference/embedding_cache.py:173
+#include "scone_common.h"
+
+namespace {
+
+// ------------------------------------------------------------------ build
+// Lock-free insert.  A slot is identified by (lo, ext); lo is claimed with a
+// 64-bit CAS, then (ext,id) is published with a second CAS on hi.  Any thread
+// whose lo matches may publish hi first -- the slot then simply belongs to that
+// key and the others move on -- so nobody ever waits on another thread.
+// Duplicate keys: atomicMin keeps the smallest id.
+__global__ __launch_bounds__(256) void k_index_insert(scone_slot *__restrict__ slots,
+                                                      unsigned long long mask,
+                                                      const uint32_t *__restrict__ keys,
+                                                      const uint8_t *__restrict__ lens,
+                                                      unsigned long long n, unsigned long long id0,
+                                                      int max_n,
+                                                      unsigned long long *__restrict__ counters,
+                                                      uint32_t *__restrict__ status) {
+  unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int len = lens[i];
+  if (len < 1 || len > max_n) {
+    atomicOr(status, SCONE_ST_BAD_TOKEN);
+    return;
+  }
+  uint32_t t[SCONE_MAX_N];
+  for (int k = 0; k < SCONE_MAX_N; ++k) t[k] = k < len ? keys[i * max_n + k] : 0u;
+  scone_key key = scone_pack_key(t, len, max_n);
+  if (!key.ok) {
+    atomicOr(status, SCONE_ST_BAD_TOKEN);
+    return;
+  }
+  unsigned long long myhi = ((unsigned long long)key.ext << 32) | (unsigned long long)(uint32_t)(id0 + i + 1ull);
+  unsigned long long s = scone_hash_key(key.lo, key.ext) & mask;
+  for (unsigned long long probe = 0; probe <= mask; ++probe) {
+    unsigned long long old = atomicCAS(&slots[s].lo, 0ull, key.lo);
+    if (old == 0ull || old == key.lo) {
+      unsigned long long prev = atomicCAS(&slots[s].hi, 0ull, myhi);
+      if (prev == 0ull) {
+        atomicAdd(&counters[0], 1ull);
+        return;
+      }
+      if ((uint32_t)(prev >> 32) == key.ext) {
+        atomicMin(&slots[s].hi, myhi);
+        atomicAdd(&counters[1], 1ull);
+        return;
+      }
+    }
+    s = (s + 1ull) & mask;
+  }
+  atomicOr(status, SCONE_ST_INDEX_FULL);
+}
+
+// ------------------------------------------------------------------ probe
+__device__ __forceinline__ int32_t probe_index(const scone_slot *__restrict__ slots,
+                                               unsigned long long mask, unsigned long long lo,
+                                               uint32_t ext) {
+  unsigned long long s = scone_hash_key(lo, ext) & mask;
+  for (unsigned long long probe = 0; probe <= mask; ++probe) {
+    // one 16-byte load per probe
+    const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(&slots[s]);
+    if (v.x == lo && (uint32_t)(v.y >> 32) == ext) return (int32_t)((uint32_t)v.y - 1u);
+    if (v.x == 0ull) return -1;
+    s = (s + 1ull) & mask;
+  }
+  return -1;
+}
+
+// One thread per (n, position): hits[(n-1)*BT + p] = id of tok[p .. p+n-1] or -1.
+// Windows never cross a sequence boundary (callers pass one sequence at a time,
+// f_gram_tokenizer.py:77) and must fit in T (n_gram_extractor.py:118).
+__global__ __launch_bounds__(256) void k_match(const scone_slot *__restrict__ slots,
+                                               unsigned long long mask,
+                                               const int32_t *__restrict__ tok, long long BT, int T,
+                                               int max_n, int32_t *__restrict__ hits) {
+  long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= BT * max_n) return;
+  int n = (int)(gid / BT) + 1;
+  long long p = gid - (long long)(n - 1) * BT;
+  int i = (int)(p % T);
+  int32_t res = -1;
+  if (i + n <= T) {
+    uint32_t t[SCONE_MAX_N] = {0u, 0u, 0u, 0u};
+    bool ok = true;
+    for (int k = 0; k < SCONE_MAX_N; ++k) {
+      if (k < n) {
+        int32_t v = tok[p + k];
+        ok = ok && v >= 0;
+        t[k] = (uint32_t)v;
+      }
+    }
+    if (ok) {
+      scone_key key = scone_pack_key(t, n, max_n);
+      if (key.ok) res = probe_index(slots, mask, key.lo, key.ext);
+    }
+  }
+  hits[gid] = res;
+}
+
+// ------------------------------------------------------------------ CSR
+// Candidate c of position j enumerates (n, s) with n = 1..max_n, s = n-1..0
+// (window start i = j - s ascending): the append order of n_gram_extractor.py:119-124.
+__device__ __forceinline__ int32_t candidate(const int32_t *__restrict__ hits, long long BT,
+                                             long long p, int i, int n, int s) {
+  if (i - s < 0) return -1;
+  return hits[(long long)(n - 1) * BT + p - s];
+}
+
+__device__ __forceinline__ int count_pos(const int32_t *__restrict__ hits, long long BT, long long p,
+                                         int T, int max_n) {
+  int i = (int)(p % T);
+  int c = 0;
+  for (int n = 1; n <= max_n; ++n)
+    for (int s = n - 1; s >= 0; --s) c += candidate(hits, BT, p, i, n, s) >= 0;
+  return c;
+}
+
+#define CSR_BLOCK 256
+#define CSR_ITEMS 4
+#define CSR_TILE (CSR_BLOCK * CSR_ITEMS)
+
+__device__ __forceinline__ int wave_incl_scan(int v) {
+  const int lane = threadIdx.x & 63;
+  for (int d = 1; d < 64; d <<= 1) {
+    int u = __shfl_up(v, d, 64);
+    if (lane >= d) v += u;
+  }
+  return v;
+}
+
+// exclusive scan of one value per thread over the block; returns the exclusive
+// prefix and the block total in *total
+__device__ __forceinline__ int block_excl_scan(int v, int *total, int *smem /*[CSR_BLOCK/64+1]*/) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  int inc = wave_incl_scan(v);
+  if (lane == 63) smem[w] = inc;
+  __syncthreads();
+  int base = 0, tot = 0;
+  for (int k = 0; k < CSR_BLOCK / 64; ++k) {
+    int x = smem[k];
+    if (k < w) base += x;
+    tot += x;
+  }
+  __syncthreads();
+  *total = tot;
+  return base + inc - v;
+}
+
+__global__ __launch_bounds__(CSR_BLOCK) void k_csr_block_sums(const int32_t *__restrict__ hits,
+                                                              long long BT, int T, int max_n,
+                                                              int32_t *__restrict__ block_sums) {
+  __shared__ int smem[CSR_BLOCK / 64 + 1];
+  long long base = (long long)blockIdx.x * CSR_TILE + (long long)threadIdx.x * CSR_ITEMS;
+  int c = 0;
+  for (int k = 0; k < CSR_ITEMS; ++k)
+    if (base + k < BT) c += count_pos(hits, BT, base + k, T, max_n);
+  int tot;
+  block_excl_scan(c, &tot, smem);
+  if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
+}
+
+// single block: exclusive scan of block_sums in place; grand total -> *total
+__global__ __launch_bounds__(CSR_BLOCK) void k_csr_scan_sums(int32_t *__restrict__ block_sums,
+                                                             long long nb,
+                                                             long long *__restrict__ total) {
+  __shared__ int smem[CSR_BLOCK / 64 + 1];
+  long long carry = 0;
+  for (long long start = 0; start < nb; start += CSR_BLOCK) {
+    long long idx = start + threadIdx.x;
+    int v = idx < nb ? block_sums[idx] : 0;
+    int tot;
+    int ex = block_excl_scan(v, &tot, smem);
+    if (idx < nb) block_sums[idx] = (int32_t)(carry + ex);
+    carry += tot;
+  }
+  if (threadIdx.x == 0) *total = carry;
+}
+
+__global__ __launch_bounds__(CSR_BLOCK) void k_csr_fill(const int32_t *__restrict__ hits, long long BT,
+                                                        int T, int max_n,
+                                                        const int32_t *__restrict__ block_sums,
+                                                        int32_t *__restrict__ offsets,
+                                                        int32_t *__restrict__ ids, long long ids_cap) {
+  __shared__ int smem[CSR_BLOCK / 64 + 1];
+  long long base = (long long)blockIdx.x * CSR_TILE + (long long)threadIdx.x * CSR_ITEMS;
+  int cnt[CSR_ITEMS];
+  int c = 0;
+  for (int k = 0; k < CSR_ITEMS; ++k) {
+    cnt[k] = base + k < BT ? count_pos(hits, BT, base + k, T, max_n) : 0;
+    c += cnt[k];
+  }
+  int tot;
+  long long off = (long long)block_sums[blockIdx.x] + block_excl_scan(c, &tot, smem);
+  for (int k = 0; k < CSR_ITEMS; ++k) {
+    long long p = base + k;
+    if (p >= BT) break;
+    offsets[p] = (int32_t)off;
+    int i = (int)(p % T);
+    long long w = off;
+    for (int n = 1; n <= max_n; ++n)
+      for (int s = n - 1; s >= 0; --s) {
+        int32_t id = candidate(hits, BT, p, i, n, s);
+        if (id >= 0) {
+          if (w < ids_cap) ids[w] = id;
+          ++w;
+        }
+      }
+    off += cnt[k];
+    if (p == BT - 1) offsets[BT] = (int32_t)off;
+  }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------ host side
+int scone_launch_match(scone_handle *h, const int32_t *d_tok, int32_t B, int32_t T, int32_t *d_hits,
+                       hipStream_t s) {
+  long long BT = (long long)B * T;
+  long long total = BT * h->cfg.max_n;
+  if (total == 0) return SCONE_OK;
+  long long blocks = (total + 255) / 256;
+  if (blocks > 0x7FFFFFFFll) return scone_fail(h, SCONE_EINVAL, "scone_match: too many tokens for one launch");
+  hipLaunchKernelGGL(k_match, dim3((unsigned)blocks), dim3(256), 0, s, h->slots, h->cap - 1, d_tok, BT, T,
+                     h->cfg.max_n, d_hits);
+  SCONE_HIP(h, hipGetLastError());
+  return SCONE_OK;
+}
+
+extern "C" int scone_index_build_device(scone_handle *h, const uint32_t *d_keys, const uint8_t *d_lens,
+                                        uint64_t n, uint64_t id0, scone_stream_t stream) {
+  if (!h) return SCONE_EINVAL;
+  if (n == 0) return SCONE_OK;
+  if (!d_keys || !d_lens) return scone_fail(h, SCONE_EINVAL, "scone_index_build: null keys/lens");
+  if (id0 + n > 0xFFFFFFFEull) return scone_fail(h, SCONE_ERANGE, "scone_index_build: ids must be < 2^32-2");
+  SCONE_HIP(h, hipSetDevice(h->device));
+  unsigned long long blocks = (n + 255) / 256;
+  if (blocks > 0x7FFFFFFFull) return scone_fail(h, SCONE_EINVAL, "scone_index_build: chunk too large");
+  hipLaunchKernelGGL(k_index_insert, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, h->slots,
+                     h->cap - 1, d_keys, d_lens, (unsigned long long)n, (unsigned long long)id0, h->cfg.max_n,
+                     h->d_counters, h->d_status);
+  SCONE_HIP(h, hipGetLastError());
+  return SCONE_OK;
+}
+
+extern "C" int scone_index_build(scone_handle *h, const uint32_t *h_keys, const uint8_t *h_lens, uint64_t n,
+                                 uint64_t id0) {
+  if (!h) return SCONE_EINVAL;
+  if (n == 0) return SCONE_OK;
+  if (!h_keys || !h_lens) return scone_fail(h, SCONE_EINVAL, "scone_index_build: null keys/lens");
+  SCONE_HIP(h, hipSetDevice(h->device));
+  const uint64_t chunk = 1ull << 22;  // keys per staging round
+  const int max_n = h->cfg.max_n;
+  uint32_t *d_keys = nullptr;
+  uint8_t *d_lens = nullptr;
+  uint64_t cn = n < chunk ? n : chunk;
+  SCONE_HIP(h, hipMalloc(&d_keys, cn * max_n * sizeof(uint32_t)));
+  hipError_t e = hipMalloc(&d_lens, cn);
+  if (e != hipSuccess) {
+    (void)hipFree(d_keys);
+    return scone_hip_fail(h, e, "hipMalloc(lens staging)");
+  }
+  int rc = SCONE_OK;
+  for (uint64_t off = 0; off < n && rc == SCONE_OK; off += chunk) {
+    uint64_t m = n - off < chunk ? n - off : chunk;
+    e = hipMemcpy(d_keys, h_keys + off * max_n, m * max_n * sizeof(uint32_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_lens, h_lens + off, m, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+      rc = scone_hip_fail(h, e, "hipMemcpy(keys staging)");
+      break;
+    }
+    rc = scone_index_build_device(h, d_keys, d_lens, m, id0 + off, nullptr);
+    if (rc == SCONE_OK) {
+      e = hipStreamSynchronize(nullptr);
+      if (e != hipSuccess) rc = scone_hip_fail(h, e, "hipStreamSynchronize(index build)");
+    }
+  }
+  (void)hipFree(d_keys);
+  (void)hipFree(d_lens);
+  if (rc != SCONE_OK) return rc;
+  uint32_t bits = 0;
+  SCONE_HIP(h, hipMemcpy(&bits, h->d_status, sizeof(bits), hipMemcpyDeviceToHost));
+  if (bits & SCONE_ST_INDEX_FULL) return scone_fail(h, SCONE_ENOMEM, "scone_index_build: index full (raise index_capacity)");
+  if (bits & SCONE_ST_BAD_TOKEN)
+    return scone_fail(h, SCONE_ERANGE, "scone_index_build: key length outside 1..max_n or token id not representable");
+  return SCONE_OK;
+}
+
+extern "C" int scone_index_stats(scone_handle *h, uint64_t *n_keys, uint64_t *capacity, uint64_t *n_dups) {
+  if (!h) return SCONE_EINVAL;
+  SCONE_HIP(h, hipSetDevice(h->device));
+  SCONE_HIP(h, hipDeviceSynchronize());
+  unsigned long long c[2] = {0, 0};
+  SCONE_HIP(h, hipMemcpy(c, h->d_counters, sizeof(c), hipMemcpyDeviceToHost));
+  if (n_keys) *n_keys = c[0];
+  if (n_dups) *n_dups = c[1];
+  if (capacity) *capacity = h->cap;
+  return SCONE_OK;
+}
+
+extern "C" int scone_match(scone_handle *h, const int32_t *d_tok, int32_t B, int32_t T, int32_t *d_hits,
+                           scone_stream_t stream) {
+  if (!h) return SCONE_EINVAL;
+  if (B < 0 || T < 0) return scone_fail(h, SCONE_EINVAL, "scone_match: negative B or T");
+  if ((long long)B * T == 0) return SCONE_OK;
+  if (!d_tok || !d_hits) return scone_fail(h, SCONE_EINVAL, "scone_match: null pointer");
+  SCONE_HIP(h, hipSetDevice(h->device));
+  return scone_launch_match(h, d_tok, B, T, d_hits, (hipStream_t)stream);
+}
+
+extern "C" int scone_match_csr(scone_handle *h, const int32_t *d_tok, int32_t B, int32_t T, int32_t *d_offsets,
+                               int32_t *d_ids, int64_t ids_cap, int64_t *h_total, scone_stream_t stream) {
+  if (!h) return SCONE_EINVAL;
+  if (B < 0 || T < 0 || ids_cap < 0) return scone_fail(h, SCONE_EINVAL, "scone_match_csr: negative size");
+  if (!d_offsets || !h_total) return scone_fail(h, SCONE_EINVAL, "scone_match_csr: null pointer");
+  SCONE_HIP(h, hipSetDevice(h->device));
+  hipStream_t s = (hipStream_t)stream;
+  long long BT = (long long)B * T;
+  if (BT == 0) {
+    SCONE_HIP(h, hipMemsetAsync(d_offsets, 0, sizeof(int32_t), s));
+    SCONE_HIP(h, hipStreamSynchronize(s));
+    *h_total = 0;
+    return SCONE_OK;
+  }
+  if (!d_tok) return scone_fail(h, SCONE_EINVAL, "scone_match_csr: null tokens");
+  if (BT * SCONE_MAX_CAND > 0x7FFFFFFFll) return scone_fail(h, SCONE_EINVAL, "scone_match_csr: B*T too large for int32 offsets");
+  int rc = scone_ensure_hits(h, BT);
+  if (rc) return rc;
+  rc = scone_launch_match(h, d_tok, B, T, h->d_hits, s);
+  if (rc) return rc;
+  long long nb = (BT + CSR_TILE - 1) / CSR_TILE;
+  if (nb > h->block_sums_cap) {
+    if (h->d_block_sums) SCONE_HIP(h, hipFree(h->d_block_sums));
+    h->d_block_sums = nullptr;
+    h->block_sums_cap = 0;
+    SCONE_HIP(h, hipMalloc(&h->d_block_sums, (size_t)nb * sizeof(int32_t)));
+    h->block_sums_cap = nb;
+  }
+  hipLaunchKernelGGL(k_csr_block_sums, dim3((unsigned)nb), dim3(CSR_BLOCK), 0, s, h->d_hits, BT, T, h->cfg.max_n,
+                     h->d_block_sums);
+  hipLaunchKernelGGL(k_csr_scan_sums, dim3(1), dim3(CSR_BLOCK), 0, s, h->d_block_sums, nb,
+                     (long long *)h->d_total);
+  hipLaunchKernelGGL(k_csr_fill, dim3((unsigned)nb), dim3(CSR_BLOCK), 0, s, h->d_hits, BT, T, h->cfg.max_n,
+                     h->d_block_sums, d_offsets, d_ids, d_ids ? (long long)ids_cap : 0ll);
+  SCONE_HIP(h, hipGetLastError());
+  long long total = 0;
+  SCONE_HIP(h, hipMemcpyAsync(&total, h->d_total, sizeof(total), hipMemcpyDeviceToHost, s));
+  SCONE_HIP(h, hipStreamSynchronize(s));
+  *h_total = total;
+  if (total > ids_cap) return scone_fail(h, SCONE_ERANGE, "scone_match_csr: ids_cap too small");
+  return SCONE_OK;
+}

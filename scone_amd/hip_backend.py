@@ -1,0 +1,301 @@
+"""Thin object wrapper over the C ABI: one :class:`SconeTable` = one ``scone_handle``
+(device f-gram index + table shard).  Tensors cross the boundary as raw pointers
+(``tensor.data_ptr()``); all work is enqueued on torch's current HIP stream."""
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+_FMT = {"fp32": L.FMT_F32, "float32": L.FMT_F32, "f32": L.FMT_F32,
+        "fp16": L.FMT_F16, "float16": L.FMT_F16, "f16": L.FMT_F16,
+        "int8": L.FMT_I8, "i8": L.FMT_I8, "int4": L.FMT_I4, "i4": L.FMT_I4}
+_PLACE = {"hbm": L.PLACE_HBM, "pinned_host": L.PLACE_PINNED_HOST}
+_REDUCE = {"mean": L.REDUCE_MEAN, "sum": L.REDUCE_SUM}
+_DT = {torch.float32: L.DT_F32, torch.float16: L.DT_F16, torch.bfloat16: L.DT_BF16}
+
+I4_GROUP = 128
+
+
+def format_code(fmt) -> int:
+    if isinstance(fmt, int):
+        return fmt
+    try:
+        return _FMT[str(fmt).lower()]
+    except KeyError:
+        raise ValueError(f"unknown table format {fmt!r} (fp32, fp16, int8, int4)") from None
+
+
+def row_bytes(fmt: int, d: int) -> int:
+    """Algorithmic bytes per table row."""
+    return {L.FMT_F32: 4 * d, L.FMT_F16: 2 * d, L.FMT_I8: d + 2,
+            L.FMT_I4: d // 2 + 2 * (d // I4_GROUP)}[fmt]
+
+
+class SconeError(RuntimeError):
+    pass
+
+
+def _raise(code: int, msg: str):
+    text = f"{msg} [{L.lib().scone_strerror(code).decode()}]"
+    if code == L.EINVAL:
+        raise ValueError(text)
+    if code == L.ERANGE:
+        raise IndexError(text)
+    if code == L.ENOMEM:
+        raise MemoryError(text)
+    raise SconeError(text)
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def require_gpu() -> torch.device:
+    if not torch.cuda.is_available():
+        raise RuntimeError("scone_amd: the f-gram lookup path needs an MI355X (no HIP device visible); "
+                           "there is no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+class SconeTable:
+    """Device-resident f-gram index (+ optional table shard)."""
+
+    def __init__(self, max_n: int, n_rows: int, dim: int = 0, table_format="fp32", placement: str = "hbm",
+                 device: Optional[torch.device] = None, row_begin: int = 0, row_end: Optional[int] = None,
+                 index_capacity: int = 0) -> None:
+        self._h = None
+        lib = L.lib()
+        dev = torch.device(device) if device is not None else require_gpu()
+        if dev.type != "cuda":
+            raise RuntimeError("scone_amd: SconeTable lives on a HIP device; got " + str(dev))
+        require_gpu()
+        self.device = torch.device("cuda", dev.index if dev.index is not None else torch.cuda.current_device())
+        self.max_n, self.n_rows, self.dim = int(max_n), int(n_rows), int(dim)
+        self.fmt = format_code(table_format)
+        self.row_begin = int(row_begin)
+        self.row_end = int(n_rows if row_end is None else row_end)
+        cfg = L.SconeCfg(C.sizeof(L.SconeCfg), self.device.index, self.max_n, self.dim, self.fmt,
+                         _PLACE[placement], self.n_rows, self.row_begin, self.row_end, int(index_capacity))
+        h = C.c_void_p()
+        rc = lib.scone_create(C.byref(cfg), C.byref(h))
+        if rc != L.OK:
+            _raise(rc, "scone_create: " + lib.scone_last_error(None).decode())
+        self._h = h
+
+    # -- plumbing ---------------------------------------------------------------
+    def _check(self, rc: int, who: str) -> None:
+        if rc != L.OK:
+            _raise(rc, f"{who}: " + L.lib().scone_last_error(self._h).decode())
+
+    def close(self) -> None:
+        if self._h is not None:
+            L.lib().scone_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def status(self) -> int:
+        bits = C.c_uint32(0)
+        with torch.cuda.device(self.device):
+            self._check(L.lib().scone_status(self._h, C.byref(bits), _stream()), "scone_status")
+        return bits.value
+
+    # -- index ------------------------------------------------------------------
+    def index_build(self, keys: np.ndarray, lens: np.ndarray, id0: int = 0) -> None:
+        keys = np.ascontiguousarray(keys, dtype=np.uint32)
+        lens = np.ascontiguousarray(lens, dtype=np.uint8)
+        n = int(lens.shape[0])
+        if n == 0:
+            return
+        if keys.shape != (n, self.max_n):
+            raise ValueError(f"keys must be [{n}, {self.max_n}] uint32, got {keys.shape}")
+        rc = L.lib().scone_index_build(self._h, keys.ctypes.data_as(C.c_void_p), lens.ctypes.data_as(C.c_void_p),
+                                       n, int(id0))
+        self._check(rc, "scone_index_build")
+
+    def index_build_device(self, keys: torch.Tensor, lens: torch.Tensor, id0: int = 0) -> None:
+        assert keys.is_cuda and lens.is_cuda and keys.is_contiguous() and lens.is_contiguous()
+        assert keys.dtype in (torch.int32, torch.uint32) and lens.dtype == torch.uint8
+        n = int(lens.shape[0])
+        with torch.cuda.device(self.device):
+            rc = L.lib().scone_index_build_device(self._h, _ptr(keys), _ptr(lens), n, int(id0), _stream())
+        self._check(rc, "scone_index_build_device")
+
+    def index_stats(self) -> Tuple[int, int, int]:
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        self._check(L.lib().scone_index_stats(self._h, C.byref(a), C.byref(b), C.byref(c)), "scone_index_stats")
+        return a.value, b.value, c.value
+
+    # -- table ------------------------------------------------------------------
+    def upload(self, rows, scales=None, row0: int = 0) -> None:
+        """Raw rows already in the table format (numpy host arrays or device tensors)."""
+        is_dev = isinstance(rows, torch.Tensor)
+        if is_dev:
+            assert rows.is_cuda and rows.is_contiguous()
+            nrows, rp = rows.shape[0], _ptr(rows)
+            sp = _ptr(scales) if scales is not None else None
+        else:
+            rows = np.ascontiguousarray(rows)
+            nrows, rp = rows.shape[0], rows.ctypes.data_as(C.c_void_p)
+            if scales is not None:
+                scales = np.ascontiguousarray(scales, dtype=np.float16)
+            sp = scales.ctypes.data_as(C.c_void_p) if scales is not None else None
+        with torch.cuda.device(self.device):
+            rc = L.lib().scone_table_upload(self._h, rp, sp, int(row0), int(nrows), int(is_dev), _stream())
+        self._check(rc, "scone_table_upload")
+
+    def store_f32(self, rows: torch.Tensor, row0: int = 0, ids: Optional[torch.Tensor] = None) -> None:
+        rows = rows.to(device=self.device, dtype=torch.float32).contiguous()
+        if rows.dim() != 2 or rows.shape[1] != self.dim:
+            raise ValueError(f"rows must be [n, {self.dim}], got {tuple(rows.shape)}")
+        with torch.cuda.device(self.device):
+            if ids is None:
+                rc = L.lib().scone_table_store_f32(self._h, _ptr(rows), int(row0), rows.shape[0], _stream())
+            else:
+                ids = ids.to(device=self.device, dtype=torch.int64).contiguous()
+                rc = L.lib().scone_table_store_f32_ids(self._h, _ptr(rows), _ptr(ids), rows.shape[0], _stream())
+            # `rows`/`ids` may be temporaries: keep them alive until the kernel has read them
+            torch.cuda.current_stream().synchronize()
+        self._check(rc, "scone_table_store_f32")
+
+    def fill_synthetic(self, seed: int, base_scale: float) -> None:
+        with torch.cuda.device(self.device):
+            rc = L.lib().scone_table_fill_synthetic(self._h, int(seed) & 0xFFFFFFFF, float(base_scale), _stream())
+        self._check(rc, "scone_table_fill_synthetic")
+
+    def gather_rows(self, ids: torch.Tensor) -> torch.Tensor:
+        ids = ids.to(device=self.device, dtype=torch.int64).contiguous()
+        out = torch.empty((ids.numel(), self.dim), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = L.lib().scone_table_gather_rows(self._h, _ptr(ids), ids.numel(), _ptr(out), _stream())
+        self._check(rc, "scone_table_gather_rows")
+        return out
+
+    # -- hot path ---------------------------------------------------------------
+    def _tok(self, tok: torch.Tensor) -> torch.Tensor:
+        if tok.dim() == 1:
+            tok = tok.unsqueeze(0)
+        if tok.dim() != 2:
+            raise ValueError("token ids must be [T] or [B, T]")
+        return tok.to(device=self.device, dtype=torch.int32).contiguous()
+
+    def match(self, tok: torch.Tensor) -> torch.Tensor:
+        """hits[max_n, B, T] int32: id of the window tok[b, i:i+n] or -1."""
+        tok = self._tok(tok)
+        B, T = tok.shape
+        hits = torch.empty((self.max_n, B, T), dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = L.lib().scone_match(self._h, _ptr(tok), B, T, _ptr(hits), _stream())
+        self._check(rc, "scone_match")
+        return hits
+
+    def match_csr(self, tok: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Per-position id lists (reference order, duplicates kept) as CSR (offsets[B*T+1], ids)."""
+        tok = self._tok(tok)
+        B, T = tok.shape
+        ncand = self.max_n * (self.max_n + 1) // 2
+        offsets = torch.empty(B * T + 1, dtype=torch.int32, device=self.device)
+        ids = torch.empty(max(B * T * ncand, 1), dtype=torch.int32, device=self.device)
+        total = C.c_int64(0)
+        with torch.cuda.device(self.device):
+            rc = L.lib().scone_match_csr(self._h, _ptr(tok), B, T, _ptr(offsets), _ptr(ids), ids.numel(),
+                                         C.byref(total), _stream())
+        self._check(rc, "scone_match_csr")
+        return offsets, ids[:total.value]
+
+    def gather_reduce(self, offsets: torch.Tensor, ids: torch.Tensor, reduce: str = "mean",
+                      base: Optional[torch.Tensor] = None, out_dtype: torch.dtype = torch.float32) -> torch.Tensor:
+        offsets = offsets.to(device=self.device, dtype=torch.int32).contiguous()
+        ids = ids.to(device=self.device, dtype=torch.int32).contiguous()
+        ntok = offsets.numel() - 1
+        out = torch.empty((ntok, self.dim), dtype=out_dtype, device=self.device)
+        if base is not None:
+            base = base.to(device=self.device, dtype=out_dtype).contiguous()
+            assert base.shape == out.shape
+        with torch.cuda.device(self.device):
+            rc = L.lib().scone_gather_reduce(self._h, _ptr(offsets), _ptr(ids), ntok, _ptr(base), _REDUCE[reduce],
+                                             _ptr(out), _DT[out_dtype], _stream())
+        self._check(rc, "scone_gather_reduce")
+        return out
+
+    def embed(self, tok: torch.Tensor, wte: Optional[torch.Tensor] = None, wpe: Optional[torch.Tensor] = None,
+              position_ids: Optional[torch.Tensor] = None, reduce: str = "mean",
+              out_dtype: Optional[torch.dtype] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Fused match + gather + dequantise + reduce (+ wte[tok] + wpe[pos]) -> [B, T, d]."""
+        tok = self._tok(tok)
+        B, T = tok.shape
+        if out_dtype is None:
+            out_dtype = wte.dtype if wte is not None else (wpe.dtype if wpe is not None else torch.float32)
+        for name, w in (("wte", wte), ("wpe", wpe)):
+            if w is not None:
+                if not (w.is_cuda and w.is_contiguous() and w.dtype == out_dtype and w.dim() == 2
+                        and w.shape[1] == self.dim):
+                    raise ValueError(f"{name} must be a contiguous [*, {self.dim}] {out_dtype} tensor on {self.device}")
+        if position_ids is not None:
+            position_ids = position_ids.to(device=self.device, dtype=torch.int32).expand(B, T).contiguous()
+        if out is None:
+            out = torch.empty((B, T, self.dim), dtype=out_dtype, device=self.device)
+        else:
+            assert out.is_cuda and out.is_contiguous() and out.dtype == out_dtype and out.numel() == B * T * self.dim
+        with torch.cuda.device(self.device):
+            rc = L.lib().scone_embed(self._h, _ptr(tok), B, T, _ptr(wte), 0 if wte is None else wte.shape[0],
+                                     _ptr(wpe), 0 if wpe is None else wpe.shape[0], _ptr(position_ids),
+                                     _REDUCE[reduce], _ptr(out), _DT[out_dtype], _stream())
+        self._check(rc, "scone_embed")
+        return out
+
+    def reserve(self, max_tokens: int) -> None:
+        with torch.cuda.device(self.device):
+            self._check(L.lib().scone_reserve(self._h, int(max_tokens)), "scone_reserve")
+
+    def profile_enable(self, enable: bool = True) -> None:
+        self._check(L.lib().scone_profile_enable(self._h, int(enable)), "scone_profile_enable")
+
+    def profile_read(self, reset: bool = True) -> Tuple[int, float]:
+        """(launches, total milliseconds) of the gather/reduce kernel since the last reset."""
+        n, ms = C.c_uint64(0), C.c_double(0.0)
+        self._check(L.lib().scone_profile_read(self._h, C.byref(n), C.byref(ms), int(reset)), "scone_profile_read")
+        return n.value, ms.value
+
+    def embed_partial(self, tok: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        tok = self._tok(tok)
+        B, T = tok.shape
+        partial = torch.empty((B * T, self.dim), dtype=torch.float32, device=self.device)
+        counts = torch.empty(B * T, dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = L.lib().scone_embed_partial(self._h, _ptr(tok), B, T, _ptr(partial), _ptr(counts), _stream())
+        self._check(rc, "scone_embed_partial")
+        return partial, counts
+
+    def finalize(self, sums: torch.Tensor, counts: torch.Tensor, tok: torch.Tensor, tok_begin: int, tok_end: int,
+                 wte: Optional[torch.Tensor] = None, wpe: Optional[torch.Tensor] = None,
+                 position_ids: Optional[torch.Tensor] = None, reduce: str = "mean",
+                 out_dtype: torch.dtype = torch.float32) -> torch.Tensor:
+        tok = self._tok(tok)
+        B, T = tok.shape
+        n = tok_end - tok_begin
+        sums = sums.to(device=self.device, dtype=torch.float32).contiguous()
+        counts = counts.to(device=self.device, dtype=torch.int32).contiguous()
+        assert sums.shape == (n, self.dim) and counts.shape == (n,)
+        if position_ids is not None:
+            position_ids = position_ids.to(device=self.device, dtype=torch.int32).expand(B, T).contiguous()
+        out = torch.empty((n, self.dim), dtype=out_dtype, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = L.lib().scone_finalize(self._h, _ptr(sums), _ptr(counts), _ptr(tok), B, T, int(tok_begin),
+                                        int(tok_end), _ptr(wte), 0 if wte is None else wte.shape[0], _ptr(wpe),
+                                        0 if wpe is None else wpe.shape[0], _ptr(position_ids), _REDUCE[reduce],
+                                        _ptr(out), _DT[out_dtype], _stream())
+        self._check(rc, "scone_finalize")
+        return out

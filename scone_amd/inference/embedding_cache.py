@@ -1,0 +1,311 @@
+"""f-gram embedding table + lookup, MI355X-native.
+
+Mirrors ``scone/inference/embedding_cache.py`` of the reference: same class name,
+constructor, attributes and method signatures (``cache_embeddings``,
+``get_embeddings``, ``get_token_embeddings``, ``save``, ``load``), the same
+exceptions and the same on-disk formats.  Host attributes (``embeddings`` dict /
+``memory_mapped_embeddings``) are kept as the reference keeps them; every *lookup*
+is served from a device copy of the table (fp32 / fp16 / INT8 / INT4 rows in HBM
+or in pinned host memory) by the kernels behind ``include/scone_hip.h``.  There is
+no CPU fallback for lookups.
+
+Additive API (not in the reference): :meth:`embed_tokens` -- the fused
+match -> gather -> dequantise -> mean -> ``+ wte + wpe`` path, :meth:`match`,
+:meth:`to_device`, :meth:`from_synthetic`.
+"""
+
+import os
+from typing import Dict, List, Optional, Sequence, Tuple, Union
+
+import numpy as np
+import torch
+
+from scone_amd.tokenization.n_gram_extractor import NGramExtractor
+
+
+class EmbeddingCache:
+    """Cache for f-gram embeddings (reference: embedding_cache.py:13-54).
+
+    Extra keyword-only arguments select the device representation:
+        table_format: "fp32" (reference-exact), "fp16", "int8", "int4".
+        placement:    "hbm" or "pinned_host" (rows stay in host DRAM, read over PCIe).
+        device:       HIP device for the table (default: current device).
+        keep_host_copy: keep the reference's host dict / memmap (needed by ``save``).
+    """
+
+    def __init__(self, n_gram_extractor: NGramExtractor, embedding_dim: int, cache_dir: Optional[str] = None,
+                 use_memory_map: bool = False, *, table_format: str = "fp32", placement: str = "hbm",
+                 device=None, keep_host_copy: bool = True) -> None:
+        self.n_gram_extractor = n_gram_extractor
+        self.embedding_dim = embedding_dim
+        self.cache_dir = cache_dir
+        self.use_memory_map = use_memory_map
+
+        self.embeddings: Dict[int, np.ndarray] = {}
+        self.memory_mapped_embeddings: Optional[np.ndarray] = None
+
+        self.table_format = table_format
+        self.placement = placement
+        self.keep_host_copy = keep_host_copy
+        self._device = device
+        self._table = None           # hip_backend.SconeTable
+        self._dirty = True           # host rows changed since the last upload
+        self._present: Optional[np.ndarray] = None   # which ids have a row (in-memory variant, no host copy)
+
+        if self.cache_dir is not None and not os.path.exists(self.cache_dir):
+            os.makedirs(self.cache_dir)
+
+    # ------------------------------------------------------------------ ingestion (a8)
+    def cache_embeddings(self, f_gram_ids: Union[Sequence[int], Dict[int, torch.Tensor]],
+                         embeddings: Optional[torch.Tensor] = None, verbose: bool = True) -> None:
+        """Cache embeddings for f-grams (embedding_cache.py:56-111).
+
+        Also accepts the ``{id: tensor}`` form that the reference's own callers pass
+        (precompute_embeddings.py:138, simple_example.py:111).
+        """
+        if isinstance(f_gram_ids, dict):
+            items = f_gram_ids
+            f_gram_ids = list(items.keys())
+            embeddings = (torch.stack([torch.as_tensor(items[i], dtype=torch.float32).reshape(-1)
+                                       for i in f_gram_ids])
+                          if f_gram_ids else torch.zeros(0, self.embedding_dim))
+        if embeddings is None:
+            raise TypeError("cache_embeddings() missing required argument: 'embeddings'")
+        ids = np.asarray(list(f_gram_ids), dtype=np.int64)
+        rows = embeddings[:len(ids)] if len(embeddings) > len(ids) else embeddings
+        ids = ids[:len(rows)]                                     # zip() semantics of the reference
+        if self.use_memory_map:
+            if self.memory_mapped_embeddings is None:
+                if self.cache_dir is None:
+                    raise ValueError("Cache directory must be provided for memory mapping")
+                mmap_path = os.path.join(self.cache_dir, "embeddings.npy")
+                shape = (len(self.n_gram_extractor.f_grams), self.embedding_dim)
+                # raw row-major fp32 [N, d], no header, zero-filled (embedding_cache.py:84-91)
+                mode = "r+" if os.path.exists(mmap_path) and os.path.getsize(mmap_path) == shape[0] * shape[1] * 4 else "w+"
+                self.memory_mapped_embeddings = np.memmap(mmap_path, dtype=np.float32, mode=mode, shape=shape)
+                if mode == "w+":
+                    self.memory_mapped_embeddings[:] = 0.0
+            if len(ids):
+                self.memory_mapped_embeddings[ids] = rows.detach().to("cpu", torch.float32).numpy()
+            if hasattr(self.memory_mapped_embeddings, "flush"):
+                self.memory_mapped_embeddings.flush()
+        elif self.keep_host_copy:
+            host = rows.detach().to("cpu", torch.float32).numpy()
+            for k, f_gram_id in enumerate(ids.tolist()):
+                self.embeddings[f_gram_id] = host[k]
+        else:
+            # device-only ingestion: rows go straight into the device table (quantised on the GPU)
+            table = self._device_only_table()
+            if len(ids):
+                if int(ids.min()) < 0 or int(ids.max()) >= table.n_rows:
+                    raise IndexError(f"f-gram id outside the table (size {table.n_rows})")
+                table.store_f32(rows, ids=torch.from_numpy(ids))
+                self._present[ids] = True
+            return
+        self._dirty = True
+
+    # ------------------------------------------------------------------ device table
+    def _n_rows(self) -> int:
+        n = len(self.n_gram_extractor)
+        if self.use_memory_map and self.memory_mapped_embeddings is not None:
+            n = max(n, self.memory_mapped_embeddings.shape[0])
+        elif self.embeddings:
+            n = max(n, max(self.embeddings.keys()) + 1)
+        if self._present is not None:
+            n = max(n, self._present.shape[0])
+        return n
+
+    def _make_table(self, n_rows: int):
+        from scone_amd.hip_backend import SconeTable
+        table = SconeTable(self.n_gram_extractor.max_n, n_rows, dim=self.embedding_dim,
+                           table_format=self.table_format, placement=self.placement, device=self._device)
+        self.n_gram_extractor.build_index(table)
+        return table
+
+    def _device_only_table(self):
+        if self._table is None:
+            n = len(self.n_gram_extractor)
+            self._table = self._make_table(n)
+            self._present = np.zeros(n, dtype=bool)
+            self._dirty = False
+        return self._table
+
+    def to_device(self, device=None, table_format: Optional[str] = None, placement: Optional[str] = None):
+        """(Re)build the device table + index from the host rows; returns the backend handle."""
+        device_only = not self.keep_host_copy and not self.use_memory_map
+        if device_only:
+            if self._table is not None and ((table_format not in (None, self.table_format))
+                                            or (placement not in (None, self.placement))):
+                raise RuntimeError("a device-only cache (keep_host_copy=False) cannot be re-laid out")
+            if device is not None and self._table is None:
+                self._device = device
+            if table_format is not None and self._table is None:
+                self.table_format = table_format
+            if placement is not None and self._table is None:
+                self.placement = placement
+            return self._device_only_table()
+        if device is not None:
+            self._device = device
+        if table_format is not None and table_format != self.table_format:
+            self.table_format, self._dirty = table_format, True
+        if placement is not None and placement != self.placement:
+            self.placement, self._dirty = placement, True
+        if self._table is not None and not self._dirty:
+            return self._table
+        table = self._make_table(self._n_rows())
+        chunk = max(1, (64 << 20) // (4 * self.embedding_dim))
+        if self.use_memory_map:
+            mm = self.memory_mapped_embeddings
+            if mm is not None:
+                for a in range(0, mm.shape[0], chunk):
+                    table.store_f32(torch.from_numpy(np.ascontiguousarray(mm[a:a + chunk])), row0=a)
+        elif self.embeddings:
+            ids = np.fromiter(self.embeddings.keys(), dtype=np.int64, count=len(self.embeddings))
+            for a in range(0, len(ids), chunk):
+                part = ids[a:a + chunk]
+                rows = np.stack([np.asarray(self.embeddings[int(i)], dtype=np.float32).reshape(-1) for i in part])
+                table.store_f32(torch.from_numpy(rows), ids=torch.from_numpy(part))
+        self._table = table
+        self._dirty = False
+        return table
+
+    @property
+    def table(self):
+        """The device handle (built on first use)."""
+        return self.to_device()
+
+    @classmethod
+    def from_synthetic(cls, n_gram_extractor: NGramExtractor, embedding_dim: int, *, table_format: str = "int8",
+                       seed: int = 7, base_scale: float = 0.02 / 127, placement: str = "hbm", device=None,
+                       n_rows: Optional[int] = None) -> "EmbeddingCache":
+        """Cache whose device table is generated on the GPU by the counter-based hash of
+        ``scone_table_fill_synthetic`` (bench / full-size tests; nothing materialised on the host)."""
+        cache = cls(n_gram_extractor, embedding_dim, table_format=table_format, placement=placement, device=device,
+                    keep_host_copy=False)
+        n = int(n_rows if n_rows is not None else len(n_gram_extractor))
+        table = cache._make_table(n)
+        table.fill_synthetic(seed, base_scale)
+        cache._table, cache._dirty = table, False
+        cache._present = np.ones(n, dtype=bool)
+        return cache
+
+    # ------------------------------------------------------------------ lookups (a4, a5)
+    def _validate_ids(self, f_gram_ids: Sequence[int]) -> np.ndarray:
+        ids = np.asarray(list(f_gram_ids), dtype=np.int64).reshape(-1)
+        if self.use_memory_map:
+            if self.memory_mapped_embeddings is None:
+                raise ValueError("Memory-mapped embeddings not initialized")
+            n = self.memory_mapped_embeddings.shape[0]
+            bad = (ids < -n) | (ids >= n)
+            if bad.any():
+                raise IndexError(f"index {int(ids[bad][0])} is out of bounds for axis 0 with size {n}")
+            ids = np.where(ids < 0, ids + n, ids)                 # numpy fancy-index semantics
+        elif self.keep_host_copy:
+            for i in ids.tolist():
+                if i not in self.embeddings:
+                    raise KeyError(i)
+        else:
+            n = 0 if self._present is None else self._present.shape[0]
+            for i in ids.tolist():
+                if not (0 <= i < n and self._present[i]):
+                    raise KeyError(i)
+        return ids
+
+    def get_embeddings(self, f_gram_ids: List[int], device: Optional[torch.device] = None) -> torch.Tensor:
+        """Rows for f-gram ids as fp32 ``[K, d]`` (embedding_cache.py:113-147); a fresh tensor every call.
+
+        ``device=None`` returns a CPU tensor as the reference does."""
+        ids = self._validate_ids(f_gram_ids)
+        if ids.size == 0 and not self.use_memory_map:
+            raise RuntimeError("stack expects a non-empty TensorList")   # torch.stack([]) in the reference
+        table = self.to_device()
+        out = table.gather_rows(torch.from_numpy(ids))
+        return out.cpu() if device is None else out.to(device)
+
+    def get_token_embeddings(self, token_ids: List[int],
+                             device: Optional[torch.device] = None) -> Dict[int, torch.Tensor]:
+        """``{position: Tensor[K_pos, d]}`` for every position covered by at least one f-gram
+        (embedding_cache.py:149-181); positions with K = 0 are omitted."""
+        if len(token_ids) == 0:
+            return {}
+        table = self.to_device()
+        tok = torch.as_tensor(np.asarray(token_ids, dtype=np.int64).clip(-1, 2**31 - 1), dtype=torch.int32)
+        offsets, ids = table.match_csr(tok)
+        off = offsets.cpu().numpy()
+        ids_host = ids.cpu().numpy()
+        if not self.use_memory_map and ids_host.size:
+            self._validate_ids(np.unique(ids_host))               # KeyError for an f-gram without a cached row
+        rows = table.gather_rows(ids.to(torch.int64)) if ids_host.size else None
+        if rows is not None:
+            rows = rows.cpu() if device is None else rows.to(device)
+        result: Dict[int, torch.Tensor] = {}
+        for pos in range(len(token_ids)):
+            a, b = int(off[pos]), int(off[pos + 1])
+            if b > a:
+                result[pos] = rows[a:b].clone()
+        return result
+
+    # ------------------------------------------------------------------ additive fused API
+    def match(self, input_ids: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Per-position f-gram id lists as CSR over the flattened ``B*T`` positions."""
+        return self.to_device().match_csr(torch.as_tensor(input_ids))
+
+    def embed_tokens(self, input_ids: torch.Tensor, *, reduce: str = "mean", wte: Optional[torch.Tensor] = None,
+                     wpe: Optional[torch.Tensor] = None, position_ids: Optional[torch.Tensor] = None,
+                     out_dtype: Optional[torch.dtype] = None, out: Optional[torch.Tensor] = None,
+                     check: bool = False) -> torch.Tensor:
+        """Fused lookup for ``input_ids [B, T]`` -> ``[B, T, d]``:
+
+            out[b, t] = (wte[input_ids[b, t]] + reduce_k row(f_gram_k)) + wpe[position_ids[b, t]]
+
+        i.e. get_token_f_grams + id map + get_embeddings + ``mean(dim=0)`` + zero-fill
+        (engine.py:234-266) and, when ``wte``/``wpe`` are given, the combine of
+        ``SconeLanguageModel.forward`` (language_model.py:239-254) with the bias-free
+        projection folded into the table.  ``check=True`` synchronises and raises
+        ``IndexError`` for token / position ids outside ``wte`` / ``wpe``.
+        """
+        table = self.to_device()
+        result = table.embed(torch.as_tensor(input_ids), wte=wte, wpe=wpe, position_ids=position_ids, reduce=reduce,
+                             out_dtype=out_dtype, out=out)
+        if check and table.status() & 1:
+            raise IndexError("index out of range in self")
+        return result
+
+    # ------------------------------------------------------------------ persistence (a9)
+    def save(self, path: str) -> None:
+        """Same on-disk format as the reference (embedding_cache.py:183-203)."""
+        if self.use_memory_map:
+            np.save(path, {"use_memory_map": True, "cache_dir": self.cache_dir,
+                           "embedding_dim": self.embedding_dim})
+        else:
+            if not self.keep_host_copy:
+                raise RuntimeError("save() needs the host copy of the rows (keep_host_copy=True)")
+            np.save(path, {"use_memory_map": False, "embeddings": self.embeddings,
+                           "embedding_dim": self.embedding_dim})
+
+    @classmethod
+    def load(cls, path: str, n_gram_extractor: NGramExtractor, cache_dir: Optional[str] = None,
+             use_memory_map: Optional[bool] = None, **device_kwargs) -> "EmbeddingCache":
+        """Load a cache written by the reference or by :meth:`save` (embedding_cache.py:205-243).
+
+        ``cache_dir`` / ``use_memory_map`` are accepted because the reference's own callers
+        pass them (engine.py:180, tests/test_embedding_cache.py:136); the file decides.
+        """
+        data = np.load(path, allow_pickle=True).item()
+        if data["use_memory_map"]:
+            cache = cls(n_gram_extractor=n_gram_extractor, embedding_dim=data["embedding_dim"],
+                        cache_dir=data["cache_dir"], use_memory_map=True, **device_kwargs)
+            mmap_path = os.path.join(data["cache_dir"], "embeddings.npy")
+            try:
+                cache.memory_mapped_embeddings = np.load(mmap_path, mmap_mode="r")
+            except ValueError:
+                # the reference writes the file raw (np.memmap, no .npy header): [N, d] fp32
+                n = os.path.getsize(mmap_path) // (4 * data["embedding_dim"])
+                cache.memory_mapped_embeddings = np.memmap(mmap_path, dtype=np.float32, mode="r",
+                                                           shape=(n, data["embedding_dim"]))
+        else:
+            cache = cls(n_gram_extractor=n_gram_extractor, embedding_dim=data["embedding_dim"],
+                        use_memory_map=False, **device_kwargs)
+            cache.embeddings = data["embeddings"]
+        cache._dirty = True
+        return cache

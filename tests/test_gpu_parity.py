@@ -1,0 +1,382 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle and the golden
+fixtures captured from the reference.  Run with ``-m gpu`` on an MI355X.
+
+Bars: id lists bit-exact; fp32 table + fp32 out bit-exact against the reference's own
+``mean`` (sequential fp32 sum, IEEE division); quantised tables / fp16 out within
+1e-3 relative of the oracle run on the dequantised table (BASELINE.json north_star).
+"""
+
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_port as R
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 1e-3     # north_star: "within 1e-3 rel for the fp16 summed embedding"
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from scone_amd import _lib
+    _lib.lib()          # fail loudly if the extension is missing
+
+
+def _extractor(keys, lens, max_n):
+    from scone_amd import NGramExtractor
+    return NGramExtractor.from_arrays(keys, lens, max_n=max_n)
+
+
+def _cache(keys, lens, max_n, table, fmt="fp32", **kw):
+    from scone_amd import EmbeddingCache
+    ex = _extractor(keys, lens, max_n)
+    c = EmbeddingCache(ex, table.shape[1], table_format=fmt, **kw)
+    c.cache_embeddings(list(range(table.shape[0])), torch.from_numpy(table), verbose=False)
+    return c
+
+
+def _rel(a, b):
+    return float(np.abs(a.astype(np.float64) - b.astype(np.float64)).max() / max(np.abs(b).max(), 1e-30))
+
+
+# ------------------------------------------------------------------ a1-a3: index + match
+def test_match_golden_bit_exact(golden_dir):
+    from scone_amd.hip_backend import SconeTable
+    z = np.load(os.path.join(golden_dir, "match.npz"))
+    for c in z["cases"]:
+        keys, lens, max_n = z[f"{c}_keys"], z[f"{c}_lens"], int(z[f"{c}_max_n"])
+        t = SconeTable(max_n, len(lens))
+        t.index_build(keys, lens)
+        nk, cap, dups = t.index_stats()
+        assert nk == len(lens) and dups == 0 and cap >= 2 * nk
+        for si in range(int(z["n_streams"])):
+            tok = torch.from_numpy(z[f"{c}_s{si}_tok"])
+            off, ids = t.match_csr(tok)
+            assert np.array_equal(off.cpu().numpy(), z[f"{c}_s{si}_off"]), (c, si)
+            assert np.array_equal(ids.cpu().numpy(), z[f"{c}_s{si}_ids"]), (c, si)
+
+
+def test_get_token_f_grams_matches_reference_dict(golden_dir):
+    z = np.load(os.path.join(golden_dir, "match.npz"))
+    c = "c12"          # the [7,7,7,7] multiplicity case
+    ex = _extractor(z[f"{c}_keys"], z[f"{c}_lens"], 3)
+    got = ex.get_token_f_grams([7, 7, 7, 7])
+    assert got[1] == [(7,), (7, 7), (7, 7), (7, 7, 7), (7, 7, 7)]
+    assert got[0] == [(7,), (7, 7), (7, 7, 7)]
+    assert ex.get_token_f_grams([]) == {}
+    assert ex.get_token_f_grams([8]) == {0: []}
+    d = {tuple(int(x) for x in z[f"{c}_keys"][i, :z[f"{c}_lens"][i]]): i for i in range(3)}
+    for toks in ([7, 8, 7, 7, 7, 9], [7, 7], [9, 9, 9]):
+        assert ex.get_token_f_grams(toks) == R.get_token_f_grams(set(d), 3, toks)
+
+
+@pytest.mark.parametrize("max_n", [1, 2, 3, 4])
+def test_match_batched_random_vs_oracle(max_n):
+    """[B, T] batches: windows never cross a sequence boundary; hits array and CSR bit-exact."""
+    from scone_amd.hip_backend import SconeTable
+    rng = np.random.default_rng(100 + max_n)
+    vocab = 23
+    n = 600
+    lens = rng.integers(1, max_n + 1, size=n).astype(np.uint8)
+    keys = rng.integers(0, vocab, size=(n, max_n)).astype(np.uint32)
+    keys[np.arange(max_n)[None, :] >= lens[:, None]] = 0
+    t = SconeTable(max_n, n)
+    t.index_build(keys, lens)
+    nk, _, dups = t.index_stats()
+    assert nk + dups == n and nk == len(R._key_dict(keys, lens))
+    for B, T in ((1, 1), (3, 2), (7, 37), (2, 1025), (64, 3)):
+        tok = rng.integers(-1, vocab + 1, size=(B, T))
+        ref_hits = R.match_hits(keys, lens, tok, max_n)
+        hits = t.match(torch.from_numpy(tok)).cpu().numpy()
+        assert np.array_equal(hits, ref_hits), (B, T)
+        off, ids = t.match_csr(torch.from_numpy(tok))
+        ro, ri = R.hits_to_csr(ref_hits)
+        assert np.array_equal(off.cpu().numpy(), ro) and np.array_equal(ids.cpu().numpy(), ri), (B, T)
+
+
+def test_index_wide_tokens_and_chunked_build():
+    """32-bit token ids (max_n <= 3) and 24-bit ids (max_n = 4); ids assigned by id0 across chunks."""
+    from scone_amd.hip_backend import SconeTable
+    rng = np.random.default_rng(9)
+    for max_n, top in ((3, 2**31 - 1), (4, 2**24 - 2)):
+        n = 5000
+        lens = rng.integers(1, max_n + 1, size=n).astype(np.uint8)
+        keys = rng.integers(0, top, size=(n, max_n), dtype=np.int64).astype(np.uint32)
+        keys[np.arange(max_n)[None, :] >= lens[:, None]] = 0
+        t = SconeTable(max_n, n)
+        t.index_build(keys[:2000], lens[:2000], id0=0)
+        t.index_build(keys[2000:], lens[2000:], id0=2000)
+        assert t.index_stats()[0] == n
+        pick = rng.integers(0, n, size=64)
+        T = max_n
+        tok = np.zeros((64, T), dtype=np.int64)
+        for r, i in enumerate(pick):
+            tok[r, :lens[i]] = keys[i, :lens[i]]
+            tok[r, lens[i]:] = top            # never part of a key
+        hits = t.match(torch.from_numpy(tok)).cpu().numpy()
+        for r, i in enumerate(pick):
+            assert hits[lens[i] - 1, r, 0] == i
+
+
+def test_index_full_and_bad_keys_raise():
+    from scone_amd.hip_backend import SconeTable
+    t = SconeTable(2, 4, index_capacity=4)
+    keys = np.arange(16, dtype=np.uint32).reshape(8, 2)
+    with pytest.raises(MemoryError):
+        t.index_build(keys, np.full(8, 2, dtype=np.uint8))
+    t2 = SconeTable(2, 4)
+    with pytest.raises(IndexError):
+        t2.index_build(keys[:2], np.array([3, 1], dtype=np.uint8))       # len > max_n
+
+
+# ------------------------------------------------------------------ a4-a6: gather + aggregate
+@pytest.mark.parametrize("use_mm", [False, True])
+def test_lookup_golden_fp32_bit_exact(golden_dir, tmp_path, use_mm):
+    from scone_amd import EmbeddingCache
+    z = np.load(os.path.join(golden_dir, "lookup.npz"))
+    for c in z["cases"]:
+        keys, lens, max_n = z[f"{c}_keys"], z[f"{c}_lens"], int(z[f"{c}_max_n"])
+        table = z[f"{c}_table"]
+        n, d = table.shape
+        ex = _extractor(keys, lens, max_n)
+        cache = EmbeddingCache(ex, d, cache_dir=str(tmp_path / f"{c}{use_mm}") if use_mm else None,
+                               use_memory_map=use_mm)
+        cache.cache_embeddings(list(range(n)), torch.from_numpy(table), verbose=False)
+        # a4: get_embeddings returns the cached rows (fresh CPU fp32 tensor)
+        g = cache.get_embeddings(z[f"{c}_gather_ids"].tolist())
+        assert g.dtype == torch.float32 and g.device.type == "cpu"
+        assert np.array_equal(g.numpy(), z[f"{c}_gather_out"])
+        assert cache.get_embeddings([0], torch.device("cuda")).is_cuda
+        # a5: per-position stacks, empty positions omitted
+        te = cache.get_token_embeddings(z[f"{c}_tok"].tolist())
+        assert sorted(te.keys()) == z[f"{c}_te_positions"].tolist()
+        p = 0
+        for pos, rows in zip(z[f"{c}_te_positions"], z[f"{c}_te_rows"]):
+            assert np.array_equal(te[int(pos)].numpy(), z[f"{c}_te_stacks"][p:p + rows])
+            p += rows
+        # a6: mean over hits, zeros where K = 0, [1, T, d]; fp32 bit-exact, .half() bit-exact
+        tok = torch.from_numpy(z[f"{c}_tok"])[None, :]
+        agg = cache.embed_tokens(tok, reduce="mean", out_dtype=torch.float32)
+        assert agg.shape == (1, tok.shape[1], d)
+        assert np.array_equal(agg.cpu().numpy(), z[f"{c}_agg_f32"]), c
+        agg16 = cache.embed_tokens(tok, reduce="mean", out_dtype=torch.float16)
+        assert np.array_equal(agg16.cpu().numpy().view(np.uint16), z[f"{c}_agg_f16"].view(np.uint16)), c
+        # CSR entry point gives the same vectors
+        off, ids = cache.match(tok)
+        agg2 = cache.table.gather_reduce(off, ids, "mean")
+        assert np.array_equal(agg2.cpu().numpy(), z[f"{c}_agg_f32"][0]), c
+
+
+def test_missing_rows_and_bad_ids_raise(golden_dir):
+    z = np.load(os.path.join(golden_dir, "lookup.npz"))
+    c = "c4"
+    cache = _cache(z[f"{c}_keys"], z[f"{c}_lens"], int(z[f"{c}_max_n"]), z[f"{c}_table"])
+    with pytest.raises(KeyError):
+        cache.get_embeddings([10_000])
+    del cache.embeddings[0]
+    cache._dirty = True
+    with pytest.raises(KeyError):
+        cache.get_embeddings([0])
+
+
+@pytest.mark.parametrize("fmt", ["fp32", "fp16", "int8", "int4"])
+@pytest.mark.parametrize("d", [128, 768, 1024])
+@pytest.mark.parametrize("max_n", [3, 4])
+def test_embed_formats_vs_oracle(fmt, d, max_n):
+    """Quantise on the GPU, read the dequantised table back, run the oracle on it."""
+    rng = np.random.default_rng(sum(map(ord, fmt)) * 10007 + d * 13 + max_n)
+    vocab, n = 31, 900
+    lens = rng.integers(1, max_n + 1, size=n).astype(np.uint8)
+    keys = rng.integers(0, vocab, size=(n, max_n)).astype(np.uint32)
+    keys[np.arange(max_n)[None, :] >= lens[:, None]] = 0
+    table = rng.standard_normal((n, d)).astype(np.float32)
+    table[5] = 0.0
+    cache = _cache(keys, lens, max_n, table, fmt)
+    # the device table is exactly the numpy statement of the format
+    deq = cache.table.gather_rows(torch.arange(n)).cpu().numpy()
+    if fmt == "fp32":
+        expect = table
+    elif fmt == "fp16":
+        expect = table.astype(np.float16).astype(np.float32)
+    elif fmt == "int8":
+        expect = R.dequantize_i8(*R.quantize_i8(table))
+    else:
+        expect = R.dequantize_i4(*R.quantize_i4(table))
+    assert np.array_equal(deq, expect), "device quantiser differs from oracle/ref_port.py"
+    B, T = 5, 70
+    tok = rng.integers(0, vocab + 1, size=(B, T))
+    ro, ri = R.hits_to_csr(R.match_hits(keys, lens, tok, max_n))
+    for reduce in ("mean", "sum"):
+        ref = R.embed_numpy(expect, ro, ri, reduce).reshape(B, T, d)
+        out = cache.embed_tokens(torch.from_numpy(tok), reduce=reduce, out_dtype=torch.float32).cpu().numpy()
+        assert np.array_equal(out, ref), (fmt, d, reduce, _rel(out, ref))
+        out16 = cache.embed_tokens(torch.from_numpy(tok), reduce=reduce, out_dtype=torch.float16)
+        assert _rel(out16.float().cpu().numpy(), ref) < REL_TOL
+        outbf = cache.embed_tokens(torch.from_numpy(tok), reduce=reduce, out_dtype=torch.bfloat16)
+        assert _rel(outbf.float().cpu().numpy(), ref) < 8e-3       # bf16 has 8 significand bits
+
+
+# ------------------------------------------------------------------ a7: combine
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
+def test_fused_combine_vs_oracle(dtype):
+    rng = np.random.default_rng(77)
+    vocab, n, d, max_n, B, T = 50, 700, 768, 3, 3, 40
+    lens = rng.integers(1, max_n + 1, size=n).astype(np.uint8)
+    keys = rng.integers(0, vocab, size=(n, max_n)).astype(np.uint32)
+    keys[np.arange(max_n)[None, :] >= lens[:, None]] = 0
+    table = rng.standard_normal((n, d)).astype(np.float32)
+    cache = _cache(keys, lens, max_n, table, "int8")
+    deq = R.dequantize_i8(*R.quantize_i8(table))
+    wte = torch.from_numpy(rng.standard_normal((vocab, d)).astype(np.float32)).to(dtype).cuda()
+    wpe = torch.from_numpy(rng.standard_normal((64, d)).astype(np.float32)).to(dtype).cuda()
+    tok = rng.integers(0, vocab, size=(B, T))
+    pos = rng.integers(0, 64, size=(B, T))
+    ro, ri = R.hits_to_csr(R.match_hits(keys, lens, tok, max_n))
+    fg = torch.from_numpy(R.embed_numpy(deq, ro, ri, "mean").reshape(B, T, d))
+    for position_ids in (None, torch.from_numpy(pos)):
+        ref = R.combine(torch.from_numpy(tok), fg, wte.float().cpu(), wpe.float().cpu(),
+                        position_ids=position_ids).numpy()
+        out = cache.embed_tokens(torch.from_numpy(tok), wte=wte, wpe=wpe, position_ids=position_ids, check=True)
+        assert out.dtype == dtype and out.shape == (B, T, d)
+        if dtype == torch.float32:
+            assert np.array_equal(out.cpu().numpy(), ref)
+        else:
+            assert _rel(out.float().cpu().numpy(), ref) < (REL_TOL if dtype == torch.float16 else 8e-3)
+    # token outside wte raises like nn.Embedding
+    bad = tok.copy()
+    bad[0, 0] = vocab + 5
+    with pytest.raises(IndexError):
+        cache.embed_tokens(torch.from_numpy(bad), wte=wte, wpe=wpe, check=True)
+
+
+def test_scone_embedding_module_paths(golden_dir):
+    """SconeEmbedding: explicit f_gram_embeddings (reference arithmetic, golden) and fused lookup."""
+    from scone_amd.models.language_model import SconeEmbedding, fold_projection
+    z = np.load(os.path.join(golden_dir, "combine.npz"))
+    for c in z["cases"]:
+        wte = torch.nn.Embedding.from_pretrained(torch.from_numpy(z[f"{c}_wte"])).cuda()
+        wpe = torch.nn.Embedding.from_pretrained(torch.from_numpy(z[f"{c}_wpe"])).cuda()
+        proj = torch.nn.Linear(z[f"{c}_proj"].shape[1], z[f"{c}_proj"].shape[0], bias=False).cuda()
+        proj.weight.data.copy_(torch.from_numpy(z[f"{c}_proj"]))
+        emb = SconeEmbedding(wte, wpe, proj)
+        pos = z[f"{c}_pos"]
+        x = emb(torch.from_numpy(z[f"{c}_input_ids"]).cuda(), torch.from_numpy(z[f"{c}_fg"]).cuda(),
+                torch.from_numpy(pos).cuda() if pos.size else None)
+        np.testing.assert_allclose(x.detach().cpu().numpy(), z[f"{c}_embeds"], rtol=1e-4, atol=1e-5)
+    # fused: projection folded into the table == project the aggregated vector (linearity)
+    rng = np.random.default_rng(5)
+    vocab, n, d_f, H, T = 40, 300, 64, 128, 33
+    lens = rng.integers(1, 4, size=n).astype(np.uint8)
+    keys = rng.integers(0, vocab, size=(n, 3)).astype(np.uint32)
+    keys[np.arange(3)[None, :] >= lens[:, None]] = 0
+    table = torch.from_numpy(rng.standard_normal((n, d_f)).astype(np.float32))
+    W = torch.from_numpy(rng.standard_normal((H, d_f)).astype(np.float32) / 8)
+    folded = fold_projection(table, W)
+    cache = _cache(keys, lens, 3, folded.numpy())
+    wte = torch.nn.Embedding(vocab, H).cuda()
+    wpe = torch.nn.Embedding(64, H).cuda()
+    fused = SconeEmbedding(wte, wpe, None, cache)
+    tok = torch.from_numpy(rng.integers(0, vocab, size=(2, T)))
+    out = fused(tok.cuda())
+    ro, ri = R.hits_to_csr(R.match_hits(keys, lens, tok.numpy(), 3))
+    fg = torch.from_numpy(R.embed_numpy(table.numpy(), ro, ri, "mean").reshape(2, T, d_f))
+    ref = R.combine(tok, fg, wte.weight.detach().cpu(), wpe.weight.detach().cpu(), proj_weight=W)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.numpy(), rtol=2e-4, atol=2e-5)
+
+
+# ------------------------------------------------------------------ edge cases
+def test_empty_and_short_inputs():
+    rng = np.random.default_rng(1)
+    keys = np.array([[1, 0, 0], [1, 2, 0], [1, 2, 3]], dtype=np.uint32)
+    lens = np.array([1, 2, 3], dtype=np.uint8)
+    table = rng.standard_normal((3, 64)).astype(np.float32)
+    cache = _cache(keys, lens, 3, table)
+    assert cache.embed_tokens(torch.zeros((0, 5), dtype=torch.int64)).shape == (0, 5, 64)
+    assert cache.embed_tokens(torch.zeros((4, 0), dtype=torch.int64)).shape == (4, 0, 64)
+    off, ids = cache.match(torch.zeros((2, 0), dtype=torch.int64))
+    assert off.cpu().tolist() == [0] and ids.numel() == 0
+    assert cache.get_token_embeddings([]) == {}
+    # T < max_n: only the windows that fit (n_gram_extractor.py:118)
+    out = cache.embed_tokens(torch.tensor([[1, 2]]), out_dtype=torch.float32).cpu().numpy()
+    assert np.array_equal(out[0, 0], (table[0] + table[1]) / np.float32(2))
+    assert np.array_equal(out[0, 1], table[1])
+    # all misses -> zeros; negative tokens never match
+    out = cache.embed_tokens(torch.tensor([[9, -1, 9]]), out_dtype=torch.float32).cpu().numpy()
+    assert not out.any()
+    # every candidate hits: K = 6 at an interior position
+    keys2 = np.array([[4, 0, 0], [4, 4, 0], [4, 4, 4]], dtype=np.uint32)
+    cache2 = _cache(keys2, lens, 3, table)
+    off, ids = cache2.match(torch.tensor([[4, 4, 4, 4, 4]]))
+    assert (off[3] - off[2]).item() == 6 and ids[off[2]:off[3]].cpu().tolist() == [0, 1, 1, 2, 2, 2]
+
+
+def test_results_independent_of_batch_shape():
+    """Idempotence / shape independence: the same sequence gives identical bits alone or inside a batch."""
+    rng = np.random.default_rng(2)
+    vocab, n, d = 17, 400, 256
+    lens = rng.integers(1, 4, size=n).astype(np.uint8)
+    keys = rng.integers(0, vocab, size=(n, 3)).astype(np.uint32)
+    keys[np.arange(3)[None, :] >= lens[:, None]] = 0
+    cache = _cache(keys, lens, 3, rng.standard_normal((n, d)).astype(np.float32), "int8")
+    tok = torch.from_numpy(rng.integers(0, vocab, size=(9, 130)))
+    full = cache.embed_tokens(tok, out_dtype=torch.float32)
+    again = cache.embed_tokens(tok, out_dtype=torch.float32)
+    assert torch.equal(full, again)
+    for b in (0, 4, 8):
+        assert torch.equal(cache.embed_tokens(tok[b:b + 1], out_dtype=torch.float32)[0], full[b])
+
+
+# ------------------------------------------------------------------ row shards (single GPU, two handles)
+def test_row_sharded_partial_sums_equal_full():
+    from scone_amd.hip_backend import SconeTable
+    rng = np.random.default_rng(4)
+    vocab, n, d, max_n = 29, 1000, 768, 3
+    lens = rng.integers(1, max_n + 1, size=n).astype(np.uint8)
+    keys = rng.integers(0, vocab, size=(n, max_n)).astype(np.uint32)
+    keys[np.arange(max_n)[None, :] >= lens[:, None]] = 0
+    table = rng.standard_normal((n, d)).astype(np.float32)
+    tok = torch.from_numpy(rng.integers(0, vocab, size=(4, 50)))
+    wte = torch.from_numpy(rng.standard_normal((vocab, d)).astype(np.float32)).half().cuda()
+    wpe = torch.from_numpy(rng.standard_normal((50, d)).astype(np.float32)).half().cuda()
+    full = SconeTable(max_n, n, d, "int8")
+    full.index_build(keys, lens)
+    full.store_f32(torch.from_numpy(table))
+    ref = full.embed(tok, wte=wte, wpe=wpe)
+    ref_sum = full.embed(tok, reduce="sum", out_dtype=torch.float32).reshape(-1, d)
+    shards = []
+    for a, b in ((0, 300), (300, 1000)):
+        s = SconeTable(max_n, n, d, "int8", row_begin=a, row_end=b)
+        s.index_build(keys, lens)                     # the index is replicated
+        s.store_f32(torch.from_numpy(table[a:b]), row0=a)
+        shards.append(s)
+    parts = [s.embed_partial(tok) for s in shards]
+    assert torch.equal(parts[0][1], parts[1][1])      # every shard knows the full K
+    total = parts[0][0] + parts[1][0]                 # what the RCCL reduce-scatter computes
+    assert _rel(total.cpu().numpy(), ref_sum.cpu().numpy()) < 1e-6
+    ntok = tok.numel()
+    halves = [shards[r].finalize(total[a:b], parts[0][1][a:b], tok, a, b, wte=wte, wpe=wpe, out_dtype=torch.float16)
+              for r, (a, b) in enumerate(((0, ntok // 2), (ntok // 2, ntok)))]
+    out = torch.cat(halves).reshape(ref.shape)
+    assert _rel(out.float().cpu().numpy(), ref.float().cpu().numpy()) < REL_TOL
+
+
+# ------------------------------------------------------------------ synthetic table (full-size property)
+@pytest.mark.parametrize("fmt", ["int8", "fp16", "fp32"])
+def test_synthetic_table_matches_host_generator(fmt):
+    from scone_amd.hip_backend import SconeTable
+    n, d = 50_000, 768
+    t = SconeTable(3, n, d, fmt)
+    t.fill_synthetic(7, 0.02 / 127)
+    ids = np.array([0, 1, 2, 777, n - 1], dtype=np.int64)
+    got = t.gather_rows(torch.from_numpy(ids)).cpu().numpy()
+    q = R.synth_rows_i8(7, ids, d).astype(np.float32)
+    s = R.synth_scale_f16(7, ids, 0.02 / 127).astype(np.float32)
+    expect = q * s[:, None]
+    if fmt == "fp16":
+        expect = expect.astype(np.float16).astype(np.float32)
+    assert np.array_equal(got, expect)

@@ -1,0 +1,123 @@
+"""CPU: host-side mirror of the reference interface (storage, persistence, error
+conventions, key arrays) -- everything that does not launch a kernel."""
+
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_port as R
+from scone_amd import EmbeddingCache, NGramExtractor
+from scone_amd.hip_backend import format_code, row_bytes
+from scone_amd import _lib
+
+
+def test_fit_matches_reference_order(golden_dir):
+    z = np.load(os.path.join(golden_dir, "match.npz"))
+    for c in z["cases"]:
+        flat, cl = z[f"{c}_corpus_flat"], z[f"{c}_corpus_lens"]
+        min_freq, max_f = (int(x) for x in z[f"{c}_fit_args"])
+        corpus, p = [], 0
+        for n in cl:
+            corpus.append(flat[p:p + n].tolist())
+            p += n
+        ex = NGramExtractor(max_n=int(z[f"{c}_max_n"]), min_freq=min_freq, max_f_grams=max_f).fit(corpus, verbose=False)
+        keys, lens = ex.key_arrays()
+        assert np.array_equal(keys, z[f"{c}_keys"]) and np.array_equal(lens, z[f"{c}_lens"])
+        assert ex.f_grams == set(ex.f_gram_to_id) and ex.id_to_f_gram[0] == tuple(int(x) for x in keys[0, :lens[0]])
+
+
+def test_extractor_reads_reference_file(golden_dir, tmp_path):
+    ex = NGramExtractor.load(os.path.join(golden_dir, "tiny_extractor.npy"))
+    assert ex.max_n == 2 and len(ex) == 40 and all(isinstance(k, tuple) for k in ex.f_gram_to_id)
+    ex.save(str(tmp_path / "again"))
+    ex2 = NGramExtractor.load(str(tmp_path / "again.npy"))
+    assert ex2.f_gram_to_id == ex.f_gram_to_id and ex2.id_to_f_gram == ex.id_to_f_gram
+
+
+def test_from_arrays_round_trip():
+    keys = np.array([[5, 0, 0], [5, 6, 0], [5, 6, 7], [5, 6, 0]], dtype=np.uint32)
+    lens = np.array([1, 2, 3, 2], dtype=np.uint8)
+    ex = NGramExtractor.from_arrays(keys, lens)
+    assert len(ex) == 4
+    assert ex.f_gram_to_id == {(5,): 0, (5, 6): 1, (5, 6, 7): 2}      # smallest id wins on duplicates
+    assert NGramExtractor(max_n=4).max_n == 4
+    with pytest.raises(ValueError):
+        NGramExtractor(max_n=5)
+
+
+def test_cache_reads_reference_file_and_keeps_host_rows(golden_dir, tmp_path):
+    ex = NGramExtractor.load(os.path.join(golden_dir, "tiny_extractor.npy"))
+    # kwargs the reference's own callers pass (engine.py:180, tests/test_embedding_cache.py:136)
+    cache = EmbeddingCache.load(os.path.join(golden_dir, "tiny_cache.npy"), ex, cache_dir=None, use_memory_map=False)
+    z = np.load(os.path.join(golden_dir, "lookup.npz"))
+    assert cache.embedding_dim == 16 and not cache.use_memory_map
+    assert np.array_equal(np.stack([cache.embeddings[i] for i in range(len(ex))]), z["c4_table"])
+    cache.save(str(tmp_path / "c"))
+    again = EmbeddingCache.load(str(tmp_path / "c.npy"), ex)
+    assert all(np.array_equal(again.embeddings[i], cache.embeddings[i]) for i in cache.embeddings)
+
+
+def test_cache_embeddings_storage_forms(tmp_path):
+    ex = NGramExtractor(max_n=2, min_freq=1).fit([[1, 2, 3, 1, 2]], verbose=False)
+    n, d = len(ex), 8
+    rows = torch.arange(n * d, dtype=torch.float32).reshape(n, d)
+    a = EmbeddingCache(ex, d)
+    a.cache_embeddings(list(range(n)), rows, verbose=False)
+    b = EmbeddingCache(ex, d)
+    b.cache_embeddings({i: rows[i] for i in range(n)})               # dict form (precompute_embeddings.py:138)
+    assert all(np.array_equal(a.embeddings[i], b.embeddings[i]) and a.embeddings[i].dtype == np.float32
+               for i in range(n))
+    # memory-mapped variant: raw [N, d] fp32 file, zero-filled (embedding_cache.py:84-91)
+    m = EmbeddingCache(ex, d, cache_dir=str(tmp_path / "mm"), use_memory_map=True)
+    m.cache_embeddings([0, 2], rows[[0, 2]], verbose=False)
+    raw = np.fromfile(os.path.join(str(tmp_path / "mm"), "embeddings.npy"), dtype=np.float32).reshape(n, d)
+    assert np.array_equal(raw[0], rows[0].numpy()) and np.all(raw[1] == 0) and np.array_equal(raw[2], rows[2].numpy())
+    m.save(str(tmp_path / "mmc"))
+    again = EmbeddingCache.load(str(tmp_path / "mmc.npy"), ex)     # the reference cannot reload this file; we can
+    assert again.use_memory_map and np.array_equal(np.asarray(again.memory_mapped_embeddings), raw)
+
+
+def test_error_conventions_match_reference(tmp_path):
+    ex = NGramExtractor(max_n=2, min_freq=1).fit([[1, 2, 3]], verbose=False)
+    with pytest.raises(ValueError, match="Cache directory must be provided for memory mapping"):
+        EmbeddingCache(ex, 4, use_memory_map=True).cache_embeddings([0], torch.zeros(1, 4), verbose=False)
+    with pytest.raises(ValueError, match="Memory-mapped embeddings not initialized"):
+        EmbeddingCache(ex, 4, cache_dir=str(tmp_path), use_memory_map=True).get_embeddings([0])
+    c = EmbeddingCache(ex, 4)
+    c.cache_embeddings([0], torch.zeros(1, 4), verbose=False)
+    with pytest.raises(KeyError):
+        c.get_embeddings([3])                                       # unknown id (embedding_cache.py:139)
+
+
+def test_row_bytes_accounting():
+    assert row_bytes(format_code("fp32"), 768) == 3072
+    assert row_bytes(format_code("fp16"), 768) == 1536
+    assert row_bytes(format_code("int8"), 768) == 770
+    assert row_bytes(format_code("int4"), 1024) == 528
+    assert format_code("int8") == _lib.FMT_I8
+    with pytest.raises(ValueError):
+        format_code("fp8")
+
+
+def test_key_packing_twin_is_injective():
+    """Python twin of scone_pack_key (csrc/scone_common.h): distinct keys -> distinct packed keys."""
+    def pack(t, max_n):
+        n = len(t)
+        if max_n <= 3:
+            v = [x + 1 for x in t] + [0] * (3 - n)
+            return (v[0] | (v[1] << 32), v[2])
+        v = [x + 1 for x in t] + [0] * (4 - n)
+        return (v[0] | (v[1] << 24) | ((v[2] & 0xFFFF) << 48), (v[2] >> 16) | (v[3] << 8))
+    rng = np.random.default_rng(3)
+    for max_n, hi in ((3, 2**32 - 2), (4, 2**24 - 2)):
+        seen = {}
+        for _ in range(20000):
+            n = int(rng.integers(1, max_n + 1))
+            t = tuple(int(x) for x in rng.integers(0, hi, size=n))
+            if rng.random() < 0.3:
+                t = tuple(int(x) for x in rng.integers(0, 3, size=n))
+            p = pack(t, max_n)
+            assert seen.setdefault(p, t) == t
+            assert p != (0, 0)

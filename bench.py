@@ -1,0 +1,255 @@
+#!/usr/bin/env python3
+"""bench.py -- f-gram embed throughput on MI355X (BASELINE.json's metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+One "step" = one pass of the hot path (n-gram match -> INT8 row gather -> dequantise ->
+mean -> + wte + wpe -> fp16 store; `scone_embed`) over one batch of B x T synthetic tokens
+already resident in HBM.  Headline workload (N = 1 and every rank at N > 1): 1M-row INT8
+f-gram table, d = 768, max_n = 3, GPT-2 vocabulary, S_uniform stream.
+
+N > 1: the 1M-row table fits one GPU, sequences are independent, so the path shards over
+tokens -- every rank holds the table and embeds its own batch; no data-path collective;
+"scaling": "weak".  (`--table-mode sharded` runs the row-sharded + RCCL exchange path used
+for tables larger than one GPU.)
+
+Prints ONE JSON line on rank 0 (contract in the task statement) including `roofline`
+(the gather/reduce kernel, HIP-event timed on its launch stream) and `cpu_baseline`
+(the line-for-line Python port of the reference loop, oracle/ref_port.py, 1 core).
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+HBM_PEAK_GBPS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--rows", type=int, default=1_000_000)
+    ap.add_argument("--dim", type=int, default=768)
+    ap.add_argument("--format", default="int8", choices=["fp32", "fp16", "int8", "int4"])
+    ap.add_argument("--batch", type=int, default=2048)
+    ap.add_argument("--seq", type=int, default=512)
+    ap.add_argument("--stream", default="uniform", choices=["uniform", "zipf"])
+    ap.add_argument("--placement", default="hbm", choices=["hbm", "pinned_host"])
+    ap.add_argument("--table-mode", default="replicated", choices=["replicated", "sharded"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    return ap.parse_args()
+
+
+def cpu_baseline(args, keys, lens, tok, seed, base_scale, gpu_out, wte, wpe):
+    """Time the reference loop (set-of-tuples match -> dict id map -> torch.stack of fp32 rows
+    -> mean -> zero-filled [1,T,d]; n_gram_extractor.py:106-126, embedding_cache.py:113-181,
+    engine.py:234-266) on a bounded sample of the same stream, 1 core, and use its output to
+    sanity-check the GPU result for the first sequence."""
+    from oracle import ref_port as R
+    torch.set_num_threads(1)
+    d = args.dim
+    f2id = R._key_dict(keys, lens)
+    cache = R.RefCache(f2id, 3, d)
+
+    def rows_for(ids):
+        ids = np.asarray(sorted(ids), dtype=np.int64)
+        if args.format == "int4":
+            raise RuntimeError("cpu baseline: int4 host generator not wired")
+        deq = R.synth_rows_i8(seed, ids, d).astype(np.float32) * \
+            R.synth_scale_f16(seed, ids, base_scale).astype(np.float32)[:, None]
+        if args.format == "fp16":
+            deq = deq.astype(np.float16).astype(np.float32)
+        return ids, deq
+
+    def load_rows(seqs):
+        need = set()
+        for s in seqs:
+            off, ids = R.match_csr_python(f2id, 3, s)
+            need.update(int(i) for i in ids)
+        need -= set(cache.embeddings.keys())
+        if need:
+            ids, deq = rows_for(need)
+            for i, r in zip(ids.tolist(), deq):
+                cache.embeddings[i] = r
+
+    seqs = [tok[b].tolist() for b in range(min(tok.shape[0], 96))]
+    # probe: 2 sequences to size the sample for ~cpu_seconds of work
+    load_rows(seqs[:2])
+    t0 = time.perf_counter()
+    first = R.aggregate(cache, seqs[0], d)
+    R.aggregate(cache, seqs[1], d)
+    per_seq = (time.perf_counter() - t0) / 2
+    nseq = int(max(2, min(len(seqs), args.cpu_seconds / max(per_seq, 1e-6))))
+    load_rows(seqs[:nseq])
+    t0 = time.perf_counter()
+    for s in seqs[:nseq]:
+        R.aggregate(cache, s, d)
+    dt = time.perf_counter() - t0
+    # parity spot check of the GPU output (first sequence) against the oracle
+    ref = R.combine(torch.from_numpy(tok[:1]), first, wte.float().cpu(), wpe.float().cpu()).numpy()
+    err = float(np.abs(gpu_out[:1].float().cpu().numpy() - ref).max() / np.abs(ref).max())
+    return {
+        "value": nseq * tok.shape[1] / dt, "unit": "tokens/s", "cores": 1, "kind": "port",
+        "sample": f"{nseq} sequences x {tok.shape[1]} tokens of the same stream "
+                  f"({dt:.1f} s; oracle/ref_port.py aggregate(), python {sys.version_info.major}.{sys.version_info.minor}, "
+                  f"torch {torch.__version__}, host cpus {os.cpu_count()})",
+        "gpu_vs_oracle_max_rel_err_seq0": err,
+    }
+
+
+def read_traffic(sig):
+    """HBM bytes per launch from committed rocprofv3 PMC passes (profiles/*.json), if the
+    workload signature matches; else None."""
+    p = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    try:
+        entries = json.load(open(p))
+        for e in entries:
+            if e.get("workload_sig") == sig:
+                return e
+    except Exception:
+        pass
+    return None
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no HIP device visible)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from scone_amd import EmbeddingCache, NGramExtractor
+    from scone_amd import synthetic as S
+    from scone_amd.hip_backend import format_code, row_bytes
+
+    d, N, B, T = args.dim, args.rows, args.batch, args.seq
+    vocab, max_n, seed, base_scale = S.GPT2_VOCAB, 3, 7, 0.02 / 127
+    keys, lens = S.make_keys(N, vocab, max_n, seed=11)
+    ex = NGramExtractor.from_arrays(keys, lens, max_n=max_n)
+
+    sharded = args.table_mode == "sharded" and world > 1
+    if sharded:
+        from scone_amd.distributed import ShardedEmbeddingCache
+        cache = ShardedEmbeddingCache.from_synthetic(ex, d, table_format=args.format, seed=seed,
+                                                     base_scale=base_scale, rank=rank, world=world)
+        stream_seed = 1234            # every rank embeds the same batch; rows are sharded
+    else:
+        cache = EmbeddingCache.from_synthetic(ex, d, table_format=args.format, seed=seed, base_scale=base_scale,
+                                              placement=args.placement)
+        stream_seed = 1234 + rank     # every rank embeds its own batch
+    if args.stream == "uniform":
+        tok_np = S.stream_uniform_ids(keys, lens, B, T, stream_seed)
+    else:
+        tok_np = S.stream_zipf(vocab, B, T, stream_seed)
+    tok = torch.from_numpy(tok_np).to("cuda", torch.int32)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    wte = (torch.randn(vocab, d, generator=g, device="cuda") * 0.02).half()
+    wpe = (torch.randn(1024, d, generator=g, device="cuda") * 0.01).half()
+    out = torch.empty(B, T, d, dtype=torch.float16, device="cuda")
+
+    # workload statistics (outside the timed region)
+    table = cache.table
+    off, ids = table.match_csr(tok)
+    counts = (off[1:] - off[:-1]).to(torch.int64)
+    sum_k = int(counts.sum().item())
+    k_hist = torch.bincount(counts, minlength=7).tolist()
+    ntok = B * T
+    fmt = format_code(args.format)
+    bytes_per_launch = sum_k * row_bytes(fmt, d) + ntok * (d * 2 + d * 2 + 4)
+    del off, ids, counts
+
+    def step():
+        cache.embed_tokens(tok, wte=wte, wpe=wpe, out=out)
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    table.profile_enable(True)
+    table.profile_read(reset=True)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    dt = time.perf_counter() - t0
+    n_launch, kern_ms = table.profile_read(reset=True)
+    table.profile_enable(False)
+    if dist is not None:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    units = ntok * args.steps * (1 if sharded else world)
+    value = units / dt
+    res = None
+    if rank == 0:
+        avg_ms = kern_ms / max(n_launch, 1)
+        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+        sig = f"{args.format}-d{d}-N{N}-B{B}-T{T}-{args.stream}-{args.placement}"
+        tr = read_traffic(sig)
+        res = {
+            "metric": "f-gram embed tokens/sec (1M-row INT8 table @ d=768)" if (N, d, args.format) == (1_000_000, 768, "int8")
+                      else f"f-gram embed tokens/sec ({N}-row {args.format} table @ d={d})",
+            "value": value, "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong" if sharded else "weak", "vs_baseline": None,
+            "dtype": {"int8": "i8->f32 accumulate, f16 out", "int4": "i4->f32 accumulate, f16 out",
+                      "fp16": "f16->f32 accumulate, f16 out", "fp32": "f32, f16 out"}[args.format],
+            "data": "synthetic",
+            "config": {
+                "workload": f"{N}-row {args.format} f-gram table d={d} max_n={max_n} vocab={vocab} in "
+                            f"{'HBM' if args.placement == 'hbm' else 'pinned host DRAM'}; S_{args.stream} stream, "
+                            f"{B}x{T} tokens/step/rank; fused match+gather+dequant+mean+wte+wpe, fp16 out",
+                "tokens_per_step_per_rank": ntok, "mean_hits_per_token": sum_k / ntok, "hits_histogram_K0_6": k_hist[:7],
+                "parallelism": ("row-sharded table + RCCL reduce-scatter/all-gather" if sharded
+                                else f"replicated table, tokens sharded over {world} rank(s), no collective"),
+            },
+            "roofline": {
+                "bound": "hbm", "kernel": "scone_gather::k_embed (gather+dequant+reduce+combine)",
+                "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                "algorithmic_bytes_per_launch": bytes_per_launch, "avg_kernel_ms": avg_ms, "timed_launches": n_launch,
+                "traffic": None if tr is None else tr.get("hbm_bytes_per_launch"),
+                "traffic_source": None if tr is None else tr.get("source"),
+            },
+        }
+        if not args.no_cpu_baseline and world == 1 and not sharded:
+            try:
+                res["cpu_baseline"] = cpu_baseline(args, keys, lens, tok_np, seed, base_scale, out, wte, wpe)
+            except Exception as e:      # the baseline is reported, never the product
+                res["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": 1, "kind": "port",
+                                       "sample": f"failed: {e!r}"}
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

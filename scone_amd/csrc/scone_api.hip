@@ -28,6 +28,16 @@ int scone_ensure_hits(scone_handle *h, int64_t ntok) {
   return SCONE_OK;
 }
 
+int scone_ensure_ell(scone_handle *h, int64_t ntok) {
+  if (ntok <= h->ell_cap_tokens) return SCONE_OK;
+  if (h->d_ell) SCONE_HIP(h, hipFree(h->d_ell));
+  h->d_ell = nullptr;
+  h->ell_cap_tokens = 0;
+  SCONE_HIP(h, hipMalloc(&h->d_ell, (size_t)ntok * SCONE_ELL_W(h->cfg.max_n) * sizeof(int32_t)));
+  h->ell_cap_tokens = ntok;
+  return SCONE_OK;
+}
+
 extern "C" int scone_abi_version(void) { return SCONE_ABI_VERSION; }
 
 extern "C" const char *scone_strerror(int code) {
@@ -107,6 +117,7 @@ extern "C" int scone_create(const scone_cfg *cfg, scone_handle **out) {
   h->slots = nullptr, h->d_counters = nullptr, h->d_status = nullptr;
   h->rows = nullptr, h->scales = nullptr, h->rows_pinned_host = false;
   h->d_hits = nullptr, h->hits_cap_tokens = 0, h->d_block_sums = nullptr, h->block_sums_cap = 0;
+  h->d_ell = nullptr, h->ell_cap_tokens = 0, h->d_zero_row = nullptr;
   h->d_total = nullptr, h->staging = nullptr, h->staging_bytes = 0;
   h->row_payload_bytes = 0, h->scale_bytes_per_row = 0;
   h->prof_on = false, h->prof_ev = nullptr, h->prof_head = 0, h->prof_n = 0, h->prof_ms = 0.0;
@@ -141,6 +152,10 @@ extern "C" int scone_create(const scone_cfg *cfg, scone_handle **out) {
   CREATE_HIP(hipMalloc(&h->d_status, sizeof(uint32_t)));
   CREATE_HIP(hipMemset(h->d_status, 0, sizeof(uint32_t)));
   CREATE_HIP(hipMalloc(&h->d_total, sizeof(int64_t)));
+  if (cfg->dim > 0) {  // a row of zeros: stands in for wte / wpe when the caller passes none
+    CREATE_HIP(hipMalloc(&h->d_zero_row, (size_t)cfg->dim * 4));
+    CREATE_HIP(hipMemset(h->d_zero_row, 0, (size_t)cfg->dim * 4));
+  }
   if (cfg->dim > 0) {
     if (!payload_geometry(h->cfg, &h->row_payload_bytes, &h->scale_bytes_per_row)) {
       h->err = "scone_create: dim not compatible with table_fmt (F32 %4, F16 %8, I8 %16, I4 %128)";
@@ -161,7 +176,7 @@ extern "C" int scone_create(const scone_cfg *cfg, scone_handle **out) {
       rc = SCONE_EINVAL;
       goto fail;
     }
-    if (scales_bytes) CREATE_HIP(hipMalloc(&h->scales, scales_bytes));
+    if (scales_bytes) CREATE_HIP(hipMalloc(&h->scales, scales_bytes + 4));  // +4: scales are also read as dword pairs
   }
 #undef CREATE_HIP
   *out = h;
@@ -185,6 +200,8 @@ extern "C" void scone_destroy(scone_handle *h) {
   }
   if (h->scales) (void)hipFree(h->scales);
   if (h->d_hits) (void)hipFree(h->d_hits);
+  if (h->d_ell) (void)hipFree(h->d_ell);
+  if (h->d_zero_row) (void)hipFree(h->d_zero_row);
   if (h->d_block_sums) (void)hipFree(h->d_block_sums);
   if (h->staging) (void)hipFree(h->staging);
   if (h->prof_ev) {
@@ -207,7 +224,8 @@ extern "C" int scone_status(scone_handle *h, uint32_t *bits, scone_stream_t stre
 extern "C" int scone_reserve(scone_handle *h, int64_t max_tokens) {
   if (!h || max_tokens < 0) return SCONE_EINVAL;
   SCONE_HIP(h, hipSetDevice(h->device));
-  return scone_ensure_hits(h, max_tokens);
+  int rc = scone_ensure_hits(h, max_tokens);
+  return rc ? rc : scone_ensure_ell(h, max_tokens);
 }
 
 // ---------------------------------------------------------------- kernel timing

@@ -99,9 +99,12 @@ struct scone_handle {
   // workspaces
   int32_t *d_hits;
   int64_t hits_cap_tokens;
+  int32_t *d_ell;  // per-token id lists for the fused lookup, [tokens, SCONE_ELL_W(max_n)]
+  int64_t ell_cap_tokens;
   int32_t *d_block_sums;
   int64_t block_sums_cap;
   int64_t *d_total;
+  void *d_zero_row;  // dim * 4 zero bytes
   void *staging;
   size_t staging_bytes;
   // optional kernel timing (scone_profile_*)
@@ -116,6 +119,7 @@ struct scone_handle {
 int scone_fail(scone_handle *h, int code, const char *what);
 int scone_hip_fail(scone_handle *h, hipError_t e, const char *what);
 int scone_ensure_hits(scone_handle *h, int64_t ntok);
+int scone_ensure_ell(scone_handle *h, int64_t ntok);
 int scone_prof_begin(scone_handle *h, hipStream_t s);  // no-ops unless profiling is enabled
 int scone_prof_end(scone_handle *h, hipStream_t s);
 
@@ -128,3 +132,6 @@ int scone_prof_end(scone_handle *h, hipStream_t s);
 // launchers implemented in the kernel translation units
 int scone_launch_match(scone_handle *h, const int32_t *d_tok, int32_t B, int32_t T, int32_t *d_hits,
                        hipStream_t s);
+int scone_launch_match_ell(scone_handle *h, const int32_t *d_tok, int32_t B, int32_t T, int32_t *d_ell,
+                           hipStream_t s);
+#define SCONE_ELL_W(max_n) ((max_n) <= 3 ? 8 : 16)

@@ -1,0 +1,327 @@
+// Wave-per-token form of the fused lookup kernel (the fast path for d = 768 / 1024).
+//
+// One 64-lane wavefront owns one token at a time, so everything that steers the
+// gather is wave-uniform: the candidate f-gram ids, the token and position ids and
+// the row base addresses live in SGPRs (scalar loads through the constant cache,
+// counted by lgkmcnt -- independent of the vector-memory queue), every branch is a
+// scalar branch, and each row is fetched by ONE wave instruction reading
+// row_bytes contiguous bytes (12 or 16 bytes per lane for INT8 at d = 768 / 1024).
+// All K_t row loads plus the wte / wpe row loads of a token are issued back to
+// back before the first one is consumed; memory-level parallelism across tokens
+// comes from occupancy (<= 64 VGPRs -> 8 waves per SIMD), and the ids of the
+// wave's NEXT token are prefetched while the current one is reduced.
+//
+// Same arithmetic as k_embed (scone_gather_impl.h): sequential fp32 accumulation in
+// the reference's list order, IEEE sum / K, (wte + mean) + wpe, one rounding to OutT.
+#pragma once
+
+#include "scone_gather_impl.h"
+
+namespace scone_gather {
+
+struct wave_params {
+  long long BT;
+  long long row_begin, row_end;
+  long long vocab, n_pos;
+  int T;
+  int max_n;
+  int reduce;
+  int tokens_per_block;  // multiple of 4
+};
+
+// NB bytes (multiple of 4) at base + off -> dwords; the backend merges these into
+// dwordx2/x3/x4 accesses (global memory only needs dword alignment).
+template <int NW>
+__device__ __forceinline__ void ld_words(const uint8_t *__restrict__ base, uint32_t off, uint32_t (&r)[NW]) {
+  const uint32_t *p = reinterpret_cast<const uint32_t *>(base + off);
+#pragma unroll
+  for (int i = 0; i < NW; ++i) r[i] = p[i];
+}
+
+template <int NW>
+__device__ __forceinline__ void st_words(uint8_t *__restrict__ base, uint32_t off, const uint32_t (&r)[NW]) {
+  uint32_t *p = reinterpret_cast<uint32_t *>(base + off);
+#pragma unroll
+  for (int i = 0; i < NW; ++i) p[i] = r[i];
+}
+
+template <typename T> struct pack_io;
+template <> struct pack_io<float> {
+  static constexpr int PER_WORD = 1;
+  static __device__ __forceinline__ void unpack(uint32_t w, float *o) { o[0] = __uint_as_float(w); }
+  static __device__ __forceinline__ uint32_t pack(const float *v) { return __float_as_uint(v[0]); }
+};
+template <> struct pack_io<__half> {
+  static constexpr int PER_WORD = 2;
+  static __device__ __forceinline__ void unpack(uint32_t w, float *o) {
+    o[0] = __half2float(__ushort_as_half((unsigned short)(w & 0xFFFFu)));
+    o[1] = __half2float(__ushort_as_half((unsigned short)(w >> 16)));
+  }
+  static __device__ __forceinline__ uint32_t pack(const float *v) {
+    return (uint32_t)__half_as_ushort(__float2half_rn(v[0])) | ((uint32_t)__half_as_ushort(__float2half_rn(v[1])) << 16);
+  }
+};
+template <> struct pack_io<__hip_bfloat16> {
+  static constexpr int PER_WORD = 2;
+  static __device__ __forceinline__ void unpack(uint32_t w, float *o) {
+    o[0] = __uint_as_float(w << 16);
+    o[1] = __uint_as_float(w & 0xFFFF0000u);
+  }
+  static __device__ __forceinline__ uint32_t pack(const float *v) {
+    const __hip_bfloat16 a = __float2bfloat16(v[0]), b = __float2bfloat16(v[1]);
+    return (uint32_t)(*reinterpret_cast<const unsigned short *>(&a)) |
+           ((uint32_t)(*reinterpret_cast<const unsigned short *>(&b)) << 16);
+  }
+};
+
+// acc[0..EPL) += dequant(raw row words); exact products (see accumulate<> in scone_gather_impl.h)
+template <int FMT, int EPL, int NW>
+__device__ __forceinline__ void acc_words(float (&acc)[EPL], const uint32_t (&w)[NW], float scale) {
+  if constexpr (FMT == SCONE_FMT_F32) {
+#pragma unroll
+    for (int i = 0; i < NW; ++i) acc[i] += __uint_as_float(w[i]);
+  } else if constexpr (FMT == SCONE_FMT_F16) {
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+      acc[2 * i] += __half2float(__ushort_as_half((unsigned short)(w[i] & 0xFFFFu)));
+      acc[2 * i + 1] += __half2float(__ushort_as_half((unsigned short)(w[i] >> 16)));
+    }
+  } else if constexpr (FMT == SCONE_FMT_I8) {
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int q = (int)(w[i] << (24 - 8 * b)) >> 24;
+        acc[4 * i + b] = fmaf(scale, (float)q, acc[4 * i + b]);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+#pragma unroll
+      for (int b = 0; b < 8; ++b) {
+        const int q = (int)((w[i] >> (4 * b)) & 0xFu) - 8;
+        acc[8 * i + b] = fmaf(scale, (float)q, acc[8 * i + b]);
+      }
+    }
+  }
+}
+
+template <int FMT, int D> struct wave_geom {
+  static constexpr int EPL = D / 64;  // elements per lane
+  static constexpr int ROW_BYTES = FMT == SCONE_FMT_F32 ? 4 * D : FMT == SCONE_FMT_F16 ? 2 * D : FMT == SCONE_FMT_I8 ? D : D / 2;
+  static constexpr int NBR = ROW_BYTES / 64;  // row bytes per lane
+  static constexpr bool OK = (D % 64 == 0) && (NBR % 4 == 0) && (FMT != SCONE_FMT_I4 || (SCONE_I4_GROUP % EPL == 0));
+};
+
+// waves per SIMD to ask of the register allocator: rows in flight (NC x NBR/4) + wte/wpe/out words +
+// accumulators + addressing, rounded to the 8-register allocation granule (512 registers per SIMD lane)
+template <int FMT, typename OutT, int D, int MAXN> struct wave_occupancy {
+  static constexpr int NC = MAXN * (MAXN + 1) / 2;
+  static constexpr int NWO = wave_geom<FMT, D>::EPL * (int)sizeof(OutT) / 4;
+  static constexpr int EST = NC * (wave_geom<FMT, D>::NBR / 4) + 3 * NWO + wave_geom<FMT, D>::EPL + 14;
+  static constexpr int ALLOC = (EST + 7) / 8 * 8;
+  static constexpr int WAVES = 512 / ALLOC >= 8 ? 8 : (512 / ALLOC < 1 ? 1 : 512 / ALLOC);
+};
+
+// One token with exactly K owned rows: straight-line code, every load unconditional and
+// issued before the first use (the K-way switch in the kernel keeps K a compile-time constant,
+// so the row registers are plain scalars and the waits are exact vmcnt counts).
+template <int FMT, typename OutT, int D, int K>
+__device__ __forceinline__ void embed_token(const uint8_t *__restrict__ rows, const void *__restrict__ scales_v,
+                                            const int32_t *__restrict__ rec, long long row_begin, int kfull, int reduce,
+                                            const uint8_t *__restrict__ wte_row, const uint8_t *__restrict__ wpe_row,
+                                            uint8_t *__restrict__ out_row, uint32_t lane) {
+  using G = wave_geom<FMT, D>;
+  constexpr int EPL = G::EPL, NBR = G::NBR, NWR = NBR / 4;
+  constexpr int NBO = EPL * (int)sizeof(OutT), NWO = NBO / 4;
+  constexpr int OPW = pack_io<OutT>::PER_WORD;
+  constexpr int KK = K > 0 ? K : 1;
+  const uint32_t row_off = lane * NBR;
+  const uint32_t out_off = lane * NBO;
+
+  uint32_t bw[NWO], bp[NWO];
+  ld_words<NWO>(wte_row, out_off, bw);
+  ld_words<NWO>(wpe_row, out_off, bp);
+  uint32_t raw[KK][NWR];
+  uint32_t scw[KK];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const long long lr = (long long)rec[k] - row_begin;
+    ld_words<NWR>(rows + lr * G::ROW_BYTES, row_off, raw[k]);
+    if constexpr (FMT == SCONE_FMT_I8) {
+      scw[k] = reinterpret_cast<const uint32_t *>(scales_v)[lr >> 1];  // two half scales per word (scalar load)
+    } else if constexpr (FMT == SCONE_FMT_I4) {
+      scw[k] = reinterpret_cast<const unsigned short *>(scales_v)[lr * (D / SCONE_I4_GROUP) + (lane * EPL) / SCONE_I4_GROUP];
+    } else {
+      scw[k] = 0;
+    }
+  }
+
+  float acc[EPL];
+#pragma unroll
+  for (int e = 0; e < EPL; ++e) acc[e] = 0.f;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    float sc = 1.0f;
+    if constexpr (FMT == SCONE_FMT_I8) {
+      const long long lr = (long long)rec[k] - row_begin;
+      sc = __half2float(__ushort_as_half((unsigned short)((lr & 1) ? (scw[k] >> 16) : (scw[k] & 0xFFFFu))));
+    } else if constexpr (FMT == SCONE_FMT_I4) {
+      sc = __half2float(__ushort_as_half((unsigned short)scw[k]));
+    }
+    acc_words<FMT, EPL, NWR>(acc, raw[k], sc);
+  }
+  if (reduce == SCONE_REDUCE_MEAN && kfull > 1) {
+    // engine.py:250: sum / K.  Correctly rounded quotient without the full division sequence
+    // (Markstein): y = RN(1/K); q0 = RN(x*y); r = x - q0*K (exact in an fma); q = RN(q0 + r*y).
+    const float kf = (float)kfull;
+    const float y = 1.0f / kf;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+      const float q0 = acc[e] * y;
+      const float r = fmaf(-kf, q0, acc[e]);
+      acc[e] = fmaf(r, y, q0);
+    }
+  }
+  uint32_t ow[NWO];
+#pragma unroll
+  for (int w = 0; w < NWO; ++w) {
+    float b[OPW], c[OPW], v[OPW];
+    pack_io<OutT>::unpack(bw[w], b);
+    pack_io<OutT>::unpack(bp[w], c);
+#pragma unroll
+    for (int k = 0; k < OPW; ++k) v[k] = (b[k] + acc[w * OPW + k]) + c[k];  // language_model.py:242-243, :253-254
+    ow[w] = pack_io<OutT>::pack(v);
+  }
+  st_words<NWO>(out_row, out_off, ow);
+}
+
+template <int FMT, typename OutT, int D, int MAXN>
+__global__ __launch_bounds__(256, (wave_occupancy<FMT, OutT, D, MAXN>::WAVES)) void k_embed_wave(const uint8_t *__restrict__ rows, const void *__restrict__ scales_v,
+                                                    const int32_t *__restrict__ ell, const int32_t *__restrict__ tok,
+                                                    const int32_t *__restrict__ pos, const OutT *__restrict__ wte,
+                                                    const OutT *__restrict__ wpe, const uint8_t *__restrict__ zero_row,
+                                                    OutT *__restrict__ out, uint32_t *__restrict__ status,
+                                                    const wave_params q) {
+  constexpr int NC = MAXN * (MAXN + 1) / 2;
+  constexpr int W = MAXN <= 3 ? 8 : 16;
+  const uint32_t lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const long long blk_begin = (long long)blockIdx.x * q.tokens_per_block;
+  long long blk_end = blk_begin + q.tokens_per_block;
+  if (blk_end > q.BT) blk_end = q.BT;
+  long long p = blk_begin + wave;
+  if (p >= blk_end) return;
+  int i = (int)(p % q.T);  // position inside its sequence; advanced incrementally below
+
+  auto load_rec = [&](long long pp, int32_t (&r)[W]) {
+#pragma unroll
+    for (int j = 0; j < W; ++j) r[j] = ell[pp * W + j];  // one aligned s_load_dwordx8 / x16
+  };
+
+  int32_t rec[W];
+  load_rec(p, rec);
+  int32_t tokv = wte ? tok[p] : 0;
+  int32_t posv = wpe ? (pos ? pos[p] : i) : 0;
+
+  while (true) {
+    const bool tok_ok = wte && tokv >= 0 && (long long)tokv < q.vocab;
+    const bool pos_ok = wpe && posv >= 0 && (long long)posv < q.n_pos;
+    if ((wte && !tok_ok) || (wpe && !pos_ok)) {
+      if (lane == 0) atomicOr(status, SCONE_ST_BAD_TOKEN);
+    }
+    // absent / out-of-range base rows read a row of zeros: the adds below stay unconditional
+    const uint8_t *wte_row = tok_ok ? reinterpret_cast<const uint8_t *>(wte + (long long)tokv * D) : zero_row;
+    const uint8_t *wpe_row = pos_ok ? reinterpret_cast<const uint8_t *>(wpe + (long long)posv * D) : zero_row;
+    uint8_t *out_row = reinterpret_cast<uint8_t *>(out + p * D);
+    const int kown = rec[W - 2] & 0xFF, kfull = rec[W - 2] >> 8;
+
+    // prefetch the record of this wave's next token (scalar loads, lgkmcnt -- not in the vmcnt queue)
+    const long long pn = p + 4;
+    int in = i + 4;
+    while (in >= q.T) in -= q.T;
+    const bool more = pn < blk_end;
+    int32_t recn[W];
+    int32_t tokn = 0, posn = 0;
+    if (more) {
+      load_rec(pn, recn);
+      tokn = wte ? tok[pn] : 0;
+      posn = wpe ? (pos ? pos[pn] : in) : 0;
+    }
+
+#define SCONE_CASE(K)                                                                                               \
+  case K:                                                                                                           \
+    if constexpr (K <= NC)                                                                                          \
+      embed_token<FMT, OutT, D, K>(rows, scales_v, rec, q.row_begin, kfull, q.reduce, wte_row, wpe_row, out_row, lane); \
+    break;
+    switch (kown) {
+      SCONE_CASE(0) SCONE_CASE(1) SCONE_CASE(2) SCONE_CASE(3) SCONE_CASE(4) SCONE_CASE(5) SCONE_CASE(6)
+      SCONE_CASE(7) SCONE_CASE(8) SCONE_CASE(9) SCONE_CASE(10)
+      default: break;
+    }
+#undef SCONE_CASE
+
+    if (!more) break;
+    p = pn;
+    i = in;
+#pragma unroll
+    for (int j = 0; j < W; ++j) rec[j] = recn[j];
+    tokv = tokn;
+    posv = posn;
+  }
+}
+
+template <int FMT, typename OutT, int D, int MAXN>
+int launch_wave(scone_handle *h, const embed_args &a, hipStream_t s) {
+  wave_params q;
+  q.BT = a.BT, q.T = a.T, q.max_n = a.max_n;
+  q.row_begin = a.tv.row_begin, q.row_end = a.tv.row_end;
+  q.vocab = a.vocab, q.n_pos = a.n_pos, q.reduce = a.reduce;
+  const long long target_blocks = 2048;  // 256 CUs x 8 workgroups of 4 waves
+  long long tpb = (a.BT + target_blocks - 1) / target_blocks;
+  tpb = (tpb + 3) / 4 * 4;
+  if (tpb < 4) tpb = 4;
+  q.tokens_per_block = (int)tpb;
+  const long long blocks = (a.BT + tpb - 1) / tpb;
+  hipLaunchKernelGGL((k_embed_wave<FMT, OutT, D, MAXN>), dim3((unsigned)blocks), dim3(256), 0, s, a.tv.rows,
+                     (const void *)a.tv.scales, a.ell, a.tok, a.pos, (const OutT *)a.wte, (const OutT *)a.wpe,
+                     (const uint8_t *)a.zero_row, (OutT *)a.out, a.status, q);
+  SCONE_HIP(h, hipGetLastError());
+  return SCONE_OK;
+}
+
+// returns -1 when the wave kernel does not cover this (format, d, max_n) -> caller falls back to k_embed
+template <int FMT, typename OutT>
+int try_launch_wave(scone_handle *h, const embed_args &a, hipStream_t s) {
+  if (!a.ell) return -1;
+  if constexpr (wave_geom<FMT, 768>::OK) {
+    if (a.tv.d == 768) return a.max_n <= 3 ? launch_wave<FMT, OutT, 768, 3>(h, a, s) : launch_wave<FMT, OutT, 768, 4>(h, a, s);
+  }
+  if constexpr (wave_geom<FMT, 1024>::OK) {
+    if (a.tv.d == 1024) return a.max_n <= 3 ? launch_wave<FMT, OutT, 1024, 3>(h, a, s) : launch_wave<FMT, OutT, 1024, 4>(h, a, s);
+  }
+  return -1;
+}
+
+template <int FMT>
+int launch_table_fmt(scone_handle *h, const embed_args &a, int src, int mode, int out_dtype, hipStream_t s) {
+  if (src == SRC_CSR) return launch_dtype<FMT, SRC_CSR, MODE_FULL>(h, a, out_dtype, s);
+  if (mode == MODE_PARTIAL) return launch_dtype<FMT, SRC_HITS, MODE_PARTIAL>(h, a, out_dtype, s);
+  if (mode == MODE_FINALIZE) {
+    if constexpr (FMT == SCONE_FMT_F32) return launch_dtype<FMT, SRC_HITS, MODE_FINALIZE>(h, a, out_dtype, s);
+    else return scone_fail(h, SCONE_EINVAL, "finalize runs on fp32 sums");
+  }
+  // fused full lookup: wave-per-token kernel where it applies, lane-group kernel otherwise
+  int rc = -1;
+  switch (out_dtype) {
+    case SCONE_DT_F32: rc = try_launch_wave<FMT, float>(h, a, s); break;
+    case SCONE_DT_F16: rc = try_launch_wave<FMT, __half>(h, a, s); break;
+    case SCONE_DT_BF16: rc = try_launch_wave<FMT, __hip_bfloat16>(h, a, s); break;
+    default: return scone_fail(h, SCONE_EINVAL, "unknown out_dtype");
+  }
+  if (rc != -1) return rc;
+  return launch_dtype<FMT, SRC_HITS, MODE_FULL>(h, a, out_dtype, s);
+}
+
+}  // namespace scone_gather

@@ -31,6 +31,12 @@ int launch_fmt(scone_handle *h, const embed_args &a, int src, int mode, int out_
     default: return scone_fail(h, SCONE_EINVAL, "unknown table_fmt");
   }
 }
+// formats / dims served by k_embed_wave (scone_embed_wave.h: wave_geom<>::OK)
+bool scone_wave_kernel_covers(int fmt, int d) {
+  if (d != 768 && d != 1024) return false;
+  return !(fmt == SCONE_FMT_I4 && d == 768);
+}
+
 void fill_table_view(const scone_handle *h, table_view &tv) {
   tv.rows = reinterpret_cast<const uint8_t *>(h->rows);
   tv.scales = reinterpret_cast<const __half *>(h->scales);
@@ -84,14 +90,25 @@ extern "C" int scone_embed(scone_handle *h, const int32_t *d_tok, int32_t B, int
     return scone_fail(h, SCONE_EINVAL, "scone_embed: wte/wpe given without vocab/n_pos");
   SCONE_HIP(h, hipSetDevice(h->device));
   hipStream_t s = (hipStream_t)stream;
-  rc = scone_ensure_hits(h, BT);
-  if (rc) return rc;
-  rc = scone_launch_match(h, d_tok, B, T, h->d_hits, s);
-  if (rc) return rc;
   embed_args a = {};
   fill_table_view(h, a.tv);
-  a.hits = h->d_hits, a.BT = BT, a.T = T, a.max_n = h->cfg.max_n;
+  a.BT = BT, a.T = T, a.max_n = h->cfg.max_n;
   a.tok_begin = 0, a.ntok = BT;
+  a.zero_row = h->d_zero_row;
+  if (scone_wave_kernel_covers(h->cfg.table_fmt, h->cfg.dim)) {
+    // fast path: per-token id records (one scalar load per token in the gather kernel)
+    rc = scone_ensure_ell(h, BT);
+    if (rc) return rc;
+    rc = scone_launch_match_ell(h, d_tok, B, T, h->d_ell, s);
+    if (rc) return rc;
+    a.ell = h->d_ell;
+  } else {
+    rc = scone_ensure_hits(h, BT);
+    if (rc) return rc;
+    rc = scone_launch_match(h, d_tok, B, T, h->d_hits, s);
+    if (rc) return rc;
+    a.hits = h->d_hits;
+  }
   a.tok = d_tok, a.pos = d_pos, a.wte = d_wte, a.vocab = vocab, a.wpe = d_wpe, a.n_pos = n_pos;
   a.reduce = reduce, a.out = d_out, a.status = h->d_status;
   rc = scone_prof_begin(h, s);

@@ -160,6 +160,8 @@ struct embed_args {
   table_view tv;
   // id source
   const int32_t *hits;     // [max_n, BT]
+  const int32_t *ell;      // per-token owned-id records (wave kernel), or null
+  const void *zero_row;    // d * 4 zero bytes
   const int32_t *offsets;  // CSR
   const int32_t *ids;
   long long BT;
@@ -393,16 +395,5 @@ int launch_f32(scone_handle *h, const embed_args &a, int src, int mode, int out_
 int launch_f16(scone_handle *h, const embed_args &a, int src, int mode, int out_dtype, hipStream_t s);
 int launch_i8(scone_handle *h, const embed_args &a, int src, int mode, int out_dtype, hipStream_t s);
 int launch_i4(scone_handle *h, const embed_args &a, int src, int mode, int out_dtype, hipStream_t s);
-
-template <int FMT>
-int launch_table_fmt(scone_handle *h, const embed_args &a, int src, int mode, int out_dtype, hipStream_t s) {
-  if (src == SRC_CSR) return launch_dtype<FMT, SRC_CSR, MODE_FULL>(h, a, out_dtype, s);
-  if (mode == MODE_PARTIAL) return launch_dtype<FMT, SRC_HITS, MODE_PARTIAL>(h, a, out_dtype, s);
-  if (mode == MODE_FINALIZE) {
-    if constexpr (FMT == SCONE_FMT_F32) return launch_dtype<FMT, SRC_HITS, MODE_FINALIZE>(h, a, out_dtype, s);
-    else return scone_fail(h, SCONE_EINVAL, "finalize runs on fp32 sums");
-  }
-  return launch_dtype<FMT, SRC_HITS, MODE_FULL>(h, a, out_dtype, s);
-}
 
 }  // namespace scone_gather

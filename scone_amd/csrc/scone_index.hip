@@ -104,6 +104,87 @@ __global__ __launch_bounds__(256) void k_match(const scone_slot *__restrict__ sl
   hits[gid] = res;
 }
 
+// ------------------------------------------------------------------ match -> per-token lists
+// The form the fused lookup consumes: for every position a fixed-width record
+//   ell[p*W + 0 .. K_own-1] = ids of the f-grams covering p whose rows THIS handle owns,
+//                             in the reference's order (n ascending, start ascending, duplicates kept)
+//   ell[p*W + W-2]          = K_own | (K_full << 8)      (K_full: all hits, the mean's divisor)
+// W = 8 (max_n <= 3, <= 6 ids) or 16 (max_n = 4, <= 10 ids), so the gather kernel fetches a
+// token's whole list with ONE aligned scalar load.  A workgroup owns ELL_TILE consecutive
+// positions: thread (n, t) probes the window of length n starting at position t of the tile
+// (plus the max_n-1 halo starts in front of the tile), the per-window ids are staged in LDS
+// ("index buckets"), then one thread per position compacts its candidates.
+#define ELL_TILE 256
+
+template <int MAXN>
+__global__ __launch_bounds__(ELL_TILE * MAXN) void k_match_ell(const scone_slot *__restrict__ slots,
+                                                               unsigned long long mask,
+                                                               const int32_t *__restrict__ tok, long long BT, int T,
+                                                               int max_n, long long row_begin, long long row_end,
+                                                               int32_t *__restrict__ ell) {
+  constexpr int HALO = MAXN - 1;
+  constexpr int W = MAXN <= 3 ? 8 : 16;
+  __shared__ int32_t win[MAXN][ELL_TILE + HALO];
+  const int t = threadIdx.x % ELL_TILE;
+  const int n = threadIdx.x / ELL_TILE + 1;  // window length handled by this thread
+  const long long tile0 = (long long)blockIdx.x * ELL_TILE;
+
+  auto probe_window = [&](long long start) -> int32_t {
+    if (start < 0 || start >= BT || n > max_n) return -1;
+    const int i = (int)(start % T);
+    if (i + n > T) return -1;  // windows never cross a sequence boundary
+    uint32_t k[SCONE_MAX_N] = {0u, 0u, 0u, 0u};
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < MAXN; ++j) {
+      if (j < n) {
+        const int32_t v = tok[start + j];
+        ok = ok && v >= 0;
+        k[j] = (uint32_t)v;
+      }
+    }
+    if (!ok) return -1;
+    const scone_key key = scone_pack_key(k, n, max_n);
+    return key.ok ? probe_index(slots, mask, key.lo, key.ext) : -1;
+  };
+
+  win[n - 1][t + HALO] = probe_window(tile0 + t);
+  if (t < HALO) win[n - 1][t] = probe_window(tile0 - HALO + t);
+  __syncthreads();
+
+  if (threadIdx.x >= ELL_TILE) return;
+  const long long p = tile0 + t;
+  if (p >= BT) return;
+  const int i = (int)(p % T);
+  int32_t rec[W];
+#pragma unroll
+  for (int j = 0; j < W; ++j) rec[j] = -1;
+  int kown = 0, kfull = 0;
+#pragma unroll
+  for (int nn = 1; nn <= MAXN; ++nn) {
+#pragma unroll
+    for (int s = nn - 1; s >= 0; --s) {
+      if (nn <= max_n && i - s >= 0) {
+        const int32_t id = win[nn - 1][t + HALO - s];
+        if (id >= 0) {
+          ++kfull;
+          if (id >= row_begin && id < row_end) {
+#pragma unroll
+            for (int j = 0; j < W - 2; ++j)
+              if (j == kown) rec[j] = id;
+            ++kown;
+          }
+        }
+      }
+    }
+  }
+  rec[W - 2] = kown | (kfull << 8);
+  rec[W - 1] = 0;
+  int4 *dst = reinterpret_cast<int4 *>(ell + p * W);
+#pragma unroll
+  for (int j = 0; j < W / 4; ++j) dst[j] = make_int4(rec[4 * j], rec[4 * j + 1], rec[4 * j + 2], rec[4 * j + 3]);
+}
+
 // ------------------------------------------------------------------ CSR
 // Candidate c of position j enumerates (n, s) with n = 1..max_n, s = n-1..0
 // (window start i = j - s ascending): the append order of n_gram_extractor.py:119-124.
@@ -229,6 +310,22 @@ int scone_launch_match(scone_handle *h, const int32_t *d_tok, int32_t B, int32_t
   if (blocks > 0x7FFFFFFFll) return scone_fail(h, SCONE_EINVAL, "scone_match: too many tokens for one launch");
   hipLaunchKernelGGL(k_match, dim3((unsigned)blocks), dim3(256), 0, s, h->slots, h->cap - 1, d_tok, BT, T,
                      h->cfg.max_n, d_hits);
+  SCONE_HIP(h, hipGetLastError());
+  return SCONE_OK;
+}
+
+int scone_launch_match_ell(scone_handle *h, const int32_t *d_tok, int32_t B, int32_t T, int32_t *d_ell, hipStream_t s) {
+  const long long BT = (long long)B * T;
+  if (BT == 0) return SCONE_OK;
+  const long long blocks = (BT + ELL_TILE - 1) / ELL_TILE;
+  if (blocks > 0x7FFFFFFFll) return scone_fail(h, SCONE_EINVAL, "scone_embed: too many tokens for one launch");
+  const long long rb = (long long)h->cfg.row_begin, re = (long long)h->cfg.row_end;
+  if (h->cfg.max_n <= 3)
+    hipLaunchKernelGGL((k_match_ell<3>), dim3((unsigned)blocks), dim3(ELL_TILE * 3), 0, s, h->slots, h->cap - 1, d_tok, BT,
+                       T, h->cfg.max_n, rb, re, d_ell);
+  else
+    hipLaunchKernelGGL((k_match_ell<4>), dim3((unsigned)blocks), dim3(ELL_TILE * 4), 0, s, h->slots, h->cap - 1, d_tok, BT,
+                       T, h->cfg.max_n, rb, re, d_ell);
   SCONE_HIP(h, hipGetLastError());
   return SCONE_OK;
 }

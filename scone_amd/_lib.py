@@ -11,7 +11,8 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libscone_hip.so")
+# SCONE_HIP_LIB: alternative build of the same library (A/B kernel experiments)
+LIB_PATH = os.environ.get("SCONE_HIP_LIB") or os.path.join(_HERE, "csrc", "libscone_hip.so")
 
 ABI_VERSION = 1
 

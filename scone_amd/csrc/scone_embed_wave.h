@@ -26,7 +26,9 @@ struct wave_params {
   int T;
   int max_n;
   int reduce;
-  int tokens_per_block;  // multiple of 4
+  int B;
+  int pos_groups;      // ceil(T / 4): a workgroup's 4 waves own 4 consecutive positions
+  int seqs_per_block;  // sequences walked by one workgroup
 };
 
 // NB bytes (multiple of 4) at base + off -> dwords; the backend merges these into
@@ -116,10 +118,14 @@ template <int FMT, int D> struct wave_geom {
 
 // waves per SIMD to ask of the register allocator: rows in flight (NC x NBR/4) + wte/wpe/out words +
 // accumulators + addressing, rounded to the 8-register allocation granule (512 registers per SIMD lane)
-template <int FMT, typename OutT, int D, int MAXN> struct wave_occupancy {
+#ifndef SCONE_WAVE_SLACK
+#define SCONE_WAVE_SLACK 14
+#endif
+template <int FMT, typename OutT, int D, int MAXN, bool FIXED_POS> struct wave_occupancy {
   static constexpr int NC = MAXN * (MAXN + 1) / 2;
   static constexpr int NWO = wave_geom<FMT, D>::EPL * (int)sizeof(OutT) / 4;
-  static constexpr int EST = NC * (wave_geom<FMT, D>::NBR / 4) + 3 * NWO + wave_geom<FMT, D>::EPL + 14;
+  static constexpr int EST = NC * (wave_geom<FMT, D>::NBR / 4) + (FIXED_POS ? 4 : 3) * NWO + wave_geom<FMT, D>::EPL +
+                             SCONE_WAVE_SLACK;
   static constexpr int ALLOC = (EST + 7) / 8 * 8;
   static constexpr int WAVES = 512 / ALLOC >= 8 ? 8 : (512 / ALLOC < 1 ? 1 : 512 / ALLOC);
 };
@@ -127,10 +133,11 @@ template <int FMT, typename OutT, int D, int MAXN> struct wave_occupancy {
 // One token with exactly K owned rows: straight-line code, every load unconditional and
 // issued before the first use (the K-way switch in the kernel keeps K a compile-time constant,
 // so the row registers are plain scalars and the waits are exact vmcnt counts).
-template <int FMT, typename OutT, int D, int K>
+template <int FMT, typename OutT, int D, int K, bool FIXED_POS>
 __device__ __forceinline__ void embed_token(const uint8_t *__restrict__ rows, const void *__restrict__ scales_v,
                                             const int32_t *__restrict__ rec, long long row_begin, int kfull, int reduce,
                                             const uint8_t *__restrict__ wte_row, const uint8_t *__restrict__ wpe_row,
+                                            const uint32_t (&wpe_words)[wave_geom<FMT, D>::EPL * (int)sizeof(OutT) / 4],
                                             uint8_t *__restrict__ out_row, uint32_t lane) {
   using G = wave_geom<FMT, D>;
   constexpr int EPL = G::EPL, NBR = G::NBR, NWR = NBR / 4;
@@ -142,7 +149,12 @@ __device__ __forceinline__ void embed_token(const uint8_t *__restrict__ rows, co
 
   uint32_t bw[NWO], bp[NWO];
   ld_words<NWO>(wte_row, out_off, bw);
-  ld_words<NWO>(wpe_row, out_off, bp);
+  if constexpr (FIXED_POS) {
+#pragma unroll
+    for (int w = 0; w < NWO; ++w) bp[w] = wpe_words[w];  // this wave's position row, loaded once
+  } else {
+    ld_words<NWO>(wpe_row, out_off, bp);
+  }
   uint32_t raw[KK][NWR];
   uint32_t scw[KK];
 #pragma unroll
@@ -197,63 +209,85 @@ __device__ __forceinline__ void embed_token(const uint8_t *__restrict__ rows, co
   st_words<NWO>(out_row, out_off, ow);
 }
 
-template <int FMT, typename OutT, int D, int MAXN>
-__global__ __launch_bounds__(256, (wave_occupancy<FMT, OutT, D, MAXN>::WAVES)) void k_embed_wave(const uint8_t *__restrict__ rows, const void *__restrict__ scales_v,
-                                                    const int32_t *__restrict__ ell, const int32_t *__restrict__ tok,
-                                                    const int32_t *__restrict__ pos, const OutT *__restrict__ wte,
-                                                    const OutT *__restrict__ wpe, const uint8_t *__restrict__ zero_row,
-                                                    OutT *__restrict__ out, uint32_t *__restrict__ status,
-                                                    const wave_params q) {
+// Work assignment: a workgroup's 4 waves own 4 CONSECUTIVE positions i0..i0+3 and walk the same
+// run of sequences b = b0..b1-1 together.  Adjacent tokens of one sequence are therefore in
+// flight on one CU at the same time (the f-gram rows they share hit L1/L2), and with the
+// default position ids (arange(T), language_model.py:248-251) a wave's wpe row never changes:
+// FIXED_POS keeps it in registers, removing d*sizeof(OutT) bytes of L1/L2 traffic per token.
+template <int FMT, typename OutT, int D, int MAXN, bool FIXED_POS>
+__global__ __launch_bounds__(256, (wave_occupancy<FMT, OutT, D, MAXN, FIXED_POS>::WAVES)) void k_embed_wave(
+    const uint8_t *__restrict__ rows, const void *__restrict__ scales_v, const int32_t *__restrict__ ell,
+    const int32_t *__restrict__ tok, const int32_t *__restrict__ pos, const OutT *__restrict__ wte,
+    const OutT *__restrict__ wpe, const uint8_t *__restrict__ zero_row, OutT *__restrict__ out,
+    uint32_t *__restrict__ status, const wave_params q) {
   constexpr int NC = MAXN * (MAXN + 1) / 2;
   constexpr int W = MAXN <= 3 ? 8 : 16;
+  constexpr int NWO = wave_geom<FMT, D>::EPL * (int)sizeof(OutT) / 4;
   const uint32_t lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const long long blk_begin = (long long)blockIdx.x * q.tokens_per_block;
-  long long blk_end = blk_begin + q.tokens_per_block;
-  if (blk_end > q.BT) blk_end = q.BT;
-  long long p = blk_begin + wave;
-  if (p >= blk_end) return;
-  int i = (int)(p % q.T);  // position inside its sequence; advanced incrementally below
+  const int pg = (int)(blockIdx.x % (unsigned)q.pos_groups);
+  const int chunk = (int)(blockIdx.x / (unsigned)q.pos_groups);
+  const int i = pg * 4 + wave;  // position inside the sequence (wave-constant)
+  if (i >= q.T) return;
+  const int b0 = chunk * q.seqs_per_block;
+  int b1 = b0 + q.seqs_per_block;
+  if (b1 > q.B) b1 = q.B;
+  if (b0 >= b1) return;
+  long long p = (long long)b0 * q.T + i;
+  const long long p_end = (long long)b1 * q.T;  // p advances by T
 
   auto load_rec = [&](long long pp, int32_t (&r)[W]) {
 #pragma unroll
     for (int j = 0; j < W; ++j) r[j] = ell[pp * W + j];  // one aligned s_load_dwordx8 / x16
   };
 
+  uint32_t wpe_words[NWO];
+#pragma unroll
+  for (int w = 0; w < NWO; ++w) wpe_words[w] = 0u;
+  if constexpr (FIXED_POS) {
+    const bool ok = wpe && (long long)i < q.n_pos;
+    if (wpe && !ok && lane == 0) atomicOr(status, SCONE_ST_BAD_TOKEN);
+    const uint8_t *r = ok ? reinterpret_cast<const uint8_t *>(wpe + (long long)i * D) : zero_row;
+    ld_words<NWO>(r, lane * (uint32_t)(NWO * 4), wpe_words);
+  }
+
   int32_t rec[W];
   load_rec(p, rec);
   int32_t tokv = wte ? tok[p] : 0;
-  int32_t posv = wpe ? (pos ? pos[p] : i) : 0;
+  int32_t posv = (!FIXED_POS && wpe) ? pos[p] : 0;
 
   while (true) {
     const bool tok_ok = wte && tokv >= 0 && (long long)tokv < q.vocab;
-    const bool pos_ok = wpe && posv >= 0 && (long long)posv < q.n_pos;
-    if ((wte && !tok_ok) || (wpe && !pos_ok)) {
+    bool pos_ok = true;
+    if constexpr (!FIXED_POS) pos_ok = wpe && posv >= 0 && (long long)posv < q.n_pos;
+    if ((wte && !tok_ok) || (!FIXED_POS && wpe && !pos_ok)) {
       if (lane == 0) atomicOr(status, SCONE_ST_BAD_TOKEN);
     }
-    // absent / out-of-range base rows read a row of zeros: the adds below stay unconditional
+    // absent / out-of-range base rows read a row of zeros: the adds stay unconditional
     const uint8_t *wte_row = tok_ok ? reinterpret_cast<const uint8_t *>(wte + (long long)tokv * D) : zero_row;
-    const uint8_t *wpe_row = pos_ok ? reinterpret_cast<const uint8_t *>(wpe + (long long)posv * D) : zero_row;
+    const uint8_t *wpe_row = zero_row;
+    if constexpr (!FIXED_POS) {
+      if (pos_ok) wpe_row = reinterpret_cast<const uint8_t *>(wpe + (long long)posv * D);
+    }
     uint8_t *out_row = reinterpret_cast<uint8_t *>(out + p * D);
     const int kown = rec[W - 2] & 0xFF, kfull = rec[W - 2] >> 8;
 
     // prefetch the record of this wave's next token (scalar loads, lgkmcnt -- not in the vmcnt queue)
-    const long long pn = p + 4;
-    int in = i + 4;
-    while (in >= q.T) in -= q.T;
-    const bool more = pn < blk_end;
+    const long long pn = p + q.T;
+    const bool more = pn < p_end;
     int32_t recn[W];
     int32_t tokn = 0, posn = 0;
     if (more) {
       load_rec(pn, recn);
       tokn = wte ? tok[pn] : 0;
-      posn = wpe ? (pos ? pos[pn] : in) : 0;
+      posn = (!FIXED_POS && wpe) ? pos[pn] : 0;
     }
 
-#define SCONE_CASE(K)                                                                                               \
-  case K:                                                                                                           \
-    if constexpr (K <= NC)                                                                                          \
-      embed_token<FMT, OutT, D, K>(rows, scales_v, rec, q.row_begin, kfull, q.reduce, wte_row, wpe_row, out_row, lane); \
+#define SCONE_CASE(K)                                                                                          \
+  case K:                                                                                                      \
+    if constexpr (K <= NC)                                                                                     \
+      embed_token<FMT, OutT, D, K, FIXED_POS>(rows, scales_v, rec, q.row_begin, kfull, q.reduce, wte_row, wpe_row, \
+                                              wpe_words, out_row, lane);                                       \
     break;
     switch (kown) {
       SCONE_CASE(0) SCONE_CASE(1) SCONE_CASE(2) SCONE_CASE(3) SCONE_CASE(4) SCONE_CASE(5) SCONE_CASE(6)
@@ -264,7 +298,6 @@ __global__ __launch_bounds__(256, (wave_occupancy<FMT, OutT, D, MAXN>::WAVES)) v
 
     if (!more) break;
     p = pn;
-    i = in;
 #pragma unroll
     for (int j = 0; j < W; ++j) rec[j] = recn[j];
     tokv = tokn;
@@ -278,15 +311,24 @@ int launch_wave(scone_handle *h, const embed_args &a, hipStream_t s) {
   q.BT = a.BT, q.T = a.T, q.max_n = a.max_n;
   q.row_begin = a.tv.row_begin, q.row_end = a.tv.row_end;
   q.vocab = a.vocab, q.n_pos = a.n_pos, q.reduce = a.reduce;
-  const long long target_blocks = 2048;  // 256 CUs x 8 workgroups of 4 waves
-  long long tpb = (a.BT + target_blocks - 1) / target_blocks;
-  tpb = (tpb + 3) / 4 * 4;
-  if (tpb < 4) tpb = 4;
-  q.tokens_per_block = (int)tpb;
-  const long long blocks = (a.BT + tpb - 1) / tpb;
-  hipLaunchKernelGGL((k_embed_wave<FMT, OutT, D, MAXN>), dim3((unsigned)blocks), dim3(256), 0, s, a.tv.rows,
-                     (const void *)a.tv.scales, a.ell, a.tok, a.pos, (const OutT *)a.wte, (const OutT *)a.wpe,
-                     (const uint8_t *)a.zero_row, (OutT *)a.out, a.status, q);
+  q.B = (int)(a.BT / a.T);
+  q.pos_groups = (a.T + 3) / 4;
+  // ~4096 workgroups (256 CUs x 8 resident x 2 rounds) when the batch allows it
+  long long chunks = 4096 / q.pos_groups;
+  if (chunks < 1) chunks = 1;
+  if (chunks > q.B) chunks = q.B;
+  q.seqs_per_block = (int)((q.B + chunks - 1) / chunks);
+  chunks = (q.B + q.seqs_per_block - 1) / q.seqs_per_block;
+  const long long blocks = chunks * q.pos_groups;
+  if (blocks > 0x7FFFFFFFll) return scone_fail(h, SCONE_EINVAL, "scone_embed: too many tokens for one launch");
+  if (a.pos)
+    hipLaunchKernelGGL((k_embed_wave<FMT, OutT, D, MAXN, false>), dim3((unsigned)blocks), dim3(256), 0, s, a.tv.rows,
+                       (const void *)a.tv.scales, a.ell, a.tok, a.pos, (const OutT *)a.wte, (const OutT *)a.wpe,
+                       (const uint8_t *)a.zero_row, (OutT *)a.out, a.status, q);
+  else
+    hipLaunchKernelGGL((k_embed_wave<FMT, OutT, D, MAXN, true>), dim3((unsigned)blocks), dim3(256), 0, s, a.tv.rows,
+                       (const void *)a.tv.scales, a.ell, a.tok, a.pos, (const OutT *)a.wte, (const OutT *)a.wpe,
+                       (const uint8_t *)a.zero_row, (OutT *)a.out, a.status, q);
   SCONE_HIP(h, hipGetLastError());
   return SCONE_OK;
 }

@@ -114,7 +114,7 @@ extern "C" int scone_create(const scone_cfg *cfg, scone_handle **out) {
     return SCONE_EINVAL;
   }
   h->local_rows = h->cfg.row_end - h->cfg.row_begin;
-  h->slots = nullptr, h->d_counters = nullptr, h->d_status = nullptr;
+  h->slots = nullptr, h->d_counters = nullptr, h->d_status = nullptr, h->d_uni = nullptr;
   h->rows = nullptr, h->scales = nullptr, h->rows_pinned_host = false;
   h->d_hits = nullptr, h->hits_cap_tokens = 0, h->d_block_sums = nullptr, h->block_sums_cap = 0;
   h->d_ell = nullptr, h->ell_cap_tokens = 0, h->d_zero_row = nullptr;
@@ -152,6 +152,8 @@ extern "C" int scone_create(const scone_cfg *cfg, scone_handle **out) {
   CREATE_HIP(hipMalloc(&h->d_status, sizeof(uint32_t)));
   CREATE_HIP(hipMemset(h->d_status, 0, sizeof(uint32_t)));
   CREATE_HIP(hipMalloc(&h->d_total, sizeof(int64_t)));
+  CREATE_HIP(hipMalloc(&h->d_uni, (size_t)SCONE_UNI_CAP * sizeof(int32_t)));
+  CREATE_HIP(hipMemset(h->d_uni, 0xFF, (size_t)SCONE_UNI_CAP * sizeof(int32_t)));
   if (cfg->dim > 0) {  // a row of zeros: stands in for wte / wpe when the caller passes none
     CREATE_HIP(hipMalloc(&h->d_zero_row, (size_t)cfg->dim * 4));
     CREATE_HIP(hipMemset(h->d_zero_row, 0, (size_t)cfg->dim * 4));
@@ -193,6 +195,7 @@ extern "C" void scone_destroy(scone_handle *h) {
   if (h->slots) (void)hipFree(h->slots);
   if (h->d_counters) (void)hipFree(h->d_counters);
   if (h->d_status) (void)hipFree(h->d_status);
+  if (h->d_uni) (void)hipFree(h->d_uni);
   if (h->d_total) (void)hipFree(h->d_total);
   if (h->rows) {
     if (h->rows_pinned_host) (void)hipHostFree(h->rows);

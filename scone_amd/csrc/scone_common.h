@@ -15,6 +15,7 @@
 #define SCONE_I4_GROUP 128
 #define SCONE_MAX_N 4
 #define SCONE_PROF_RING 1024
+#define SCONE_UNI_CAP (1 << 18)  // direct unigram table: token ids below this skip the hash probe
 #define SCONE_MAX_CAND 10  // max_n (max_n + 1) / 2 at max_n = 4
 
 #define SCONE_ST_BAD_TOKEN 1u
@@ -89,6 +90,7 @@ struct scone_handle {
   uint64_t cap;  // power of two
   unsigned long long *d_counters;  // [0] inserted, [1] duplicates
   uint32_t *d_status;              // sticky status bits
+  int32_t *d_uni;                  // [SCONE_UNI_CAP] token -> unigram id, 0xFFFFFFFF (= -1) if none
   // table
   void *rows;        // payload rows, local row r = global id - row_begin
   void *scales;      // I8: half[rows]; I4: half[rows, d/128]

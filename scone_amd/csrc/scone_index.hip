@@ -22,7 +22,8 @@ __global__ __launch_bounds__(256) void k_index_insert(scone_slot *__restrict__ s
                                                       unsigned long long n, unsigned long long id0,
                                                       int max_n,
                                                       unsigned long long *__restrict__ counters,
-                                                      uint32_t *__restrict__ status) {
+                                                      uint32_t *__restrict__ status, int32_t *__restrict__ uni,
+                                                      int uni_cap) {
   unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   int len = lens[i];
@@ -37,6 +38,8 @@ __global__ __launch_bounds__(256) void k_index_insert(scone_slot *__restrict__ s
     atomicOr(status, SCONE_ST_BAD_TOKEN);
     return;
   }
+  // unigrams are also kept in a direct table (token -> smallest id), read by the fused match
+  if (len == 1 && uni && t[0] < (uint32_t)uni_cap) atomicMin(reinterpret_cast<unsigned int *>(&uni[t[0]]), (unsigned int)(id0 + i));
   unsigned long long myhi = ((unsigned long long)key.ext << 32) | (unsigned long long)(uint32_t)(id0 + i + 1ull);
   unsigned long long s = scone_hash_key(key.lo, key.ext) & mask;
   for (unsigned long long probe = 0; probe <= mask; ++probe) {
@@ -116,46 +119,92 @@ __global__ __launch_bounds__(256) void k_match(const scone_slot *__restrict__ sl
 // ("index buckets"), then one thread per position compacts its candidates.
 #define ELL_TILE 256
 
+// Resolve one probe whose first slot has already been fetched (v = slots[s]).
+__device__ __forceinline__ int32_t probe_finish(const scone_slot *__restrict__ slots, unsigned long long mask,
+                                                unsigned long long lo, uint32_t ext, unsigned long long s, ulonglong2 v) {
+  for (unsigned long long probe = 0; probe <= mask; ++probe) {
+    if (v.x == lo && (uint32_t)(v.y >> 32) == ext) return (int32_t)((uint32_t)v.y - 1u);
+    if (v.x == 0ull) return -1;
+    s = (s + 1ull) & mask;
+    v = *reinterpret_cast<const ulonglong2 *>(&slots[s]);
+  }
+  return -1;
+}
+
+// All windows (n = 1..MAXN) that START at position `start`: the MAXN first-slot loads are
+// issued back to back (memory-level parallelism inside one lane), unigrams come from the
+// direct table when it covers the token.
 template <int MAXN>
-__global__ __launch_bounds__(ELL_TILE * MAXN) void k_match_ell(const scone_slot *__restrict__ slots,
-                                                               unsigned long long mask,
-                                                               const int32_t *__restrict__ tok, long long BT, int T,
-                                                               int max_n, long long row_begin, long long row_end,
-                                                               int32_t *__restrict__ ell) {
+__device__ __forceinline__ void probe_starts(const scone_slot *__restrict__ slots, unsigned long long mask,
+                                             const int32_t *__restrict__ uni, int uni_cap,
+                                             const int32_t *__restrict__ tok, long long BT, int T, int max_n,
+                                             long long start, int32_t (&res)[MAXN]) {
+#pragma unroll
+  for (int n = 0; n < MAXN; ++n) res[n] = -1;
+  if (start < 0 || start >= BT) return;
+  const int i = BT <= 0x7FFFFFFFll ? (int)((unsigned)start % (unsigned)T) : (int)(start % T);
+  uint32_t k[SCONE_MAX_N] = {0u, 0u, 0u, 0u};
+  int nvalid = 0;  // longest window starting here that fits in the sequence and has only valid tokens
+#pragma unroll
+  for (int j = 0; j < MAXN; ++j) {
+    if (j < max_n && i + j < T && nvalid == j) {
+      const int32_t v = tok[start + j];
+      if (v >= 0) {
+        k[j] = (uint32_t)v;
+        nvalid = j + 1;
+      }
+    }
+  }
+  unsigned long long lo[MAXN], sl[MAXN];
+  uint32_t ext[MAXN];
+  ulonglong2 first[MAXN];
+  bool live[MAXN];
+#pragma unroll
+  for (int n = 1; n <= MAXN; ++n) {
+    live[n - 1] = false;
+    if (n > nvalid) continue;
+    if (n == 1 && uni && k[0] < (uint32_t)uni_cap) {
+      res[0] = uni[k[0]];
+      continue;
+    }
+    const scone_key key = scone_pack_key(k, n, max_n);
+    if (!key.ok) continue;
+    lo[n - 1] = key.lo, ext[n - 1] = key.ext;
+    sl[n - 1] = scone_hash_key(key.lo, key.ext) & mask;
+    first[n - 1] = *reinterpret_cast<const ulonglong2 *>(&slots[sl[n - 1]]);
+    live[n - 1] = true;
+  }
+#pragma unroll
+  for (int n = 0; n < MAXN; ++n)
+    if (live[n]) res[n] = probe_finish(slots, mask, lo[n], ext[n], sl[n], first[n]);
+}
+
+template <int MAXN>
+__global__ __launch_bounds__(ELL_TILE) void k_match_ell(const scone_slot *__restrict__ slots, unsigned long long mask,
+                                                        const int32_t *__restrict__ uni, int uni_cap,
+                                                        const int32_t *__restrict__ tok, long long BT, int T, int max_n,
+                                                        long long row_begin, long long row_end,
+                                                        int32_t *__restrict__ ell) {
   constexpr int HALO = MAXN - 1;
   constexpr int W = MAXN <= 3 ? 8 : 16;
   __shared__ int32_t win[MAXN][ELL_TILE + HALO];
-  const int t = threadIdx.x % ELL_TILE;
-  const int n = threadIdx.x / ELL_TILE + 1;  // window length handled by this thread
+  const int t = threadIdx.x;
   const long long tile0 = (long long)blockIdx.x * ELL_TILE;
 
-  auto probe_window = [&](long long start) -> int32_t {
-    if (start < 0 || start >= BT || n > max_n) return -1;
-    const int i = (int)(start % T);
-    if (i + n > T) return -1;  // windows never cross a sequence boundary
-    uint32_t k[SCONE_MAX_N] = {0u, 0u, 0u, 0u};
-    bool ok = true;
+  int32_t r[MAXN];
+  probe_starts<MAXN>(slots, mask, uni, uni_cap, tok, BT, T, max_n, tile0 + t, r);
 #pragma unroll
-    for (int j = 0; j < MAXN; ++j) {
-      if (j < n) {
-        const int32_t v = tok[start + j];
-        ok = ok && v >= 0;
-        k[j] = (uint32_t)v;
-      }
-    }
-    if (!ok) return -1;
-    const scone_key key = scone_pack_key(k, n, max_n);
-    return key.ok ? probe_index(slots, mask, key.lo, key.ext) : -1;
-  };
-
-  win[n - 1][t + HALO] = probe_window(tile0 + t);
-  if (t < HALO) win[n - 1][t] = probe_window(tile0 - HALO + t);
+  for (int n = 0; n < MAXN; ++n) win[n][t + HALO] = r[n];
+  if (t < HALO) {  // the max_n-1 starts in front of the tile
+    probe_starts<MAXN>(slots, mask, uni, uni_cap, tok, BT, T, max_n, tile0 - HALO + t, r);
+#pragma unroll
+    for (int n = 0; n < MAXN; ++n) win[n][t] = r[n];
+  }
   __syncthreads();
 
-  if (threadIdx.x >= ELL_TILE) return;
   const long long p = tile0 + t;
   if (p >= BT) return;
-  const int i = (int)(p % T);
+  const int i = BT <= 0x7FFFFFFFll ? (int)((unsigned)p % (unsigned)T) : (int)(p % T);
   int32_t rec[W];
 #pragma unroll
   for (int j = 0; j < W; ++j) rec[j] = -1;
@@ -321,11 +370,11 @@ int scone_launch_match_ell(scone_handle *h, const int32_t *d_tok, int32_t B, int
   if (blocks > 0x7FFFFFFFll) return scone_fail(h, SCONE_EINVAL, "scone_embed: too many tokens for one launch");
   const long long rb = (long long)h->cfg.row_begin, re = (long long)h->cfg.row_end;
   if (h->cfg.max_n <= 3)
-    hipLaunchKernelGGL((k_match_ell<3>), dim3((unsigned)blocks), dim3(ELL_TILE * 3), 0, s, h->slots, h->cap - 1, d_tok, BT,
-                       T, h->cfg.max_n, rb, re, d_ell);
+    hipLaunchKernelGGL((k_match_ell<3>), dim3((unsigned)blocks), dim3(ELL_TILE), 0, s, h->slots, h->cap - 1, h->d_uni,
+                       SCONE_UNI_CAP, d_tok, BT, T, h->cfg.max_n, rb, re, d_ell);
   else
-    hipLaunchKernelGGL((k_match_ell<4>), dim3((unsigned)blocks), dim3(ELL_TILE * 4), 0, s, h->slots, h->cap - 1, d_tok, BT,
-                       T, h->cfg.max_n, rb, re, d_ell);
+    hipLaunchKernelGGL((k_match_ell<4>), dim3((unsigned)blocks), dim3(ELL_TILE), 0, s, h->slots, h->cap - 1, h->d_uni,
+                       SCONE_UNI_CAP, d_tok, BT, T, h->cfg.max_n, rb, re, d_ell);
   SCONE_HIP(h, hipGetLastError());
   return SCONE_OK;
 }
@@ -341,7 +390,7 @@ extern "C" int scone_index_build_device(scone_handle *h, const uint32_t *d_keys,
   if (blocks > 0x7FFFFFFFull) return scone_fail(h, SCONE_EINVAL, "scone_index_build: chunk too large");
   hipLaunchKernelGGL(k_index_insert, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, h->slots,
                      h->cap - 1, d_keys, d_lens, (unsigned long long)n, (unsigned long long)id0, h->cfg.max_n,
-                     h->d_counters, h->d_status);
+                     h->d_counters, h->d_status, h->d_uni, SCONE_UNI_CAP);
   SCONE_HIP(h, hipGetLastError());
   return SCONE_OK;
 }

@@ -48,7 +48,7 @@ def parse():
     ap.add_argument("--placement", default="hbm", choices=["hbm", "pinned_host"])
     ap.add_argument("--table-mode", default="replicated", choices=["replicated", "sharded"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
 
 
@@ -84,25 +84,24 @@ def cpu_baseline(args, keys, lens, tok, seed, base_scale, gpu_out, wte, wpe):
             for i, r in zip(ids.tolist(), deq):
                 cache.embeddings[i] = r
 
-    seqs = [tok[b].tolist() for b in range(min(tok.shape[0], 96))]
-    # probe: 2 sequences to size the sample for ~cpu_seconds of work
-    load_rows(seqs[:2])
-    t0 = time.perf_counter()
+    seqs = [tok[b].tolist() for b in range(min(tok.shape[0], 128))]
+    load_rows(seqs)                       # host copies of the rows the sample touches (not timed)
     first = R.aggregate(cache, seqs[0], d)
-    R.aggregate(cache, seqs[1], d)
-    per_seq = (time.perf_counter() - t0) / 2
-    nseq = int(max(2, min(len(seqs), args.cpu_seconds / max(per_seq, 1e-6))))
-    load_rows(seqs[:nseq])
+    # whole passes over the sample until ~cpu_seconds of CPU work have been timed
+    done, dt = 0, 0.0
     t0 = time.perf_counter()
-    for s in seqs[:nseq]:
-        R.aggregate(cache, s, d)
-    dt = time.perf_counter() - t0
+    while dt < args.cpu_seconds:
+        for s in seqs:
+            R.aggregate(cache, s, d)
+        done += len(seqs)
+        dt = time.perf_counter() - t0
+    nseq = done
     # parity spot check of the GPU output (first sequence) against the oracle
     ref = R.combine(torch.from_numpy(tok[:1]), first, wte.float().cpu(), wpe.float().cpu()).numpy()
     err = float(np.abs(gpu_out[:1].float().cpu().numpy() - ref).max() / np.abs(ref).max())
     return {
         "value": nseq * tok.shape[1] / dt, "unit": "tokens/s", "cores": 1, "kind": "port",
-        "sample": f"{nseq} sequences x {tok.shape[1]} tokens of the same stream "
+        "sample": f"{nseq} sequences x {tok.shape[1]} tokens ({len(seqs)} distinct sequences of the same stream, repeated) "
                   f"({dt:.1f} s; oracle/ref_port.py aggregate(), python {sys.version_info.major}.{sys.version_info.minor}, "
                   f"torch {torch.__version__}, host cpus {os.cpu_count()})",
         "gpu_vs_oracle_max_rel_err_seq0": err,
@@ -222,7 +221,7 @@ def main():
             "scaling": "strong" if sharded else "weak", "vs_baseline": None,
             "dtype": {"int8": "i8->f32 accumulate, f16 out", "int4": "i4->f32 accumulate, f16 out",
                       "fp16": "f16->f32 accumulate, f16 out", "fp32": "f32, f16 out"}[args.format],
-            "data": "synthetic",
+            "data": "synthetic", "workload_sig": sig,
             "config": {
                 "workload": f"{N}-row {args.format} f-gram table d={d} max_n={max_n} vocab={vocab} in "
                             f"{'HBM' if args.placement == 'hbm' else 'pinned host DRAM'}; S_{args.stream} stream, "

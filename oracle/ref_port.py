@@ -99,17 +99,21 @@ class RefCache:
             for f_gram_id, embedding in zip(f_gram_ids, embeddings):
                 self.embeddings[f_gram_id] = embedding.cpu().numpy()
 
-    def get_embeddings(self, f_gram_ids: Sequence[int]) -> torch.Tensor:
-        """embedding_cache.py:113-147 (device move omitted: CPU oracle)."""
+    def get_embeddings(self, f_gram_ids: Sequence[int], device: Optional[torch.device] = None) -> torch.Tensor:
+        """embedding_cache.py:113-147."""
         if self.use_memory_map:
             if self.memory_mapped_embeddings is None:
                 raise ValueError("Memory-mapped embeddings not initialized")
-            return torch.tensor(self.memory_mapped_embeddings[list(f_gram_ids)],
-                                dtype=torch.float32)
-        return torch.stack([
-            torch.tensor(self.embeddings[f_gram_id], dtype=torch.float32)
-            for f_gram_id in f_gram_ids
-        ])
+            embeddings = torch.tensor(self.memory_mapped_embeddings[list(f_gram_ids)],
+                                      dtype=torch.float32)
+        else:
+            embeddings = torch.stack([
+                torch.tensor(self.embeddings[f_gram_id], dtype=torch.float32)
+                for f_gram_id in f_gram_ids
+            ])
+        if device is not None:                                       # :144-145
+            embeddings = embeddings.to(device)
+        return embeddings
 
     def get_token_embeddings(self, token_ids: Sequence[int]) -> Dict[int, torch.Tensor]:
         """embedding_cache.py:149-181: positions with no f-gram are omitted (:169-170)."""
@@ -124,17 +128,19 @@ class RefCache:
 
 
 def aggregate(cache: RefCache, token_ids: Sequence[int], hidden_size: int,
-              half: bool = False) -> torch.Tensor:
-    """engine.py:234-266: mean over the K_t rows, zeros where K_t = 0, optional .half()."""
+              half: bool = False, device: torch.device = torch.device("cpu")) -> torch.Tensor:
+    """engine.py:234-266: mean over the K_t rows, zeros where K_t = 0, optional .half().
+    ``device`` plays engine.device (the CPU here), so the per-position ``.to(device)`` of
+    embedding_cache.py:144-145 is executed as in the reference."""
     token_f_grams = get_token_f_grams(cache.f_grams, cache.max_n, token_ids)
     token_embeddings = {}
     for pos, f_grams in token_f_grams.items():
         if not f_grams:
             continue
         f_gram_ids = [cache.f_gram_to_id[g] for g in f_grams]
-        embeddings = cache.get_embeddings(f_gram_ids)
+        embeddings = cache.get_embeddings(f_gram_ids, device)      # engine.py:247
         token_embeddings[pos] = embeddings.mean(dim=0)            # engine.py:250
-    f_gram_embeddings = torch.zeros((1, len(token_ids), hidden_size))  # :253-256
+    f_gram_embeddings = torch.zeros((1, len(token_ids), hidden_size), device=device)  # :253-256
     for pos, embedding in token_embeddings.items():
         f_gram_embeddings[0, pos] = embedding                        # :258-259
     if half:

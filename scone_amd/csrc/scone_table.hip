@@ -75,6 +75,14 @@ __global__ __launch_bounds__(256) void k_store_f32(const float *__restrict__ src
   }
 }
 
+// hipcc selects v_fma_mixlo_f16 for "convert(a * b)" even with -ffp-contract=off: one rounding of
+// the exact product instead of the two roundings (fp32, then fp16) the format is specified with.
+// Passing the fp32 product through this keeps the two steps apart.
+__device__ __forceinline__ float rounded_f32(float x) {
+  asm volatile("" : "+v"(x));
+  return x;
+}
+
 __device__ __forceinline__ uint32_t synth_row_base(uint32_t seed, unsigned long long g) {
   return scone_hash32((uint32_t)g + 0x9E3779B9u * (uint32_t)(g >> 32)) ^ seed;
 }
@@ -82,7 +90,7 @@ __device__ __forceinline__ uint32_t synth_row_base(uint32_t seed, unsigned long 
 __device__ __forceinline__ __half synth_scale(uint32_t seed, unsigned long long counter, float base_scale) {
   uint32_t hsh = scone_hash32(synth_row_base(seed, counter) + 0x51ED27u);
   float u = (float)(hsh >> 8) * (1.0f / 16777216.0f);
-  return __float2half_rn(base_scale * (0.5f + u));
+  return __float2half_rn(rounded_f32(base_scale * (0.5f + u)));
 }
 
 // One wave per row, one 4-byte hash word per lane per step.
@@ -112,7 +120,7 @@ __global__ __launch_bounds__(256) void k_fill_synth(unsigned long long row_begin
       reinterpret_cast<uint32_t *>(reinterpret_cast<int8_t *>(rows) + lr * d)[w] = word;
     } else {
       float v[4];
-      for (int k = 0; k < 4; ++k) v[k] = (float)(int8_t)(word >> (8 * k)) * sf;
+      for (int k = 0; k < 4; ++k) v[k] = rounded_f32((float)(int8_t)(word >> (8 * k)) * sf);
       if (FMT == SCONE_FMT_F32) {
         reinterpret_cast<float4 *>(reinterpret_cast<float *>(rows) + lr * d)[w] = make_float4(v[0], v[1], v[2], v[3]);
       } else {

@@ -1,0 +1,122 @@
+"""Row-sharded f-gram tables across GPUs (one process per GPU, ``torch.distributed``;
+backend "nccl" is RCCL over xGMI on ROCm).
+
+The reference keeps its table in one process (``embedding_cache.py:49-50``); sharding is new
+here and only needed when the table does not fit one GPU's 288 GB (BASELINE config C5:
+1e9 rows INT4 d=1024 = 528 GB).  Layout:
+
+* rows: contiguous id ranges, rank r owns ``[r*N/W, (r+1)*N/W)``;
+* index (f-gram -> id): replicated, so every rank matches the full batch locally and knows
+  every token's full hit count K_t -- no id exchange;
+* per step, every rank gathers + dequantises + sums only the rows it owns
+  (``scone_embed_partial``: fp32 ``[ntok, d]`` partial sums);
+* exchange: ``reduce_scatter`` (sum) over the token dimension -> each rank finalises its
+  ``ntok/W`` slice (``/ K_t``, ``+ wte``, ``+ wpe``, cast; ``scone_finalize``) ->
+  ``all_gather`` of the finished vectors, which travel in the output dtype (fp16 halves the
+  bytes on the wire).  xGMI is point-to-point: with both collectives every link carries only
+  its 1/W slice.
+
+Sequences are independent, so when the table DOES fit one GPU the path needs no collective
+at all: replicate the table and shard the tokens (bench.py's default at N > 1).
+"""
+
+from typing import Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+from scone_amd.tokenization.n_gram_extractor import NGramExtractor
+
+
+def shard_range(n_rows: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous row range owned by ``rank``: ``[rank*N//W, (rank+1)*N//W)``."""
+    return (rank * n_rows) // world, ((rank + 1) * n_rows) // world
+
+
+def owner_of(ids: torch.Tensor, n_rows: int, world: int) -> torch.Tensor:
+    """Rank owning each id under :func:`shard_range` (inverse of the floor partition)."""
+    return ((ids.to(torch.int64) + 1) * world - 1) // n_rows
+
+
+class ShardedEmbeddingCache:
+    """``EmbeddingCache.embed_tokens`` for a table whose rows are split over the ranks of ``group``.
+
+    ``table`` is this rank's device handle (``hip_backend.SconeTable`` created with
+    ``row_begin/row_end``); it is built here unless the caller supplies one (tests inject a
+    stand-in to exercise the exchange logic over gloo on CPU).
+    """
+
+    def __init__(self, n_gram_extractor: NGramExtractor, embedding_dim: int, *, table_format: str = "int8",
+                 rank: Optional[int] = None, world: Optional[int] = None, group=None, device=None,
+                 n_rows: Optional[int] = None, placement: str = "hbm", table=None) -> None:
+        self.group = group
+        self.rank = dist.get_rank(group) if rank is None else int(rank)
+        self.world = dist.get_world_size(group) if world is None else int(world)
+        self.n_gram_extractor = n_gram_extractor
+        self.embedding_dim = int(embedding_dim)
+        self.n_rows = int(len(n_gram_extractor) if n_rows is None else n_rows)
+        self.row_begin, self.row_end = shard_range(self.n_rows, self.rank, self.world)
+        if table is None:
+            from scone_amd.hip_backend import SconeTable
+            table = SconeTable(n_gram_extractor.max_n, self.n_rows, dim=self.embedding_dim, table_format=table_format,
+                               placement=placement, device=device, row_begin=self.row_begin, row_end=self.row_end)
+            n_gram_extractor.build_index(table)          # replicated index
+        self.table = table
+
+    @classmethod
+    def from_synthetic(cls, n_gram_extractor: NGramExtractor, embedding_dim: int, *, table_format: str = "int8",
+                       seed: int = 7, base_scale: float = 0.02 / 127, **kw) -> "ShardedEmbeddingCache":
+        """Every rank generates exactly its own rows on its GPU (counter-based, so the union equals
+        the single-GPU synthetic table)."""
+        self = cls(n_gram_extractor, embedding_dim, table_format=table_format, **kw)
+        self.table.fill_synthetic(seed, base_scale)
+        return self
+
+    def load_rows(self, rows_f32: torch.Tensor, row0: int) -> None:
+        """Store the part of ``rows_f32`` (global rows ``row0 ..``) that this rank owns."""
+        a = max(row0, self.row_begin)
+        b = min(row0 + rows_f32.shape[0], self.row_end)
+        if b > a:
+            self.table.store_f32(rows_f32[a - row0:b - row0], row0=a)
+
+    # ------------------------------------------------------------------
+    def embed_tokens(self, input_ids: torch.Tensor, *, reduce: str = "mean", wte: Optional[torch.Tensor] = None,
+                     wpe: Optional[torch.Tensor] = None, position_ids: Optional[torch.Tensor] = None,
+                     out_dtype: Optional[torch.dtype] = None, gather_output: bool = True) -> torch.Tensor:
+        """Same result as ``EmbeddingCache.embed_tokens`` on the unsharded table (up to the fp32
+        summation order across shards).  Every rank passes the SAME ``input_ids [B, T]``.
+
+        ``gather_output=False`` stops after the reduce-scatter + finalise and returns only this
+        rank's ``[ntok/W (padded), d]`` slice (for consumers that are themselves data-parallel
+        over tokens)."""
+        tok = torch.as_tensor(input_ids)
+        if tok.dim() == 1:
+            tok = tok.unsqueeze(0)
+        B, T = tok.shape
+        ntok, d, W = B * T, self.embedding_dim, self.world
+        if out_dtype is None:
+            out_dtype = wte.dtype if wte is not None else (wpe.dtype if wpe is not None else torch.float32)
+        partial, counts = self.table.embed_partial(tok)                      # [ntok, d] fp32, [ntok] int32
+        per = (ntok + W - 1) // W                                             # tokens per rank (last slices padded)
+        pad = per * W - ntok
+        if pad:
+            partial = torch.cat([partial, partial.new_zeros((pad, d))])
+        mine = torch.empty((per, d), dtype=torch.float32, device=partial.device)
+        if W > 1:
+            dist.reduce_scatter_tensor(mine, partial, op=dist.ReduceOp.SUM, group=self.group)
+        else:
+            mine.copy_(partial[:per])
+        a = min(self.rank * per, ntok)
+        b = min(a + per, ntok)
+        out_slice = torch.zeros((per, d), dtype=out_dtype, device=partial.device)
+        if b > a:
+            out_slice[:b - a] = self.table.finalize(mine[:b - a], counts[a:b], tok, a, b, wte=wte, wpe=wpe,
+                                                    position_ids=position_ids, reduce=reduce, out_dtype=out_dtype)
+        if not gather_output:
+            return out_slice
+        if W > 1:
+            full = torch.empty((per * W, d), dtype=out_dtype, device=partial.device)
+            dist.all_gather_into_tensor(full, out_slice, group=self.group)
+        else:
+            full = out_slice
+        return full[:ntok].reshape(B, T, d)

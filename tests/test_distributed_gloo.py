@@ -1,0 +1,133 @@
+"""CPU, world_size 2, gloo: the row-sharded exchange (reduce-scatter of partial sums ->
+finalise 1/W of the tokens -> all-gather) against the single-table oracle.  The device
+handle is replaced by an oracle-backed stand-in (test infrastructure) so that the host
+logic -- shard ranges, padding, slice bookkeeping, collective pattern -- runs here."""
+
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+class OracleShard:
+    """Stand-in for hip_backend.SconeTable on a shard: same embed_partial / finalize contract,
+    computed with oracle/ref_port.py."""
+
+    def __init__(self, keys, lens, max_n, table, row_begin, row_end):
+        from oracle import ref_port as R
+        self.R, self.keys, self.lens, self.max_n = R, keys, lens, max_n
+        self.table, self.row_begin, self.row_end = table, row_begin, row_end
+        self.n_rows, self.dim = table.shape[0], table.shape[1]
+
+    def embed_partial(self, tok):
+        R = self.R
+        t = tok.numpy()
+        off, ids = R.hits_to_csr(R.match_hits(self.keys, self.lens, t, self.max_n))
+        counts = np.diff(off).astype(np.int32)
+        owned = (ids >= self.row_begin) & (ids < self.row_end)
+        # drop the ids of other shards, keep order
+        seg = np.repeat(np.arange(len(counts)), counts)
+        off_own = np.zeros(len(counts) + 1, dtype=np.int64)
+        np.cumsum(np.bincount(seg[owned], minlength=len(counts)), out=off_own[1:])
+        partial = R.embed_numpy(self.table, off_own, ids[owned], "sum")
+        return torch.from_numpy(partial), torch.from_numpy(counts)
+
+    def finalize(self, sums, counts, tok, a, b, wte=None, wpe=None, position_ids=None, reduce="mean",
+                 out_dtype=torch.float32):
+        x = sums.clone()
+        if reduce == "mean":
+            k = counts.to(torch.float32).clamp(min=1).unsqueeze(1)
+            x = torch.where(counts.unsqueeze(1) > 1, x / k, x)
+        B, T = tok.shape
+        flat = tok.reshape(-1)[a:b].long()
+        if wte is not None:
+            x = wte.float()[flat] + x
+        if wpe is not None:
+            pos = (torch.arange(B * T) % T)[a:b] if position_ids is None else position_ids.reshape(-1)[a:b].long()
+            x = x + wpe.float()[pos]
+        return x.to(out_dtype)
+
+
+def _worker(rank, world, port, ntok_shape, out_dtype_name, q):
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from oracle import ref_port as R
+        from scone_amd import NGramExtractor
+        from scone_amd.distributed import ShardedEmbeddingCache, shard_range
+        rng = np.random.default_rng(42)
+        vocab, n, d, max_n = 19, 301, 32, 3
+        lens = rng.integers(1, max_n + 1, size=n).astype(np.uint8)
+        keys = rng.integers(0, vocab, size=(n, max_n)).astype(np.uint32)
+        keys[np.arange(max_n)[None, :] >= lens[:, None]] = 0
+        table = rng.standard_normal((n, d)).astype(np.float32)
+        B, T = ntok_shape
+        tok = torch.from_numpy(rng.integers(0, vocab, size=(B, T)))
+        wte = torch.from_numpy(rng.standard_normal((vocab, d)).astype(np.float32))
+        wpe = torch.from_numpy(rng.standard_normal((T, d)).astype(np.float32))
+        out_dtype = getattr(torch, out_dtype_name)
+        ex = NGramExtractor.from_arrays(keys, lens, max_n=max_n)
+        a, b = shard_range(n, rank, world)
+        cache = ShardedEmbeddingCache(ex, d, rank=rank, world=world, n_rows=n,
+                                      table=OracleShard(keys, lens, max_n, table, a, b))
+        assert (cache.row_begin, cache.row_end) == (a, b)
+        out = cache.embed_tokens(tok, wte=wte.to(out_dtype), wpe=wpe.to(out_dtype), out_dtype=out_dtype)
+        ro, ri = R.hits_to_csr(R.match_hits(keys, lens, tok.numpy(), max_n))
+        fg = torch.from_numpy(R.embed_numpy(table, ro, ri, "mean").reshape(B, T, d))
+        ref = R.combine(tok, fg, wte.to(out_dtype).float(), wpe.to(out_dtype).float())
+        err = float((out.float() - ref).abs().max() / ref.abs().max())
+        # the slice-only form returns this rank's finished tokens
+        sl = cache.embed_tokens(tok, wte=wte.to(out_dtype), wpe=wpe.to(out_dtype), out_dtype=out_dtype,
+                                gather_output=False)
+        per = (B * T + world - 1) // world
+        lo, hi = min(rank * per, B * T), min(rank * per + per, B * T)
+        ok_slice = torch.equal(sl[:hi - lo], out.reshape(-1, d)[lo:hi])
+        q.put((rank, err, tuple(out.shape), ok_slice))
+        dist.destroy_process_group()
+    except Exception as e:      # surface the failure in the parent
+        q.put((rank, repr(e), None, False))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("shape,dtype", [((3, 17), "float32"), ((2, 8), "float16"), ((1, 5), "float32")])
+def test_sharded_exchange_world2_gloo(shape, dtype):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, shape, dtype, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, err, out_shape, ok_slice in results:
+        assert isinstance(err, float), f"rank {rank} failed: {err}"
+        assert out_shape == (shape[0], shape[1], 32)
+        assert err < (1e-6 if dtype == "float32" else 2e-3), (rank, err)
+        assert ok_slice
+
+
+def test_shard_ranges_partition_and_owner():
+    from scone_amd.distributed import owner_of, shard_range
+    for n, w in ((10, 3), (1_000_000, 8), (7, 8), (1, 2), (1000, 1)):
+        rs = [shard_range(n, r, w) for r in range(w)]
+        assert rs[0][0] == 0 and rs[-1][1] == n
+        assert all(rs[r][1] == rs[r + 1][0] for r in range(w - 1))
+        ids = torch.arange(n)
+        own = owner_of(ids, n, w)
+        for r, (a, b) in enumerate(rs):
+            assert torch.all(own[a:b] == r)

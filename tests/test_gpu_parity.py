@@ -380,3 +380,74 @@ def test_synthetic_table_matches_host_generator(fmt):
     if fmt == "fp16":
         expect = expect.astype(np.float16).astype(np.float32)
     assert np.array_equal(got, expect)
+
+
+def test_sharded_cache_world1_equals_plain_cache():
+    """ShardedEmbeddingCache on one rank (no collective) goes through embed_partial + finalize."""
+    from scone_amd import EmbeddingCache
+    from scone_amd.distributed import ShardedEmbeddingCache
+    rng = np.random.default_rng(8)
+    vocab, n, d = 37, 800, 1024
+    lens = rng.integers(1, 4, size=n).astype(np.uint8)
+    keys = rng.integers(0, vocab, size=(n, 3)).astype(np.uint32)
+    keys[np.arange(3)[None, :] >= lens[:, None]] = 0
+    ex = _extractor(keys, lens, 3)
+    plain = EmbeddingCache.from_synthetic(ex, d, table_format="int8", seed=3)
+    sharded = ShardedEmbeddingCache.from_synthetic(ex, d, table_format="int8", seed=3, rank=0, world=1)
+    tok = torch.from_numpy(rng.integers(0, vocab, size=(3, 41)))
+    wte = torch.from_numpy(rng.standard_normal((vocab, d)).astype(np.float32)).half().cuda()
+    wpe = torch.from_numpy(rng.standard_normal((41, d)).astype(np.float32)).half().cuda()
+    a = plain.embed_tokens(tok, wte=wte, wpe=wpe)
+    b = sharded.embed_tokens(tok, wte=wte, wpe=wpe)
+    assert torch.equal(a, b)
+
+
+# ------------------------------------------------------------------ BASELINE.json full size
+@pytest.mark.parametrize("fmt,d,n_rows", [("int8", 768, 1_000_000), ("fp16", 768, 1_000_000), ("int4", 1024, 1_000_000)])
+def test_full_size_table_spot_check_vs_oracle(fmt, d, n_rows):
+    """Headline-size table (1M rows, synthetic on the GPU): ids bit-exact and embeddings within
+    1e-3 rel against the oracle, which recomputes only the referenced rows from the counter-based
+    generator; plus size-independent properties (sum == K * mean, determinism)."""
+    from scone_amd import EmbeddingCache
+    from scone_amd import synthetic as S
+    keys, lens = S.make_keys(n_rows, S.GPT2_VOCAB, 3, seed=11)
+    ex = _extractor(keys, lens, 3)
+    cache = EmbeddingCache.from_synthetic(ex, d, table_format=fmt, seed=7, base_scale=0.02 / 127)
+    nk, cap, dups = cache.table.index_stats()
+    assert nk == n_rows and dups == 0
+    B, T = 16, 512
+    tok_np = np.concatenate([S.stream_uniform_ids(keys, lens, B // 2, T, 99), S.stream_zipf(S.GPT2_VOCAB, B // 2, T, 98)])
+    tok = torch.from_numpy(tok_np)
+    off, ids = cache.match(tok)
+    ro, ri = R.hits_to_csr(R.match_hits(keys, lens, tok_np, 3))
+    assert np.array_equal(off.cpu().numpy(), ro) and np.array_equal(ids.cpu().numpy(), ri)
+    # oracle table restricted to the referenced rows
+    uniq, inv = np.unique(ri, return_inverse=True)
+    if fmt == "int4":
+        rows = cache.table.gather_rows(torch.from_numpy(uniq)).cpu().numpy()      # generator twin exists for i8 only
+        words = R.hash32((R.hash32(uniq.astype(np.uint32)) ^ np.uint32(7))[:, None] + np.arange(d // 8, dtype=np.uint32)[None, :])
+        nib = words.view(np.uint8).reshape(len(uniq), d // 2)
+        q = np.empty((len(uniq), d), dtype=np.float32)
+        q[:, 0::2], q[:, 1::2] = (nib & 0xF).astype(np.float32) - 8, (nib >> 4).astype(np.float32) - 8
+        ng = d // 128
+        sc = R.synth_scale_f16(7, (uniq[:, None] * ng + np.arange(ng)[None, :]).reshape(-1), 0.02 / 127).astype(np.float32)
+        expect = q * np.repeat(sc.reshape(len(uniq), ng), 128, axis=1)
+        assert np.array_equal(rows, expect)
+    else:
+        expect = R.synth_rows_i8(7, uniq, d).astype(np.float32) * R.synth_scale_f16(7, uniq, 0.02 / 127).astype(np.float32)[:, None]
+        if fmt == "fp16":
+            expect = expect.astype(np.float16).astype(np.float32)
+    ref = R.embed_numpy(expect, ro, inv, "mean").reshape(B, T, d)
+    out = cache.embed_tokens(tok, out_dtype=torch.float32)
+    assert np.array_equal(out.cpu().numpy(), ref)
+    g = torch.Generator().manual_seed(1)
+    wte = (torch.randn(S.GPT2_VOCAB, d, generator=g) * 0.02).half().cuda()
+    wpe = (torch.randn(T, d, generator=g) * 0.01).half().cuda()
+    fused = cache.embed_tokens(tok, wte=wte, wpe=wpe, check=True)
+    want = R.combine(tok, torch.from_numpy(ref), wte.float().cpu(), wpe.float().cpu()).numpy()
+    assert _rel(fused.float().cpu().numpy(), want) < REL_TOL
+    # properties: sum == K * mean (within fp32 rounding); repeat run identical
+    s = cache.embed_tokens(tok, reduce="sum", out_dtype=torch.float32).cpu().numpy().reshape(B * T, d)
+    k = np.diff(ro).astype(np.float32)[:, None]
+    np.testing.assert_allclose(s, ref.reshape(B * T, d) * np.maximum(k, 1), rtol=2e-6, atol=1e-9)
+    assert torch.equal(fused, cache.embed_tokens(tok, wte=wte, wpe=wpe))

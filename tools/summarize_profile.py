@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Turn gpurun_out/<tag>/ (tools/profile_round.sh) into the committed summary profiles/<tag>/:
+kernel_stats.csv (rocprofv3 --kernel-trace --stats), pmc_summary.json (per-kernel counter means),
+bench.json, and an entry in profiles/hbm_traffic.json that bench.py reads for `roofline.traffic`.
+
+HBM bytes per launch of the gather kernel = 2 * FETCH_SIZE + WRITE_SIZE (KB -> bytes):
+MI355X_MICROARCH.md section HBM -- on gfx950 FETCH_SIZE tallies 128-B read requests at 64 B,
+WRITE_SIZE is exact; Infinity-Cache hits are included (memory-side counters)."""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def main(tag):
+    src = os.path.join(ROOT, "gpurun_out", tag)
+    dst = os.path.join(ROOT, "profiles", tag)
+    os.makedirs(dst, exist_ok=True)
+    shutil.copy(os.path.join(src, "kernel_stats.csv"), os.path.join(dst, "kernel_stats.csv"))
+    bench = json.loads(open(os.path.join(src, "bench.json")).read().strip().splitlines()[-1])
+    json.dump(bench, open(os.path.join(dst, "bench.json"), "w"), indent=1)
+    out = {}
+    for d in sorted(glob.glob(os.path.join(src, "pmc_*/"))):
+        f = glob.glob(d + "*/*counter_collection.csv")
+        if not f:
+            continue
+        agg = collections.defaultdict(list)
+        for r in csv.DictReader(open(f[0])):
+            k = r["Kernel_Name"]
+            short = next((s for s in ("k_embed_wave", "k_embed", "k_match_ell", "k_match") if s in k), None)
+            if short:
+                agg[(short, r["Counter_Name"])].append(float(r["Counter_Value"]))
+        for (k, c), v in agg.items():
+            out.setdefault(k, {})[c] = sum(v) / len(v)
+    json.dump(out, open(os.path.join(dst, "pmc_summary.json"), "w"), indent=1, sort_keys=True)
+    kern = "k_embed_wave" if "k_embed_wave" in out else "k_embed"
+    if kern in out and "FETCH_SIZE" in out[kern] and "WRITE_SIZE" in out[kern]:
+        fetch_kb, write_kb = out[kern]["FETCH_SIZE"], out[kern]["WRITE_SIZE"]
+        entry = {
+            "workload_sig": bench.get("workload_sig"),
+            "hbm_bytes_per_launch": int((2 * fetch_kb + write_kb) * 1024),
+            "fetch_size_kb_raw": fetch_kb, "write_size_kb": write_kb,
+            "source": f"profiles/{tag}/pmc_summary.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), "
+                      f"{kern}; 2*FETCH_SIZE + WRITE_SIZE per the gfx950 correction",
+        }
+        p = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        entries = json.load(open(p)) if os.path.exists(p) else []
+        entries = [e for e in entries if e.get("workload_sig") != entry["workload_sig"]] + [entry]
+        json.dump(entries, open(p, "w"), indent=1)
+        print("traffic entry:", entry)
+    print("wrote", dst)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])

@@ -115,11 +115,25 @@ __device__ __forceinline__ void acc_words(float (&acc)[EPL], const uint32_t (&w)
   }
 }
 
+// Lane <-> element map.  A row is cut into segments of 512 elements; inside a segment lane l owns
+// 8 consecutive elements (4 in a trailing 256-element segment).  With this map every wave
+// instruction -- INT8 row loads (8 or 4 B/lane), fp16 wte / wpe loads and output stores
+// (16 or 8 B/lane) -- covers a CONTIGUOUS run of bytes, so every 64-B sector it touches is
+// touched whole (a plain "12 consecutive elements per lane" map makes each fp16 access
+// 16-of-every-24 bytes: two partial writes per sector).
 template <int FMT, int D> struct wave_geom {
   static constexpr int EPL = D / 64;  // elements per lane
-  static constexpr int ROW_BYTES = FMT == SCONE_FMT_F32 ? 4 * D : FMT == SCONE_FMT_F16 ? 2 * D : FMT == SCONE_FMT_I8 ? D : D / 2;
+  static constexpr int NSEG = (D + 511) / 512;
+  static constexpr int BPE4 = FMT == SCONE_FMT_F32 ? 16 : FMT == SCONE_FMT_F16 ? 8 : FMT == SCONE_FMT_I8 ? 4 : 2;  // bytes per 4 elements
+  static constexpr int ROW_BYTES = D / 4 * BPE4;
   static constexpr int NBR = ROW_BYTES / 64;  // row bytes per lane
-  static constexpr bool OK = (D % 64 == 0) && (NBR % 4 == 0) && (FMT != SCONE_FMT_I4 || (SCONE_I4_GROUP % EPL == 0));
+  static constexpr int seg_elems(int s) { return ((D - 512 * s) >= 512 ? 512 : (D - 512 * s)) / 64; }  // per lane
+  static constexpr int seg_first(int s) { return 512 * s; }                                            // first element
+  static constexpr int seg_acc(int s) { return 8 * s; }                                                // index into acc[]
+  static constexpr int seg_row_words(int s) { return seg_elems(s) * BPE4 / 16; }
+  static constexpr int seg_row_word0(int s) { return 8 * s * BPE4 / 16; }
+  static constexpr bool OK = (D % 64 == 0) && (D <= 1024) && (seg_elems(NSEG - 1) * BPE4 % 16 == 0) &&
+                             (FMT != SCONE_FMT_I4 || SCONE_I4_GROUP % 8 == 0);
 };
 
 // waves per SIMD to ask of the register allocator: rows in flight (NC x NBR/4) + wte/wpe/out words +
@@ -136,6 +150,43 @@ template <int FMT, typename OutT, int D, int MAXN, bool FIXED_POS> struct wave_o
   static constexpr int WAVES = 512 / ALLOC >= 8 ? 8 : (512 / ALLOC < 1 ? 1 : 512 / ALLOC);
 };
 
+// words of an OutT vector (wte / wpe / out row) owned by this lane, segment by segment
+template <int FMT, typename OutT, int D>
+__device__ __forceinline__ void ld_out_row(const uint8_t *__restrict__ row, uint32_t lane,
+                                           uint32_t (&w)[wave_geom<FMT, D>::EPL * (int)sizeof(OutT) / 4]) {
+  using G = wave_geom<FMT, D>;
+#pragma unroll
+  for (int s = 0; s < G::NSEG; ++s) {
+    constexpr int dummy = 0;
+    (void)dummy;
+    const int nw = G::seg_elems(s) * (int)sizeof(OutT) / 4;
+    const uint32_t *p = reinterpret_cast<const uint32_t *>(row + G::seg_first(s) * (int)sizeof(OutT) +
+                                                            lane * (uint32_t)(G::seg_elems(s) * (int)sizeof(OutT)));
+#pragma unroll
+    for (int i = 0; i < nw; ++i) w[G::seg_acc(s) * (int)sizeof(OutT) / 4 + i] = p[i];
+  }
+}
+
+template <int FMT, typename OutT, int D>
+__device__ __forceinline__ void st_out_row(uint8_t *__restrict__ row, uint32_t lane,
+                                           const uint32_t (&w)[wave_geom<FMT, D>::EPL * (int)sizeof(OutT) / 4]) {
+  using G = wave_geom<FMT, D>;
+#pragma unroll
+  for (int s = 0; s < G::NSEG; ++s) {
+    const int nw = G::seg_elems(s) * (int)sizeof(OutT) / 4;
+    uint32_t *p = reinterpret_cast<uint32_t *>(row + G::seg_first(s) * (int)sizeof(OutT) +
+                                               lane * (uint32_t)(G::seg_elems(s) * (int)sizeof(OutT)));
+#pragma unroll
+    for (int i = 0; i < nw; ++i) {
+#ifndef SCONE_PLAIN_STORE
+      __builtin_nontemporal_store(w[G::seg_acc(s) * (int)sizeof(OutT) / 4 + i], p + i);  // write-once output
+#else
+      p[i] = w[G::seg_acc(s) * (int)sizeof(OutT) / 4 + i];
+#endif
+    }
+  }
+}
+
 // One token with exactly K owned rows: straight-line code, every load unconditional and
 // issued before the first use (the K-way switch in the kernel keeps K a compile-time constant,
 // so the row registers are plain scalars and the waits are exact vmcnt counts).
@@ -146,33 +197,39 @@ __device__ __forceinline__ void embed_token(const uint8_t *__restrict__ rows, co
                                             const uint32_t (&wpe_words)[wave_geom<FMT, D>::EPL * (int)sizeof(OutT) / 4],
                                             uint8_t *__restrict__ out_row, uint32_t lane) {
   using G = wave_geom<FMT, D>;
-  constexpr int EPL = G::EPL, NBR = G::NBR, NWR = NBR / 4;
-  constexpr int NBO = EPL * (int)sizeof(OutT), NWO = NBO / 4;
+  constexpr int EPL = G::EPL, NWR = G::NBR / 4, NSEG = G::NSEG;
+  constexpr int NWO = EPL * (int)sizeof(OutT) / 4;
   constexpr int OPW = pack_io<OutT>::PER_WORD;
   constexpr int KK = K > 0 ? K : 1;
-  const uint32_t row_off = lane * NBR;
-  const uint32_t out_off = lane * NBO;
 
   uint32_t bw[NWO], bp[NWO];
-  ld_words<NWO>(wte_row, out_off, bw);
+  ld_out_row<FMT, OutT, D>(wte_row, lane, bw);
   if constexpr (FIXED_POS) {
 #pragma unroll
     for (int w = 0; w < NWO; ++w) bp[w] = wpe_words[w];  // this wave's position row, loaded once
   } else {
-    ld_words<NWO>(wpe_row, out_off, bp);
+    ld_out_row<FMT, OutT, D>(wpe_row, lane, bp);
   }
   uint32_t raw[KK][NWR];
-  uint32_t scw[KK];
+  uint32_t scw[KK][NSEG];
 #pragma unroll
   for (int k = 0; k < K; ++k) {
     const long long lr = (long long)rec[k] - row_begin;
-    ld_words<NWR>(rows + lr * G::ROW_BYTES, row_off, raw[k]);
-    if constexpr (FMT == SCONE_FMT_I8) {
-      scw[k] = reinterpret_cast<const uint32_t *>(scales_v)[lr >> 1];  // two half scales per word (scalar load)
-    } else if constexpr (FMT == SCONE_FMT_I4) {
-      scw[k] = reinterpret_cast<const unsigned short *>(scales_v)[lr * (D / SCONE_I4_GROUP) + (lane * EPL) / SCONE_I4_GROUP];
-    } else {
-      scw[k] = 0;
+    const uint8_t *rp = rows + lr * G::ROW_BYTES;
+#pragma unroll
+    for (int s = 0; s < NSEG; ++s) {
+      const uint32_t *p = reinterpret_cast<const uint32_t *>(rp + G::seg_first(s) / 4 * G::BPE4 +
+                                                              lane * (uint32_t)(G::seg_elems(s) * G::BPE4 / 4));
+#pragma unroll
+      for (int i = 0; i < G::seg_row_words(s); ++i) raw[k][G::seg_row_word0(s) + i] = p[i];
+      if constexpr (FMT == SCONE_FMT_I8) {
+        scw[k][s] = s == 0 ? reinterpret_cast<const uint32_t *>(scales_v)[lr >> 1] : 0u;  // two half scales per word (scalar load)
+      } else if constexpr (FMT == SCONE_FMT_I4) {
+        scw[k][s] = reinterpret_cast<const unsigned short *>(scales_v)[lr * (D / SCONE_I4_GROUP) +
+                                                                       (G::seg_first(s) + lane * G::seg_elems(s)) / SCONE_I4_GROUP];
+      } else {
+        scw[k][s] = 0;
+      }
     }
   }
 
@@ -181,14 +238,39 @@ __device__ __forceinline__ void embed_token(const uint8_t *__restrict__ rows, co
   for (int e = 0; e < EPL; ++e) acc[e] = 0.f;
 #pragma unroll
   for (int k = 0; k < K; ++k) {
-    float sc = 1.0f;
+    float sc0 = 1.0f;
     if constexpr (FMT == SCONE_FMT_I8) {
       const long long lr = (long long)rec[k] - row_begin;
-      sc = __half2float(__ushort_as_half((unsigned short)((lr & 1) ? (scw[k] >> 16) : (scw[k] & 0xFFFFu))));
-    } else if constexpr (FMT == SCONE_FMT_I4) {
-      sc = __half2float(__ushort_as_half((unsigned short)scw[k]));
+      sc0 = __half2float(__ushort_as_half((unsigned short)((lr & 1) ? (scw[k][0] >> 16) : (scw[k][0] & 0xFFFFu))));
     }
-    acc_words<FMT, EPL, NWR>(acc, raw[k], sc);
+#pragma unroll
+    for (int s = 0; s < NSEG; ++s) {
+      float sc = sc0;
+      if constexpr (FMT == SCONE_FMT_I4) sc = __half2float(__ushort_as_half((unsigned short)scw[k][s]));
+      // acc[seg_acc(s) ..] += dequant(raw[k][seg words]); exact products, list order (see accumulate<>)
+#pragma unroll
+      for (int i = 0; i < G::seg_row_words(s); ++i) {
+        const uint32_t w = raw[k][G::seg_row_word0(s) + i];
+        if constexpr (FMT == SCONE_FMT_F32) {
+          acc[G::seg_acc(s) + i] += __uint_as_float(w);
+        } else if constexpr (FMT == SCONE_FMT_F16) {
+          acc[G::seg_acc(s) + 2 * i] += __half2float(__ushort_as_half((unsigned short)(w & 0xFFFFu)));
+          acc[G::seg_acc(s) + 2 * i + 1] += __half2float(__ushort_as_half((unsigned short)(w >> 16)));
+        } else if constexpr (FMT == SCONE_FMT_I8) {
+#pragma unroll
+          for (int b = 0; b < 4; ++b) {
+            const int q = (int)(w << (24 - 8 * b)) >> 24;
+            acc[G::seg_acc(s) + 4 * i + b] = fmaf(sc, (float)q, acc[G::seg_acc(s) + 4 * i + b]);
+          }
+        } else {
+#pragma unroll
+          for (int b = 0; b < 8; ++b) {
+            const int q = (int)((w >> (4 * b)) & 0xFu) - 8;
+            acc[G::seg_acc(s) + 8 * i + b] = fmaf(sc, (float)q, acc[G::seg_acc(s) + 8 * i + b]);
+          }
+        }
+      }
+    }
   }
   if (reduce == SCONE_REDUCE_MEAN && kfull > 1) {
     // engine.py:250: sum / K.  Correctly rounded quotient without the full division sequence
@@ -212,7 +294,7 @@ __device__ __forceinline__ void embed_token(const uint8_t *__restrict__ rows, co
     for (int k = 0; k < OPW; ++k) v[k] = (b[k] + acc[w * OPW + k]) + c[k];  // language_model.py:242-243, :253-254
     ow[w] = pack_io<OutT>::pack(v);
   }
-  st_words<NWO>(out_row, out_off, ow);
+  st_out_row<FMT, OutT, D>(out_row, lane, ow);
 }
 
 // Work assignment: a workgroup's 4 waves own 4 CONSECUTIVE positions i0..i0+3 and walk the same
@@ -254,7 +336,7 @@ __global__ __launch_bounds__(256, (wave_occupancy<FMT, OutT, D, MAXN, FIXED_POS>
     const bool ok = wpe && (long long)i < q.n_pos;
     if (wpe && !ok && lane == 0) atomicOr(status, SCONE_ST_BAD_TOKEN);
     const uint8_t *r = ok ? reinterpret_cast<const uint8_t *>(wpe + (long long)i * D) : zero_row;
-    ld_words<NWO>(r, lane * (uint32_t)(NWO * 4), wpe_words);
+    ld_out_row<FMT, OutT, D>(r, lane, wpe_words);
   }
 
   int32_t rec[W];

@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--placement", default="hbm", choices=["hbm", "pinned_host"])
     ap.add_argument("--table-mode", default="replicated", choices=["replicated", "sharded"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="init torch.distributed even with one rank (tests the N>1 code path)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
 
@@ -133,9 +134,12 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no HIP device visible)")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
@@ -148,7 +152,7 @@ def main():
     keys, lens = S.make_keys(N, vocab, max_n, seed=11)
     ex = NGramExtractor.from_arrays(keys, lens, max_n=max_n)
 
-    sharded = args.table_mode == "sharded" and world > 1
+    sharded = args.table_mode == "sharded" and dist is not None
     if sharded:
         from scone_amd.distributed import ShardedEmbeddingCache
         cache = ShardedEmbeddingCache.from_synthetic(ex, d, table_format=args.format, seed=seed,
@@ -180,7 +184,10 @@ def main():
     del off, ids, counts
 
     def step():
-        cache.embed_tokens(tok, wte=wte, wpe=wpe, out=out)
+        if sharded:
+            cache.embed_tokens(tok, wte=wte, wpe=wpe)      # partial sums -> reduce-scatter -> finalise -> all-gather
+        else:
+            cache.embed_tokens(tok, wte=wte, wpe=wpe, out=out)
 
     def sync():
         torch.cuda.synchronize()
@@ -209,9 +216,11 @@ def main():
     value = units / dt
     res = None
     if rank == 0:
-        avg_ms = kern_ms / max(n_launch, 1)
+        # the sharded path launches other kernels (partial + finalise); without a timed launch fall
+        # back to the whole step so that the line stays well-formed
+        avg_ms = kern_ms / n_launch if n_launch else dt / args.steps * 1e3
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
-        sig = f"{args.format}-d{d}-N{N}-B{B}-T{T}-{args.stream}-{args.placement}"
+        sig = f"{args.format}-d{d}-N{N}-B{B}-T{T}-{args.stream}-{args.placement}" + ("-sharded" if sharded else "")
         tr = read_traffic(sig)
         res = {
             "metric": "f-gram embed tokens/sec (1M-row INT8 table @ d=768)" if (N, d, args.format) == (1_000_000, 768, "int8")
@@ -231,7 +240,8 @@ def main():
                                 else f"replicated table, tokens sharded over {world} rank(s), no collective"),
             },
             "roofline": {
-                "bound": "hbm", "kernel": "scone_gather::k_embed (gather+dequant+reduce+combine)",
+                "bound": "hbm", "kernel": ("scone_gather::k_embed_wave (gather+dequant+reduce+combine), HIP-event timed" if n_launch
+                                           else "whole step (sharded path: k_embed partial + RCCL + finalise)"),
                 "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                 "algorithmic_bytes_per_launch": bytes_per_launch, "avg_kernel_ms": avg_ms, "timed_launches": n_launch,
                 "traffic": None if tr is None else tr.get("hbm_bytes_per_launch"),
@@ -244,10 +254,19 @@ def main():
             except Exception as e:      # the baseline is reported, never the product
                 res["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": 1, "kind": "port",
                                        "sample": f"failed: {e!r}"}
+        # RCCL prints its version banner through C stdio; flush it first so that the JSON line is
+        # the last thing on stdout
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    sys.stdout.flush()
+    os._exit(0) if dist is not None else None   # skip RCCL's exit-time stdout chatter after the JSON line
 
 
 if __name__ == "__main__":

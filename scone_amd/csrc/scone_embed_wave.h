@@ -31,28 +31,6 @@ struct wave_params {
   int seqs_per_block;  // sequences walked by one workgroup
 };
 
-// NB bytes (multiple of 4) at base + off -> dwords; the backend merges these into
-// dwordx2/x3/x4 accesses (global memory only needs dword alignment).
-template <int NW>
-__device__ __forceinline__ void ld_words(const uint8_t *__restrict__ base, uint32_t off, uint32_t (&r)[NW]) {
-  const uint32_t *p = reinterpret_cast<const uint32_t *>(base + off);
-#pragma unroll
-  for (int i = 0; i < NW; ++i) r[i] = p[i];
-}
-
-template <int NW>
-__device__ __forceinline__ void st_words(uint8_t *__restrict__ base, uint32_t off, const uint32_t (&r)[NW]) {
-  uint32_t *p = reinterpret_cast<uint32_t *>(base + off);
-#pragma unroll
-  for (int i = 0; i < NW; ++i) {
-#ifndef SCONE_PLAIN_STORE
-    __builtin_nontemporal_store(r[i], p + i);  // write-once output: streaming stores (measured -8 % kernel time)
-#else
-    p[i] = r[i];
-#endif
-  }
-}
-
 template <typename T> struct pack_io;
 template <> struct pack_io<float> {
   static constexpr int PER_WORD = 1;
@@ -81,39 +59,6 @@ template <> struct pack_io<__hip_bfloat16> {
            ((uint32_t)(*reinterpret_cast<const unsigned short *>(&b)) << 16);
   }
 };
-
-// acc[0..EPL) += dequant(raw row words); exact products (see accumulate<> in scone_gather_impl.h)
-template <int FMT, int EPL, int NW>
-__device__ __forceinline__ void acc_words(float (&acc)[EPL], const uint32_t (&w)[NW], float scale) {
-  if constexpr (FMT == SCONE_FMT_F32) {
-#pragma unroll
-    for (int i = 0; i < NW; ++i) acc[i] += __uint_as_float(w[i]);
-  } else if constexpr (FMT == SCONE_FMT_F16) {
-#pragma unroll
-    for (int i = 0; i < NW; ++i) {
-      acc[2 * i] += __half2float(__ushort_as_half((unsigned short)(w[i] & 0xFFFFu)));
-      acc[2 * i + 1] += __half2float(__ushort_as_half((unsigned short)(w[i] >> 16)));
-    }
-  } else if constexpr (FMT == SCONE_FMT_I8) {
-#pragma unroll
-    for (int i = 0; i < NW; ++i) {
-#pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        const int q = (int)(w[i] << (24 - 8 * b)) >> 24;
-        acc[4 * i + b] = fmaf(scale, (float)q, acc[4 * i + b]);
-      }
-    }
-  } else {
-#pragma unroll
-    for (int i = 0; i < NW; ++i) {
-#pragma unroll
-      for (int b = 0; b < 8; ++b) {
-        const int q = (int)((w[i] >> (4 * b)) & 0xFu) - 8;
-        acc[8 * i + b] = fmaf(scale, (float)q, acc[8 * i + b]);
-      }
-    }
-  }
-}
 
 // Lane <-> element map.  A row is cut into segments of 512 elements; inside a segment lane l owns
 // 8 consecutive elements (4 in a trailing 256-element segment).  With this map every wave
@@ -167,7 +112,7 @@ __device__ __forceinline__ void ld_out_row(const uint8_t *__restrict__ row, uint
   }
 }
 
-template <int FMT, typename OutT, int D>
+template <int FMT, typename OutT, int D, bool STREAMING = true>
 __device__ __forceinline__ void st_out_row(uint8_t *__restrict__ row, uint32_t lane,
                                            const uint32_t (&w)[wave_geom<FMT, D>::EPL * (int)sizeof(OutT) / 4]) {
   using G = wave_geom<FMT, D>;
@@ -178,11 +123,10 @@ __device__ __forceinline__ void st_out_row(uint8_t *__restrict__ row, uint32_t l
                                                lane * (uint32_t)(G::seg_elems(s) * (int)sizeof(OutT)));
 #pragma unroll
     for (int i = 0; i < nw; ++i) {
-#ifndef SCONE_PLAIN_STORE
-      __builtin_nontemporal_store(w[G::seg_acc(s) * (int)sizeof(OutT) / 4 + i], p + i);  // write-once output
-#else
-      p[i] = w[G::seg_acc(s) * (int)sizeof(OutT) / 4 + i];
-#endif
+      if constexpr (STREAMING)
+        __builtin_nontemporal_store(w[G::seg_acc(s) * (int)sizeof(OutT) / 4 + i], p + i);  // write-once output
+      else
+        p[i] = w[G::seg_acc(s) * (int)sizeof(OutT) / 4 + i];
     }
   }
 }
@@ -190,7 +134,7 @@ __device__ __forceinline__ void st_out_row(uint8_t *__restrict__ row, uint32_t l
 // One token with exactly K owned rows: straight-line code, every load unconditional and
 // issued before the first use (the K-way switch in the kernel keeps K a compile-time constant,
 // so the row registers are plain scalars and the waits are exact vmcnt counts).
-template <int FMT, typename OutT, int D, int K, bool FIXED_POS>
+template <int FMT, typename OutT, int D, int K, bool FIXED_POS, bool PARTIAL>
 __device__ __forceinline__ void embed_token(const uint8_t *__restrict__ rows, const void *__restrict__ scales_v,
                                             const int32_t *__restrict__ rec, long long row_begin, int kfull, int reduce,
                                             const uint8_t *__restrict__ wte_row, const uint8_t *__restrict__ wpe_row,
@@ -203,8 +147,14 @@ __device__ __forceinline__ void embed_token(const uint8_t *__restrict__ rows, co
   constexpr int KK = K > 0 ? K : 1;
 
   uint32_t bw[NWO], bp[NWO];
-  ld_out_row<FMT, OutT, D>(wte_row, lane, bw);
-  if constexpr (FIXED_POS) {
+  if constexpr (PARTIAL) {
+#pragma unroll
+    for (int w = 0; w < NWO; ++w) bw[w] = bp[w] = 0u;
+  } else {
+    ld_out_row<FMT, OutT, D>(wte_row, lane, bw);
+  }
+  if constexpr (PARTIAL) {
+  } else if constexpr (FIXED_POS) {
 #pragma unroll
     for (int w = 0; w < NWO; ++w) bp[w] = wpe_words[w];  // this wave's position row, loaded once
   } else {
@@ -272,6 +222,15 @@ __device__ __forceinline__ void embed_token(const uint8_t *__restrict__ rows, co
       }
     }
   }
+  if constexpr (PARTIAL) {
+    // row-sharded tables: the fp32 sum over the rows THIS handle owns goes out as is (the other
+    // shards' sums are added by the reduce-scatter; scone_finalize divides and combines)
+    uint32_t pw[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) pw[e] = __float_as_uint(acc[e]);
+    st_out_row<FMT, float, D, false>(out_row, lane, pw);
+    return;
+  }
   if (reduce == SCONE_REDUCE_MEAN && kfull > 1) {
     // engine.py:250: sum / K.  Correctly rounded quotient without the full division sequence
     // (Markstein): y = RN(1/K); q0 = RN(x*y); r = x - q0*K (exact in an fma); q = RN(q0 + r*y).
@@ -302,12 +261,12 @@ __device__ __forceinline__ void embed_token(const uint8_t *__restrict__ rows, co
 // flight on one CU at the same time (the f-gram rows they share hit L1/L2), and with the
 // default position ids (arange(T), language_model.py:248-251) a wave's wpe row never changes:
 // FIXED_POS keeps it in registers, removing d*sizeof(OutT) bytes of L1/L2 traffic per token.
-template <int FMT, typename OutT, int D, int MAXN, bool FIXED_POS>
+template <int FMT, typename OutT, int D, int MAXN, bool FIXED_POS, bool PARTIAL = false>
 __global__ __launch_bounds__(256, (wave_occupancy<FMT, OutT, D, MAXN, FIXED_POS>::WAVES)) void k_embed_wave(
     const uint8_t *__restrict__ rows, const void *__restrict__ scales_v, const int32_t *__restrict__ ell,
     const int32_t *__restrict__ tok, const int32_t *__restrict__ pos, const OutT *__restrict__ wte,
     const OutT *__restrict__ wpe, const uint8_t *__restrict__ zero_row, OutT *__restrict__ out,
-    uint32_t *__restrict__ status, const wave_params q) {
+    int32_t *__restrict__ counts, uint32_t *__restrict__ status, const wave_params q) {
   constexpr int NC = MAXN * (MAXN + 1) / 2;
   constexpr int W = MAXN <= 3 ? 8 : 16;
   constexpr int NWO = wave_geom<FMT, D>::EPL * (int)sizeof(OutT) / 4;
@@ -359,6 +318,9 @@ __global__ __launch_bounds__(256, (wave_occupancy<FMT, OutT, D, MAXN, FIXED_POS>
     }
     uint8_t *out_row = reinterpret_cast<uint8_t *>(out + p * D);
     const int kown = rec[W - 2] & 0xFF, kfull = rec[W - 2] >> 8;
+    if constexpr (PARTIAL) {
+      if (lane == 0) counts[p] = kfull;
+    }
 
     // prefetch the record of this wave's next token (scalar loads, lgkmcnt -- not in the vmcnt queue)
     const long long pn = p + q.T;
@@ -374,8 +336,8 @@ __global__ __launch_bounds__(256, (wave_occupancy<FMT, OutT, D, MAXN, FIXED_POS>
 #define SCONE_CASE(K)                                                                                          \
   case K:                                                                                                      \
     if constexpr (K <= NC)                                                                                     \
-      embed_token<FMT, OutT, D, K, FIXED_POS>(rows, scales_v, rec, q.row_begin, kfull, q.reduce, wte_row, wpe_row, \
-                                              wpe_words, out_row, lane);                                       \
+      embed_token<FMT, OutT, D, K, FIXED_POS, PARTIAL>(rows, scales_v, rec, q.row_begin, kfull, q.reduce, wte_row, \
+                                                       wpe_row, wpe_words, out_row, lane);                     \
     break;
     switch (kown) {
       SCONE_CASE(0) SCONE_CASE(1) SCONE_CASE(2) SCONE_CASE(3) SCONE_CASE(4) SCONE_CASE(5) SCONE_CASE(6)
@@ -412,14 +374,99 @@ int launch_wave(scone_handle *h, const embed_args &a, hipStream_t s) {
   chunks = (q.B + q.seqs_per_block - 1) / q.seqs_per_block;
   const long long blocks = chunks * q.pos_groups;
   if (blocks > 0x7FFFFFFFll) return scone_fail(h, SCONE_EINVAL, "scone_embed: too many tokens for one launch");
+  if constexpr (std::is_same<OutT, float>::value) {
+    if (a.partial) {  // shard mode: fp32 partial sums + full hit counts
+      hipLaunchKernelGGL((k_embed_wave<FMT, float, D, MAXN, true, true>), dim3((unsigned)blocks), dim3(256), 0, s,
+                         a.tv.rows, (const void *)a.tv.scales, a.ell, a.tok, (const int32_t *)nullptr,
+                         (const float *)nullptr, (const float *)nullptr, (const uint8_t *)a.zero_row, a.partial,
+                         a.counts, a.status, q);
+      SCONE_HIP(h, hipGetLastError());
+      return SCONE_OK;
+    }
+  }
   if (a.pos)
     hipLaunchKernelGGL((k_embed_wave<FMT, OutT, D, MAXN, false>), dim3((unsigned)blocks), dim3(256), 0, s, a.tv.rows,
                        (const void *)a.tv.scales, a.ell, a.tok, a.pos, (const OutT *)a.wte, (const OutT *)a.wpe,
-                       (const uint8_t *)a.zero_row, (OutT *)a.out, a.status, q);
+                       (const uint8_t *)a.zero_row, (OutT *)a.out, (int32_t *)nullptr, a.status, q);
   else
     hipLaunchKernelGGL((k_embed_wave<FMT, OutT, D, MAXN, true>), dim3((unsigned)blocks), dim3(256), 0, s, a.tv.rows,
                        (const void *)a.tv.scales, a.ell, a.tok, a.pos, (const OutT *)a.wte, (const OutT *)a.wpe,
-                       (const uint8_t *)a.zero_row, (OutT *)a.out, a.status, q);
+                       (const uint8_t *)a.zero_row, (OutT *)a.out, (int32_t *)nullptr, a.status, q);
+  SCONE_HIP(h, hipGetLastError());
+  return SCONE_OK;
+}
+
+// Shard mode, second half: out[t] = cast((wte[tok] + sum[t] / K_t) + wpe[pos]) for the tokens of one
+// slice.  One wave per token, same lane map; sums are read once (fp32), output streamed.
+template <typename OutT, int D>
+__global__ __launch_bounds__(256) void k_finalize_wave(const float *__restrict__ sums, const int32_t *__restrict__ counts,
+                                                       const int32_t *__restrict__ tok, const int32_t *__restrict__ pos,
+                                                       const OutT *__restrict__ wte, const OutT *__restrict__ wpe,
+                                                       const uint8_t *__restrict__ zero_row, OutT *__restrict__ out,
+                                                       uint32_t *__restrict__ status, long long tok_begin, long long ntok,
+                                                       int T, long long vocab, long long n_pos, int reduce) {
+  constexpr int FMT = SCONE_FMT_F32;  // lane map of an fp32 row
+  using G = wave_geom<FMT, D>;
+  constexpr int EPL = G::EPL, NWO = EPL * (int)sizeof(OutT) / 4, OPW = pack_io<OutT>::PER_WORD;
+  const uint32_t lane = threadIdx.x & 63;
+  const long long nwaves = (long long)gridDim.x * (blockDim.x >> 6);
+  long long t = (long long)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  for (; t < ntok; t += nwaves) {
+    const long long p = tok_begin + t;
+    const int kfull = counts[t];
+    const int32_t tokv = wte ? tok[p] : 0;
+    const int32_t posv = wpe ? (pos ? pos[p] : (int32_t)(p % T)) : 0;
+    const bool tok_ok = wte && tokv >= 0 && (long long)tokv < vocab;
+    const bool pos_ok = wpe && posv >= 0 && (long long)posv < n_pos;
+    if ((wte && !tok_ok) || (wpe && !pos_ok)) {
+      if (lane == 0) atomicOr(status, SCONE_ST_BAD_TOKEN);
+    }
+    const uint8_t *wte_row = tok_ok ? reinterpret_cast<const uint8_t *>(wte + (long long)tokv * D) : zero_row;
+    const uint8_t *wpe_row = pos_ok ? reinterpret_cast<const uint8_t *>(wpe + (long long)posv * D) : zero_row;
+    uint32_t bw[NWO], bp[NWO], sw[EPL];
+    ld_out_row<FMT, OutT, D>(wte_row, lane, bw);
+    ld_out_row<FMT, OutT, D>(wpe_row, lane, bp);
+    ld_out_row<FMT, float, D>(reinterpret_cast<const uint8_t *>(sums + t * D), lane, sw);
+    float acc[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) acc[e] = __uint_as_float(sw[e]);
+    if (reduce == SCONE_REDUCE_MEAN && kfull > 1) {
+      const float kf = (float)kfull;
+      const float y = 1.0f / kf;
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) {  // correctly rounded x / K (see embed_token)
+        const float q0 = acc[e] * y;
+        const float r = fmaf(-kf, q0, acc[e]);
+        acc[e] = fmaf(r, y, q0);
+      }
+    }
+    uint32_t ow[NWO];
+#pragma unroll
+    for (int w = 0; w < NWO; ++w) {
+      float b[OPW], c[OPW], v[OPW];
+      pack_io<OutT>::unpack(bw[w], b);
+      pack_io<OutT>::unpack(bp[w], c);
+#pragma unroll
+      for (int k = 0; k < OPW; ++k) v[k] = (b[k] + acc[w * OPW + k]) + c[k];
+      ow[w] = pack_io<OutT>::pack(v);
+    }
+    st_out_row<FMT, OutT, D>(reinterpret_cast<uint8_t *>(out + t * D), lane, ow);
+  }
+}
+
+// returns -1 when d is not covered
+template <typename OutT>
+int try_launch_finalize_wave(scone_handle *h, const embed_args &a, hipStream_t s) {
+  if (a.tv.d != 768 && a.tv.d != 1024) return -1;
+  long long blocks = (a.ntok + 3) / 4;
+  if (blocks > 8192) blocks = 8192;
+#define SCONE_FIN(DD)                                                                                              \
+  hipLaunchKernelGGL((k_finalize_wave<OutT, DD>), dim3((unsigned)blocks), dim3(256), 0, s, a.sums, a.counts, a.tok, \
+                     a.pos, (const OutT *)a.wte, (const OutT *)a.wpe, (const uint8_t *)a.zero_row, (OutT *)a.out,   \
+                     a.status, a.tok_begin, a.ntok, a.T, a.vocab, a.n_pos, a.reduce)
+  if (a.tv.d == 768) SCONE_FIN(768);
+  else SCONE_FIN(1024);
+#undef SCONE_FIN
   SCONE_HIP(h, hipGetLastError());
   return SCONE_OK;
 }
@@ -440,10 +487,23 @@ int try_launch_wave(scone_handle *h, const embed_args &a, hipStream_t s) {
 template <int FMT>
 int launch_table_fmt(scone_handle *h, const embed_args &a, int src, int mode, int out_dtype, hipStream_t s) {
   if (src == SRC_CSR) return launch_dtype<FMT, SRC_CSR, MODE_FULL>(h, a, out_dtype, s);
-  if (mode == MODE_PARTIAL) return launch_dtype<FMT, SRC_HITS, MODE_PARTIAL>(h, a, out_dtype, s);
+  if (mode == MODE_PARTIAL) {
+    const int rc = try_launch_wave<FMT, float>(h, a, s);
+    return rc != -1 ? rc : launch_dtype<FMT, SRC_HITS, MODE_PARTIAL>(h, a, out_dtype, s);
+  }
   if (mode == MODE_FINALIZE) {
-    if constexpr (FMT == SCONE_FMT_F32) return launch_dtype<FMT, SRC_HITS, MODE_FINALIZE>(h, a, out_dtype, s);
-    else return scone_fail(h, SCONE_EINVAL, "finalize runs on fp32 sums");
+    if constexpr (FMT == SCONE_FMT_F32) {
+      int rc = -1;
+      switch (out_dtype) {
+        case SCONE_DT_F32: rc = try_launch_finalize_wave<float>(h, a, s); break;
+        case SCONE_DT_F16: rc = try_launch_finalize_wave<__half>(h, a, s); break;
+        case SCONE_DT_BF16: rc = try_launch_finalize_wave<__hip_bfloat16>(h, a, s); break;
+        default: return scone_fail(h, SCONE_EINVAL, "unknown out_dtype");
+      }
+      return rc != -1 ? rc : launch_dtype<FMT, SRC_HITS, MODE_FINALIZE>(h, a, out_dtype, s);
+    } else {
+      return scone_fail(h, SCONE_EINVAL, "finalize runs on fp32 sums");
+    }
   }
   // fused full lookup: wave-per-token kernel where it applies, lane-group kernel otherwise
   int rc = -1;

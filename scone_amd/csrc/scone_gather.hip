@@ -128,14 +128,24 @@ extern "C" int scone_embed_partial(scone_handle *h, const int32_t *d_tok, int32_
   if (!d_tok || !d_partial || !d_counts) return scone_fail(h, SCONE_EINVAL, "scone_embed_partial: null pointer");
   SCONE_HIP(h, hipSetDevice(h->device));
   hipStream_t s = (hipStream_t)stream;
-  rc = scone_ensure_hits(h, BT);
-  if (rc) return rc;
-  rc = scone_launch_match(h, d_tok, B, T, h->d_hits, s);
-  if (rc) return rc;
   embed_args a = {};
   fill_table_view(h, a.tv);
-  a.hits = h->d_hits, a.BT = BT, a.T = T, a.max_n = h->cfg.max_n;
+  a.BT = BT, a.T = T, a.max_n = h->cfg.max_n;
   a.tok_begin = 0, a.ntok = BT;
+  a.zero_row = h->d_zero_row, a.tok = d_tok;
+  if (scone_wave_kernel_covers(h->cfg.table_fmt, h->cfg.dim)) {
+    rc = scone_ensure_ell(h, BT);
+    if (rc) return rc;
+    rc = scone_launch_match_ell(h, d_tok, B, T, h->d_ell, s);
+    if (rc) return rc;
+    a.ell = h->d_ell;
+  } else {
+    rc = scone_ensure_hits(h, BT);
+    if (rc) return rc;
+    rc = scone_launch_match(h, d_tok, B, T, h->d_hits, s);
+    if (rc) return rc;
+    a.hits = h->d_hits;
+  }
   a.reduce = SCONE_REDUCE_SUM, a.partial = d_partial, a.counts = d_counts, a.status = h->d_status;
   return launch_fmt(h, a, SRC_HITS, MODE_PARTIAL, SCONE_DT_F32, s);
 }
@@ -161,6 +171,7 @@ extern "C" int scone_finalize(scone_handle *h, const float *d_sum, const int32_t
   a.tok_begin = tok_begin, a.ntok = tok_end - tok_begin;
   a.tok = d_tok, a.pos = d_pos, a.wte = d_wte, a.vocab = vocab, a.wpe = d_wpe, a.n_pos = n_pos;
   a.reduce = reduce, a.out = d_out, a.sums = d_sum, a.counts = const_cast<int32_t *>(d_counts);
+  a.zero_row = h->d_zero_row;
   a.status = h->d_status;
   return launch_fmt(h, a, SRC_HITS, MODE_FINALIZE, out_dtype, (hipStream_t)stream);
 }

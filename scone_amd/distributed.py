@@ -98,20 +98,23 @@ class ShardedEmbeddingCache:
             out_dtype = wte.dtype if wte is not None else (wpe.dtype if wpe is not None else torch.float32)
         partial, counts = self.table.embed_partial(tok)                      # [ntok, d] fp32, [ntok] int32
         per = (ntok + W - 1) // W                                             # tokens per rank (last slices padded)
-        pad = per * W - ntok
-        if pad:
-            partial = torch.cat([partial, partial.new_zeros((pad, d))])
-        mine = torch.empty((per, d), dtype=torch.float32, device=partial.device)
-        if W > 1:
-            dist.reduce_scatter_tensor(mine, partial, op=dist.ReduceOp.SUM, group=self.group)
-        else:
-            mine.copy_(partial[:per])
         a = min(self.rank * per, ntok)
         b = min(a + per, ntok)
-        out_slice = torch.zeros((per, d), dtype=out_dtype, device=partial.device)
+        if W > 1:
+            pad = per * W - ntok
+            if pad:
+                partial = torch.cat([partial, partial.new_zeros((pad, d))])
+            mine = torch.empty((per, d), dtype=torch.float32, device=partial.device)
+            dist.reduce_scatter_tensor(mine, partial, op=dist.ReduceOp.SUM, group=self.group)
+        else:
+            mine = partial                                                    # one shard: nothing to exchange
+        if b - a == per:
+            out_slice = torch.empty((per, d), dtype=out_dtype, device=partial.device)
+        else:
+            out_slice = torch.zeros((per, d), dtype=out_dtype, device=partial.device)   # padded tail slice
         if b > a:
-            out_slice[:b - a] = self.table.finalize(mine[:b - a], counts[a:b], tok, a, b, wte=wte, wpe=wpe,
-                                                    position_ids=position_ids, reduce=reduce, out_dtype=out_dtype)
+            self.table.finalize(mine[:b - a], counts[a:b], tok, a, b, wte=wte, wpe=wpe, position_ids=position_ids,
+                                reduce=reduce, out_dtype=out_dtype, out=out_slice[:b - a])
         if not gather_output:
             return out_slice
         if W > 1:

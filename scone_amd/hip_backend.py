@@ -282,7 +282,7 @@ class SconeTable:
     def finalize(self, sums: torch.Tensor, counts: torch.Tensor, tok: torch.Tensor, tok_begin: int, tok_end: int,
                  wte: Optional[torch.Tensor] = None, wpe: Optional[torch.Tensor] = None,
                  position_ids: Optional[torch.Tensor] = None, reduce: str = "mean",
-                 out_dtype: torch.dtype = torch.float32) -> torch.Tensor:
+                 out_dtype: torch.dtype = torch.float32, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         tok = self._tok(tok)
         B, T = tok.shape
         n = tok_end - tok_begin
@@ -291,7 +291,10 @@ class SconeTable:
         assert sums.shape == (n, self.dim) and counts.shape == (n,)
         if position_ids is not None:
             position_ids = position_ids.to(device=self.device, dtype=torch.int32).expand(B, T).contiguous()
-        out = torch.empty((n, self.dim), dtype=out_dtype, device=self.device)
+        if out is None:
+            out = torch.empty((n, self.dim), dtype=out_dtype, device=self.device)
+        else:
+            assert out.is_cuda and out.is_contiguous() and out.dtype == out_dtype and out.shape == (n, self.dim)
         with torch.cuda.device(self.device):
             rc = L.lib().scone_finalize(self._h, _ptr(sums), _ptr(counts), _ptr(tok), B, T, int(tok_begin),
                                         int(tok_end), _ptr(wte), 0 if wte is None else wte.shape[0], _ptr(wpe),

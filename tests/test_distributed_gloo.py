@@ -42,7 +42,7 @@ class OracleShard:
         return torch.from_numpy(partial), torch.from_numpy(counts)
 
     def finalize(self, sums, counts, tok, a, b, wte=None, wpe=None, position_ids=None, reduce="mean",
-                 out_dtype=torch.float32):
+                 out_dtype=torch.float32, out=None):
         x = sums.clone()
         if reduce == "mean":
             k = counts.to(torch.float32).clamp(min=1).unsqueeze(1)
@@ -54,7 +54,11 @@ class OracleShard:
         if wpe is not None:
             pos = (torch.arange(B * T) % T)[a:b] if position_ids is None else position_ids.reshape(-1)[a:b].long()
             x = x + wpe.float()[pos]
-        return x.to(out_dtype)
+        x = x.to(out_dtype)
+        if out is not None:
+            out.copy_(x)
+            return out
+        return x
 
 
 def _worker(rank, world, port, ntok_shape, out_dtype_name, q):

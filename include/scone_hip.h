@@ -44,7 +44,10 @@ enum {
   SCONE_FMT_I4 = 3   /* [N,d/2] offset-binary nibbles (elem 2k = low)   row_bytes d/2+2*d/128
                         + scales[N,d/128] half (per 128-group)                            */
 };
-enum { SCONE_PLACE_HBM = 0, SCONE_PLACE_PINNED_HOST = 1 };
+enum {
+  SCONE_PLACE_HBM = 0,        /* rows in device memory                                              */
+  SCONE_PLACE_PINNED_HOST = 1 /* rows >= cfg.hot_rows in pinned host DRAM mapped into the GPU, read over PCIe */
+};
 enum { SCONE_REDUCE_MEAN = 0, SCONE_REDUCE_SUM = 1 };
 enum { SCONE_DT_F32 = 0, SCONE_DT_F16 = 1, SCONE_DT_BF16 = 2 };
 
@@ -71,6 +74,10 @@ typedef struct scone_cfg {
   uint64_t row_begin;      /* rows owned by this handle: [row_begin, row_end); the whole   */
   uint64_t row_end;        /* table is 0..N (row_end = 0 means N)                          */
   uint64_t index_capacity; /* hash slots; 0 = smallest power of two >= 2*N                 */
+  uint64_t hot_rows;       /* SCONE_PLACE_PINNED_HOST only: global rows [0, hot_rows) stay in HBM, the
+                              rest in pinned host DRAM.  f-gram ids are frequency-ordered
+                              (Counter.most_common, n_gram_extractor.py:91-99), so the head of
+                              the table takes most of the hits.                              */
 } scone_cfg;
 
 /* ---- lifecycle ----------------------------------------------------------- */

@@ -38,6 +38,7 @@ class SconeCfg(C.Structure):
         ("row_begin", C.c_uint64),
         ("row_end", C.c_uint64),
         ("index_capacity", C.c_uint64),
+        ("hot_rows", C.c_uint64),
     ]
 
 

@@ -18,6 +18,15 @@ int scone_hip_fail(scone_handle *h, hipError_t e, const char *what) {
   return e == hipErrorOutOfMemory ? SCONE_ENOMEM : SCONE_EHIP;
 }
 
+scone_row_store scone_store_of(const scone_handle *h) {
+  scone_row_store st;
+  st.hot = reinterpret_cast<uint8_t *>(h->rows);
+  st.cold = reinterpret_cast<uint8_t *>(h->rows_host);
+  st.n_hot = h->hot_local;
+  st.row_bytes = (unsigned int)h->row_payload_bytes;
+  return st;
+}
+
 int scone_ensure_hits(scone_handle *h, int64_t ntok) {
   if (ntok <= h->hits_cap_tokens) return SCONE_OK;
   if (h->d_hits) SCONE_HIP(h, hipFree(h->d_hits));
@@ -115,7 +124,7 @@ extern "C" int scone_create(const scone_cfg *cfg, scone_handle **out) {
   }
   h->local_rows = h->cfg.row_end - h->cfg.row_begin;
   h->slots = nullptr, h->d_counters = nullptr, h->d_status = nullptr, h->d_uni = nullptr;
-  h->rows = nullptr, h->scales = nullptr, h->rows_pinned_host = false;
+  h->rows = nullptr, h->rows_host = nullptr, h->scales = nullptr, h->hot_local = 0;
   h->d_hits = nullptr, h->hits_cap_tokens = 0, h->d_block_sums = nullptr, h->block_sums_cap = 0;
   h->d_ell = nullptr, h->ell_cap_tokens = 0, h->d_zero_row = nullptr;
   h->d_total = nullptr, h->staging = nullptr, h->staging_bytes = 0;
@@ -164,19 +173,24 @@ extern "C" int scone_create(const scone_cfg *cfg, scone_handle **out) {
       rc = SCONE_EINVAL;
       goto fail;
     }
-    size_t rows_bytes = (size_t)h->local_rows * h->row_payload_bytes;
     size_t scales_bytes = (size_t)h->local_rows * h->scale_bytes_per_row;
-    if (rows_bytes == 0) rows_bytes = 16;
-    if (cfg->placement == SCONE_PLACE_PINNED_HOST) {
-      // rows stay in host DRAM, mapped into the GPU's address space; scales stay in HBM
-      CREATE_HIP(hipHostMalloc(&h->rows, rows_bytes, hipHostMallocMapped | hipHostMallocPortable));
-      h->rows_pinned_host = true;
-    } else if (cfg->placement == SCONE_PLACE_HBM) {
-      CREATE_HIP(hipMalloc(&h->rows, rows_bytes));
+    if (cfg->placement == SCONE_PLACE_HBM) {
+      h->hot_local = h->local_rows;
+    } else if (cfg->placement == SCONE_PLACE_PINNED_HOST) {
+      // global rows [0, hot_rows) stay in HBM; the rest of this shard lives in host DRAM mapped
+      // into the GPU's address space (scales always stay in HBM)
+      uint64_t hot_end = cfg->hot_rows < h->cfg.row_end ? cfg->hot_rows : h->cfg.row_end;
+      h->hot_local = hot_end > h->cfg.row_begin ? hot_end - h->cfg.row_begin : 0;
     } else {
       h->err = "scone_create: unknown placement";
       rc = SCONE_EINVAL;
       goto fail;
+    }
+    {
+      size_t hot_bytes = (size_t)h->hot_local * h->row_payload_bytes;
+      size_t cold_bytes = (size_t)(h->local_rows - h->hot_local) * h->row_payload_bytes;
+      CREATE_HIP(hipMalloc(&h->rows, hot_bytes ? hot_bytes : 16));
+      if (cold_bytes) CREATE_HIP(hipHostMalloc(&h->rows_host, cold_bytes, hipHostMallocMapped | hipHostMallocPortable));
     }
     if (scales_bytes) CREATE_HIP(hipMalloc(&h->scales, scales_bytes + 4));  // +4: scales are also read as dword pairs
   }
@@ -197,10 +211,8 @@ extern "C" void scone_destroy(scone_handle *h) {
   if (h->d_status) (void)hipFree(h->d_status);
   if (h->d_uni) (void)hipFree(h->d_uni);
   if (h->d_total) (void)hipFree(h->d_total);
-  if (h->rows) {
-    if (h->rows_pinned_host) (void)hipHostFree(h->rows);
-    else (void)hipFree(h->rows);
-  }
+  if (h->rows) (void)hipFree(h->rows);
+  if (h->rows_host) (void)hipHostFree(h->rows_host);
   if (h->scales) (void)hipFree(h->scales);
   if (h->d_hits) (void)hipFree(h->d_hits);
   if (h->d_ell) (void)hipFree(h->d_ell);

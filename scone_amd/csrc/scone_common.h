@@ -81,6 +81,17 @@ __host__ __device__ inline uint32_t scone_hash32(uint32_t x) {
   return x;
 }
 
+// Where a local row lives: rows [0, hot) in HBM, the rest (if any) in mapped pinned host memory.
+struct scone_row_store {
+  uint8_t *hot;
+  uint8_t *cold;
+  unsigned long long n_hot;
+  unsigned int row_bytes;
+  __host__ __device__ inline uint8_t *row(unsigned long long lr) const {
+    return lr < n_hot ? hot + lr * row_bytes : cold + (lr - n_hot) * row_bytes;
+  }
+};
+
 // ---------------------------------------------------------------- handle
 struct scone_handle {
   scone_cfg cfg;
@@ -92,12 +103,13 @@ struct scone_handle {
   uint32_t *d_status;              // sticky status bits
   int32_t *d_uni;                  // [SCONE_UNI_CAP] token -> unigram id, 0xFFFFFFFF (= -1) if none
   // table
-  void *rows;        // payload rows, local row r = global id - row_begin
+  void *rows;        // payload rows in HBM: local rows [0, hot_local)
+  void *rows_host;   // payload rows in pinned host DRAM: local rows [hot_local, local_rows) (or null)
+  uint64_t hot_local;
   void *scales;      // I8: half[rows]; I4: half[rows, d/128]
   size_t row_payload_bytes;
   size_t scale_bytes_per_row;
   uint64_t local_rows;
-  bool rows_pinned_host;
   // workspaces
   int32_t *d_hits;
   int64_t hits_cap_tokens;
@@ -120,6 +132,7 @@ struct scone_handle {
 
 int scone_fail(scone_handle *h, int code, const char *what);
 int scone_hip_fail(scone_handle *h, hipError_t e, const char *what);
+scone_row_store scone_store_of(const scone_handle *h);
 int scone_ensure_hits(scone_handle *h, int64_t ntok);
 int scone_ensure_ell(scone_handle *h, int64_t ntok);
 int scone_prof_begin(scone_handle *h, hipStream_t s);  // no-ops unless profiling is enabled

@@ -135,7 +135,7 @@ __device__ __forceinline__ void st_out_row(uint8_t *__restrict__ row, uint32_t l
 // issued before the first use (the K-way switch in the kernel keeps K a compile-time constant,
 // so the row registers are plain scalars and the waits are exact vmcnt counts).
 template <int FMT, typename OutT, int D, int K, bool FIXED_POS, bool PARTIAL>
-__device__ __forceinline__ void embed_token(const uint8_t *__restrict__ rows, const void *__restrict__ scales_v,
+__device__ __forceinline__ void embed_token(const scone_row_store &rows, const void *__restrict__ scales_v,
                                             const int32_t *__restrict__ rec, long long row_begin, int kfull, int reduce,
                                             const uint8_t *__restrict__ wte_row, const uint8_t *__restrict__ wpe_row,
                                             const uint32_t (&wpe_words)[wave_geom<FMT, D>::EPL * (int)sizeof(OutT) / 4],
@@ -165,7 +165,7 @@ __device__ __forceinline__ void embed_token(const uint8_t *__restrict__ rows, co
 #pragma unroll
   for (int k = 0; k < K; ++k) {
     const long long lr = (long long)rec[k] - row_begin;
-    const uint8_t *rp = rows + lr * G::ROW_BYTES;
+    const uint8_t *rp = rows.row((unsigned long long)lr);  // HBM or mapped host DRAM (wave-uniform select)
 #pragma unroll
     for (int s = 0; s < NSEG; ++s) {
       const uint32_t *p = reinterpret_cast<const uint32_t *>(rp + G::seg_first(s) / 4 * G::BPE4 +
@@ -263,7 +263,7 @@ __device__ __forceinline__ void embed_token(const uint8_t *__restrict__ rows, co
 // FIXED_POS keeps it in registers, removing d*sizeof(OutT) bytes of L1/L2 traffic per token.
 template <int FMT, typename OutT, int D, int MAXN, bool FIXED_POS, bool PARTIAL = false>
 __global__ __launch_bounds__(256, (wave_occupancy<FMT, OutT, D, MAXN, FIXED_POS>::WAVES)) void k_embed_wave(
-    const uint8_t *__restrict__ rows, const void *__restrict__ scales_v, const int32_t *__restrict__ ell,
+    const scone_row_store rows, const void *__restrict__ scales_v, const int32_t *__restrict__ ell,
     const int32_t *__restrict__ tok, const int32_t *__restrict__ pos, const OutT *__restrict__ wte,
     const OutT *__restrict__ wpe, const uint8_t *__restrict__ zero_row, OutT *__restrict__ out,
     int32_t *__restrict__ counts, uint32_t *__restrict__ status, const wave_params q) {
@@ -377,7 +377,7 @@ int launch_wave(scone_handle *h, const embed_args &a, hipStream_t s) {
   if constexpr (std::is_same<OutT, float>::value) {
     if (a.partial) {  // shard mode: fp32 partial sums + full hit counts
       hipLaunchKernelGGL((k_embed_wave<FMT, float, D, MAXN, true, true>), dim3((unsigned)blocks), dim3(256), 0, s,
-                         a.tv.rows, (const void *)a.tv.scales, a.ell, a.tok, (const int32_t *)nullptr,
+                         a.tv.st, (const void *)a.tv.scales, a.ell, a.tok, (const int32_t *)nullptr,
                          (const float *)nullptr, (const float *)nullptr, (const uint8_t *)a.zero_row, a.partial,
                          a.counts, a.status, q);
       SCONE_HIP(h, hipGetLastError());
@@ -385,11 +385,11 @@ int launch_wave(scone_handle *h, const embed_args &a, hipStream_t s) {
     }
   }
   if (a.pos)
-    hipLaunchKernelGGL((k_embed_wave<FMT, OutT, D, MAXN, false>), dim3((unsigned)blocks), dim3(256), 0, s, a.tv.rows,
+    hipLaunchKernelGGL((k_embed_wave<FMT, OutT, D, MAXN, false>), dim3((unsigned)blocks), dim3(256), 0, s, a.tv.st,
                        (const void *)a.tv.scales, a.ell, a.tok, a.pos, (const OutT *)a.wte, (const OutT *)a.wpe,
                        (const uint8_t *)a.zero_row, (OutT *)a.out, (int32_t *)nullptr, a.status, q);
   else
-    hipLaunchKernelGGL((k_embed_wave<FMT, OutT, D, MAXN, true>), dim3((unsigned)blocks), dim3(256), 0, s, a.tv.rows,
+    hipLaunchKernelGGL((k_embed_wave<FMT, OutT, D, MAXN, true>), dim3((unsigned)blocks), dim3(256), 0, s, a.tv.st,
                        (const void *)a.tv.scales, a.ell, a.tok, a.pos, (const OutT *)a.wte, (const OutT *)a.wpe,
                        (const uint8_t *)a.zero_row, (OutT *)a.out, (int32_t *)nullptr, a.status, q);
   SCONE_HIP(h, hipGetLastError());

@@ -38,7 +38,7 @@ bool scone_wave_kernel_covers(int fmt, int d) {
 }
 
 void fill_table_view(const scone_handle *h, table_view &tv) {
-  tv.rows = reinterpret_cast<const uint8_t *>(h->rows);
+  tv.st = scone_store_of(h);
   tv.scales = reinterpret_cast<const __half *>(h->scales);
   tv.row_begin = (long long)h->cfg.row_begin;
   tv.row_end = (long long)h->cfg.row_end;

@@ -30,7 +30,7 @@ template <> struct fmt_traits<SCONE_FMT_I8> { static constexpr int VEC = 16; };
 template <> struct fmt_traits<SCONE_FMT_I4> { static constexpr int VEC = 32; };
 
 struct table_view {
-  const uint8_t *rows;   // payload rows (local)
+  scone_row_store st;    // payload rows (local): HBM part + pinned-host part
   const __half *scales;  // I8: [rows]; I4: [rows, d/128]
   long long row_begin;   // owned global id range
   long long row_end;
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(256) void k_embed(const embed_args a) {
         const long long id = idc[c];
         if (id >= row_begin && id < row_end) {
           const long long lr = id - row_begin;
-          raw[c] = *reinterpret_cast<const uint4 *>(a.tv.rows + lr * a.tv.row_bytes + (long long)v * 16);
+          raw[c] = *reinterpret_cast<const uint4 *>(a.tv.st.row((unsigned long long)lr) + (long long)v * 16);
           sc[c] = load_scale<FMT>(a.tv, lr, v);
         }
       }
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(256) void k_embed(const embed_args a) {
             } else if (id >= row_begin && id < row_end) {
               own[c] = true;
               const long long lr = id - row_begin;
-              raw[c] = *reinterpret_cast<const uint4 *>(a.tv.rows + lr * a.tv.row_bytes + (long long)v * 16);
+              raw[c] = *reinterpret_cast<const uint4 *>(a.tv.st.row((unsigned long long)lr) + (long long)v * 16);
               sc[c] = load_scale<FMT>(a.tv, lr, v);
             }
           }

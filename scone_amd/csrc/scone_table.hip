@@ -24,7 +24,7 @@ template <int FMT>
 __global__ __launch_bounds__(256) void k_store_f32(const float *__restrict__ src, const int64_t *__restrict__ ids,
                                                    unsigned long long row0, unsigned long long nrows,
                                                    unsigned long long row_begin, unsigned long long row_end,
-                                                   int d, void *__restrict__ rows, __half *__restrict__ scales,
+                                                   int d, scone_row_store st, __half *__restrict__ scales,
                                                    uint32_t *__restrict__ status) {
   const int lane = threadIdx.x & 63;
   unsigned long long r = (unsigned long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -37,10 +37,10 @@ __global__ __launch_bounds__(256) void k_store_f32(const float *__restrict__ src
   const unsigned long long lr = g - row_begin;
   const float *x = src + r * (unsigned long long)d;
   if (FMT == SCONE_FMT_F32) {
-    float *o = reinterpret_cast<float *>(rows) + lr * d;
+    float *o = reinterpret_cast<float *>(st.row(lr));
     for (int e = lane; e < d; e += 64) o[e] = x[e];
   } else if (FMT == SCONE_FMT_F16) {
-    __half *o = reinterpret_cast<__half *>(rows) + lr * d;
+    __half *o = reinterpret_cast<__half *>(st.row(lr));
     for (int e = lane; e < d; e += 64) o[e] = __float2half_rn(x[e]);
   } else if (FMT == SCONE_FMT_I8) {
     float m = 0.f;
@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void k_store_f32(const float *__restrict__ src
     m = wave_max(m);
     const __half sh = __float2half_rn(m / 127.0f);
     const float sf = __half2float(sh);
-    int8_t *o = reinterpret_cast<int8_t *>(rows) + lr * d;
+    int8_t *o = reinterpret_cast<int8_t *>(st.row(lr));
     for (int e = lane; e < d; e += 64) {
       float q = 0.f;
       if (sf > 0.f) q = fminf(fmaxf(rintf(x[e] / sf), -127.f), 127.f);
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void k_store_f32(const float *__restrict__ src
     if (lane == 0) scales[lr] = sh;
   } else {  // I4: groups of 128, two elements per lane per group
     const int ng = d / SCONE_I4_GROUP;
-    uint8_t *o = reinterpret_cast<uint8_t *>(rows) + lr * (d / 2);
+    uint8_t *o = st.row(lr);
     for (int grp = 0; grp < ng; ++grp) {
       const float a = x[grp * SCONE_I4_GROUP + 2 * lane];
       const float b = x[grp * SCONE_I4_GROUP + 2 * lane + 1];
@@ -96,7 +96,7 @@ __device__ __forceinline__ __half synth_scale(uint32_t seed, unsigned long long 
 // One wave per row, one 4-byte hash word per lane per step.
 template <int FMT>
 __global__ __launch_bounds__(256) void k_fill_synth(unsigned long long row_begin, unsigned long long local_rows, int d,
-                                                    uint32_t seed, float base_scale, void *__restrict__ rows,
+                                                    uint32_t seed, float base_scale, scone_row_store st,
                                                     __half *__restrict__ scales) {
   const int lane = threadIdx.x & 63;
   unsigned long long lr = (unsigned long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void k_fill_synth(unsigned long long row_begin
   const uint32_t base = synth_row_base(seed, g);
   if (FMT == SCONE_FMT_I4) {
     const int nw = d / 8, ng = d / SCONE_I4_GROUP;
-    uint32_t *o = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(rows) + lr * (d / 2));
+    uint32_t *o = reinterpret_cast<uint32_t *>(st.row(lr));
     for (int w = lane; w < nw; w += 64) o[w] = scone_hash32(base + (uint32_t)w);
     for (int grp = lane; grp < ng; grp += 64)
       scales[lr * ng + grp] = synth_scale(seed, g * (unsigned long long)ng + grp, base_scale);
@@ -117,14 +117,14 @@ __global__ __launch_bounds__(256) void k_fill_synth(unsigned long long row_begin
   for (int w = lane; w < nw; w += 64) {
     const uint32_t word = scone_hash32(base + (uint32_t)w);
     if (FMT == SCONE_FMT_I8) {
-      reinterpret_cast<uint32_t *>(reinterpret_cast<int8_t *>(rows) + lr * d)[w] = word;
+      reinterpret_cast<uint32_t *>(st.row(lr))[w] = word;
     } else {
       float v[4];
       for (int k = 0; k < 4; ++k) v[k] = rounded_f32((float)(int8_t)(word >> (8 * k)) * sf);
       if (FMT == SCONE_FMT_F32) {
-        reinterpret_cast<float4 *>(reinterpret_cast<float *>(rows) + lr * d)[w] = make_float4(v[0], v[1], v[2], v[3]);
+        reinterpret_cast<float4 *>(st.row(lr))[w] = make_float4(v[0], v[1], v[2], v[3]);
       } else {
-        __half *o = reinterpret_cast<__half *>(rows) + lr * d + 4 * w;
+        __half *o = reinterpret_cast<__half *>(st.row(lr)) + 4 * w;
         for (int k = 0; k < 4; ++k) o[k] = __float2half_rn(v[k]);
       }
     }
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256) void k_fill_synth(unsigned long long row_begin
 
 // out[i, :] = dequantised row ids[i]; one wave per output row.
 template <int FMT>
-__global__ __launch_bounds__(256) void k_gather_rows(const void *__restrict__ rows, const __half *__restrict__ scales,
+__global__ __launch_bounds__(256) void k_gather_rows(scone_row_store st, const __half *__restrict__ scales,
                                                      const int64_t *__restrict__ ids, unsigned long long n,
                                                      unsigned long long row_begin, unsigned long long row_end, int d,
                                                      float *__restrict__ out, uint32_t *__restrict__ status) {
@@ -150,17 +150,17 @@ __global__ __launch_bounds__(256) void k_gather_rows(const void *__restrict__ ro
   }
   const unsigned long long lr = (unsigned long long)id - row_begin;
   if (FMT == SCONE_FMT_F32) {
-    const float *x = reinterpret_cast<const float *>(rows) + lr * d;
+    const float *x = reinterpret_cast<const float *>(st.row(lr));
     for (int e = lane; e < d; e += 64) o[e] = x[e];
   } else if (FMT == SCONE_FMT_F16) {
-    const __half *x = reinterpret_cast<const __half *>(rows) + lr * d;
+    const __half *x = reinterpret_cast<const __half *>(st.row(lr));
     for (int e = lane; e < d; e += 64) o[e] = __half2float(x[e]);
   } else if (FMT == SCONE_FMT_I8) {
-    const int8_t *x = reinterpret_cast<const int8_t *>(rows) + lr * d;
+    const int8_t *x = reinterpret_cast<const int8_t *>(st.row(lr));
     const float sf = __half2float(scales[lr]);
     for (int e = lane; e < d; e += 64) o[e] = (float)x[e] * sf;
   } else {
-    const uint8_t *x = reinterpret_cast<const uint8_t *>(rows) + lr * (d / 2);
+    const uint8_t *x = st.row(lr);
     const int ng = d / SCONE_I4_GROUP;
     for (int b = lane; b < d / 2; b += 64) {
       const float sf = __half2float(scales[lr * ng + (2 * b) / SCONE_I4_GROUP]);
@@ -202,10 +202,15 @@ extern "C" int scone_table_upload(scone_handle *h, const void *rows, const void 
   SCONE_HIP(h, hipSetDevice(h->device));
   hipStream_t s = (hipStream_t)stream;
   const uint64_t lr = row0 - h->cfg.row_begin;
-  hipMemcpyKind kind = src_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
-  if (h->rows_pinned_host) kind = src_is_device ? hipMemcpyDeviceToHost : hipMemcpyHostToHost;
-  SCONE_HIP(h, hipMemcpyAsync(reinterpret_cast<uint8_t *>(h->rows) + lr * h->row_payload_bytes, rows,
-                              nrows * h->row_payload_bytes, kind, s));
+  const size_t rb = h->row_payload_bytes;
+  const uint64_t n_hot = lr < h->hot_local ? (lr + nrows <= h->hot_local ? nrows : h->hot_local - lr) : 0;
+  if (n_hot)  // part that lives in HBM
+    SCONE_HIP(h, hipMemcpyAsync(reinterpret_cast<uint8_t *>(h->rows) + lr * rb, rows, n_hot * rb,
+                                src_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
+  if (n_hot < nrows)  // part that lives in pinned host memory
+    SCONE_HIP(h, hipMemcpyAsync(reinterpret_cast<uint8_t *>(h->rows_host) + (lr + n_hot - h->hot_local) * rb,
+                                reinterpret_cast<const uint8_t *>(rows) + n_hot * rb, (nrows - n_hot) * rb,
+                                src_is_device ? hipMemcpyDeviceToHost : hipMemcpyHostToHost, s));
   if (h->scale_bytes_per_row)
     SCONE_HIP(h, hipMemcpyAsync(reinterpret_cast<uint8_t *>(h->scales) + lr * h->scale_bytes_per_row, scales,
                                 nrows * h->scale_bytes_per_row,
@@ -223,7 +228,7 @@ static int store_f32_common(scone_handle *h, const float *d_src, const int64_t *
   int bad = dispatch_fmt(h->cfg.table_fmt, [&](auto F) {
     hipLaunchKernelGGL((k_store_f32<decltype(F)::value>), dim3(blocks), dim3(256), 0, s, d_src, d_ids,
                        (unsigned long long)row0, (unsigned long long)nrows, (unsigned long long)h->cfg.row_begin,
-                       (unsigned long long)h->cfg.row_end, h->cfg.dim, h->rows, (__half *)h->scales, h->d_status);
+                       (unsigned long long)h->cfg.row_end, h->cfg.dim, scone_store_of(h), (__half *)h->scales, h->d_status);
   });
   if (bad) return scone_fail(h, SCONE_EINVAL, "scone_table_store_f32: bad format");
   SCONE_HIP(h, hipGetLastError());
@@ -257,7 +262,7 @@ extern "C" int scone_table_fill_synthetic(scone_handle *h, uint32_t seed, float 
   int bad = dispatch_fmt(h->cfg.table_fmt, [&](auto F) {
     hipLaunchKernelGGL((k_fill_synth<decltype(F)::value>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
                        (unsigned long long)h->cfg.row_begin, (unsigned long long)h->local_rows, h->cfg.dim, seed,
-                       base_scale, h->rows, (__half *)h->scales);
+                       base_scale, scone_store_of(h), (__half *)h->scales);
   });
   if (bad) return scone_fail(h, SCONE_EINVAL, "scone_table_fill_synthetic: bad format");
   SCONE_HIP(h, hipGetLastError());
@@ -274,7 +279,7 @@ extern "C" int scone_table_gather_rows(scone_handle *h, const int64_t *d_ids, ui
   const unsigned long long blocks = (n + 3) / 4;
   int bad = dispatch_fmt(h->cfg.table_fmt, [&](auto F) {
     hipLaunchKernelGGL((k_gather_rows<decltype(F)::value>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
-                       h->rows, (const __half *)h->scales, d_ids, (unsigned long long)n,
+                       scone_store_of(h), (const __half *)h->scales, d_ids, (unsigned long long)n,
                        (unsigned long long)h->cfg.row_begin, (unsigned long long)h->cfg.row_end, h->cfg.dim, d_out,
                        h->d_status);
   });

@@ -28,14 +28,15 @@ class EmbeddingCache:
 
     Extra keyword-only arguments select the device representation:
         table_format: "fp32" (reference-exact), "fp16", "int8", "int4".
-        placement:    "hbm" or "pinned_host" (rows stay in host DRAM, read over PCIe).
+        placement:    "hbm" or "pinned_host" (rows >= hot_rows stay in host DRAM, read over PCIe).
+        hot_rows:     with "pinned_host", the head of the table (ids are frequency-ordered) kept in HBM.
         device:       HIP device for the table (default: current device).
         keep_host_copy: keep the reference's host dict / memmap (needed by ``save``).
     """
 
     def __init__(self, n_gram_extractor: NGramExtractor, embedding_dim: int, cache_dir: Optional[str] = None,
                  use_memory_map: bool = False, *, table_format: str = "fp32", placement: str = "hbm",
-                 device=None, keep_host_copy: bool = True) -> None:
+                 device=None, keep_host_copy: bool = True, hot_rows: int = 0) -> None:
         self.n_gram_extractor = n_gram_extractor
         self.embedding_dim = embedding_dim
         self.cache_dir = cache_dir
@@ -46,6 +47,7 @@ class EmbeddingCache:
 
         self.table_format = table_format
         self.placement = placement
+        self.hot_rows = int(hot_rows)          # placement='pinned_host': rows [0, hot_rows) stay in HBM
         self.keep_host_copy = keep_host_copy
         self._device = device
         self._table = None           # hip_backend.SconeTable
@@ -118,7 +120,8 @@ class EmbeddingCache:
     def _make_table(self, n_rows: int):
         from scone_amd.hip_backend import SconeTable
         table = SconeTable(self.n_gram_extractor.max_n, n_rows, dim=self.embedding_dim,
-                           table_format=self.table_format, placement=self.placement, device=self._device)
+                           table_format=self.table_format, placement=self.placement, device=self._device,
+                           hot_rows=self.hot_rows)
         self.n_gram_extractor.build_index(table)
         return table
 
@@ -177,11 +180,11 @@ class EmbeddingCache:
     @classmethod
     def from_synthetic(cls, n_gram_extractor: NGramExtractor, embedding_dim: int, *, table_format: str = "int8",
                        seed: int = 7, base_scale: float = 0.02 / 127, placement: str = "hbm", device=None,
-                       n_rows: Optional[int] = None) -> "EmbeddingCache":
+                       n_rows: Optional[int] = None, hot_rows: int = 0) -> "EmbeddingCache":
         """Cache whose device table is generated on the GPU by the counter-based hash of
         ``scone_table_fill_synthetic`` (bench / full-size tests; nothing materialised on the host)."""
         cache = cls(n_gram_extractor, embedding_dim, table_format=table_format, placement=placement, device=device,
-                    keep_host_copy=False)
+                    keep_host_copy=False, hot_rows=hot_rows)
         n = int(n_rows if n_rows is not None else len(n_gram_extractor))
         table = cache._make_table(n)
         table.fill_synthetic(seed, base_scale)

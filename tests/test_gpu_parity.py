@@ -451,3 +451,45 @@ def test_full_size_table_spot_check_vs_oracle(fmt, d, n_rows):
     k = np.diff(ro).astype(np.float32)[:, None]
     np.testing.assert_allclose(s, ref.reshape(B * T, d) * np.maximum(k, 1), rtol=2e-6, atol=1e-9)
     assert torch.equal(fused, cache.embed_tokens(tok, wte=wte, wpe=wpe))
+
+
+def test_plain_c_client(tmp_path):
+    """The ABI is usable from plain C (no Python/torch in the loop): tests/cabi_smoke.c."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "cabi_smoke")
+    lib = os.path.join(root, "scone_amd", "csrc")
+    subprocess.run(["gcc", os.path.join(root, "tests", "cabi_smoke.c"), "-I" + os.path.join(root, "include"),
+                    "-I/opt/rocm/include", "-D__HIP_PLATFORM_AMD__", "-L" + lib, "-lscone_hip", "-L/opt/rocm/lib",
+                    "-lamdhip64", "-Wl,-rpath," + lib, "-Wl,-rpath,/opt/rocm/lib", "-o", exe], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert "cabi_smoke ok: 16 hits" in r.stdout
+
+
+@pytest.mark.parametrize("hot_rows", [0, 137, 10_000])
+@pytest.mark.parametrize("fmt", ["int8", "fp32"])
+def test_pinned_host_placement_matches_hbm(fmt, hot_rows):
+    """Rows in mapped pinned host DRAM (optionally with the head of the table in HBM) give the same
+    bits as the HBM-resident table; uploads and fp32 stores that straddle the boundary included."""
+    from scone_amd.hip_backend import SconeTable
+    rng = np.random.default_rng(31)
+    vocab, n, d = 41, 900, 768
+    lens = rng.integers(1, 4, size=n).astype(np.uint8)
+    keys = rng.integers(0, vocab, size=(n, 3)).astype(np.uint32)
+    keys[np.arange(3)[None, :] >= lens[:, None]] = 0
+    table = rng.standard_normal((n, d)).astype(np.float32)
+    tok = torch.from_numpy(rng.integers(0, vocab, size=(4, 64)))
+    outs = []
+    for placement, hot in (("hbm", 0), ("pinned_host", hot_rows)):
+        t = SconeTable(3, n, d, fmt, placement=placement, hot_rows=hot)
+        t.index_build(keys, lens)
+        t.store_f32(torch.from_numpy(table[:500]), row0=0)          # straddles the hot/cold boundary
+        t.store_f32(torch.from_numpy(table[500:]), row0=500)
+        outs.append((t.embed(tok, out_dtype=torch.float32), t.gather_rows(torch.arange(n))))
+        if fmt == "fp32":                                             # raw upload path, split at the boundary
+            t2 = SconeTable(3, n, d, fmt, placement=placement, hot_rows=hot)
+            t2.index_build(keys, lens)
+            t2.upload(table, row0=0)
+            assert torch.equal(t2.gather_rows(torch.arange(n)), outs[-1][1])
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])

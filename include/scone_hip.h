@@ -113,6 +113,11 @@ int scone_index_stats(scone_handle *h, uint64_t *n_keys, uint64_t *capacity, uin
  * lie inside [row_begin,row_end). */
 int scone_table_upload(scone_handle *h, const void *rows, const void *scales, uint64_t row0,
                        uint64_t nrows, int src_is_device, scone_stream_t stream);
+/* Inverse of scone_table_upload: raw payload rows (+ scales) of global rows [row0, row0+nrows)
+ * in the handle's format, to host or device buffers; synchronises for host destinations.
+ * With it a quantised table can be saved and reloaded without re-quantising. */
+int scone_table_download(scone_handle *h, void *rows, void *scales, uint64_t row0, uint64_t nrows,
+                         int dst_is_device, scone_stream_t stream);
 /* fp32 rows on the device -> the handle's format (quantised on the GPU). */
 int scone_table_store_f32(scone_handle *h, const float *d_rows_f32, uint64_t row0, uint64_t nrows,
                           scone_stream_t stream);

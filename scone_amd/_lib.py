@@ -57,6 +57,7 @@ SIGNATURES = {
     "scone_index_build_device": (C.c_int, [_P, _P, _P, _U64, _U64, _P]),
     "scone_index_stats": (C.c_int, [_P, C.POINTER(_U64), C.POINTER(_U64), C.POINTER(_U64)]),
     "scone_table_upload": (C.c_int, [_P, _P, _P, _U64, _U64, C.c_int, _P]),
+    "scone_table_download": (C.c_int, [_P, _P, _P, _U64, _U64, C.c_int, _P]),
     "scone_table_store_f32": (C.c_int, [_P, _P, _U64, _U64, _P]),
     "scone_table_store_f32_ids": (C.c_int, [_P, _P, _P, _U64, _P]),
     "scone_table_fill_synthetic": (C.c_int, [_P, _U32, C.c_float, _P]),

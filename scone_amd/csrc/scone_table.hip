@@ -219,6 +219,35 @@ extern "C" int scone_table_upload(scone_handle *h, const void *rows, const void 
   return SCONE_OK;
 }
 
+extern "C" int scone_table_download(scone_handle *h, void *rows, void *scales, uint64_t row0, uint64_t nrows,
+                                    int dst_is_device, scone_stream_t stream) {
+  int rc = check_table(h, "scone_table_download: handle has no table (dim == 0)");
+  if (rc) return rc;
+  if (nrows == 0) return SCONE_OK;
+  if (!rows) return scone_fail(h, SCONE_EINVAL, "scone_table_download: null rows");
+  if (h->scale_bytes_per_row && !scales) return scone_fail(h, SCONE_EINVAL, "scone_table_download: format has scales");
+  if (row0 < h->cfg.row_begin || row0 + nrows > h->cfg.row_end)
+    return scone_fail(h, SCONE_ERANGE, "scone_table_download: rows outside [row_begin,row_end)");
+  SCONE_HIP(h, hipSetDevice(h->device));
+  hipStream_t s = (hipStream_t)stream;
+  const uint64_t lr = row0 - h->cfg.row_begin;
+  const size_t rb = h->row_payload_bytes;
+  const uint64_t n_hot = lr < h->hot_local ? (lr + nrows <= h->hot_local ? nrows : h->hot_local - lr) : 0;
+  if (n_hot)
+    SCONE_HIP(h, hipMemcpyAsync(rows, reinterpret_cast<const uint8_t *>(h->rows) + lr * rb, n_hot * rb,
+                                dst_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s));
+  if (n_hot < nrows)
+    SCONE_HIP(h, hipMemcpyAsync(reinterpret_cast<uint8_t *>(rows) + n_hot * rb,
+                                reinterpret_cast<const uint8_t *>(h->rows_host) + (lr + n_hot - h->hot_local) * rb,
+                                (nrows - n_hot) * rb, dst_is_device ? hipMemcpyHostToDevice : hipMemcpyHostToHost, s));
+  if (h->scale_bytes_per_row)
+    SCONE_HIP(h, hipMemcpyAsync(scales, reinterpret_cast<const uint8_t *>(h->scales) + lr * h->scale_bytes_per_row,
+                                nrows * h->scale_bytes_per_row,
+                                dst_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s));
+  if (!dst_is_device) SCONE_HIP(h, hipStreamSynchronize(s));
+  return SCONE_OK;
+}
+
 static int store_f32_common(scone_handle *h, const float *d_src, const int64_t *d_ids, uint64_t row0, uint64_t nrows,
                             hipStream_t s) {
   if (nrows == 0) return SCONE_OK;

@@ -157,6 +157,24 @@ class SconeTable:
             rc = L.lib().scone_table_upload(self._h, rp, sp, int(row0), int(nrows), int(is_dev), _stream())
         self._check(rc, "scone_table_upload")
 
+    def payload_bytes(self) -> int:
+        return {L.FMT_F32: 4 * self.dim, L.FMT_F16: 2 * self.dim, L.FMT_I8: self.dim, L.FMT_I4: self.dim // 2}[self.fmt]
+
+    def scales_per_row(self) -> int:
+        return {L.FMT_F32: 0, L.FMT_F16: 0, L.FMT_I8: 1, L.FMT_I4: self.dim // I4_GROUP}[self.fmt]
+
+    def download(self, row0: int, nrows: int) -> Tuple[np.ndarray, Optional[np.ndarray]]:
+        """Raw payload rows ``uint8 [nrows, payload_bytes]`` and fp16 scales of global rows ``row0 ..``."""
+        rows = np.empty((nrows, self.payload_bytes()), dtype=np.uint8)
+        spr = self.scales_per_row()
+        scales = np.empty((nrows, spr), dtype=np.float16) if spr else None
+        with torch.cuda.device(self.device):
+            rc = L.lib().scone_table_download(self._h, rows.ctypes.data_as(C.c_void_p),
+                                              scales.ctypes.data_as(C.c_void_p) if spr else None, int(row0), int(nrows),
+                                              0, _stream())
+        self._check(rc, "scone_table_download")
+        return rows, scales
+
     def store_f32(self, rows: torch.Tensor, row0: int = 0, ids: Optional[torch.Tensor] = None) -> None:
         rows = rows.to(device=self.device, dtype=torch.float32).contiguous()
         if rows.dim() != 2 or rows.shape[1] != self.dim:

@@ -274,6 +274,54 @@ class EmbeddingCache:
             raise IndexError("index out of range in self")
         return result
 
+    # ------------------------------------------------------------------ native shard format
+    NATIVE_MAGIC = "scone_amd.table.v1"
+
+    def save_native(self, path: str, chunk_rows: int = 1 << 18) -> None:
+        """Write the device table as it is stored (quantised rows + scales) together with the
+        f-gram keys, so :meth:`load_native` restores it without re-quantising.  One ``.npz``
+        (uncompressed): ``meta`` (json), ``keys [N, max_n] uint32``, ``lens [N] uint8``,
+        ``rows [N, payload_bytes] uint8``, ``scales [N, scales_per_row] float16``."""
+        import json
+        table = self.to_device()
+        n = table.n_rows
+        rows = np.empty((n, table.payload_bytes()), dtype=np.uint8)
+        spr = table.scales_per_row()
+        scales = np.empty((n, spr), dtype=np.float16)
+        for a in range(table.row_begin, table.row_end, chunk_rows):
+            m = min(chunk_rows, table.row_end - a)
+            r, sc = table.download(a, m)
+            rows[a:a + m] = r
+            if spr:
+                scales[a:a + m] = sc
+        keys, lens = self.n_gram_extractor.key_arrays()
+        meta = {"magic": self.NATIVE_MAGIC, "table_format": self.table_format, "embedding_dim": self.embedding_dim,
+                "max_n": self.n_gram_extractor.max_n, "n_rows": n, "row_begin": table.row_begin, "row_end": table.row_end}
+        np.savez(path, meta=np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8), keys=keys, lens=lens, rows=rows,
+                 scales=scales)
+
+    @classmethod
+    def load_native(cls, path: str, *, placement: str = "hbm", device=None, hot_rows: int = 0) -> "EmbeddingCache":
+        """Restore a cache written by :meth:`save_native` (extractor included)."""
+        import json
+        z = np.load(path if str(path).endswith(".npz") else str(path) + ".npz")
+        meta = json.loads(bytes(z["meta"]).decode())
+        if meta.get("magic") != cls.NATIVE_MAGIC:
+            raise ValueError("not a scone_amd native table file")
+        ex = NGramExtractor.from_arrays(z["keys"], z["lens"], max_n=meta["max_n"])
+        cache = cls(ex, meta["embedding_dim"], table_format=meta["table_format"], placement=placement, device=device,
+                    keep_host_copy=False, hot_rows=hot_rows)
+        table = cache._make_table(meta["n_rows"])
+        a, b = meta["row_begin"], meta["row_end"]
+        rows, scales = z["rows"], z["scales"]
+        chunk = 1 << 18
+        for r0 in range(a, b, chunk):
+            m = min(chunk, b - r0)
+            table.upload(rows[r0:r0 + m], scales[r0:r0 + m] if scales.shape[1] else None, row0=r0)
+        cache._table, cache._dirty = table, False
+        cache._present = np.ones(meta["n_rows"], dtype=bool)
+        return cache
+
     # ------------------------------------------------------------------ persistence (a9)
     def save(self, path: str) -> None:
         """Same on-disk format as the reference (embedding_cache.py:183-203)."""

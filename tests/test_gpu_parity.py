@@ -493,3 +493,61 @@ def test_pinned_host_placement_matches_hbm(fmt, hot_rows):
             t2.upload(table, row0=0)
             assert torch.equal(t2.gather_rows(torch.arange(n)), outs[-1][1])
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.parametrize("fmt,d,max_n", [("int8", 768, 3), ("int8", 1024, 4), ("int4", 1024, 3), ("fp16", 768, 4),
+                                         ("fp32", 1024, 3), ("int8", 768, 4)])
+def test_wave_kernel_shape_sweep(fmt, d, max_n):
+    """Every (B, T) geometry of the wave kernel -- T not a multiple of 4, T < max_n, one sequence, many short
+    sequences, explicit and default position ids, all output dtypes -- bit-exact in fp32 against the oracle."""
+    rng = np.random.default_rng(1000 + d + max_n)
+    vocab, n = 13, 500
+    lens = rng.integers(1, max_n + 1, size=n).astype(np.uint8)
+    keys = rng.integers(0, vocab, size=(n, max_n)).astype(np.uint32)
+    keys[np.arange(max_n)[None, :] >= lens[:, None]] = 0
+    from scone_amd import EmbeddingCache
+    ex = _extractor(keys, lens, max_n)
+    cache = EmbeddingCache.from_synthetic(ex, d, table_format=fmt, seed=5, base_scale=0.01)
+    deq = cache.table.gather_rows(torch.arange(n)).cpu().numpy()
+    wte32 = rng.standard_normal((vocab, d)).astype(np.float32)
+    wpe32 = rng.standard_normal((600, d)).astype(np.float32)
+    for B, T in ((1, 1), (1, 2), (1, 3), (2, 5), (3, 7), (1, 513), (9, 130), (257, 4), (64, 9), (5, 1)):
+        tok = rng.integers(0, vocab + 1, size=(B, T))          # vocab itself never matches
+        tokc = np.minimum(tok, vocab - 1)
+        ro, ri = R.hits_to_csr(R.match_hits(keys, lens, tok, max_n))
+        fg = R.embed_numpy(deq, ro, ri, "mean").reshape(B, T, d)
+        out = cache.embed_tokens(torch.from_numpy(tok), out_dtype=torch.float32).cpu().numpy()
+        assert np.array_equal(out, fg), (B, T)
+        pos = rng.integers(0, 600, size=(B, T))
+        for position_ids in (None, torch.from_numpy(pos)):
+            ref = R.combine(torch.from_numpy(tokc), torch.from_numpy(fg), torch.from_numpy(wte32),
+                            torch.from_numpy(wpe32), position_ids=position_ids).numpy()
+            got = cache.embed_tokens(torch.from_numpy(tokc), wte=torch.from_numpy(wte32).cuda(),
+                                     wpe=torch.from_numpy(wpe32).cuda(), position_ids=position_ids,
+                                     out_dtype=torch.float32, check=True)
+            # tokens equal to `vocab` were clamped for wte but must still not match any f-gram: compare where equal
+            same = (tok == tokc).all(axis=1)
+            assert np.array_equal(got.cpu().numpy()[same], ref[same]), (B, T, position_ids is None)
+        h16 = cache.embed_tokens(torch.from_numpy(tok), out_dtype=torch.float16).float().cpu().numpy()
+        assert _rel(h16, fg) < REL_TOL if np.abs(fg).max() > 0 else not h16.any()
+
+
+@pytest.mark.parametrize("fmt", ["int8", "int4", "fp16"])
+def test_native_table_file_round_trip(tmp_path, fmt):
+    """save_native / load_native: quantised rows + scales + keys restored bit for bit, no re-quantisation."""
+    from scone_amd import EmbeddingCache
+    rng = np.random.default_rng(77)
+    vocab, n, d = 23, 600, 1024
+    lens = rng.integers(1, 4, size=n).astype(np.uint8)
+    keys = rng.integers(0, vocab, size=(n, 3)).astype(np.uint32)
+    keys[np.arange(3)[None, :] >= lens[:, None]] = 0
+    cache = _cache(keys, lens, 3, rng.standard_normal((n, d)).astype(np.float32), fmt)
+    tok = torch.from_numpy(rng.integers(0, vocab, size=(3, 50)))
+    want = cache.embed_tokens(tok, out_dtype=torch.float32)
+    p = str(tmp_path / "table")
+    cache.save_native(p)
+    for placement, hot in (("hbm", 0), ("pinned_host", 100)):
+        again = EmbeddingCache.load_native(p, placement=placement, hot_rows=hot)
+        assert again.table_format == fmt and again.embedding_dim == d and len(again.n_gram_extractor) == n
+        assert torch.equal(again.embed_tokens(tok, out_dtype=torch.float32), want)
+        assert torch.equal(again.table.gather_rows(torch.arange(n)), cache.table.gather_rows(torch.arange(n)))

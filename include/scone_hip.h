@@ -105,6 +105,19 @@ int scone_index_build_device(scone_handle *h, const uint32_t *d_keys, const uint
 /* Synchronises.  n_keys = distinct keys stored, n_dups = duplicate insertions seen. */
 int scone_index_stats(scone_handle *h, uint64_t *n_keys, uint64_t *capacity, uint64_t *n_dups);
 
+/* ---- vocabulary construction on the GPU (NGramExtractor.fit, n_gram_extractor.py:72-104) -----
+ * d_tokens[n_tokens] int32: the corpus, texts back to back; d_text_offsets[n_texts+1] int64.
+ * Counts every n-gram (n = 1..max_n, windows inside one text), keeps those with
+ * count >= min_freq, orders them by count descending with ties in first-insertion order
+ * (Counter.most_common: texts in order; per text all 1-grams, then all 2-grams, ...;
+ * extract_all_n_grams :59-70) and writes the first min(max_f_grams, out_cap) as
+ * d_keys_out[*, max_n] / d_lens_out[*] (/ d_counts_out[*], optional): row r is f-gram id r.
+ * *h_n_out = rows written, *h_n_distinct = distinct n-grams seen (optional).  Synchronises. */
+int scone_fit(int32_t device, const int32_t *d_tokens, int64_t n_tokens, const int64_t *d_text_offsets,
+              int64_t n_texts, int32_t max_n, uint32_t min_freq, uint64_t max_f_grams,
+              uint32_t *d_keys_out, uint8_t *d_lens_out, uint32_t *d_counts_out, uint64_t out_cap,
+              uint64_t *h_n_out, uint64_t *h_n_distinct, scone_stream_t stream);
+
 /* ---- table: rows (replaces EmbeddingCache.cache_embeddings storage,
  *      embedding_cache.py:56-111) ------------------------------------------- */
 /* Raw rows already in the handle's format.  rows: nrows * payload bytes

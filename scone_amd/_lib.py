@@ -56,6 +56,8 @@ SIGNATURES = {
     "scone_index_build": (C.c_int, [_P, _P, _P, _U64, _U64]),
     "scone_index_build_device": (C.c_int, [_P, _P, _P, _U64, _U64, _P]),
     "scone_index_stats": (C.c_int, [_P, C.POINTER(_U64), C.POINTER(_U64), C.POINTER(_U64)]),
+    "scone_fit": (C.c_int, [_I32, _P, _I64, _P, _I64, _I32, _U32, _U64, _P, _P, _P, _U64, C.POINTER(_U64),
+                            C.POINTER(_U64), _P]),
     "scone_table_upload": (C.c_int, [_P, _P, _P, _U64, _U64, C.c_int, _P]),
     "scone_table_download": (C.c_int, [_P, _P, _P, _U64, _U64, C.c_int, _P]),
     "scone_table_store_f32": (C.c_int, [_P, _P, _U64, _U64, _P]),

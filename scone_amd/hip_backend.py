@@ -65,6 +65,33 @@ def require_gpu() -> torch.device:
     return torch.device("cuda", torch.cuda.current_device())
 
 
+def fit_gpu(tokens: torch.Tensor, text_offsets: torch.Tensor, max_n: int, min_freq: int, max_f_grams: int,
+            device: Optional[torch.device] = None):
+    """``scone_fit``: f-gram vocabulary of a tokenised corpus, built on the GPU.
+    Returns ``(keys [S, max_n] uint32, lens [S] uint8, counts [S] uint32, n_distinct)`` as numpy arrays;
+    row r is f-gram id r (the reference's ``Counter.most_common`` order)."""
+    dev = torch.device(device) if device is not None else require_gpu()
+    require_gpu()
+    dev = torch.device("cuda", dev.index if dev.index is not None else torch.cuda.current_device())
+    tok = tokens.to(device=dev, dtype=torch.int32).contiguous()
+    off = text_offsets.to(device=dev, dtype=torch.int64).contiguous()
+    n_tok, n_texts = tok.numel(), off.numel() - 1
+    cap = int(min(max_f_grams, max(1, n_tok * max_n)))
+    keys = torch.zeros((cap, max_n), dtype=torch.int32, device=dev)
+    lens = torch.zeros(cap, dtype=torch.uint8, device=dev)
+    counts = torch.zeros(cap, dtype=torch.int32, device=dev)
+    n_out, n_distinct = C.c_uint64(0), C.c_uint64(0)
+    with torch.cuda.device(dev):
+        rc = L.lib().scone_fit(dev.index, _ptr(tok), n_tok, _ptr(off), n_texts, int(max_n), int(max(min_freq, 0)),
+                               int(max_f_grams), _ptr(keys), _ptr(lens), _ptr(counts), cap, C.byref(n_out),
+                               C.byref(n_distinct), _stream())
+    if rc != L.OK:
+        _raise(rc, "scone_fit failed (negative or too large token ids, or out of memory)")
+    n = n_out.value
+    return (keys[:n].cpu().numpy().view(np.uint32), lens[:n].cpu().numpy(), counts[:n].cpu().numpy().view(np.uint32),
+            n_distinct.value)
+
+
 class SconeTable:
     """Device-resident f-gram index (+ optional table shard)."""
 

@@ -110,6 +110,29 @@ class NGramExtractor:
             print(f"Extracted {len(self.f_grams)} f-grams")
         return self
 
+    def fit_gpu(self, tokenized_texts: Iterable[Sequence[int]], verbose: bool = True, device=None) -> "NGramExtractor":
+        """Same result as :meth:`fit` (identical f-grams and ids), computed on the GPU by ``scone_fit``:
+        hash-table counting of every n-gram + two stable radix sorts (count descending, first-seen
+        ascending).  Needs a GPU; the vocabulary stays in array form (see :meth:`from_arrays`)."""
+        import torch
+        from scone_amd.hip_backend import fit_gpu
+        texts = [np.asarray(t, dtype=np.int64) for t in tokenized_texts]
+        lens = np.fromiter((len(t) for t in texts), dtype=np.int64, count=len(texts))
+        offsets = np.zeros(len(texts) + 1, dtype=np.int64)
+        np.cumsum(lens, out=offsets[1:])
+        flat = np.concatenate(texts) if texts else np.zeros(0, dtype=np.int64)
+        if flat.size and (flat.min() < 0 or flat.max() > 2**31 - 2):
+            raise ValueError("fit_gpu: token ids must be in [0, 2**31 - 2]")
+        keys, klens, counts, _ = fit_gpu(torch.from_numpy(flat), torch.from_numpy(offsets), self.max_n, self.min_freq,
+                                         self.max_f_grams, device=device)
+        self._keys, self._lens = np.ascontiguousarray(keys), np.ascontiguousarray(klens)
+        self._f_gram_to_id = self._id_to_f_gram = self._f_grams = None
+        self._index = None
+        self.counts = counts
+        if verbose:
+            print(f"Extracted {len(self)} f-grams")
+        return self
+
     def _set_from_list(self, grams: List[Tuple[int, ...]]) -> None:
         self._f_grams = set(grams)
         self._f_gram_to_id = {g: i for i, g in enumerate(grams)}

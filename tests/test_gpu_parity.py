@@ -551,3 +551,38 @@ def test_native_table_file_round_trip(tmp_path, fmt):
         assert again.table_format == fmt and again.embedding_dim == d and len(again.n_gram_extractor) == n
         assert torch.equal(again.embed_tokens(tok, out_dtype=torch.float32), want)
         assert torch.equal(again.table.gather_rows(torch.arange(n)), cache.table.gather_rows(torch.arange(n)))
+
+
+# ------------------------------------------------------------------ vocabulary construction
+def test_fit_gpu_matches_reference_order(golden_dir):
+    """scone_fit reproduces the reference's fit: same f-grams, same ids (Counter.most_common order with
+    first-seen ties), on every golden corpus (max_n 1..4, tiny and GPT-2-sized vocabularies)."""
+    from scone_amd import NGramExtractor
+    z = np.load(os.path.join(golden_dir, "match.npz"))
+    for c in z["cases"]:
+        flat, cl = z[f"{c}_corpus_flat"], z[f"{c}_corpus_lens"]
+        min_freq, max_f = (int(x) for x in z[f"{c}_fit_args"])
+        corpus, p = [], 0
+        for n in cl:
+            corpus.append(flat[p:p + n].tolist())
+            p += n
+        ex = NGramExtractor(max_n=int(z[f"{c}_max_n"]), min_freq=min_freq, max_f_grams=max_f).fit_gpu(corpus, verbose=False)
+        keys, lens = ex.key_arrays()
+        assert np.array_equal(lens, z[f"{c}_lens"]), c
+        assert np.array_equal(keys, z[f"{c}_keys"]), c
+
+
+def test_fit_gpu_large_corpus_vs_host_fit():
+    from scone_amd import NGramExtractor
+    from scone_amd import synthetic as S
+    rng = np.random.default_rng(4)
+    cdf = S.zipf_cdf(5000)
+    corpus = [S.zipf_tokens(rng, cdf, int(rng.integers(1, 600))).tolist() for _ in range(700)] + [[], [3]]
+    for max_n, min_freq, max_f in ((3, 2, 50_000), (4, 1, 20_000), (2, 5, 10**9)):
+        host = NGramExtractor(max_n=max_n, min_freq=min_freq, max_f_grams=max_f).fit(corpus, verbose=False)
+        dev = NGramExtractor(max_n=max_n, min_freq=min_freq, max_f_grams=max_f).fit_gpu(corpus, verbose=False)
+        hk, hl = host.key_arrays()
+        dk, dl = dev.key_arrays()
+        assert np.array_equal(hl, dl) and np.array_equal(hk, dk), (max_n, min_freq)
+    with pytest.raises(ValueError):
+        NGramExtractor(max_n=2, min_freq=1).fit_gpu([[1, -2, 3]], verbose=False)

@@ -49,6 +49,13 @@ enum {
   SCONE_PLACE_PINNED_HOST = 1 /* rows >= cfg.hot_rows in pinned host DRAM mapped into the GPU, read over PCIe */
 };
 enum { SCONE_REDUCE_MEAN = 0, SCONE_REDUCE_SUM = 1 };
+enum {
+  SCONE_MODE_COVER = 0,         /* the reference CODE: every f-gram covering the token, aggregated and ADDED to
+                                   the token embedding (n_gram_extractor.py:106-126, engine.py:250,
+                                   language_model.py:242-243)                                             */
+  SCONE_MODE_LONGEST_SUFFIX = 1 /* the PAPER (Algorithm 2, assets/algorithm.png): the longest f-gram of length
+                                   >= 2 ENDING at the token REPLACES the token embedding; causal           */
+};
 enum { SCONE_DT_F32 = 0, SCONE_DT_F16 = 1, SCONE_DT_BF16 = 2 };
 
 enum {
@@ -78,6 +85,8 @@ typedef struct scone_cfg {
                               rest in pinned host DRAM.  f-gram ids are frequency-ordered
                               (Counter.most_common, n_gram_extractor.py:91-99), so the head of
                               the table takes most of the hits.                              */
+  uint32_t lookup_mode;    /* SCONE_MODE_* for scone_embed / scone_embed_partial / scone_finalize           */
+  uint32_t reserved;       /* 0                                                                             */
 } scone_cfg;
 
 /* ---- lifecycle ----------------------------------------------------------- */

@@ -176,6 +176,50 @@ def match_csr_python(f_gram_to_id: Dict[Tuple[int, ...], int], max_n: int,
 
 
 # --------------------------------------------------------------------------
+# The PAPER's lookup (Algorithm 2 in assets/algorithm.png, shown at README.md:28-32).  The
+# reference CODE does not implement it (it uses the covering / mean / add scheme above), so this
+# restatement is pinned to the published algorithm only: "parity unpinned" by reference code.
+#   for i = 1..m: j <- smallest j' < i s.t. (sigma_j', ..., sigma_i) in V_f-gram, else i
+#                 e_i <- T(sigma_i) if j == i else F(sigma_j, ..., sigma_i)
+# V_f-gram holds n-grams of length 2..n only, so unigram keys never match.
+# --------------------------------------------------------------------------
+
+def paper_lookup(f_gram_to_id: Dict[Tuple[int, ...], int], max_n: int, token_ids: Sequence[int]) -> List[int]:
+    """Per position: id of the longest f-gram (length 2..max_n) ending there, or -1."""
+    out = []
+    for i in range(len(token_ids)):
+        hit = -1
+        for j in range(max(0, i - max_n + 1), i):              # smallest j' first = longest f-gram
+            g = tuple(int(x) for x in token_ids[j:i + 1])
+            if g in f_gram_to_id:
+                hit = f_gram_to_id[g]
+                break
+        out.append(hit)
+    return out
+
+
+def paper_embed(f_gram_to_id: Dict[Tuple[int, ...], int], max_n: int, tok: np.ndarray, table_f32: np.ndarray,
+                wte: Optional[np.ndarray] = None, wpe: Optional[np.ndarray] = None) -> np.ndarray:
+    """e_i = F(f-gram) if one ends at i else T(sigma_i); then + position embedding (the model adds it
+    to whatever the embedding layer returns, language_model.py:253-254).  fp32, [B, T, d]."""
+    B, T = tok.shape
+    d = table_f32.shape[1]
+    out = np.zeros((B, T, d), dtype=np.float32)
+    for b in range(B):
+        ids = paper_lookup(f_gram_to_id, max_n, tok[b].tolist())
+        for i, fid in enumerate(ids):
+            if fid >= 0:
+                e = table_f32[fid].astype(np.float32)
+            elif wte is not None:
+                e = wte[tok[b, i]].astype(np.float32)
+            else:
+                e = np.zeros(d, dtype=np.float32)
+            # same fp32 association as the kernel: (base + f_gram) + pos with the unused term = 0
+            out[b, i] = (np.float32(0) + e) + (wpe[i].astype(np.float32) if wpe is not None else np.float32(0))
+    return out
+
+
+# --------------------------------------------------------------------------
 # numpy-vectorised equivalents (same results; for larger parity cases)
 # --------------------------------------------------------------------------
 

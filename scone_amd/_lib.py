@@ -19,6 +19,7 @@ ABI_VERSION = 1
 FMT_F32, FMT_F16, FMT_I8, FMT_I4 = 0, 1, 2, 3
 PLACE_HBM, PLACE_PINNED_HOST = 0, 1
 REDUCE_MEAN, REDUCE_SUM = 0, 1
+MODE_COVER, MODE_LONGEST_SUFFIX = 0, 1
 DT_F32, DT_F16, DT_BF16 = 0, 1, 2
 
 OK, ESTATE, EHIP, ENOMEM, ENODEV, EINVAL, ERANGE = 0, -1, -5, -12, -19, -22, -34
@@ -39,6 +40,8 @@ class SconeCfg(C.Structure):
         ("row_end", C.c_uint64),
         ("index_capacity", C.c_uint64),
         ("hot_rows", C.c_uint64),
+        ("lookup_mode", C.c_uint32),
+        ("reserved", C.c_uint32),
     ]
 
 

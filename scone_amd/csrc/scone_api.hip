@@ -98,6 +98,10 @@ extern "C" int scone_create(const scone_cfg *cfg, scone_handle **out) {
     g_create_err = "scone_create: struct_size mismatch (ABI)";
     return SCONE_EINVAL;
   }
+  if (cfg->lookup_mode > SCONE_MODE_LONGEST_SUFFIX) {
+    g_create_err = "scone_create: unknown lookup_mode";
+    return SCONE_EINVAL;
+  }
   if (cfg->max_n < 1 || cfg->max_n > SCONE_MAX_N || cfg->dim < 0) {
     g_create_err = "scone_create: max_n must be 1..4 and dim >= 0";
     return SCONE_EINVAL;

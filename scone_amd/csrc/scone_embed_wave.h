@@ -27,6 +27,7 @@ struct wave_params {
   int max_n;
   int reduce;
   int B;
+  int mode;            // SCONE_MODE_*
   int pos_groups;      // ceil(T / 4): a workgroup's 4 waves own 4 consecutive positions
   int seqs_per_block;  // sequences walked by one workgroup
 };
@@ -311,13 +312,15 @@ __global__ __launch_bounds__(256, (wave_occupancy<FMT, OutT, D, MAXN, FIXED_POS>
       if (lane == 0) atomicOr(status, SCONE_ST_BAD_TOKEN);
     }
     // absent / out-of-range base rows read a row of zeros: the adds stay unconditional
-    const uint8_t *wte_row = tok_ok ? reinterpret_cast<const uint8_t *>(wte + (long long)tokv * D) : zero_row;
+    const int kown = rec[W - 2] & 0xFF, kfull = rec[W - 2] >> 8;
+    // paper mode: a matched f-gram REPLACES the token embedding (Algorithm 2), so wte is skipped
+    const bool use_wte = tok_ok && !(q.mode == SCONE_MODE_LONGEST_SUFFIX && kfull > 0);
+    const uint8_t *wte_row = use_wte ? reinterpret_cast<const uint8_t *>(wte + (long long)tokv * D) : zero_row;
     const uint8_t *wpe_row = zero_row;
     if constexpr (!FIXED_POS) {
       if (pos_ok) wpe_row = reinterpret_cast<const uint8_t *>(wpe + (long long)posv * D);
     }
     uint8_t *out_row = reinterpret_cast<uint8_t *>(out + p * D);
-    const int kown = rec[W - 2] & 0xFF, kfull = rec[W - 2] >> 8;
     if constexpr (PARTIAL) {
       if (lane == 0) counts[p] = kfull;
     }
@@ -360,7 +363,7 @@ int launch_wave(scone_handle *h, const embed_args &a, hipStream_t s) {
   wave_params q;
   q.BT = a.BT, q.T = a.T, q.max_n = a.max_n;
   q.row_begin = a.tv.row_begin, q.row_end = a.tv.row_end;
-  q.vocab = a.vocab, q.n_pos = a.n_pos, q.reduce = a.reduce;
+  q.vocab = a.vocab, q.n_pos = a.n_pos, q.reduce = a.reduce, q.mode = a.mode;
   q.B = (int)(a.BT / a.T);
   q.pos_groups = (a.T + 3) / 4;
   // ~4096 workgroups (256 CUs x 8 resident x 2 rounds) when the batch allows it
@@ -404,7 +407,7 @@ __global__ __launch_bounds__(256) void k_finalize_wave(const float *__restrict__
                                                        const OutT *__restrict__ wte, const OutT *__restrict__ wpe,
                                                        const uint8_t *__restrict__ zero_row, OutT *__restrict__ out,
                                                        uint32_t *__restrict__ status, long long tok_begin, long long ntok,
-                                                       int T, long long vocab, long long n_pos, int reduce) {
+                                                       int T, long long vocab, long long n_pos, int reduce, int mode) {
   constexpr int FMT = SCONE_FMT_F32;  // lane map of an fp32 row
   using G = wave_geom<FMT, D>;
   constexpr int EPL = G::EPL, NWO = EPL * (int)sizeof(OutT) / 4, OPW = pack_io<OutT>::PER_WORD;
@@ -421,7 +424,8 @@ __global__ __launch_bounds__(256) void k_finalize_wave(const float *__restrict__
     if ((wte && !tok_ok) || (wpe && !pos_ok)) {
       if (lane == 0) atomicOr(status, SCONE_ST_BAD_TOKEN);
     }
-    const uint8_t *wte_row = tok_ok ? reinterpret_cast<const uint8_t *>(wte + (long long)tokv * D) : zero_row;
+    const bool use_wte = tok_ok && !(mode == SCONE_MODE_LONGEST_SUFFIX && kfull > 0);
+    const uint8_t *wte_row = use_wte ? reinterpret_cast<const uint8_t *>(wte + (long long)tokv * D) : zero_row;
     const uint8_t *wpe_row = pos_ok ? reinterpret_cast<const uint8_t *>(wpe + (long long)posv * D) : zero_row;
     uint32_t bw[NWO], bp[NWO], sw[EPL];
     ld_out_row<FMT, OutT, D>(wte_row, lane, bw);
@@ -463,7 +467,7 @@ int try_launch_finalize_wave(scone_handle *h, const embed_args &a, hipStream_t s
 #define SCONE_FIN(DD)                                                                                              \
   hipLaunchKernelGGL((k_finalize_wave<OutT, DD>), dim3((unsigned)blocks), dim3(256), 0, s, a.sums, a.counts, a.tok, \
                      a.pos, (const OutT *)a.wte, (const OutT *)a.wpe, (const uint8_t *)a.zero_row, (OutT *)a.out,   \
-                     a.status, a.tok_begin, a.ntok, a.T, a.vocab, a.n_pos, a.reduce)
+                     a.status, a.tok_begin, a.ntok, a.T, a.vocab, a.n_pos, a.reduce, a.mode)
   if (a.tv.d == 768) SCONE_FIN(768);
   else SCONE_FIN(1024);
 #undef SCONE_FIN

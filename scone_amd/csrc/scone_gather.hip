@@ -47,6 +47,12 @@ void fill_table_view(const scone_handle *h, table_view &tv) {
   tv.d = h->cfg.dim;
 }
 
+int check_mode(scone_handle *h, const char *who) {
+  if (h->cfg.lookup_mode == SCONE_MODE_COVER) return SCONE_OK;
+  if (h->cfg.lookup_mode == SCONE_MODE_LONGEST_SUFFIX && scone_wave_kernel_covers(h->cfg.table_fmt, h->cfg.dim)) return SCONE_OK;
+  return scone_fail(h, SCONE_EINVAL, who);
+}
+
 int need_table(scone_handle *h, const char *who) {
   if (!h) return SCONE_EINVAL;
   if (h->cfg.dim <= 0 || !h->rows) return scone_fail(h, SCONE_ESTATE, who);
@@ -94,7 +100,9 @@ extern "C" int scone_embed(scone_handle *h, const int32_t *d_tok, int32_t B, int
   fill_table_view(h, a.tv);
   a.BT = BT, a.T = T, a.max_n = h->cfg.max_n;
   a.tok_begin = 0, a.ntok = BT;
-  a.zero_row = h->d_zero_row;
+  a.zero_row = h->d_zero_row, a.mode = (int)h->cfg.lookup_mode;
+  rc = check_mode(h, "scone_embed: lookup_mode longest_suffix needs d = 768 / 1024");
+  if (rc) return rc;
   if (scone_wave_kernel_covers(h->cfg.table_fmt, h->cfg.dim)) {
     // fast path: per-token id records (one scalar load per token in the gather kernel)
     rc = scone_ensure_ell(h, BT);
@@ -132,7 +140,9 @@ extern "C" int scone_embed_partial(scone_handle *h, const int32_t *d_tok, int32_
   fill_table_view(h, a.tv);
   a.BT = BT, a.T = T, a.max_n = h->cfg.max_n;
   a.tok_begin = 0, a.ntok = BT;
-  a.zero_row = h->d_zero_row, a.tok = d_tok;
+  a.zero_row = h->d_zero_row, a.tok = d_tok, a.mode = (int)h->cfg.lookup_mode;
+  rc = check_mode(h, "scone_embed_partial: lookup_mode longest_suffix needs d = 768 / 1024");
+  if (rc) return rc;
   if (scone_wave_kernel_covers(h->cfg.table_fmt, h->cfg.dim)) {
     rc = scone_ensure_ell(h, BT);
     if (rc) return rc;
@@ -171,7 +181,7 @@ extern "C" int scone_finalize(scone_handle *h, const float *d_sum, const int32_t
   a.tok_begin = tok_begin, a.ntok = tok_end - tok_begin;
   a.tok = d_tok, a.pos = d_pos, a.wte = d_wte, a.vocab = vocab, a.wpe = d_wpe, a.n_pos = n_pos;
   a.reduce = reduce, a.out = d_out, a.sums = d_sum, a.counts = const_cast<int32_t *>(d_counts);
-  a.zero_row = h->d_zero_row;
+  a.zero_row = h->d_zero_row, a.mode = (int)h->cfg.lookup_mode;
   a.status = h->d_status;
   return launch_fmt(h, a, SRC_HITS, MODE_FINALIZE, out_dtype, (hipStream_t)stream);
 }

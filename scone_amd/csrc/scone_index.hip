@@ -183,7 +183,7 @@ template <int MAXN>
 __global__ __launch_bounds__(ELL_TILE) void k_match_ell(const scone_slot *__restrict__ slots, unsigned long long mask,
                                                         const int32_t *__restrict__ uni, int uni_cap,
                                                         const int32_t *__restrict__ tok, long long BT, int T, int max_n,
-                                                        long long row_begin, long long row_end,
+                                                        long long row_begin, long long row_end, int mode,
                                                         int32_t *__restrict__ ell) {
   constexpr int HALO = MAXN - 1;
   constexpr int W = MAXN <= 3 ? 8 : 16;
@@ -209,11 +209,25 @@ __global__ __launch_bounds__(ELL_TILE) void k_match_ell(const scone_slot *__rest
 #pragma unroll
   for (int j = 0; j < W; ++j) rec[j] = -1;
   int kown = 0, kfull = 0;
+  if (mode == SCONE_MODE_LONGEST_SUFFIX) {
+    // paper, Algorithm 2: j = smallest j' < i with (sigma_j' .. sigma_i) an f-gram -> the LONGEST
+    // f-gram of length >= 2 that ENDS at this position (window start p - (n-1))
+#pragma unroll
+    for (int nn = MAXN; nn >= 2; --nn) {
+      if (kfull == 0 && nn <= max_n && i - (nn - 1) >= 0) {
+        const int32_t id = win[nn - 1][t + HALO - (nn - 1)];
+        if (id >= 0) {
+          kfull = 1;
+          if (id >= row_begin && id < row_end) rec[0] = id, kown = 1;
+        }
+      }
+    }
+  }
 #pragma unroll
   for (int nn = 1; nn <= MAXN; ++nn) {
 #pragma unroll
     for (int s = nn - 1; s >= 0; --s) {
-      if (nn <= max_n && i - s >= 0) {
+      if (mode == SCONE_MODE_COVER && nn <= max_n && i - s >= 0) {
         const int32_t id = win[nn - 1][t + HALO - s];
         if (id >= 0) {
           ++kfull;
@@ -371,10 +385,10 @@ int scone_launch_match_ell(scone_handle *h, const int32_t *d_tok, int32_t B, int
   const long long rb = (long long)h->cfg.row_begin, re = (long long)h->cfg.row_end;
   if (h->cfg.max_n <= 3)
     hipLaunchKernelGGL((k_match_ell<3>), dim3((unsigned)blocks), dim3(ELL_TILE), 0, s, h->slots, h->cap - 1, h->d_uni,
-                       SCONE_UNI_CAP, d_tok, BT, T, h->cfg.max_n, rb, re, d_ell);
+                       SCONE_UNI_CAP, d_tok, BT, T, h->cfg.max_n, rb, re, (int)h->cfg.lookup_mode, d_ell);
   else
     hipLaunchKernelGGL((k_match_ell<4>), dim3((unsigned)blocks), dim3(ELL_TILE), 0, s, h->slots, h->cap - 1, h->d_uni,
-                       SCONE_UNI_CAP, d_tok, BT, T, h->cfg.max_n, rb, re, d_ell);
+                       SCONE_UNI_CAP, d_tok, BT, T, h->cfg.max_n, rb, re, (int)h->cfg.lookup_mode, d_ell);
   SCONE_HIP(h, hipGetLastError());
   return SCONE_OK;
 }

@@ -15,6 +15,7 @@ _FMT = {"fp32": L.FMT_F32, "float32": L.FMT_F32, "f32": L.FMT_F32,
         "int8": L.FMT_I8, "i8": L.FMT_I8, "int4": L.FMT_I4, "i4": L.FMT_I4}
 _PLACE = {"hbm": L.PLACE_HBM, "pinned_host": L.PLACE_PINNED_HOST}
 _REDUCE = {"mean": L.REDUCE_MEAN, "sum": L.REDUCE_SUM}
+_MODE = {"cover": L.MODE_COVER, "longest_suffix": L.MODE_LONGEST_SUFFIX}
 _DT = {torch.float32: L.DT_F32, torch.float16: L.DT_F16, torch.bfloat16: L.DT_BF16}
 
 I4_GROUP = 128
@@ -97,7 +98,7 @@ class SconeTable:
 
     def __init__(self, max_n: int, n_rows: int, dim: int = 0, table_format="fp32", placement: str = "hbm",
                  device: Optional[torch.device] = None, row_begin: int = 0, row_end: Optional[int] = None,
-                 index_capacity: int = 0, hot_rows: int = 0) -> None:
+                 index_capacity: int = 0, hot_rows: int = 0, lookup_mode: str = "cover") -> None:
         self._h = None
         lib = L.lib()
         dev = torch.device(device) if device is not None else require_gpu()
@@ -111,7 +112,7 @@ class SconeTable:
         self.row_end = int(n_rows if row_end is None else row_end)
         cfg = L.SconeCfg(C.sizeof(L.SconeCfg), self.device.index, self.max_n, self.dim, self.fmt,
                          _PLACE[placement], self.n_rows, self.row_begin, self.row_end, int(index_capacity),
-                         int(hot_rows))
+                         int(hot_rows), _MODE[lookup_mode], 0)
         h = C.c_void_p()
         rc = lib.scone_create(C.byref(cfg), C.byref(h))
         if rc != L.OK:

@@ -586,3 +586,37 @@ def test_fit_gpu_large_corpus_vs_host_fit():
         assert np.array_equal(hl, dl) and np.array_equal(hk, dk), (max_n, min_freq)
     with pytest.raises(ValueError):
         NGramExtractor(max_n=2, min_freq=1).fit_gpu([[1, -2, 3]], verbose=False)
+
+
+# ------------------------------------------------------------------ the paper's lookup
+@pytest.mark.parametrize("fmt,d,max_n", [("fp32", 768, 3), ("int8", 1024, 4), ("int8", 768, 2)])
+def test_paper_mode_longest_suffix_vs_oracle(fmt, d, max_n):
+    """lookup_mode='longest_suffix' (paper, Algorithm 2): the longest f-gram of length >= 2 ending at the token
+    replaces the token embedding; otherwise wte; + wpe.  Bit-exact in fp32 against oracle.paper_embed."""
+    from scone_amd import EmbeddingCache
+    rng = np.random.default_rng(11 + max_n)
+    vocab, n = 9, 400
+    lens = rng.integers(1, max_n + 1, size=n).astype(np.uint8)
+    keys = rng.integers(0, vocab, size=(n, max_n)).astype(np.uint32)
+    keys[np.arange(max_n)[None, :] >= lens[:, None]] = 0
+    ex = _extractor(keys, lens, max_n)
+    table = rng.standard_normal((n, d)).astype(np.float32)
+    cache = EmbeddingCache(ex, d, table_format=fmt, lookup_mode="longest_suffix")
+    cache.cache_embeddings(list(range(n)), torch.from_numpy(table), verbose=False)
+    deq = cache.table.gather_rows(torch.arange(n)).cpu().numpy()
+    f2id = R._key_dict(keys, lens)
+    wte = rng.standard_normal((vocab, d)).astype(np.float32)
+    wpe = rng.standard_normal((64, d)).astype(np.float32)
+    for B, T in ((1, 1), (2, 7), (5, 64), (33, 3)):
+        tok = rng.integers(0, vocab, size=(B, T))
+        ref = R.paper_embed(f2id, max_n, tok, deq, wte=wte, wpe=wpe)
+        got = cache.embed_tokens(torch.from_numpy(tok), wte=torch.from_numpy(wte).cuda(), wpe=torch.from_numpy(wpe).cuda(),
+                                 out_dtype=torch.float32)
+        assert np.array_equal(got.cpu().numpy(), ref), (B, T)
+        only = cache.embed_tokens(torch.from_numpy(tok), out_dtype=torch.float32).cpu().numpy()
+        assert np.array_equal(only, R.paper_embed(f2id, max_n, tok, deq))
+    # the mode needs the wave kernel's dims
+    bad = EmbeddingCache(ex, 128, table_format="fp32", lookup_mode="longest_suffix")
+    bad.cache_embeddings(list(range(n)), torch.zeros(n, 128), verbose=False)
+    with pytest.raises(ValueError):
+        bad.embed_tokens(torch.zeros((1, 4), dtype=torch.int64))

@@ -141,3 +141,16 @@ def test_synth_generators_are_deterministic():
     assert not np.array_equal(a[0], a[1])
     s = R.synth_scale_f16(7, np.arange(100), 0.02 / 127)
     assert s.dtype == np.float16 and np.all(s > 0)
+
+
+def test_paper_lookup_known_answers():
+    """Algorithm 2 (assets/algorithm.png): longest f-gram of length >= 2 ending at the token; unigrams never match."""
+    d = {(5,): 0, (5, 6): 1, (4, 5, 6): 2, (6, 7): 3, (9, 9): 4, (9, 9, 9): 5}
+    assert R.paper_lookup(d, 3, [4, 5, 6, 7]) == [-1, -1, 2, 3]
+    assert R.paper_lookup(d, 2, [4, 5, 6, 7]) == [-1, -1, 1, 3]
+    assert R.paper_lookup(d, 3, [9, 9, 9, 9]) == [-1, 4, 5, 5]
+    assert R.paper_lookup(d, 3, [5]) == [-1] and R.paper_lookup(d, 3, []) == []
+    table = np.arange(6 * 4, dtype=np.float32).reshape(6, 4)
+    wte = 100 + np.arange(10 * 4, dtype=np.float32).reshape(10, 4)
+    e = R.paper_embed(d, 3, np.array([[4, 5, 6, 7]]), table, wte=wte)
+    assert np.array_equal(e[0, 0], wte[4]) and np.array_equal(e[0, 2], table[2]) and np.array_equal(e[0, 3], table[3])

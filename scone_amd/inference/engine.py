@@ -1,0 +1,162 @@
+"""Inference glue around the fused f-gram lookup.
+
+Mirrors the constructor and the ``generate`` / ``benchmark_inference`` entry points of
+``scone/inference/engine.py`` of the reference, with three differences that follow from what the
+reference does around the lookup path:
+
+* the per-position Python loop of ``engine.py:234-266`` (ids -> rows -> mean -> scatter) is ONE
+  fused GPU pass, ``EmbeddingCache.embed_tokens``, batched over ``[B, T]``;
+* the embeddings are actually consumed: the reference hands ``f_gram_embeddings`` to HF
+  ``generate``, which never routes them back into ``SconeLanguageModel.forward``
+  (``language_model.py:349-376``); here every decoding step makes the call that ``forward`` makes,
+  ``transformer(inputs_embeds=wte + f_gram + wpe)`` (``language_model.py:257-264``), so the logits of a
+  step equal ``SconeLanguageModel.forward(input_ids)["logits"][:, -1]``;
+* with the paper's causal lookup (``lookup_mode="longest_suffix"``) decoding is incremental: a new
+  token only needs its own embedding (computed from the last ``max_n`` tokens) and the KV cache.
+  With the reference code's covering lookup (``"cover"``) a new token changes the f-gram sets of
+  the ``max_n - 1`` positions before it, so the prefix is re-embedded every step (exact, O(T^2)).
+
+The transformer itself is any HF-style causal LM (``.transformer``, ``.lm_head``); tokenisation is
+delegated to the tokenizer object the caller passes (``encode`` / ``decode``).
+"""
+
+import time
+from typing import Dict, List, Optional, Sequence, Union
+
+import torch
+
+
+class SconeInferenceEngine:
+    """``SconeInferenceEngine(model, tokenizer, f_gram_tokenizer, embedding_cache, device, quantization)``
+    (reference: engine.py:33-67).  ``model`` is a ``scone_amd.models.SconeLanguageModel`` (or any
+    object with ``.base_model.transformer`` / ``.base_model.lm_head``); ``embedding_cache`` must hold a
+    table in hidden size (``fold_projection``).  ``f_gram_tokenizer`` is accepted for signature
+    compatibility; matching happens on the GPU inside the cache."""
+
+    def __init__(self, model, tokenizer=None, f_gram_tokenizer=None, embedding_cache=None,
+                 device: Optional[torch.device] = None, quantization: Optional[str] = None) -> None:
+        if embedding_cache is None:
+            raise ValueError("SconeInferenceEngine needs an embedding_cache")
+        self.model = model
+        self.tokenizer = tokenizer
+        self.f_gram_tokenizer = f_gram_tokenizer
+        self.embedding_cache = embedding_cache
+        self.quantization = quantization
+        self.device = torch.device(device) if device is not None else torch.device("cuda")
+        if self.device.type != "cuda":
+            raise RuntimeError("scone_amd: the lookup path runs on the GPU (no CPU fallback)")
+        if quantization == "fp16":                         # engine.py:118-121
+            self.model.half()
+        elif quantization not in (None, "int8", "int4"):
+            raise ValueError(f"Unknown quantization mode: {quantization}")
+        # int8 / int4 in the reference quantise the transformer's nn.Linear layers (engine.py:75-116),
+        # which is outside this layer; the f-gram TABLE format is chosen on the cache (table_format=).
+        self.model.to(self.device)
+        self.base = model.base_model
+        self.causal = getattr(embedding_cache, "lookup_mode", "cover") == "longest_suffix"
+        self.max_n = embedding_cache.n_gram_extractor.max_n
+
+    # ------------------------------------------------------------------ lookup
+    def _weights(self):
+        wte = self.base.transformer.wte.weight.detach().contiguous()
+        wpe = self.base.transformer.wpe.weight.detach().contiguous()
+        return wte, wpe
+
+    def embed(self, input_ids: torch.Tensor, position_ids: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """``inputs_embeds [B, T, H]`` for the transformer: fused match + gather + mean + wte + wpe."""
+        wte, wpe = self._weights()
+        return self.embedding_cache.embed_tokens(input_ids, wte=wte, wpe=wpe, position_ids=position_ids,
+                                                 out_dtype=wte.dtype)
+
+    def _encode(self, text: Union[str, Sequence[int], torch.Tensor]) -> torch.Tensor:
+        if isinstance(text, str):
+            if self.tokenizer is None:
+                raise ValueError("a tokenizer is needed to generate from text")
+            ids = self.tokenizer.encode(text)
+        else:
+            ids = text
+        ids = torch.as_tensor(ids, dtype=torch.long)
+        return ids.reshape(1, -1) if ids.dim() == 1 else ids
+
+    # ------------------------------------------------------------------ generation
+    @torch.no_grad()
+    def generate_ids(self, input_ids: torch.Tensor, max_length: int = 50, min_length: int = 0, do_sample: bool = True,
+                     temperature: float = 1.0, top_k: int = 50, top_p: float = 1.0, eos_token_id: Optional[int] = None,
+                     generator: Optional[torch.Generator] = None) -> torch.Tensor:
+        """Decode until ``max_length`` total tokens.  Batch of prompts of equal length ``[B, T0]``."""
+        ids = input_ids.to(self.device)
+        B = ids.shape[0]
+        past = None
+        finished = torch.zeros(B, dtype=torch.bool, device=self.device)
+        while ids.shape[1] < max_length:
+            T = ids.shape[1]
+            if self.causal and past is not None:
+                # only the new position: its f-gram is decided by the last max_n tokens
+                tail = ids[:, -self.max_n:]
+                pos = torch.arange(T - tail.shape[1], T, device=self.device).unsqueeze(0).expand(B, -1)
+                x = self.embed(tail, position_ids=pos)[:, -1:, :]
+                out = self.base.transformer(inputs_embeds=x, past_key_values=past, position_ids=pos[:, -1:],
+                                            use_cache=True, return_dict=True)
+            else:
+                pos = torch.arange(T, device=self.device).unsqueeze(0).expand(B, -1)
+                x = self.embed(ids, position_ids=pos)
+                # the same call SconeLanguageModel.forward makes (language_model.py:257-264)
+                out = self.base.transformer(inputs_embeds=x, position_ids=pos, use_cache=self.causal, return_dict=True)
+            past = out.past_key_values if self.causal else None
+            logits = self.base.lm_head(out.last_hidden_state[:, -1, :]).float()
+            if eos_token_id is not None and T < min_length:
+                logits[:, eos_token_id] = -float("inf")
+            nxt = self._pick(logits, do_sample, temperature, top_k, top_p, generator)
+            if eos_token_id is not None:
+                nxt = torch.where(finished, torch.full_like(nxt, eos_token_id), nxt)
+                finished |= nxt == eos_token_id
+            ids = torch.cat([ids, nxt.unsqueeze(1)], dim=1)
+            if eos_token_id is not None and bool(finished.all()):
+                break
+        return ids
+
+    @staticmethod
+    def _pick(logits, do_sample, temperature, top_k, top_p, generator):
+        if not do_sample:
+            return logits.argmax(dim=-1)
+        logits = logits / max(temperature, 1e-6)
+        if top_k and top_k > 0:
+            kth = torch.topk(logits, min(top_k, logits.shape[-1]), dim=-1).values[:, -1:]
+            logits = logits.masked_fill(logits < kth, -float("inf"))
+        if top_p < 1.0:
+            srt, idx = torch.sort(logits, descending=True, dim=-1)
+            cum = torch.softmax(srt, dim=-1).cumsum(dim=-1)
+            drop = cum - torch.softmax(srt, dim=-1) > top_p
+            srt = srt.masked_fill(drop, -float("inf"))
+            logits = torch.full_like(logits, -float("inf")).scatter(-1, idx, srt)
+        return torch.multinomial(torch.softmax(logits, dim=-1), 1, generator=generator).squeeze(1)
+
+    def generate(self, text, max_length: int = 50, min_length: int = 0, do_sample: bool = True, num_beams: int = 1,
+                 temperature: float = 1.0, top_k: int = 50, top_p: float = 1.0, repetition_penalty: float = 1.0,
+                 num_return_sequences: int = 1) -> List:
+        """Same arguments as the reference's ``generate`` (engine.py:192-204); beam search and repetition
+        penalty are not implemented (``num_beams`` must be 1, ``repetition_penalty`` 1.0)."""
+        if num_beams != 1 or repetition_penalty != 1.0:
+            raise NotImplementedError("beam search / repetition penalty are outside the lookup layer")
+        ids = self._encode(text).repeat(num_return_sequences, 1) if num_return_sequences > 1 else self._encode(text)
+        out = self.generate_ids(ids, max_length=max_length, min_length=min_length, do_sample=do_sample,
+                                temperature=temperature, top_k=top_k, top_p=top_p,
+                                eos_token_id=getattr(self.tokenizer, "eos_token_id", None))
+        if self.tokenizer is None:
+            return [o.tolist() for o in out]
+        return [self.tokenizer.decode(o.tolist()) for o in out]
+
+    def benchmark_inference(self, text, max_length: int = 50, num_runs: int = 10, warmup_runs: int = 2) -> Dict[str, float]:
+        """engine.py:292-395: greedy decoding timed with synchronisation around the runs."""
+        ids = self._encode(text)
+        for _ in range(warmup_runs):
+            self.generate_ids(ids, max_length=max_length, do_sample=False)
+        torch.cuda.synchronize()
+        t0 = time.time()
+        for _ in range(num_runs):
+            self.generate_ids(ids, max_length=max_length, do_sample=False)
+            torch.cuda.synchronize()
+        total = time.time() - t0
+        avg = total / num_runs
+        return {"total_time_seconds": total, "avg_time_seconds": avg, "tokens_per_second": max_length / avg,
+                "quantization": self.quantization}

@@ -620,3 +620,43 @@ def test_paper_mode_longest_suffix_vs_oracle(fmt, d, max_n):
     bad.cache_embeddings(list(range(n)), torch.zeros(n, 128), verbose=False)
     with pytest.raises(ValueError):
         bad.embed_tokens(torch.zeros((1, 4), dtype=torch.int64))
+
+
+# ------------------------------------------------------------------ engine glue
+@pytest.mark.parametrize("mode", ["cover", "longest_suffix"])
+def test_engine_generation_consumes_fgram_embeddings(mode):
+    """Greedy decoding through SconeInferenceEngine equals a naive loop over SconeLanguageModel.forward with the
+    cache attached (the call the reference's forward makes); in causal (paper) mode the incremental
+    KV-cache path gives the same tokens as full recomputation."""
+    from transformers import GPT2Config, GPT2LMHeadModel
+    from scone_amd import EmbeddingCache, SconeLanguageModel
+    from scone_amd.inference import SconeInferenceEngine
+    torch.manual_seed(0)
+    rng = np.random.default_rng(3)
+    vocab, H, n = 61, 768, 500
+    lens = rng.integers(1, 4, size=n).astype(np.uint8)
+    keys = rng.integers(0, vocab, size=(n, 3)).astype(np.uint32)
+    keys[np.arange(3)[None, :] >= lens[:, None]] = 0
+    ex = _extractor(keys, lens, 3)
+    cache = EmbeddingCache(ex, H, table_format="fp32", lookup_mode=mode)
+    cache.cache_embeddings(list(range(n)), torch.from_numpy(rng.standard_normal((n, H)).astype(np.float32) * 0.5), verbose=False)
+    base = GPT2LMHeadModel(GPT2Config(vocab_size=vocab, n_positions=64, n_embd=H, n_layer=2, n_head=4)).eval()
+    model = SconeLanguageModel(base, None, cache).cuda().eval()
+    engine = SconeInferenceEngine(model, tokenizer=None, f_gram_tokenizer=None, embedding_cache=cache)
+    prompt = torch.from_numpy(rng.integers(0, vocab, size=(2, 6)))
+    got = engine.generate_ids(prompt, max_length=18, do_sample=False)
+    ids = prompt.cuda()
+    with torch.no_grad():
+        while ids.shape[1] < 18:
+            logits = model(input_ids=ids)["logits"][:, -1, :].float()
+            ids = torch.cat([ids, logits.argmax(-1, keepdim=True)], dim=1)
+    assert torch.equal(got, ids)
+    # the f-gram table matters: with an all-zero table the continuation differs
+    zero = EmbeddingCache(ex, H, table_format="fp32", lookup_mode=mode)
+    zero.cache_embeddings(list(range(n)), torch.zeros(n, H), verbose=False)
+    plain = SconeInferenceEngine(SconeLanguageModel(base, None, zero).cuda().eval(), embedding_cache=zero)
+    assert not torch.equal(plain.generate_ids(prompt, max_length=18, do_sample=False), got)
+    out = engine.generate(prompt[0].tolist(), max_length=10, do_sample=True, top_k=5, top_p=0.9)
+    assert len(out) == 1 and len(out[0]) == 10
+    stats = engine.benchmark_inference(prompt[0].tolist(), max_length=10, num_runs=2, warmup_runs=1)
+    assert stats["tokens_per_second"] > 0

@@ -78,7 +78,7 @@ template <int FMT, int D> struct wave_geom {
   static constexpr int seg_acc(int s) { return 8 * s; }                                                // index into acc[]
   static constexpr int seg_row_words(int s) { return seg_elems(s) * BPE4 / 16; }
   static constexpr int seg_row_word0(int s) { return 8 * s * BPE4 / 16; }
-  static constexpr bool OK = (D % 64 == 0) && (D <= 1024) && (seg_elems(NSEG - 1) * BPE4 % 16 == 0) &&
+  static constexpr bool OK = (D % 256 == 0) && (D <= 1280) && (seg_elems(NSEG - 1) * BPE4 % 16 == 0) &&
                              (FMT != SCONE_FMT_I4 || SCONE_I4_GROUP % 8 == 0);
 };
 
@@ -461,7 +461,7 @@ __global__ __launch_bounds__(256) void k_finalize_wave(const float *__restrict__
 // returns -1 when d is not covered
 template <typename OutT>
 int try_launch_finalize_wave(scone_handle *h, const embed_args &a, hipStream_t s) {
-  if (a.tv.d != 768 && a.tv.d != 1024) return -1;
+  if (a.tv.d != 768 && a.tv.d != 1024 && a.tv.d != 1280) return -1;
   long long blocks = (a.ntok + 3) / 4;
   if (blocks > 8192) blocks = 8192;
 #define SCONE_FIN(DD)                                                                                              \
@@ -469,7 +469,8 @@ int try_launch_finalize_wave(scone_handle *h, const embed_args &a, hipStream_t s
                      a.pos, (const OutT *)a.wte, (const OutT *)a.wpe, (const uint8_t *)a.zero_row, (OutT *)a.out,   \
                      a.status, a.tok_begin, a.ntok, a.T, a.vocab, a.n_pos, a.reduce, a.mode)
   if (a.tv.d == 768) SCONE_FIN(768);
-  else SCONE_FIN(1024);
+  else if (a.tv.d == 1024) SCONE_FIN(1024);
+  else SCONE_FIN(1280);
 #undef SCONE_FIN
   SCONE_HIP(h, hipGetLastError());
   return SCONE_OK;
@@ -484,6 +485,9 @@ int try_launch_wave(scone_handle *h, const embed_args &a, hipStream_t s) {
   }
   if constexpr (wave_geom<FMT, 1024>::OK) {
     if (a.tv.d == 1024) return a.max_n <= 3 ? launch_wave<FMT, OutT, 1024, 3>(h, a, s) : launch_wave<FMT, OutT, 1024, 4>(h, a, s);
+  }
+  if constexpr (wave_geom<FMT, 1280>::OK) {  // gpt2-large (configs/large_config.yaml:16)
+    if (a.tv.d == 1280) return a.max_n <= 3 ? launch_wave<FMT, OutT, 1280, 3>(h, a, s) : launch_wave<FMT, OutT, 1280, 4>(h, a, s);
   }
   return -1;
 }

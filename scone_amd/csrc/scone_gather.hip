@@ -33,8 +33,8 @@ int launch_fmt(scone_handle *h, const embed_args &a, int src, int mode, int out_
 }
 // formats / dims served by k_embed_wave (scone_embed_wave.h: wave_geom<>::OK)
 bool scone_wave_kernel_covers(int fmt, int d) {
-  if (d != 768 && d != 1024) return false;
-  return !(fmt == SCONE_FMT_I4 && d == 768);
+  if (d != 768 && d != 1024 && d != 1280) return false;
+  return !(fmt == SCONE_FMT_I4 && d != 1024);  // INT4 needs whole 512-element segments
 }
 
 void fill_table_view(const scone_handle *h, table_view &tv) {
@@ -101,7 +101,7 @@ extern "C" int scone_embed(scone_handle *h, const int32_t *d_tok, int32_t B, int
   a.BT = BT, a.T = T, a.max_n = h->cfg.max_n;
   a.tok_begin = 0, a.ntok = BT;
   a.zero_row = h->d_zero_row, a.mode = (int)h->cfg.lookup_mode;
-  rc = check_mode(h, "scone_embed: lookup_mode longest_suffix needs d = 768 / 1024");
+  rc = check_mode(h, "scone_embed: lookup_mode longest_suffix needs d = 768 / 1024 / 1280");
   if (rc) return rc;
   if (scone_wave_kernel_covers(h->cfg.table_fmt, h->cfg.dim)) {
     // fast path: per-token id records (one scalar load per token in the gather kernel)
@@ -141,7 +141,7 @@ extern "C" int scone_embed_partial(scone_handle *h, const int32_t *d_tok, int32_
   a.BT = BT, a.T = T, a.max_n = h->cfg.max_n;
   a.tok_begin = 0, a.ntok = BT;
   a.zero_row = h->d_zero_row, a.tok = d_tok, a.mode = (int)h->cfg.lookup_mode;
-  rc = check_mode(h, "scone_embed_partial: lookup_mode longest_suffix needs d = 768 / 1024");
+  rc = check_mode(h, "scone_embed_partial: lookup_mode longest_suffix needs d = 768 / 1024 / 1280");
   if (rc) return rc;
   if (scone_wave_kernel_covers(h->cfg.table_fmt, h->cfg.dim)) {
     rc = scone_ensure_ell(h, BT);

@@ -496,7 +496,8 @@ def test_pinned_host_placement_matches_hbm(fmt, hot_rows):
 
 
 @pytest.mark.parametrize("fmt,d,max_n", [("int8", 768, 3), ("int8", 1024, 4), ("int4", 1024, 3), ("fp16", 768, 4),
-                                         ("fp32", 1024, 3), ("int8", 768, 4)])
+                                         ("fp32", 1024, 3), ("int8", 768, 4), ("int8", 1280, 4), ("fp16", 1280, 3),
+                                         ("int4", 1280, 3), ("int8", 2048, 3)])
 def test_wave_kernel_shape_sweep(fmt, d, max_n):
     """Every (B, T) geometry of the wave kernel -- T not a multiple of 4, T < max_n, one sequence, many short
     sequences, explicit and default position ids, all output dtypes -- bit-exact in fp32 against the oracle."""

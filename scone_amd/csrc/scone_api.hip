@@ -127,7 +127,7 @@ extern "C" int scone_create(const scone_cfg *cfg, scone_handle **out) {
     return SCONE_EINVAL;
   }
   h->local_rows = h->cfg.row_end - h->cfg.row_begin;
-  h->slots = nullptr, h->d_counters = nullptr, h->d_status = nullptr, h->d_uni = nullptr;
+  h->slots = nullptr, h->d_counters = nullptr, h->d_status = nullptr, h->d_uni = nullptr, h->d_bloom = nullptr, h->bloom_mask = 0;
   h->rows = nullptr, h->rows_host = nullptr, h->scales = nullptr, h->hot_local = 0;
   h->d_hits = nullptr, h->hits_cap_tokens = 0, h->d_block_sums = nullptr, h->block_sums_cap = 0;
   h->d_ell = nullptr, h->ell_cap_tokens = 0, h->d_zero_row = nullptr;
@@ -167,6 +167,14 @@ extern "C" int scone_create(const scone_cfg *cfg, scone_handle **out) {
   CREATE_HIP(hipMalloc(&h->d_total, sizeof(int64_t)));
   CREATE_HIP(hipMalloc(&h->d_uni, (size_t)SCONE_UNI_CAP * sizeof(int32_t)));
   CREATE_HIP(hipMemset(h->d_uni, 0xFF, (size_t)SCONE_UNI_CAP * sizeof(int32_t)));
+  {  // presence bitmap: 8 bits of room per slot (16 per key at load 0.5), capped at 128 MB
+    unsigned long long bits = cap * 8ull;
+    if (bits > (1ull << 30)) bits = 1ull << 30;
+    if (bits < 1024) bits = 1024;
+    CREATE_HIP(hipMalloc(&h->d_bloom, bits / 8));
+    CREATE_HIP(hipMemset(h->d_bloom, 0, bits / 8));
+    h->bloom_mask = bits - 1;
+  }
   if (cfg->dim > 0) {  // a row of zeros: stands in for wte / wpe when the caller passes none
     CREATE_HIP(hipMalloc(&h->d_zero_row, (size_t)cfg->dim * 4));
     CREATE_HIP(hipMemset(h->d_zero_row, 0, (size_t)cfg->dim * 4));
@@ -214,6 +222,7 @@ extern "C" void scone_destroy(scone_handle *h) {
   if (h->d_counters) (void)hipFree(h->d_counters);
   if (h->d_status) (void)hipFree(h->d_status);
   if (h->d_uni) (void)hipFree(h->d_uni);
+  if (h->d_bloom) (void)hipFree(h->d_bloom);
   if (h->d_total) (void)hipFree(h->d_total);
   if (h->rows) (void)hipFree(h->rows);
   if (h->rows_host) (void)hipHostFree(h->rows_host);

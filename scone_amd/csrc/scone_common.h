@@ -71,6 +71,13 @@ __host__ __device__ inline unsigned long long scone_hash_key(unsigned long long 
   return x;
 }
 
+// Presence filter in front of the hash probes of the fused match: bit (hash >> 20) & mask is set for
+// every inserted key, so a clear bit proves the window is not an f-gram without touching the table
+// (most bigram / trigram windows are misses, and every table probe costs a 128-B line).
+__host__ __device__ inline unsigned long long scone_bloom_bit(unsigned long long hash, unsigned long long mask) {
+  return (hash >> 20) & mask;
+}
+
 // lowbias32 finaliser; numpy twin: oracle/ref_port.py hash32
 __host__ __device__ inline uint32_t scone_hash32(uint32_t x) {
   x ^= x >> 16;
@@ -102,6 +109,8 @@ struct scone_handle {
   unsigned long long *d_counters;  // [0] inserted, [1] duplicates
   uint32_t *d_status;              // sticky status bits
   int32_t *d_uni;                  // [SCONE_UNI_CAP] token -> unigram id, 0xFFFFFFFF (= -1) if none
+  uint32_t *d_bloom;               // presence bitmap over key hashes (one bit per key, ~16 bits of room per key)
+  unsigned long long bloom_mask;   // bits - 1 (power of two), 0 = filter disabled
   // table
   void *rows;        // payload rows in HBM: local rows [0, hot_local)
   void *rows_host;   // payload rows in pinned host DRAM: local rows [hot_local, local_rows) (or null)

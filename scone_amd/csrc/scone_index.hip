@@ -23,7 +23,8 @@ __global__ __launch_bounds__(256) void k_index_insert(scone_slot *__restrict__ s
                                                       int max_n,
                                                       unsigned long long *__restrict__ counters,
                                                       uint32_t *__restrict__ status, int32_t *__restrict__ uni,
-                                                      int uni_cap) {
+                                                      int uni_cap, uint32_t *__restrict__ bloom,
+                                                      unsigned long long bloom_mask) {
   unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   int len = lens[i];
@@ -41,7 +42,12 @@ __global__ __launch_bounds__(256) void k_index_insert(scone_slot *__restrict__ s
   // unigrams are also kept in a direct table (token -> smallest id), read by the fused match
   if (len == 1 && uni && t[0] < (uint32_t)uni_cap) atomicMin(reinterpret_cast<unsigned int *>(&uni[t[0]]), (unsigned int)(id0 + i));
   unsigned long long myhi = ((unsigned long long)key.ext << 32) | (unsigned long long)(uint32_t)(id0 + i + 1ull);
-  unsigned long long s = scone_hash_key(key.lo, key.ext) & mask;
+  const unsigned long long hash = scone_hash_key(key.lo, key.ext);
+  if (bloom) {
+    const unsigned long long bit = scone_bloom_bit(hash, bloom_mask);
+    atomicOr(&bloom[bit >> 5], 1u << (bit & 31));
+  }
+  unsigned long long s = hash & mask;
   for (unsigned long long probe = 0; probe <= mask; ++probe) {
     unsigned long long old = atomicCAS(&slots[s].lo, 0ull, key.lo);
     if (old == 0ull || old == key.lo) {
@@ -137,6 +143,7 @@ __device__ __forceinline__ int32_t probe_finish(const scone_slot *__restrict__ s
 template <int MAXN>
 __device__ __forceinline__ void probe_starts(const scone_slot *__restrict__ slots, unsigned long long mask,
                                              const int32_t *__restrict__ uni, int uni_cap,
+                                             const uint32_t *__restrict__ bloom, unsigned long long bloom_mask,
                                              const int32_t *__restrict__ tok, long long BT, int T, int max_n,
                                              long long start, int32_t (&res)[MAXN]) {
 #pragma unroll
@@ -170,10 +177,17 @@ __device__ __forceinline__ void probe_starts(const scone_slot *__restrict__ slot
     const scone_key key = scone_pack_key(k, n, max_n);
     if (!key.ok) continue;
     lo[n - 1] = key.lo, ext[n - 1] = key.ext;
-    sl[n - 1] = scone_hash_key(key.lo, key.ext) & mask;
-    first[n - 1] = *reinterpret_cast<const ulonglong2 *>(&slots[sl[n - 1]]);
+    const unsigned long long hash = scone_hash_key(key.lo, key.ext);
+    sl[n - 1] = hash & mask;
     live[n - 1] = true;
+    if (bloom) {  // a clear presence bit proves a miss (the bitmap is small enough to live in L2)
+      const unsigned long long bit = scone_bloom_bit(hash, bloom_mask);
+      live[n - 1] = (bloom[bit >> 5] >> (bit & 31)) & 1u;
+    }
   }
+#pragma unroll
+  for (int n = 0; n < MAXN; ++n)
+    if (live[n]) first[n] = *reinterpret_cast<const ulonglong2 *>(&slots[sl[n]]);
 #pragma unroll
   for (int n = 0; n < MAXN; ++n)
     if (live[n]) res[n] = probe_finish(slots, mask, lo[n], ext[n], sl[n], first[n]);
@@ -182,6 +196,7 @@ __device__ __forceinline__ void probe_starts(const scone_slot *__restrict__ slot
 template <int MAXN>
 __global__ __launch_bounds__(ELL_TILE) void k_match_ell(const scone_slot *__restrict__ slots, unsigned long long mask,
                                                         const int32_t *__restrict__ uni, int uni_cap,
+                                                        const uint32_t *__restrict__ bloom, unsigned long long bloom_mask,
                                                         const int32_t *__restrict__ tok, long long BT, int T, int max_n,
                                                         long long row_begin, long long row_end, int mode,
                                                         int32_t *__restrict__ ell) {
@@ -192,11 +207,11 @@ __global__ __launch_bounds__(ELL_TILE) void k_match_ell(const scone_slot *__rest
   const long long tile0 = (long long)blockIdx.x * ELL_TILE;
 
   int32_t r[MAXN];
-  probe_starts<MAXN>(slots, mask, uni, uni_cap, tok, BT, T, max_n, tile0 + t, r);
+  probe_starts<MAXN>(slots, mask, uni, uni_cap, bloom, bloom_mask, tok, BT, T, max_n, tile0 + t, r);
 #pragma unroll
   for (int n = 0; n < MAXN; ++n) win[n][t + HALO] = r[n];
   if (t < HALO) {  // the max_n-1 starts in front of the tile
-    probe_starts<MAXN>(slots, mask, uni, uni_cap, tok, BT, T, max_n, tile0 - HALO + t, r);
+    probe_starts<MAXN>(slots, mask, uni, uni_cap, bloom, bloom_mask, tok, BT, T, max_n, tile0 - HALO + t, r);
 #pragma unroll
     for (int n = 0; n < MAXN; ++n) win[n][t] = r[n];
   }
@@ -385,10 +400,10 @@ int scone_launch_match_ell(scone_handle *h, const int32_t *d_tok, int32_t B, int
   const long long rb = (long long)h->cfg.row_begin, re = (long long)h->cfg.row_end;
   if (h->cfg.max_n <= 3)
     hipLaunchKernelGGL((k_match_ell<3>), dim3((unsigned)blocks), dim3(ELL_TILE), 0, s, h->slots, h->cap - 1, h->d_uni,
-                       SCONE_UNI_CAP, d_tok, BT, T, h->cfg.max_n, rb, re, (int)h->cfg.lookup_mode, d_ell);
+                       SCONE_UNI_CAP, h->d_bloom, h->bloom_mask, d_tok, BT, T, h->cfg.max_n, rb, re, (int)h->cfg.lookup_mode, d_ell);
   else
     hipLaunchKernelGGL((k_match_ell<4>), dim3((unsigned)blocks), dim3(ELL_TILE), 0, s, h->slots, h->cap - 1, h->d_uni,
-                       SCONE_UNI_CAP, d_tok, BT, T, h->cfg.max_n, rb, re, (int)h->cfg.lookup_mode, d_ell);
+                       SCONE_UNI_CAP, h->d_bloom, h->bloom_mask, d_tok, BT, T, h->cfg.max_n, rb, re, (int)h->cfg.lookup_mode, d_ell);
   SCONE_HIP(h, hipGetLastError());
   return SCONE_OK;
 }
@@ -404,7 +419,7 @@ extern "C" int scone_index_build_device(scone_handle *h, const uint32_t *d_keys,
   if (blocks > 0x7FFFFFFFull) return scone_fail(h, SCONE_EINVAL, "scone_index_build: chunk too large");
   hipLaunchKernelGGL(k_index_insert, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, h->slots,
                      h->cap - 1, d_keys, d_lens, (unsigned long long)n, (unsigned long long)id0, h->cfg.max_n,
-                     h->d_counters, h->d_status, h->d_uni, SCONE_UNI_CAP);
+                     h->d_counters, h->d_status, h->d_uni, SCONE_UNI_CAP, h->d_bloom, h->bloom_mask);
   SCONE_HIP(h, hipGetLastError());
   return SCONE_OK;
 }

@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--stream", default="uniform", choices=["uniform", "zipf"])
     ap.add_argument("--placement", default="hbm", choices=["hbm", "pinned_host"])
     ap.add_argument("--hot-rows", type=int, default=0, help="pinned_host: leading rows kept in HBM")
+    ap.add_argument("--stage-tokens", type=int, default=0, help="pinned_host: staged prefetch chunk size (0 = zero-copy)")
     ap.add_argument("--table-mode", default="replicated", choices=["replicated", "sharded"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="init torch.distributed even with one rank (tests the N>1 code path)")
@@ -161,7 +162,8 @@ def main():
         stream_seed = 1234            # every rank embeds the same batch; rows are sharded
     else:
         cache = EmbeddingCache.from_synthetic(ex, d, table_format=args.format, seed=seed, base_scale=base_scale,
-                                              placement=args.placement, hot_rows=args.hot_rows)
+                                              placement=args.placement, hot_rows=args.hot_rows,
+                                              stage_tokens=args.stage_tokens)
         stream_seed = 1234 + rank     # every rank embeds its own batch
     if args.stream == "uniform":
         tok_np = S.stream_uniform_ids(keys, lens, B, T, stream_seed)
@@ -222,7 +224,7 @@ def main():
         avg_ms = kern_ms / n_launch if n_launch else dt / args.steps * 1e3
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
         sig = (f"{args.format}-d{d}-N{N}-B{B}-T{T}-{args.stream}-{args.placement}" + ("-sharded" if sharded else "")
-               + (f"-hot{args.hot_rows}" if args.placement != "hbm" else ""))
+               + (f"-hot{args.hot_rows}-stage{args.stage_tokens}" if args.placement != "hbm" else ""))
         tr = read_traffic(sig)
         res = {
             "metric": "f-gram embed tokens/sec (1M-row INT8 table @ d=768)" if (N, d, args.format) == (1_000_000, 768, "int8")

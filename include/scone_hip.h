@@ -86,7 +86,11 @@ typedef struct scone_cfg {
                               (Counter.most_common, n_gram_extractor.py:91-99), so the head of
                               the table takes most of the hits.                              */
   uint32_t lookup_mode;    /* SCONE_MODE_* for scone_embed / scone_embed_partial / scone_finalize           */
-  uint32_t reserved;       /* 0                                                                             */
+  uint32_t stage_tokens;   /* SCONE_PLACE_PINNED_HOST only.  0: the lookup kernel reads host rows in place over
+                              PCIe.  > 0: staged prefetch -- the batch is processed in chunks of about this
+                              many tokens; on a side stream each chunk is matched and its distinct host rows
+                              are copied once into an HBM staging buffer (double-buffered) while the previous
+                              chunk is reduced on the caller's stream                                        */
 } scone_cfg;
 
 /* ---- lifecycle ----------------------------------------------------------- */

@@ -41,7 +41,7 @@ class SconeCfg(C.Structure):
         ("index_capacity", C.c_uint64),
         ("hot_rows", C.c_uint64),
         ("lookup_mode", C.c_uint32),
-        ("reserved", C.c_uint32),
+        ("stage_tokens", C.c_uint32),
     ]
 
 

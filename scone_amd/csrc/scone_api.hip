@@ -98,6 +98,11 @@ extern "C" int scone_create(const scone_cfg *cfg, scone_handle **out) {
     g_create_err = "scone_create: struct_size mismatch (ABI)";
     return SCONE_EINVAL;
   }
+  if (cfg->stage_tokens && (cfg->placement != SCONE_PLACE_PINNED_HOST || cfg->row_begin != 0 ||
+                            (cfg->row_end != 0 && cfg->row_end != cfg->n_rows))) {
+    g_create_err = "scone_create: stage_tokens needs SCONE_PLACE_PINNED_HOST and an unsharded table";
+    return SCONE_EINVAL;
+  }
   if (cfg->lookup_mode > SCONE_MODE_LONGEST_SUFFIX) {
     g_create_err = "scone_create: unknown lookup_mode";
     return SCONE_EINVAL;
@@ -133,6 +138,7 @@ extern "C" int scone_create(const scone_cfg *cfg, scone_handle **out) {
   h->d_ell = nullptr, h->ell_cap_tokens = 0, h->d_zero_row = nullptr;
   h->d_total = nullptr, h->staging = nullptr, h->staging_bytes = 0;
   h->row_payload_bytes = 0, h->scale_bytes_per_row = 0;
+  h->stage = nullptr;
   h->prof_on = false, h->prof_ev = nullptr, h->prof_head = 0, h->prof_n = 0, h->prof_ms = 0.0;
 
   uint64_t cap = cfg->index_capacity;
@@ -232,6 +238,7 @@ extern "C" void scone_destroy(scone_handle *h) {
   if (h->d_zero_row) (void)hipFree(h->d_zero_row);
   if (h->d_block_sums) (void)hipFree(h->d_block_sums);
   if (h->staging) (void)hipFree(h->staging);
+  scone_stage_destroy(h);
   if (h->prof_ev) {
     for (int i = 0; i < 2 * SCONE_PROF_RING; ++i) (void)hipEventDestroy(h->prof_ev[i]);
     delete[] h->prof_ev;

@@ -99,6 +99,8 @@ struct scone_row_store {
   }
 };
 
+struct scone_stage_state;
+
 // ---------------------------------------------------------------- handle
 struct scone_handle {
   scone_cfg cfg;
@@ -130,6 +132,7 @@ struct scone_handle {
   void *d_zero_row;  // dim * 4 zero bytes
   void *staging;
   size_t staging_bytes;
+  scone_stage_state *stage;  // staged host->HBM prefetch (scone_stage.hip), created on first use
   // optional kernel timing (scone_profile_*)
   bool prof_on;
   hipEvent_t *prof_ev;  // [2 * SCONE_PROF_RING]
@@ -159,3 +162,16 @@ int scone_launch_match(scone_handle *h, const int32_t *d_tok, int32_t B, int32_t
 int scone_launch_match_ell(scone_handle *h, const int32_t *d_tok, int32_t B, int32_t T, int32_t *d_ell,
                            hipStream_t s);
 #define SCONE_ELL_W(max_n) ((max_n) <= 3 ? 8 : 16)
+
+// staged prefetch of host-resident rows (scone_stage.hip)
+void scone_stage_destroy(scone_handle *h);
+int scone_stage_prepare(scone_handle *h, long long chunk_tokens);
+int scone_stage_chunk(scone_handle *h, int buf, const int32_t *d_tok, int32_t Bc, int32_t T);
+hipStream_t scone_stage_side(scone_handle *h);
+hipEvent_t scone_stage_start_event(scone_handle *h);
+hipEvent_t scone_stage_staged_event(scone_handle *h, int buf);
+int scone_stage_mark_consumed(scone_handle *h, int buf, hipStream_t main_stream);
+const int32_t *scone_stage_ell(scone_handle *h, int buf);
+uint8_t *scone_stage_rows(scone_handle *h, int buf);
+const void *scone_stage_scales(scone_handle *h, int buf);
+long long scone_stage_chunk_tokens(scone_handle *h);

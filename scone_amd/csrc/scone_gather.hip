@@ -61,6 +61,52 @@ int need_table(scone_handle *h, const char *who) {
 
 }  // namespace
 
+// Pinned-host table, staged prefetch (scone_stage.hip): chunks of whole sequences; the side stream
+// matches + stages chunk c+1 while the caller's stream reduces chunk c out of the HBM staging buffer.
+static int embed_staged(scone_handle *h, const embed_args &full, int32_t B, int32_t T, int32_t out_dtype, hipStream_t s) {
+  long long seqs = (long long)h->cfg.stage_tokens / T;
+  if (seqs < 1) seqs = 1;
+  if (seqs > B) seqs = B;
+  int rc = scone_stage_prepare(h, seqs * T);
+  if (rc) return rc;
+  seqs = scone_stage_chunk_tokens(h) / T;
+  if (seqs > B) seqs = B;
+  const size_t esz = out_dtype == SCONE_DT_F32 ? 4 : 2;
+  const long long nchunks = (B + seqs - 1) / seqs;
+  // the side stream starts after everything already queued on the caller's stream (tokens may be produced there)
+  SCONE_HIP(h, hipEventRecord(scone_stage_start_event(h), s));
+  SCONE_HIP(h, hipStreamWaitEvent(scone_stage_side(h), scone_stage_start_event(h), 0));
+  auto chunk_b = [&](long long c) { return (int32_t)((c + 1) * seqs <= B ? seqs : B - c * seqs); };
+  rc = scone_stage_chunk(h, 0, full.tok, chunk_b(0), T);
+  if (rc) return rc;
+  for (long long c = 0; c < nchunks; ++c) {
+    const int buf = (int)(c & 1);
+    if (c + 1 < nchunks) {  // prefetch the next chunk while this one is reduced
+      rc = scone_stage_chunk(h, buf ^ 1, full.tok + (c + 1) * seqs * T, chunk_b(c + 1), T);
+      if (rc) return rc;
+    }
+    const long long t0 = c * seqs * T;
+    embed_args a = full;
+    a.BT = (long long)chunk_b(c) * T, a.ntok = a.BT;
+    a.tok = full.tok + t0;
+    a.pos = full.pos ? full.pos + t0 : nullptr;
+    a.out = reinterpret_cast<uint8_t *>(full.out) + (size_t)t0 * h->cfg.dim * esz;
+    a.ell = scone_stage_ell(h, buf);
+    a.tv.st.cold = scone_stage_rows(h, buf);  // rows [n_hot, ..) now live in the HBM staging buffer
+    if (h->scale_bytes_per_row) a.tv.scales = reinterpret_cast<const __half *>(scone_stage_scales(h, buf));
+    SCONE_HIP(h, hipStreamWaitEvent(s, scone_stage_staged_event(h, buf), 0));
+    rc = scone_prof_begin(h, s);
+    if (rc) return rc;
+    rc = launch_fmt(h, a, SRC_HITS, MODE_FULL, out_dtype, s);
+    if (rc) return rc;
+    rc = scone_prof_end(h, s);
+    if (rc) return rc;
+    rc = scone_stage_mark_consumed(h, buf, s);
+    if (rc) return rc;
+  }
+  return SCONE_OK;
+}
+
 extern "C" int scone_gather_reduce(scone_handle *h, const int32_t *d_offsets, const int32_t *d_ids, int64_t ntok,
                                    const void *d_base, int32_t reduce, void *d_out, int32_t out_dtype,
                                    scone_stream_t stream) {
@@ -103,6 +149,13 @@ extern "C" int scone_embed(scone_handle *h, const int32_t *d_tok, int32_t B, int
   a.zero_row = h->d_zero_row, a.mode = (int)h->cfg.lookup_mode;
   rc = check_mode(h, "scone_embed: lookup_mode longest_suffix needs d = 768 / 1024 / 1280");
   if (rc) return rc;
+  a.tok = d_tok, a.pos = d_pos, a.wte = d_wte, a.vocab = vocab, a.wpe = d_wpe, a.n_pos = n_pos;
+  a.reduce = reduce, a.out = d_out, a.status = h->d_status;
+  if (h->cfg.stage_tokens && h->rows_host) {
+    if (!scone_wave_kernel_covers(h->cfg.table_fmt, h->cfg.dim))
+      return scone_fail(h, SCONE_EINVAL, "scone_embed: staged prefetch needs d = 768 / 1024 / 1280");
+    return embed_staged(h, a, B, T, out_dtype, s);
+  }
   if (scone_wave_kernel_covers(h->cfg.table_fmt, h->cfg.dim)) {
     // fast path: per-token id records (one scalar load per token in the gather kernel)
     rc = scone_ensure_ell(h, BT);

@@ -188,6 +188,11 @@ int check_table(scone_handle *h, const char *who) {
   return SCONE_OK;
 }
 
+// the staged-prefetch state caches the scales of the HBM-resident head: drop it when the table changes
+void table_modified(scone_handle *h) {
+  if (h->stage) scone_stage_destroy(h);
+}
+
 }  // namespace
 
 extern "C" int scone_table_upload(scone_handle *h, const void *rows, const void *scales, uint64_t row0, uint64_t nrows,
@@ -200,6 +205,7 @@ extern "C" int scone_table_upload(scone_handle *h, const void *rows, const void 
   if (row0 < h->cfg.row_begin || row0 + nrows > h->cfg.row_end)
     return scone_fail(h, SCONE_ERANGE, "scone_table_upload: rows outside [row_begin,row_end)");
   SCONE_HIP(h, hipSetDevice(h->device));
+  table_modified(h);
   hipStream_t s = (hipStream_t)stream;
   const uint64_t lr = row0 - h->cfg.row_begin;
   const size_t rb = h->row_payload_bytes;
@@ -253,6 +259,7 @@ static int store_f32_common(scone_handle *h, const float *d_src, const int64_t *
   if (nrows == 0) return SCONE_OK;
   if (!d_src) return scone_fail(h, SCONE_EINVAL, "scone_table_store_f32: null rows");
   SCONE_HIP(h, hipSetDevice(h->device));
+  table_modified(h);
   const unsigned blocks = (unsigned)((nrows + 3) / 4);
   int bad = dispatch_fmt(h->cfg.table_fmt, [&](auto F) {
     hipLaunchKernelGGL((k_store_f32<decltype(F)::value>), dim3(blocks), dim3(256), 0, s, d_src, d_ids,
@@ -286,6 +293,7 @@ extern "C" int scone_table_fill_synthetic(scone_handle *h, uint32_t seed, float 
   if (rc) return rc;
   if (h->local_rows == 0) return SCONE_OK;
   SCONE_HIP(h, hipSetDevice(h->device));
+  table_modified(h);
   const unsigned long long blocks = (h->local_rows + 3) / 4;
   if (blocks > 0x7FFFFFFFull) return scone_fail(h, SCONE_EINVAL, "scone_table_fill_synthetic: too many rows per launch");
   int bad = dispatch_fmt(h->cfg.table_fmt, [&](auto F) {

@@ -98,7 +98,8 @@ class SconeTable:
 
     def __init__(self, max_n: int, n_rows: int, dim: int = 0, table_format="fp32", placement: str = "hbm",
                  device: Optional[torch.device] = None, row_begin: int = 0, row_end: Optional[int] = None,
-                 index_capacity: int = 0, hot_rows: int = 0, lookup_mode: str = "cover") -> None:
+                 index_capacity: int = 0, hot_rows: int = 0, lookup_mode: str = "cover",
+                 stage_tokens: int = 0) -> None:
         self._h = None
         lib = L.lib()
         dev = torch.device(device) if device is not None else require_gpu()
@@ -112,7 +113,7 @@ class SconeTable:
         self.row_end = int(n_rows if row_end is None else row_end)
         cfg = L.SconeCfg(C.sizeof(L.SconeCfg), self.device.index, self.max_n, self.dim, self.fmt,
                          _PLACE[placement], self.n_rows, self.row_begin, self.row_end, int(index_capacity),
-                         int(hot_rows), _MODE[lookup_mode], 0)
+                         int(hot_rows), _MODE[lookup_mode], int(stage_tokens))
         h = C.c_void_p()
         rc = lib.scone_create(C.byref(cfg), C.byref(h))
         if rc != L.OK:

@@ -661,3 +661,41 @@ def test_engine_generation_consumes_fgram_embeddings(mode):
     assert len(out) == 1 and len(out[0]) == 10
     stats = engine.benchmark_inference(prompt[0].tolist(), max_length=10, num_runs=2, warmup_runs=1)
     assert stats["tokens_per_second"] > 0
+
+
+@pytest.mark.parametrize("fmt,d", [("int8", 768), ("int4", 1024), ("fp16", 1280)])
+def test_staged_prefetch_matches_hbm(fmt, d):
+    """SCONE_PLACE_PINNED_HOST with stage_tokens > 0 (side-stream match + de-duplicated host->HBM staging,
+    double-buffered) gives the same bits as the HBM-resident table: several chunks, ragged last chunk,
+    repeated calls (generation tags, buffer reuse), table modified between calls."""
+    from scone_amd.hip_backend import SconeTable
+    rng = np.random.default_rng(55)
+    vocab, n, max_n = 37, 3000, 3
+    lens = rng.integers(1, max_n + 1, size=n).astype(np.uint8)
+    keys = rng.integers(0, vocab, size=(n, max_n)).astype(np.uint32)
+    keys[np.arange(max_n)[None, :] >= lens[:, None]] = 0
+    table = rng.standard_normal((n, d)).astype(np.float32)
+    ref = SconeTable(max_n, n, d, fmt)
+    ref.index_build(keys, lens)
+    ref.store_f32(torch.from_numpy(table))
+    wte = torch.from_numpy(rng.standard_normal((vocab, d)).astype(np.float32)).half().cuda()
+    wpe = torch.from_numpy(rng.standard_normal((40, d)).astype(np.float32)).half().cuda()
+    for hot, stage in ((0, 64), (100, 200), (2999, 40), (500, 10_000)):
+        t = SconeTable(max_n, n, d, fmt, placement="pinned_host", hot_rows=hot, stage_tokens=stage)
+        t.index_build(keys, lens)
+        t.store_f32(torch.from_numpy(table))
+        for B, T in ((7, 40), (1, 33), (300, 5), (64, 40)):
+            tok = torch.from_numpy(rng.integers(0, vocab, size=(B, T)))
+            for _ in range(2):
+                assert torch.equal(t.embed(tok, wte=wte, wpe=wpe), ref.embed(tok, wte=wte, wpe=wpe)), (hot, stage, B, T)
+            assert torch.equal(t.embed(tok, out_dtype=torch.float32), ref.embed(tok, out_dtype=torch.float32))
+        # modify some rows (head and tail of the table), both tables alike
+        upd = torch.from_numpy(rng.standard_normal((50, d)).astype(np.float32))
+        for tb in (t, ref):
+            tb.store_f32(upd[:25], row0=10)
+            tb.store_f32(upd[25:], row0=n - 25)
+        tok = torch.from_numpy(rng.integers(0, vocab, size=(9, 40)))
+        assert torch.equal(t.embed(tok, wte=wte, wpe=wpe), ref.embed(tok, wte=wte, wpe=wpe))
+        for tb in (ref,):
+            tb.store_f32(torch.from_numpy(table[10:35]), row0=10)
+            tb.store_f32(torch.from_numpy(table[n - 25:]), row0=n - 25)

@@ -699,3 +699,58 @@ def test_staged_prefetch_matches_hbm(fmt, d):
         for tb in (ref,):
             tb.store_f32(torch.from_numpy(table[10:35]), row0=10)
             tb.store_f32(torch.from_numpy(table[n - 25:]), row0=n - 25)
+
+
+def test_hipgraph_capture_of_the_fused_lookup():
+    """scone_embed does no allocation or synchronisation once its workspace exists (scone_reserve), so the
+    two-kernel step can be captured in a hipGraph and replayed (decode-size batches are launch-bound)."""
+    from scone_amd import EmbeddingCache
+    rng = np.random.default_rng(12)
+    vocab, n, d = 50, 2000, 768
+    lens = rng.integers(1, 4, size=n).astype(np.uint8)
+    keys = rng.integers(0, vocab, size=(n, 3)).astype(np.uint32)
+    keys[np.arange(3)[None, :] >= lens[:, None]] = 0
+    cache = EmbeddingCache.from_synthetic(_extractor(keys, lens, 3), d, table_format="int8", seed=2)
+    wte = torch.randn(vocab, d, device="cuda").half()
+    wpe = torch.randn(64, d, device="cuda").half()
+    tok = torch.from_numpy(rng.integers(0, vocab, size=(8, 64))).to("cuda", torch.int32)
+    out = torch.empty(8, 64, d, dtype=torch.float16, device="cuda")
+    cache.table.reserve(tok.numel())
+    want = cache.embed_tokens(tok, wte=wte, wpe=wpe).clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        cache.embed_tokens(tok, wte=wte, wpe=wpe, out=out)         # warm-up on the capture stream
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        cache.embed_tokens(tok, wte=wte, wpe=wpe, out=out)
+    out.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, want)
+    tok.copy_(torch.from_numpy(rng.integers(0, vocab, size=(8, 64))))   # new tokens, same graph
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, cache.embed_tokens(tok, wte=wte, wpe=wpe))
+
+
+def test_abi_argument_errors():
+    """Error behaviour of the boundary: negative sizes, wrong dtype, missing table -> exceptions, never a crash."""
+    from scone_amd.hip_backend import SconeTable
+    t = SconeTable(3, 10, 768, "int8")
+    tok = torch.zeros((2, 4), dtype=torch.int32, device="cuda")
+    with pytest.raises(KeyError):
+        t.embed(tok, out_dtype=torch.float64)
+    with pytest.raises(ValueError):
+        t.embed(tok, wte=torch.zeros(5, 64, device="cuda"))            # wrong width
+    idx_only = SconeTable(3, 10)
+    with pytest.raises(Exception, match="no table"):
+        idx_only.embed(tok)
+    with pytest.raises(ValueError):
+        SconeTable(3, 10, 100, "int8")                                  # dim not a multiple of 16
+    with pytest.raises(ValueError):
+        SconeTable(3, 10, 768, "int8", row_begin=8, row_end=4)
+    with pytest.raises(IndexError):
+        t.upload(np.zeros((4, 768), dtype=np.int8), np.ones(4, dtype=np.float16), row0=8)   # rows 8..11 of 10
+    assert t.status() == 0

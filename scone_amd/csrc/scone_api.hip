@@ -136,7 +136,7 @@ extern "C" int scone_create(const scone_cfg *cfg, scone_handle **out) {
   h->rows = nullptr, h->rows_host = nullptr, h->scales = nullptr, h->hot_local = 0;
   h->d_hits = nullptr, h->hits_cap_tokens = 0, h->d_block_sums = nullptr, h->block_sums_cap = 0;
   h->d_ell = nullptr, h->ell_cap_tokens = 0, h->d_zero_row = nullptr;
-  h->d_total = nullptr, h->staging = nullptr, h->staging_bytes = 0;
+  h->d_total = nullptr;
   h->row_payload_bytes = 0, h->scale_bytes_per_row = 0;
   h->stage = nullptr;
   h->prof_on = false, h->prof_ev = nullptr, h->prof_head = 0, h->prof_n = 0, h->prof_ms = 0.0;
@@ -237,7 +237,6 @@ extern "C" void scone_destroy(scone_handle *h) {
   if (h->d_ell) (void)hipFree(h->d_ell);
   if (h->d_zero_row) (void)hipFree(h->d_zero_row);
   if (h->d_block_sums) (void)hipFree(h->d_block_sums);
-  if (h->staging) (void)hipFree(h->staging);
   scone_stage_destroy(h);
   if (h->prof_ev) {
     for (int i = 0; i < 2 * SCONE_PROF_RING; ++i) (void)hipEventDestroy(h->prof_ev[i]);

@@ -11,7 +11,6 @@
 
 #include "../../include/scone_hip.h"
 
-#define SCONE_WAVE 64
 #define SCONE_I4_GROUP 128
 #define SCONE_MAX_N 4
 #define SCONE_PROF_RING 1024
@@ -130,8 +129,6 @@ struct scone_handle {
   int64_t block_sums_cap;
   int64_t *d_total;
   void *d_zero_row;  // dim * 4 zero bytes
-  void *staging;
-  size_t staging_bytes;
   scone_stage_state *stage;  // staged host->HBM prefetch (scone_stage.hip), created on first use
   // optional kernel timing (scone_profile_*)
   bool prof_on;

@@ -45,6 +45,9 @@ def parse():
     ap.add_argument("--batch", type=int, default=2048)
     ap.add_argument("--seq", type=int, default=512)
     ap.add_argument("--stream", default="uniform", choices=["uniform", "zipf"])
+    ap.add_argument("--keygen", default="zipf", choices=["zipf", "structured"],
+                    help="vocabulary generator: seeded Zipf n-grams with de-duplication (default) or the "
+                         "distinct-by-construction generator for >= 1e8 rows")
     ap.add_argument("--placement", default="hbm", choices=["hbm", "pinned_host"])
     ap.add_argument("--hot-rows", type=int, default=0, help="pinned_host: leading rows kept in HBM")
     ap.add_argument("--stage-tokens", type=int, default=0, help="pinned_host: staged prefetch chunk size (0 = zero-copy)")
@@ -56,6 +59,8 @@ def parse():
 
 
 def cpu_baseline(args, keys, lens, tok, seed, base_scale, gpu_out, wte, wpe):
+    if keys.shape[0] > 20_000_000:
+        raise RuntimeError("cpu baseline skipped: a Python dict of > 2e7 f-grams does not fit the time budget")
     """Time the reference loop (set-of-tuples match -> dict id map -> torch.stack of fp32 rows
     -> mean -> zero-filled [1,T,d]; n_gram_extractor.py:106-126, embedding_cache.py:113-181,
     engine.py:234-266) on a bounded sample of the same stream, 1 core, and use its output to
@@ -151,7 +156,8 @@ def main():
 
     d, N, B, T = args.dim, args.rows, args.batch, args.seq
     vocab, max_n, seed, base_scale = S.GPT2_VOCAB, 3, 7, 0.02 / 127
-    keys, lens = S.make_keys(N, vocab, max_n, seed=11)
+    keys, lens = (S.make_keys(N, vocab, max_n, seed=11) if args.keygen == "zipf"
+                  else S.make_keys_structured(N, vocab, max_n))
     ex = NGramExtractor.from_arrays(keys, lens, max_n=max_n)
 
     sharded = args.table_mode == "sharded" and dist is not None

@@ -46,6 +46,30 @@ def make_keys(n_rows: int, vocab: int = GPT2_VOCAB, max_n: int = 3, seed: int = 
     return keys, lens
 
 
+def make_keys_structured(n_rows: int, vocab: int = GPT2_VOCAB, max_n: int = 3) -> Tuple[np.ndarray, np.ndarray]:
+    """Distinct-by-construction vocabulary for very large tables (1e8 .. 1e9 rows), no de-duplication
+    pass: ids 0..vocab-1 are the unigrams, then half bigrams and half trigrams whose tokens are the
+    mixed-radix digits of a running counter (multiplied by odd constants mod vocab, so neighbouring
+    ids do not share tokens)."""
+    assert max_n >= 3 and n_rows >= vocab
+    keys = np.zeros((n_rows, max_n), dtype=np.uint32)
+    lens = np.ones(n_rows, dtype=np.uint8)
+    keys[:vocab, 0] = np.arange(vocab, dtype=np.uint32)
+    rest = n_rows - vocab
+    nb = rest // 2
+    j = np.arange(nb, dtype=np.uint64)
+    V = np.uint64(vocab)
+    keys[vocab:vocab + nb, 0] = ((j % V) * np.uint64(40503) + np.uint64(17)) % V
+    keys[vocab:vocab + nb, 1] = (((j // V) % V) * np.uint64(30011) + np.uint64(5)) % V
+    lens[vocab:vocab + nb] = 2
+    j = np.arange(rest - nb, dtype=np.uint64)
+    keys[vocab + nb:, 0] = ((j % V) * np.uint64(40503) + np.uint64(29)) % V
+    keys[vocab + nb:, 1] = (((j // V) % V) * np.uint64(30011) + np.uint64(3)) % V
+    keys[vocab + nb:, 2] = (((j // (V * V)) % V) * np.uint64(20011) + np.uint64(11)) % V
+    lens[vocab + nb:] = 3
+    return keys, lens
+
+
 def stream_uniform_ids(keys: np.ndarray, lens: np.ndarray, B: int, T: int, seed: int) -> np.ndarray:
     """S_uniform: f-grams with ids uniform in [0, N) laid end to end -- row reads that defeat
     L2 / Infinity-Cache reuse (the roofline run)."""

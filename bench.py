@@ -52,6 +52,11 @@ def parse():
     ap.add_argument("--hot-rows", type=int, default=0, help="pinned_host: leading rows kept in HBM")
     ap.add_argument("--stage-tokens", type=int, default=0, help="pinned_host: staged prefetch chunk size (0 = zero-copy)")
     ap.add_argument("--table-mode", default="replicated", choices=["replicated", "sharded"])
+    ap.add_argument("--exchange", default="rows", choices=["rows", "partial_sums"],
+                    help="sharded mode: all-to-all of quantised rows (default) or reduce-scatter of fp32 partial sums")
+    ap.add_argument("--shard-of", default="", help="R/W: build only shard R of a W-way row-sharded table on this one GPU "
+                    "and time its local work (partial sums + finalise of its 1/W token slice); no exchange -- "
+                    "capacity / kernel check for tables that need W GPUs (C5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="init torch.distributed even with one rank (tests the N>1 code path)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -161,7 +166,16 @@ def main():
     ex = NGramExtractor.from_arrays(keys, lens, max_n=max_n)
 
     sharded = args.table_mode == "sharded" and dist is not None
-    if sharded:
+    emu = None
+    if args.shard_of:
+        r_, w_ = (int(x) for x in args.shard_of.split("/"))
+        emu = (r_, w_)
+    if emu is not None:
+        from scone_amd.distributed import ShardedEmbeddingCache
+        cache = ShardedEmbeddingCache.from_synthetic(ex, d, table_format=args.format, seed=seed, base_scale=base_scale,
+                                                     rank=emu[0], world=emu[1])
+        stream_seed = 1234
+    elif sharded:
         from scone_amd.distributed import ShardedEmbeddingCache
         cache = ShardedEmbeddingCache.from_synthetic(ex, d, table_format=args.format, seed=seed,
                                                      base_scale=base_scale, rank=rank, world=world)
@@ -193,8 +207,16 @@ def main():
     del off, ids, counts
 
     def step():
-        if sharded:
-            cache.embed_tokens(tok, wte=wte, wpe=wpe)      # partial sums -> reduce-scatter -> finalise -> all-gather
+        if emu is not None:
+            # this shard's local work only: partial sums over owned rows, then finalise 1/W of the tokens
+            partial, counts = table.embed_partial(tok)
+            per = (ntok + emu[1] - 1) // emu[1]
+            a0 = min(emu[0] * per, ntok)
+            b0 = min(a0 + per, ntok)
+            table.finalize(partial[a0:b0], counts[a0:b0], tok, a0, b0, wte=wte, wpe=wpe, out_dtype=torch.float16,
+                           out=out.view(-1, d)[a0:b0])
+        elif sharded:
+            cache.embed_tokens(tok, wte=wte, wpe=wpe, exchange=args.exchange)
         else:
             cache.embed_tokens(tok, wte=wte, wpe=wpe, out=out)
 
@@ -229,7 +251,7 @@ def main():
         # back to the whole step so that the line stays well-formed
         avg_ms = kern_ms / n_launch if n_launch else dt / args.steps * 1e3
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
-        sig = (f"{args.format}-d{d}-N{N}-B{B}-T{T}-{args.stream}-{args.placement}" + ("-sharded" if sharded else "")
+        sig = (f"{args.format}-d{d}-N{N}-B{B}-T{T}-{args.stream}-{args.placement}" + ("-sharded" if sharded else "") + (f"-shard{args.shard_of}" if emu else "")
                + (f"-hot{args.hot_rows}-stage{args.stage_tokens}" if args.placement != "hbm" else ""))
         tr = read_traffic(sig)
         res = {
@@ -246,12 +268,14 @@ def main():
                             f"{'HBM' if args.placement == 'hbm' else 'pinned host DRAM'}; S_{args.stream} stream, "
                             f"{B}x{T} tokens/step/rank; fused match+gather+dequant+mean+wte+wpe, fp16 out",
                 "tokens_per_step_per_rank": ntok, "mean_hits_per_token": sum_k / ntok, "hits_histogram_K0_6": k_hist[:7],
-                "parallelism": ("row-sharded table + RCCL reduce-scatter/all-gather" if sharded
+                "parallelism": (f"shard {args.shard_of} of a row-sharded table, local work only (no exchange)" if emu else
+                                ("row-sharded table, RCCL all-to-all of quantised rows + all-gather" if args.exchange == "rows" else
+                                 "row-sharded table, RCCL reduce-scatter of fp32 partial sums + all-gather") if sharded
                                 else f"replicated table, tokens sharded over {world} rank(s), no collective"),
             },
             "roofline": {
                 "bound": "hbm", "kernel": ("scone_gather::k_embed_wave (gather+dequant+reduce+combine), HIP-event timed" if n_launch
-                                           else "whole step (sharded path: k_embed partial + RCCL + finalise)"),
+                                           else "whole step (sharded path: match + pack + RCCL + gather)"),
                 "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                 "algorithmic_bytes_per_launch": bytes_per_launch, "avg_kernel_ms": avg_ms, "timed_launches": n_launch,
                 "traffic": None if tr is None else tr.get("hbm_bytes_per_launch"),

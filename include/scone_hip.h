@@ -213,6 +213,28 @@ int scone_finalize(scone_handle *h, const float *d_sum, const int32_t *d_counts,
                    const int32_t *d_pos, int32_t reduce, void *d_out, int32_t out_dtype,
                    scone_stream_t stream);
 
+/* ---- row-sharded tables, row exchange (preferred over the partial-sum pair above: the wire carries
+ *      quantised rows -- 528 B for an INT4 d=1024 row instead of a 4096-B fp32 partial sum per token and
+ *      rank -- and the receiving rank reduces them in the reference's order, so results are bit-identical
+ *      to the unsharded table).  Rank r finalises slice r of the batch: sequences
+ *      [r*ceil(B/world), (r+1)*ceil(B/world)).  Tokens and index are replicated, so both ends of a transfer
+ *      derive what is sent; the caller only moves the record buffers (one all_to_all_single). -------------- */
+int scone_shard_record_bytes(scone_handle *h, uint64_t *bytes);
+/* Matches the batch, fills h_send_counts[q] (records this rank sends to rank q) and h_recv_counts[q]
+ * (records it receives from rank q); synchronises.  world <= 64. */
+int scone_shard_plan(scone_handle *h, const int32_t *d_tok, int32_t B, int32_t T, int32_t world, int32_t rank,
+                     uint32_t *h_send_counts, uint32_t *h_recv_counts, scone_stream_t stream);
+/* Writes sum(h_send_counts) records to d_send_buf, grouped by destination in rank order; synchronises. */
+int scone_shard_pack(scone_handle *h, int32_t B, int32_t T, int32_t world, const uint32_t *h_send_counts,
+                     void *d_send_buf, scone_stream_t stream);
+/* d_recv_buf: the n_recv records received (any order within a source).  Writes this rank's slice of the output,
+ * [slice tokens, d] in out_dtype; d_tok / d_pos are the full [B,T] arrays.  The records are read in place: keep
+ * d_recv_buf alive until the stream has passed this call. */
+int scone_shard_embed(scone_handle *h, const int32_t *d_tok, int32_t B, int32_t T, int32_t world, int32_t rank,
+                      const void *d_recv_buf, uint64_t n_recv, const void *d_wte, int64_t vocab, const void *d_wpe,
+                      int64_t n_pos, const int32_t *d_pos, int32_t reduce, void *d_out_slice, int32_t out_dtype,
+                      scone_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

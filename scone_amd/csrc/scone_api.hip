@@ -138,7 +138,7 @@ extern "C" int scone_create(const scone_cfg *cfg, scone_handle **out) {
   h->d_ell = nullptr, h->ell_cap_tokens = 0, h->d_zero_row = nullptr;
   h->d_total = nullptr;
   h->row_payload_bytes = 0, h->scale_bytes_per_row = 0;
-  h->stage = nullptr;
+  h->stage = nullptr, h->shard = nullptr;
   h->prof_on = false, h->prof_ev = nullptr, h->prof_head = 0, h->prof_n = 0, h->prof_ms = 0.0;
 
   uint64_t cap = cfg->index_capacity;
@@ -238,6 +238,7 @@ extern "C" void scone_destroy(scone_handle *h) {
   if (h->d_zero_row) (void)hipFree(h->d_zero_row);
   if (h->d_block_sums) (void)hipFree(h->d_block_sums);
   scone_stage_destroy(h);
+  scone_shard_destroy(h);
   if (h->prof_ev) {
     for (int i = 0; i < 2 * SCONE_PROF_RING; ++i) (void)hipEventDestroy(h->prof_ev[i]);
     delete[] h->prof_ev;

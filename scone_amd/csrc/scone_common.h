@@ -99,6 +99,7 @@ struct scone_row_store {
 };
 
 struct scone_stage_state;
+struct scone_shard_state;
 
 // ---------------------------------------------------------------- handle
 struct scone_handle {
@@ -130,6 +131,7 @@ struct scone_handle {
   int64_t *d_total;
   void *d_zero_row;  // dim * 4 zero bytes
   scone_stage_state *stage;  // staged host->HBM prefetch (scone_stage.hip), created on first use
+  scone_shard_state *shard;  // row exchange between shards (scone_shard.hip), created on first use
   // optional kernel timing (scone_profile_*)
   bool prof_on;
   hipEvent_t *prof_ev;  // [2 * SCONE_PROF_RING]
@@ -158,7 +160,17 @@ int scone_launch_match(scone_handle *h, const int32_t *d_tok, int32_t B, int32_t
                        hipStream_t s);
 int scone_launch_match_ell(scone_handle *h, const int32_t *d_tok, int32_t B, int32_t T, int32_t *d_ell,
                            hipStream_t s);
+// explicit owned range; keep_pos: owned ids stay at their index in the full list (holes = -1)
+int scone_launch_match_ell_ex(scone_handle *h, const int32_t *d_tok, int32_t B, int32_t T, int32_t *d_ell,
+                              long long row_begin, long long row_end, int keep_pos, hipStream_t s);
 #define SCONE_ELL_W(max_n) ((max_n) <= 3 ? 8 : 16)
+
+// row exchange between shards (scone_shard.hip)
+void scone_shard_destroy(scone_handle *h);
+int scone_shard_rec_bytes(const scone_handle *h);
+int scone_shard_prepare_embed(scone_handle *h, int32_t B, int32_t T, int32_t world, int32_t rank, const void *d_recv,
+                              uint64_t n_recv, const int32_t **ell, const void **scales, int32_t *b0, int32_t *b1,
+                              hipStream_t s);
 
 // staged prefetch of host-resident rows (scone_stage.hip)
 void scone_stage_destroy(scone_handle *h);

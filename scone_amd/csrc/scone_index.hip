@@ -199,7 +199,7 @@ __global__ __launch_bounds__(ELL_TILE) void k_match_ell(const scone_slot *__rest
                                                         const uint32_t *__restrict__ bloom, unsigned long long bloom_mask,
                                                         const int32_t *__restrict__ tok, long long BT, int T, int max_n,
                                                         long long row_begin, long long row_end, int mode,
-                                                        int32_t *__restrict__ ell) {
+                                                        int keep_pos, int32_t *__restrict__ ell) {
   constexpr int HALO = MAXN - 1;
   constexpr int W = MAXN <= 3 ? 8 : 16;
   __shared__ int32_t win[MAXN][ELL_TILE + HALO];
@@ -245,11 +245,14 @@ __global__ __launch_bounds__(ELL_TILE) void k_match_ell(const scone_slot *__rest
       if (mode == SCONE_MODE_COVER && nn <= max_n && i - s >= 0) {
         const int32_t id = win[nn - 1][t + HALO - s];
         if (id >= 0) {
+          // keep_pos (row exchange between shards): an owned id stays at its index in the FULL list,
+          // ids of other shards leave a hole (-1); otherwise owned ids are compacted
+          const int at = keep_pos ? kfull : kown;
           ++kfull;
           if (id >= row_begin && id < row_end) {
 #pragma unroll
             for (int j = 0; j < W - 2; ++j)
-              if (j == kown) rec[j] = id;
+              if (j == at) rec[j] = id;
             ++kown;
           }
         }
@@ -393,17 +396,21 @@ int scone_launch_match(scone_handle *h, const int32_t *d_tok, int32_t B, int32_t
 }
 
 int scone_launch_match_ell(scone_handle *h, const int32_t *d_tok, int32_t B, int32_t T, int32_t *d_ell, hipStream_t s) {
+  return scone_launch_match_ell_ex(h, d_tok, B, T, d_ell, (long long)h->cfg.row_begin, (long long)h->cfg.row_end, 0, s);
+}
+
+int scone_launch_match_ell_ex(scone_handle *h, const int32_t *d_tok, int32_t B, int32_t T, int32_t *d_ell, long long rb,
+                              long long re, int keep_pos, hipStream_t s) {
   const long long BT = (long long)B * T;
   if (BT == 0) return SCONE_OK;
   const long long blocks = (BT + ELL_TILE - 1) / ELL_TILE;
   if (blocks > 0x7FFFFFFFll) return scone_fail(h, SCONE_EINVAL, "scone_embed: too many tokens for one launch");
-  const long long rb = (long long)h->cfg.row_begin, re = (long long)h->cfg.row_end;
   if (h->cfg.max_n <= 3)
     hipLaunchKernelGGL((k_match_ell<3>), dim3((unsigned)blocks), dim3(ELL_TILE), 0, s, h->slots, h->cap - 1, h->d_uni,
-                       SCONE_UNI_CAP, h->d_bloom, h->bloom_mask, d_tok, BT, T, h->cfg.max_n, rb, re, (int)h->cfg.lookup_mode, d_ell);
+                       SCONE_UNI_CAP, h->d_bloom, h->bloom_mask, d_tok, BT, T, h->cfg.max_n, rb, re, (int)h->cfg.lookup_mode, keep_pos, d_ell);
   else
     hipLaunchKernelGGL((k_match_ell<4>), dim3((unsigned)blocks), dim3(ELL_TILE), 0, s, h->slots, h->cap - 1, h->d_uni,
-                       SCONE_UNI_CAP, h->d_bloom, h->bloom_mask, d_tok, BT, T, h->cfg.max_n, rb, re, (int)h->cfg.lookup_mode, d_ell);
+                       SCONE_UNI_CAP, h->d_bloom, h->bloom_mask, d_tok, BT, T, h->cfg.max_n, rb, re, (int)h->cfg.lookup_mode, keep_pos, d_ell);
   SCONE_HIP(h, hipGetLastError());
   return SCONE_OK;
 }

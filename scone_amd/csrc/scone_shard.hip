@@ -1,0 +1,302 @@
+// Row exchange for row-sharded tables (tables larger than one GPU; BASELINE config C5).
+//
+// Every rank holds the replicated index and a contiguous range of table rows, and finalises the
+// tokens of its own SLICE of the batch (whole sequences: slice q = sequences [q*Bper, (q+1)*Bper)).
+// What crosses xGMI are the QUANTISED ROWS a slice needs from the other shards, not partial sums:
+// an INT4 d=1024 row is 528 B where an fp32 partial sum is 4096 B per token and rank, and the
+// receiver reduces the rows in the reference's order, so the result is bit-identical to the
+// unsharded table.  Because tokens and index are replicated, both sides of every transfer can work
+// out what is sent without asking: no request round, one all-to-all of records.
+//
+//   plan    match the whole batch against MY rows (ids keep their index in the full list)  -> what I send
+//           match MY slice against all rows                                                -> what I need
+//           count records per destination / per source                                     -> all-to-all split sizes
+//   pack    one record per (token, list index) I own:  [row payload | scales | token-in-slice, list index]
+//   (all_to_all_single of the record buffers: torch.distributed / RCCL, done by the caller)
+//   embed   received records -> slot map (by the header), scales unpacked, ids of my slice remapped to
+//           record numbers, then the ordinary fused lookup kernel reads the rows straight out of the
+//           receive buffer (row store stride = record size)
+#include "scone_common.h"
+
+#include <new>
+
+struct scone_shard_state {
+  long long cap_tok = 0, cap_slice = 0, cap_recv = 0;
+  int32_t *ell_send = nullptr;   // [ntok, W] my rows at their index in the full list
+  int32_t *ell_slice = nullptr;  // [slice tokens, W] all rows, compacted; remapped in place by embed
+  uint32_t *counters = nullptr;  // [3 * 64]: send counts, recv counts, pack cursors
+  unsigned long long *send_off = nullptr;  // [64] record offsets per destination
+  uint32_t *send_src = nullptr;  // [total_send] packed (token, list index) per record
+  uint32_t *slot_of_ref = nullptr;  // [slice tokens * NC]
+  uint8_t *scales = nullptr;     // unpacked scales of the received records
+  long long cap_send = 0;
+};
+
+namespace {
+
+__device__ __forceinline__ int owner_of(long long id, long long n_rows, int world) {
+  return (int)((((unsigned long long)id + 1ull) * (unsigned long long)world - 1ull) / (unsigned long long)n_rows);
+}
+
+// Counting / claiming use per-workgroup LDS bins and ONE global atomic per bin and workgroup: slices
+// are contiguous token ranges, so a workgroup's references go to one or two destinations, and
+// millions of global atomics on one counter would serialise (~90 atomics per microsecond per address).
+__global__ __launch_bounds__(256) void k_shard_count_send(const int32_t *__restrict__ ell, long long ntok, int W, int NC,
+                                                          long long slice_tokens, uint32_t *__restrict__ send_cnt) {
+  __shared__ uint32_t bins[64];
+  if (threadIdx.x < 64) bins[threadIdx.x] = 0;
+  __syncthreads();
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long t = gid / NC;
+  const int j = (int)(gid - t * NC);
+  if (t < ntok && j < (ell[t * W + W - 2] >> 8) && ell[t * W + j] >= 0) atomicAdd(&bins[t / slice_tokens], 1u);
+  __syncthreads();
+  if (threadIdx.x < 64 && bins[threadIdx.x]) atomicAdd(&send_cnt[threadIdx.x], bins[threadIdx.x]);
+}
+
+__global__ __launch_bounds__(256) void k_shard_count_recv(const int32_t *__restrict__ ell, long long ntok, int W, int NC,
+                                                          long long n_rows, int world, uint32_t *__restrict__ recv_cnt) {
+  __shared__ uint32_t bins[64];
+  if (threadIdx.x < 64) bins[threadIdx.x] = 0;
+  __syncthreads();
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long t = gid / NC;
+  const int j = (int)(gid - t * NC);
+  if (t < ntok && j < (ell[t * W + W - 2] & 0xFF)) atomicAdd(&bins[owner_of(ell[t * W + j], n_rows, world)], 1u);
+  __syncthreads();
+  if (threadIdx.x < 64 && bins[threadIdx.x]) atomicAdd(&recv_cnt[threadIdx.x], bins[threadIdx.x]);
+}
+
+// claim a record number for every (token, list index) I own: position = destination's offset +
+// workgroup's reserved range + index inside the workgroup
+__global__ __launch_bounds__(256) void k_shard_claim(const int32_t *__restrict__ ell, long long ntok, int W, int NC,
+                                                     long long slice_tokens, const unsigned long long *__restrict__ send_off,
+                                                     uint32_t *__restrict__ cursor, uint32_t *__restrict__ send_src) {
+  __shared__ uint32_t bins[64], base[64];
+  if (threadIdx.x < 64) bins[threadIdx.x] = 0;
+  __syncthreads();
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long t = gid / NC;
+  const int j = (int)(gid - t * NC);
+  const bool mine = t < ntok && j < (ell[t * W + W - 2] >> 8) && ell[t * W + j] >= 0;
+  const int q = mine ? (int)(t / slice_tokens) : 0;
+  uint32_t local = 0;
+  if (mine) local = atomicAdd(&bins[q], 1u);
+  __syncthreads();
+  if (threadIdx.x < 64 && bins[threadIdx.x]) base[threadIdx.x] = atomicAdd(&cursor[threadIdx.x], bins[threadIdx.x]);
+  __syncthreads();
+  if (!mine) return;
+  const unsigned long long p = send_off[q] + base[q] + local;
+  send_src[2 * p] = (uint32_t)t;
+  send_src[2 * p + 1] = (uint32_t)j;
+}
+
+// one wave per record: row payload + scales + header
+__global__ __launch_bounds__(256) void k_shard_pack(const int32_t *__restrict__ ell, int W, long long slice_tokens,
+                                                    const uint32_t *__restrict__ send_src, unsigned long long n_send,
+                                                    scone_row_store st, long long row_begin, const uint8_t *__restrict__ scales,
+                                                    int scale_bytes, int rec_bytes, uint8_t *__restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const unsigned long long nwaves = (unsigned long long)gridDim.x * (blockDim.x >> 6);
+  for (unsigned long long p = (unsigned long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); p < n_send; p += nwaves) {
+    const uint32_t t = send_src[2 * p], j = send_src[2 * p + 1];
+    const unsigned long long lr = (unsigned long long)(ell[(long long)t * W + j] - row_begin);
+    const uint4 *src = reinterpret_cast<const uint4 *>(st.row(lr));
+    uint8_t *rec = out + p * (unsigned long long)rec_bytes;
+    uint4 *dst = reinterpret_cast<uint4 *>(rec);
+    for (unsigned v = lane; v < st.row_bytes / 16; v += 64) dst[v] = src[v];
+    if (lane < scale_bytes / 2)
+      reinterpret_cast<unsigned short *>(rec + st.row_bytes)[lane] =
+          reinterpret_cast<const unsigned short *>(scales + lr * scale_bytes)[lane];
+    if (lane == 0) {
+      uint32_t *hdr = reinterpret_cast<uint32_t *>(rec + rec_bytes - 8);
+      hdr[0] = (uint32_t)(t % slice_tokens);
+      hdr[1] = j;
+    }
+  }
+}
+
+// one thread per received record: slot map + scales
+__global__ __launch_bounds__(256) void k_shard_unpack(const uint8_t *__restrict__ recv, unsigned long long n_recv, int rec_bytes,
+                                                      int row_bytes, int scale_bytes, int NC, long long slice_tokens,
+                                                      uint32_t *__restrict__ slot_of_ref, uint8_t *__restrict__ scales,
+                                                      uint32_t *__restrict__ status) {
+  const unsigned long long p = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_recv) return;
+  const uint8_t *rec = recv + p * (unsigned long long)rec_bytes;
+  const uint32_t *hdr = reinterpret_cast<const uint32_t *>(rec + rec_bytes - 8);
+  if (hdr[0] >= (uint32_t)slice_tokens || hdr[1] >= (uint32_t)NC) {
+    atomicOr(status, SCONE_ST_BAD_ID);
+    return;
+  }
+  slot_of_ref[(unsigned long long)hdr[0] * NC + hdr[1]] = (uint32_t)p;
+  for (int b = 0; b < scale_bytes / 2; ++b)
+    reinterpret_cast<unsigned short *>(scales + p * scale_bytes)[b] = reinterpret_cast<const unsigned short *>(rec + row_bytes)[b];
+}
+
+__global__ __launch_bounds__(256) void k_shard_remap(int32_t *__restrict__ ell, long long ntok, int W, int NC,
+                                                     const uint32_t *__restrict__ slot_of_ref) {
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long t = gid / NC;
+  const int j = (int)(gid - t * NC);
+  if (t >= ntok) return;
+  if (j >= (ell[t * W + W - 2] & 0xFF)) return;
+  ell[t * W + j] = (int32_t)slot_of_ref[t * NC + j];
+}
+
+template <typename T>
+int grow(scone_handle *h, T **p, long long *cap, long long need, size_t elems_per) {
+  if (need <= *cap && *p) return SCONE_OK;
+  if (*p) SCONE_HIP(h, hipFree(*p));
+  *p = nullptr;
+  *cap = 0;
+  SCONE_HIP(h, hipMalloc(p, (size_t)(need > 0 ? need : 1) * elems_per * sizeof(T) + 16));
+  *cap = need;
+  return SCONE_OK;
+}
+
+}  // namespace
+
+void scone_shard_destroy(scone_handle *h) {
+  scone_shard_state *st = h->shard;
+  if (!st) return;
+  void *ptrs[] = {st->ell_send, st->ell_slice, st->counters, st->send_off, st->send_src, st->slot_of_ref, st->scales};
+  for (void *p : ptrs)
+    if (p) (void)hipFree(p);
+  delete st;
+  h->shard = nullptr;
+}
+
+int scone_shard_rec_bytes(const scone_handle *h) {
+  return (int)((h->row_payload_bytes + h->scale_bytes_per_row + 8 + 15) / 16 * 16);
+}
+
+static void slice_of(int32_t B, int32_t world, int32_t rank, int32_t *bper, int32_t *b0, int32_t *b1) {
+  *bper = (B + world - 1) / world;
+  long long a = (long long)rank * *bper, b = a + *bper;
+  *b0 = (int32_t)(a < B ? a : B);
+  *b1 = (int32_t)(b < B ? b : B);
+}
+
+extern "C" int scone_shard_record_bytes(scone_handle *h, uint64_t *bytes) {
+  if (!h || !bytes) return SCONE_EINVAL;
+  if (h->cfg.dim <= 0) return scone_fail(h, SCONE_ESTATE, "scone_shard_record_bytes: handle has no table");
+  *bytes = (uint64_t)scone_shard_rec_bytes(h);
+  return SCONE_OK;
+}
+
+extern "C" int scone_shard_plan(scone_handle *h, const int32_t *d_tok, int32_t B, int32_t T, int32_t world, int32_t rank,
+                                uint32_t *h_send_counts, uint32_t *h_recv_counts, scone_stream_t stream) {
+  if (!h) return SCONE_EINVAL;
+  if (h->cfg.dim <= 0 || !h->rows) return scone_fail(h, SCONE_ESTATE, "scone_shard_plan: handle has no table");
+  if (B < 0 || T <= 0 || world < 1 || world > 64 || rank < 0 || rank >= world || !h_send_counts || !h_recv_counts || !d_tok)
+    return scone_fail(h, SCONE_EINVAL, "scone_shard_plan: bad argument (world <= 64)");
+  SCONE_HIP(h, hipSetDevice(h->device));
+  hipStream_t s = (hipStream_t)stream;
+  if (!h->shard) {
+    h->shard = new (std::nothrow) scone_shard_state();
+    if (!h->shard) return scone_fail(h, SCONE_ENOMEM, "scone_shard_plan: out of memory");
+  }
+  scone_shard_state *st = h->shard;
+  const int W = SCONE_ELL_W(h->cfg.max_n), NC = h->cfg.max_n * (h->cfg.max_n + 1) / 2;
+  int32_t bper, b0, b1;
+  slice_of(B, world, rank, &bper, &b0, &b1);
+  const long long ntok = (long long)B * T, slice_tokens = (long long)bper * T, my_tokens = (long long)(b1 - b0) * T;
+  int rc = grow(h, &st->ell_send, &st->cap_tok, ntok, (size_t)W);
+  if (rc) return rc;
+  long long cs = st->cap_slice;
+  rc = grow(h, &st->ell_slice, &cs, slice_tokens, (size_t)W);
+  if (rc) return rc;
+  long long cs2 = st->cap_slice;
+  rc = grow(h, &st->slot_of_ref, &cs2, slice_tokens, (size_t)NC);
+  if (rc) return rc;
+  st->cap_slice = cs;
+  if (!st->counters) SCONE_HIP(h, hipMalloc(&st->counters, 3 * 64 * sizeof(uint32_t)));
+  if (!st->send_off) SCONE_HIP(h, hipMalloc(&st->send_off, 64 * sizeof(unsigned long long)));
+  SCONE_HIP(h, hipMemsetAsync(st->counters, 0, 3 * 64 * sizeof(uint32_t), s));
+  for (int q = 0; q < world; ++q) h_send_counts[q] = h_recv_counts[q] = 0;
+  if (ntok == 0) return SCONE_OK;
+  // what I send: the whole batch against my rows, ids at their index in the full list
+  rc = scone_launch_match_ell_ex(h, d_tok, B, T, st->ell_send, (long long)h->cfg.row_begin, (long long)h->cfg.row_end, 1, s);
+  if (rc) return rc;
+  const unsigned blocks = (unsigned)((ntok * NC + 255) / 256);
+  hipLaunchKernelGGL(k_shard_count_send, dim3(blocks), dim3(256), 0, s, st->ell_send, ntok, W, NC, slice_tokens, st->counters);
+  // what I need: my slice against every row
+  if (my_tokens > 0) {
+    rc = scone_launch_match_ell_ex(h, d_tok + (long long)b0 * T, b1 - b0, T, st->ell_slice, 0, (long long)h->cfg.n_rows, 0, s);
+    if (rc) return rc;
+    const unsigned blocks2 = (unsigned)((my_tokens * NC + 255) / 256);
+    hipLaunchKernelGGL(k_shard_count_recv, dim3(blocks2), dim3(256), 0, s, st->ell_slice, my_tokens, W, NC,
+                       (long long)h->cfg.n_rows, world, st->counters + 64);
+  }
+  SCONE_HIP(h, hipGetLastError());
+  uint32_t host[128];
+  SCONE_HIP(h, hipMemcpyAsync(host, st->counters, sizeof(host), hipMemcpyDeviceToHost, s));
+  SCONE_HIP(h, hipStreamSynchronize(s));
+  for (int q = 0; q < world; ++q) h_send_counts[q] = host[q], h_recv_counts[q] = host[64 + q];
+  return SCONE_OK;
+}
+
+extern "C" int scone_shard_pack(scone_handle *h, int32_t B, int32_t T, int32_t world, const uint32_t *h_send_counts,
+                                void *d_send_buf, scone_stream_t stream) {
+  if (!h || !h->shard) return h ? scone_fail(h, SCONE_ESTATE, "scone_shard_pack: call scone_shard_plan first") : SCONE_EINVAL;
+  if (world < 1 || world > 64 || !h_send_counts) return scone_fail(h, SCONE_EINVAL, "scone_shard_pack: bad argument");
+  SCONE_HIP(h, hipSetDevice(h->device));
+  hipStream_t s = (hipStream_t)stream;
+  scone_shard_state *st = h->shard;
+  const int W = SCONE_ELL_W(h->cfg.max_n), NC = h->cfg.max_n * (h->cfg.max_n + 1) / 2;
+  const int32_t bper = (B + world - 1) / world;
+  const long long ntok = (long long)B * T, slice_tokens = (long long)bper * T;
+  unsigned long long off[64], total = 0;
+  for (int q = 0; q < world; ++q) off[q] = total, total += h_send_counts[q];
+  if (total == 0) return SCONE_OK;
+  if (!d_send_buf) return scone_fail(h, SCONE_EINVAL, "scone_shard_pack: null send buffer");
+  long long cap = st->cap_send;
+  int rc = grow(h, &st->send_src, &cap, (long long)total, 2);
+  if (rc) return rc;
+  st->cap_send = cap;
+  SCONE_HIP(h, hipMemcpyAsync(st->send_off, off, world * sizeof(unsigned long long), hipMemcpyHostToDevice, s));
+  const unsigned blocks = (unsigned)((ntok * NC + 255) / 256);
+  hipLaunchKernelGGL(k_shard_claim, dim3(blocks), dim3(256), 0, s, st->ell_send, ntok, W, NC, slice_tokens, st->send_off,
+                     st->counters + 128, st->send_src);
+  unsigned pb = (unsigned)((total + 3) / 4);
+  if (pb > 4096) pb = 4096;
+  hipLaunchKernelGGL(k_shard_pack, dim3(pb), dim3(256), 0, s, st->ell_send, W, slice_tokens, st->send_src, total,
+                     scone_store_of(h), (long long)h->cfg.row_begin, (const uint8_t *)h->scales, (int)h->scale_bytes_per_row,
+                     scone_shard_rec_bytes(h), (uint8_t *)d_send_buf);
+  SCONE_HIP(h, hipGetLastError());
+  SCONE_HIP(h, hipStreamSynchronize(s));  // `off` lives on this stack frame
+  return SCONE_OK;
+}
+
+// unpack + remap; on return ell_slice holds record numbers and *scales the unpacked scale array
+int scone_shard_prepare_embed(scone_handle *h, int32_t B, int32_t T, int32_t world, int32_t rank, const void *d_recv,
+                              uint64_t n_recv, const int32_t **ell, const void **scales, int32_t *b0_out, int32_t *b1_out,
+                              hipStream_t s) {
+  scone_shard_state *st = h->shard;
+  const int W = SCONE_ELL_W(h->cfg.max_n), NC = h->cfg.max_n * (h->cfg.max_n + 1) / 2;
+  int32_t bper, b0, b1;
+  slice_of(B, world, rank, &bper, &b0, &b1);
+  *b0_out = b0, *b1_out = b1;
+  const long long my_tokens = (long long)(b1 - b0) * T, slice_tokens = (long long)bper * T;
+  const size_t sb = h->scale_bytes_per_row;
+  if (sb) {
+    long long cap = st->cap_recv;
+    uint8_t *p = st->scales;
+    int rc = grow(h, &p, &cap, (long long)n_recv, sb);
+    st->scales = p, st->cap_recv = cap;
+    if (rc) return rc;
+  }
+  if (n_recv) {
+    hipLaunchKernelGGL(k_shard_unpack, dim3((unsigned)((n_recv + 255) / 256)), dim3(256), 0, s, (const uint8_t *)d_recv,
+                       (unsigned long long)n_recv, scone_shard_rec_bytes(h), (int)h->row_payload_bytes, (int)sb, NC,
+                       slice_tokens, st->slot_of_ref, st->scales, h->d_status);
+  }
+  if (my_tokens > 0)
+    hipLaunchKernelGGL(k_shard_remap, dim3((unsigned)((my_tokens * NC + 255) / 256)), dim3(256), 0, s, st->ell_slice,
+                       my_tokens, W, NC, st->slot_of_ref);
+  SCONE_HIP(h, hipGetLastError());
+  *ell = st->ell_slice;
+  *scales = st->scales;
+  return SCONE_OK;
+}

@@ -8,13 +8,18 @@ here and only needed when the table does not fit one GPU's 288 GB (BASELINE conf
 * rows: contiguous id ranges, rank r owns ``[r*N/W, (r+1)*N/W)``;
 * index (f-gram -> id): replicated, so every rank matches the full batch locally and knows
   every token's full hit count K_t -- no id exchange;
-* per step, every rank gathers + dequantises + sums only the rows it owns
-  (``scone_embed_partial``: fp32 ``[ntok, d]`` partial sums);
-* exchange: ``reduce_scatter`` (sum) over the token dimension -> each rank finalises its
-  ``ntok/W`` slice (``/ K_t``, ``+ wte``, ``+ wpe``, cast; ``scone_finalize``) ->
-  ``all_gather`` of the finished vectors, which travel in the output dtype (fp16 halves the
-  bytes on the wire).  xGMI is point-to-point: with both collectives every link carries only
-  its 1/W slice.
+* rank r finalises slice r of the batch (whole sequences);
+* exchange ``"rows"`` (default): what crosses xGMI are the QUANTISED ROWS a slice needs from the
+  other shards -- ``scone_shard_plan`` (both ends derive what is sent from the replicated tokens
+  and index: no request round) -> ``scone_shard_pack`` -> ONE ``all_to_all_single`` of records ->
+  ``scone_shard_embed`` (the ordinary fused kernel reads the records in place).  An INT4 d=1024
+  row is 544 B on the wire where an fp32 partial sum is 4096 B per token AND rank: for the C5
+  workload about 0.2 GB per rank and step instead of 3.7 GB, spread over all 7 xGMI links by the
+  all-to-all, and the result is bit-identical to the unsharded table (same reduction order);
+* exchange ``"partial_sums"`` (kept for comparison): every rank sums the rows it owns
+  (``scone_embed_partial``) -> ``reduce_scatter`` -> ``scone_finalize``;
+* finally an ``all_gather`` of the finished vectors in the output dtype (skippable when the
+  consumer is data-parallel over the same slices).
 
 Sequences are independent, so when the table DOES fit one GPU the path needs no collective
 at all: replicate the table and shard the tokens (bench.py's default at N > 1).
@@ -82,7 +87,8 @@ class ShardedEmbeddingCache:
     # ------------------------------------------------------------------
     def embed_tokens(self, input_ids: torch.Tensor, *, reduce: str = "mean", wte: Optional[torch.Tensor] = None,
                      wpe: Optional[torch.Tensor] = None, position_ids: Optional[torch.Tensor] = None,
-                     out_dtype: Optional[torch.dtype] = None, gather_output: bool = True) -> torch.Tensor:
+                     out_dtype: Optional[torch.dtype] = None, gather_output: bool = True,
+                     exchange: str = "rows") -> torch.Tensor:
         """Same result as ``EmbeddingCache.embed_tokens`` on the unsharded table (up to the fp32
         summation order across shards).  Every rank passes the SAME ``input_ids [B, T]``.
 
@@ -96,6 +102,10 @@ class ShardedEmbeddingCache:
         ntok, d, W = B * T, self.embedding_dim, self.world
         if out_dtype is None:
             out_dtype = wte.dtype if wte is not None else (wpe.dtype if wpe is not None else torch.float32)
+        if exchange == "rows":
+            return self._embed_row_exchange(tok, reduce, wte, wpe, position_ids, out_dtype, gather_output)
+        if exchange != "partial_sums":
+            raise ValueError("exchange must be 'rows' or 'partial_sums'")
         partial, counts = self.table.embed_partial(tok)                      # [ntok, d] fp32, [ntok] int32
         per = (ntok + W - 1) // W                                             # tokens per rank (last slices padded)
         a = min(self.rank * per, ntok)
@@ -123,3 +133,31 @@ class ShardedEmbeddingCache:
         else:
             full = out_slice
         return full[:ntok].reshape(B, T, d)
+
+    def _embed_row_exchange(self, tok, reduce, wte, wpe, position_ids, out_dtype, gather_output):
+        B, T = tok.shape
+        d, W, r = self.embedding_dim, self.world, self.rank
+        bper = (B + W - 1) // W                                              # sequences per slice
+        send_counts, recv_counts = self.table.shard_plan(tok, W, r)
+        send = self.table.shard_pack(B, T, W, send_counts)                   # uint8 [n_send, record_bytes]
+        rec = send.shape[1]
+        if W > 1:
+            recv = torch.empty((int(sum(recv_counts)), rec), dtype=torch.uint8, device=send.device)
+            dist.all_to_all_single(recv, send, output_split_sizes=[int(c) for c in recv_counts],
+                                   input_split_sizes=[int(c) for c in send_counts], group=self.group)
+        else:
+            recv = send
+        b0, b1 = min(r * bper, B), min(r * bper + bper, B)
+        out_slice = torch.zeros((bper * T, d), dtype=out_dtype, device=send.device) if (b1 - b0) < bper else \
+            torch.empty((bper * T, d), dtype=out_dtype, device=send.device)
+        if b1 > b0:
+            self.table.shard_embed(tok, W, r, recv, wte=wte, wpe=wpe, position_ids=position_ids, reduce=reduce,
+                                   out_dtype=out_dtype, out=out_slice[:(b1 - b0) * T])
+        if not gather_output:
+            return out_slice
+        if W > 1:
+            full = torch.empty((bper * T * W, d), dtype=out_dtype, device=send.device)
+            dist.all_gather_into_tensor(full, out_slice, group=self.group)
+        else:
+            full = out_slice
+        return full[:B * T].reshape(B, T, d)

@@ -41,6 +41,72 @@ class OracleShard:
         partial = R.embed_numpy(self.table, off_own, ids[owned], "sum")
         return torch.from_numpy(partial), torch.from_numpy(counts)
 
+    # ---- row exchange stand-ins: same contract as SconeTable.shard_plan / shard_pack / shard_embed,
+    #      a record = [fp32 row | int32 token-in-slice | int32 list index]
+    def _refs(self, tok):
+        R = self.R
+        t = tok.numpy()
+        off, ids = R.hits_to_csr(R.match_hits(self.keys, self.lens, t, self.max_n))
+        counts = np.diff(off)
+        tix = np.repeat(np.arange(len(counts)), counts)
+        jix = np.arange(len(ids)) - np.repeat(off[:-1], counts)
+        return off, ids, tix, jix
+
+    def shard_plan(self, tok, world, rank):
+        from scone_amd.distributed import owner_of
+        B, T = tok.shape
+        bper = (B + world - 1) // world
+        off, ids, tix, jix = self._refs(tok)
+        mine = (ids >= self.row_begin) & (ids < self.row_end)
+        dest = tix // (bper * T)
+        send = [int((mine & (dest == q)).sum()) for q in range(world)]
+        owner = owner_of(torch.from_numpy(ids), self.n_rows, world).numpy() if len(ids) else np.zeros(0, dtype=np.int64)
+        recv = [int(((dest == rank) & (owner == r)).sum()) for r in range(world)]
+        self._plan = (tix, jix, ids, mine, dest, bper * T)
+        return send, recv
+
+    def shard_pack(self, B, T, world, send_counts):
+        tix, jix, ids, mine, dest, st = self._plan
+        recs = []
+        for q in range(world):
+            sel = np.nonzero(mine & (dest == q))[0][::-1]        # any order inside a destination is allowed
+            assert len(sel) == send_counts[q]
+            for i in sel:
+                hdr = np.array([tix[i] % st, jix[i]], dtype=np.int32).view(np.uint8)
+                recs.append(np.concatenate([self.table[ids[i]].view(np.uint8), hdr]))
+        n = self.dim * 4 + 8
+        return torch.from_numpy(np.stack(recs) if recs else np.zeros((0, n), dtype=np.uint8))
+
+    def shard_embed(self, tok, world, rank, recv, wte=None, wpe=None, position_ids=None, reduce="mean",
+                    out_dtype=torch.float32, out=None):
+        B, T = tok.shape
+        bper = (B + world - 1) // world
+        b0, b1 = min(rank * bper, B), min(rank * bper + bper, B)
+        sl = tok[b0:b1]
+        off, ids, tix, jix = self._refs(sl)
+        r = recv.numpy()
+        rows = np.zeros((len(ids), self.dim), dtype=np.float32)
+        seen = np.zeros(len(ids), dtype=bool)
+        for rec in r:
+            t_local, j = rec[self.dim * 4:].view(np.int32)
+            k = off[t_local] + j
+            rows[k] = rec[:self.dim * 4].view(np.float32)
+            seen[k] = True
+        assert seen.all(), "a needed row did not arrive"
+        assert np.array_equal(rows, self.table[ids])
+        x = torch.from_numpy(self.R.embed_numpy(rows, off, np.arange(len(ids)), reduce))
+        flat = sl.reshape(-1).long()
+        if wte is not None:
+            x = wte.float()[flat] + x
+        if wpe is not None:
+            pos = (torch.arange(flat.numel()) % T) if position_ids is None else position_ids[b0:b1].reshape(-1).long()
+            x = x + wpe.float()[pos]
+        x = x.to(out_dtype)
+        if out is not None:
+            out.copy_(x)
+            return out
+        return x
+
     def finalize(self, sums, counts, tok, a, b, wte=None, wpe=None, position_ids=None, reduce="mean",
                  out_dtype=torch.float32, out=None):
         x = sums.clone()
@@ -61,7 +127,7 @@ class OracleShard:
         return x
 
 
-def _worker(rank, world, port, ntok_shape, out_dtype_name, q):
+def _worker(rank, world, port, ntok_shape, out_dtype_name, exchange, q):
     try:
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -84,15 +150,16 @@ def _worker(rank, world, port, ntok_shape, out_dtype_name, q):
         cache = ShardedEmbeddingCache(ex, d, rank=rank, world=world, n_rows=n,
                                       table=OracleShard(keys, lens, max_n, table, a, b))
         assert (cache.row_begin, cache.row_end) == (a, b)
-        out = cache.embed_tokens(tok, wte=wte.to(out_dtype), wpe=wpe.to(out_dtype), out_dtype=out_dtype)
+        out = cache.embed_tokens(tok, wte=wte.to(out_dtype), wpe=wpe.to(out_dtype), out_dtype=out_dtype,
+                                 exchange=exchange)
         ro, ri = R.hits_to_csr(R.match_hits(keys, lens, tok.numpy(), max_n))
         fg = torch.from_numpy(R.embed_numpy(table, ro, ri, "mean").reshape(B, T, d))
         ref = R.combine(tok, fg, wte.to(out_dtype).float(), wpe.to(out_dtype).float())
         err = float((out.float() - ref).abs().max() / ref.abs().max())
         # the slice-only form returns this rank's finished tokens
         sl = cache.embed_tokens(tok, wte=wte.to(out_dtype), wpe=wpe.to(out_dtype), out_dtype=out_dtype,
-                                gather_output=False)
-        per = (B * T + world - 1) // world
+                                gather_output=False, exchange=exchange)
+        per = (B * T + world - 1) // world if exchange == "partial_sums" else ((B + world - 1) // world) * T
         lo, hi = min(rank * per, B * T), min(rank * per + per, B * T)
         ok_slice = torch.equal(sl[:hi - lo], out.reshape(-1, d)[lo:hi])
         q.put((rank, err, tuple(out.shape), ok_slice))
@@ -107,12 +174,13 @@ def _free_port():
         return s.getsockname()[1]
 
 
+@pytest.mark.parametrize("exchange", ["rows", "partial_sums"])
 @pytest.mark.parametrize("shape,dtype", [((3, 17), "float32"), ((2, 8), "float16"), ((1, 5), "float32")])
-def test_sharded_exchange_world2_gloo(shape, dtype):
+def test_sharded_exchange_world2_gloo(shape, dtype, exchange):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, shape, dtype, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, shape, dtype, exchange, q)) for r in range(2)]
     for p in procs:
         p.start()
     results = [q.get(timeout=180) for _ in procs]

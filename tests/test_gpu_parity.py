@@ -754,3 +754,72 @@ def test_abi_argument_errors():
     with pytest.raises(IndexError):
         t.upload(np.zeros((4, 768), dtype=np.int8), np.ones(4, dtype=np.float16), row0=8)   # rows 8..11 of 10
     assert t.status() == 0
+
+
+@pytest.mark.parametrize("fmt,d,max_n,world", [("int8", 768, 3, 3), ("int4", 1024, 4, 8), ("fp16", 1280, 3, 2)])
+def test_row_exchange_between_shards_is_bit_exact(fmt, d, max_n, world):
+    """The row exchange for row-sharded tables (plan -> pack -> all-to-all of quantised rows -> embed), with the
+    W shards living on one GPU and the all-to-all done by hand: every slice equals the unsharded table BIT FOR
+    BIT (the receiver reduces the rows in the reference's order), and the wire carries sum(K) records."""
+    from scone_amd.hip_backend import SconeTable
+    from scone_amd.distributed import shard_range
+    rng = np.random.default_rng(90 + world)
+    vocab, n = 29, 2000
+    lens = rng.integers(1, max_n + 1, size=n).astype(np.uint8)
+    keys = rng.integers(0, vocab, size=(n, max_n)).astype(np.uint32)
+    keys[np.arange(max_n)[None, :] >= lens[:, None]] = 0
+    table = rng.standard_normal((n, d)).astype(np.float32)
+    full = SconeTable(max_n, n, d, fmt)
+    full.index_build(keys, lens)
+    full.store_f32(torch.from_numpy(table))
+    shards = []
+    for r in range(world):
+        a, b = shard_range(n, r, world)
+        s = SconeTable(max_n, n, d, fmt, row_begin=a, row_end=b)
+        s.index_build(keys, lens)
+        s.store_f32(torch.from_numpy(table[a:b]), row0=a)
+        shards.append(s)
+    wte = torch.from_numpy(rng.standard_normal((vocab, d)).astype(np.float32)).half().cuda()
+    wpe = torch.from_numpy(rng.standard_normal((40, d)).astype(np.float32)).half().cuda()
+    for B, T in ((11, 40), (2, 7), (64, 3), (1, 40)):
+        tok = torch.from_numpy(rng.integers(0, vocab, size=(B, T)))
+        pos = torch.from_numpy(rng.integers(0, 40, size=(B, T)))
+        for position_ids in (None, pos):
+            want = full.embed(tok, wte=wte, wpe=wpe, position_ids=position_ids).reshape(B * T, d)
+            plans = [s.shard_plan(tok, world, r) for r, s in enumerate(shards)]
+            for r in range(world):                                   # both ends agree on every transfer size
+                for q in range(world):
+                    assert plans[r][0][q] == plans[q][1][r]
+            off, ids = full.match_csr(tok)
+            assert sum(sum(p[0]) for p in plans) == ids.numel()       # one record per (token, f-gram) reference
+            sends = [s.shard_pack(B, T, world, plans[r][0]) for r, s in enumerate(shards)]
+            bper = (B + world - 1) // world
+            for q in range(world):
+                parts = []
+                for r in range(world):
+                    o = sum(plans[r][0][:q])
+                    parts.append(sends[r][o:o + plans[r][0][q]])
+                recv = torch.cat(parts).contiguous()
+                got = shards[q].shard_embed(tok, world, q, recv, wte=wte, wpe=wpe, position_ids=position_ids,
+                                            out_dtype=torch.float16)
+                b0, b1 = min(q * bper, B), min(q * bper + bper, B)
+                assert torch.equal(got, want[b0 * T:b1 * T]), (B, T, q)
+
+
+def test_sharded_cache_world1_row_exchange():
+    from scone_amd import EmbeddingCache
+    from scone_amd.distributed import ShardedEmbeddingCache
+    rng = np.random.default_rng(8)
+    vocab, n, d = 37, 800, 768
+    lens = rng.integers(1, 4, size=n).astype(np.uint8)
+    keys = rng.integers(0, vocab, size=(n, 3)).astype(np.uint32)
+    keys[np.arange(3)[None, :] >= lens[:, None]] = 0
+    ex = _extractor(keys, lens, 3)
+    plain = EmbeddingCache.from_synthetic(ex, d, table_format="int8", seed=3)
+    sharded = ShardedEmbeddingCache.from_synthetic(ex, d, table_format="int8", seed=3, rank=0, world=1)
+    tok = torch.from_numpy(rng.integers(0, vocab, size=(3, 41)))
+    wte = torch.from_numpy(rng.standard_normal((vocab, d)).astype(np.float32)).half().cuda()
+    wpe = torch.from_numpy(rng.standard_normal((41, d)).astype(np.float32)).half().cuda()
+    a = plain.embed_tokens(tok, wte=wte, wpe=wpe)
+    assert torch.equal(a, sharded.embed_tokens(tok, wte=wte, wpe=wpe, exchange="rows"))
+    assert torch.equal(a, sharded.embed_tokens(tok, wte=wte, wpe=wpe, exchange="partial_sums"))

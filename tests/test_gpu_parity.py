@@ -823,3 +823,55 @@ def test_sharded_cache_world1_row_exchange():
     a = plain.embed_tokens(tok, wte=wte, wpe=wpe)
     assert torch.equal(a, sharded.embed_tokens(tok, wte=wte, wpe=wpe, exchange="rows"))
     assert torch.equal(a, sharded.embed_tokens(tok, wte=wte, wpe=wpe, exchange="partial_sums"))
+
+
+def test_integration_stub_from_the_docs():
+    """The ctypes binding shown in INTEGRATION.md section 2 (independent of scone_amd._lib) drives the library."""
+    import ctypes as C
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = C.CDLL(os.path.join(root, "scone_amd", "csrc", "libscone_hip.so"))
+
+    class _Cfg(C.Structure):
+        _fields_ = [("struct_size", C.c_uint32), ("device", C.c_int32), ("max_n", C.c_int32),
+                    ("dim", C.c_int32), ("table_fmt", C.c_int32), ("placement", C.c_int32),
+                    ("n_rows", C.c_uint64), ("row_begin", C.c_uint64), ("row_end", C.c_uint64),
+                    ("index_capacity", C.c_uint64), ("hot_rows", C.c_uint64),
+                    ("lookup_mode", C.c_uint32), ("stage_tokens", C.c_uint32)]
+
+    lib.scone_create.argtypes = [C.POINTER(_Cfg), C.POINTER(C.c_void_p)]
+    lib.scone_index_build.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64]
+    lib.scone_table_store_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]
+    lib.scone_embed.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int64,
+                                C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]
+    lib.scone_destroy.argtypes = [C.c_void_p]
+    rng = np.random.default_rng(0)
+    f_gram_to_id = {(3,): 0, (3, 4): 1, (4,): 2, (3, 4, 5): 3}
+    n, d, max_n = 4, 768, 3
+    cfg = _Cfg(C.sizeof(_Cfg), torch.cuda.current_device(), max_n, d, 2, 0, n, 0, 0, 0, 0, 0, 0)
+    h = C.c_void_p()
+    assert lib.scone_create(C.byref(cfg), C.byref(h)) == 0
+    keys = torch.zeros(n, max_n, dtype=torch.int32)
+    lens = torch.zeros(n, dtype=torch.uint8)
+    for g, i in f_gram_to_id.items():
+        keys[i, :len(g)] = torch.tensor(g, dtype=torch.int32)
+        lens[i] = len(g)
+    assert lib.scone_index_build(h, keys.data_ptr(), lens.data_ptr(), n, 0) == 0
+    table = rng.standard_normal((n, d)).astype(np.float32)
+    rows = torch.from_numpy(table).cuda()
+    assert lib.scone_table_store_f32(h, rows.data_ptr(), 0, n, None) == 0
+    torch.cuda.synchronize()
+    wte = torch.randn(8, d, device="cuda").half()
+    wpe = torch.randn(8, d, device="cuda").half()
+    tok = torch.tensor([[3, 4, 5, 6]], dtype=torch.int32, device="cuda")
+    out = torch.empty(1, 4, d, dtype=torch.float16, device="cuda")
+    rc = lib.scone_embed(h, tok.data_ptr(), 1, 4, wte.data_ptr(), 8, wpe.data_ptr(), 8, None, 0, out.data_ptr(), 1,
+                         torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    torch.cuda.synchronize()
+    keys_np, lens_np = keys.numpy().astype(np.uint32), lens.numpy()
+    ro, ri = R.hits_to_csr(R.match_hits(keys_np, lens_np, tok.cpu().numpy(), max_n))
+    deq = R.dequantize_i8(*R.quantize_i8(table))
+    fg = torch.from_numpy(R.embed_numpy(deq, ro, ri, "mean").reshape(1, 4, d))
+    ref = R.combine(tok.cpu().long(), fg, wte.float().cpu(), wpe.float().cpu()).numpy()
+    assert _rel(out.float().cpu().numpy(), ref) < REL_TOL
+    lib.scone_destroy(h)

@@ -87,6 +87,9 @@ template <int FMT, int D> struct wave_geom {
 #ifndef SCONE_WAVE_SLACK
 #define SCONE_WAVE_SLACK 14
 #endif
+#ifndef SCONE_WAVE_BLOCKS
+#define SCONE_WAVE_BLOCKS 4096  // ~256 CUs x 8 resident workgroups x 2 rounds
+#endif
 template <int FMT, typename OutT, int D, int MAXN, bool FIXED_POS> struct wave_occupancy {
   static constexpr int NC = MAXN * (MAXN + 1) / 2;
   static constexpr int NWO = wave_geom<FMT, D>::EPL * (int)sizeof(OutT) / 4;
@@ -367,9 +370,6 @@ int launch_wave(scone_handle *h, const embed_args &a, hipStream_t s) {
   q.B = (int)(a.BT / a.T);
   q.pos_groups = (a.T + 3) / 4;
   // ~4096 workgroups (256 CUs x 8 resident x 2 rounds) when the batch allows it
-#ifndef SCONE_WAVE_BLOCKS
-#define SCONE_WAVE_BLOCKS 4096
-#endif
   long long chunks = SCONE_WAVE_BLOCKS / q.pos_groups;
   if (chunks < 1) chunks = 1;
   if (chunks > q.B) chunks = q.B;
@@ -395,6 +395,202 @@ int launch_wave(scone_handle *h, const embed_args &a, hipStream_t s) {
     hipLaunchKernelGGL((k_embed_wave<FMT, OutT, D, MAXN, true>), dim3((unsigned)blocks), dim3(256), 0, s, a.tv.st,
                        (const void *)a.tv.scales, a.ell, a.tok, a.pos, (const OutT *)a.wte, (const OutT *)a.wpe,
                        (const uint8_t *)a.zero_row, (OutT *)a.out, (int32_t *)nullptr, a.status, q);
+  SCONE_HIP(h, hipGetLastError());
+  return SCONE_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Any embedding dim that is a multiple of 8 (2048, 4096, ... -- the specialised kernel above covers
+// 768 / 1024 / 1280).  Same wave-per-token scheme and the same arithmetic; the row is walked in UNITS
+// of 8 elements (INT8 8 B, fp16 16 B, fp32 32 B, INT4 4 B per lane; 16 B of fp16 output), lane l
+// taking units l, l+64, ...: every access is a contiguous run, every 64-B sector is touched whole.
+// K stays a compile-time constant (switch outside the unit loop), so the K loads of a unit are issued
+// back to back.
+template <int FMT, typename OutT, int K, bool PARTIAL>
+__device__ __forceinline__ void embed_units(const scone_row_store &rows, const void *__restrict__ scales_v,
+                                            const int32_t *__restrict__ rec, long long row_begin, int d, int kfull,
+                                            int reduce, const uint8_t *__restrict__ wte_row,
+                                            const uint8_t *__restrict__ wpe_row, uint8_t *__restrict__ out_row, uint32_t lane) {
+  constexpr int U = 8;                                  // elements per unit
+  constexpr int RW = FMT == SCONE_FMT_F32 ? 8 : FMT == SCONE_FMT_F16 ? 4 : FMT == SCONE_FMT_I8 ? 2 : 1;  // row words per unit
+  constexpr int OW = U * (int)sizeof(OutT) / 4;         // output words per unit
+  constexpr int OPW = pack_io<OutT>::PER_WORD;
+  constexpr int KK = K > 0 ? K : 1;
+  const int nu = d / U;
+  const uint8_t *rp[KK];
+  float sc8[KK];
+  long long lrs[KK];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    lrs[k] = (long long)rec[k] - row_begin;
+    rp[k] = rows.row((unsigned long long)lrs[k]);
+    sc8[k] = 1.0f;
+    if constexpr (FMT == SCONE_FMT_I8) {
+      const uint32_t w = reinterpret_cast<const uint32_t *>(scales_v)[lrs[k] >> 1];
+      sc8[k] = __half2float(__ushort_as_half((unsigned short)((lrs[k] & 1) ? (w >> 16) : (w & 0xFFFFu))));
+    }
+  }
+  float kf = (float)kfull, y = 1.0f;
+  const bool do_mean = reduce == SCONE_REDUCE_MEAN && kfull > 1;
+  if (do_mean) y = 1.0f / kf;
+  for (int u = (int)lane; u < nu; u += 64) {
+    uint32_t raw[KK][RW];
+    uint32_t scw[KK];
+    uint32_t bw[OW], bp[OW];
+    if constexpr (!PARTIAL) {
+      const uint32_t *pw = reinterpret_cast<const uint32_t *>(wte_row) + (size_t)u * OW;
+      const uint32_t *pp = reinterpret_cast<const uint32_t *>(wpe_row) + (size_t)u * OW;
+#pragma unroll
+      for (int i = 0; i < OW; ++i) bw[i] = pw[i], bp[i] = pp[i];
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const uint32_t *p = reinterpret_cast<const uint32_t *>(rp[k]) + (size_t)u * RW;
+#pragma unroll
+      for (int i = 0; i < RW; ++i) raw[k][i] = p[i];
+      scw[k] = 0;
+      if constexpr (FMT == SCONE_FMT_I4)
+        scw[k] = reinterpret_cast<const unsigned short *>(scales_v)[lrs[k] * (d / SCONE_I4_GROUP) + (u * U) / SCONE_I4_GROUP];
+    }
+    float acc[U];
+#pragma unroll
+    for (int e = 0; e < U; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      float sc = sc8[k];
+      if constexpr (FMT == SCONE_FMT_I4) sc = __half2float(__ushort_as_half((unsigned short)scw[k]));
+#pragma unroll
+      for (int i = 0; i < RW; ++i) {
+        const uint32_t w = raw[k][i];
+        if constexpr (FMT == SCONE_FMT_F32) {
+          acc[i] += __uint_as_float(w);
+        } else if constexpr (FMT == SCONE_FMT_F16) {
+          acc[2 * i] += __half2float(__ushort_as_half((unsigned short)(w & 0xFFFFu)));
+          acc[2 * i + 1] += __half2float(__ushort_as_half((unsigned short)(w >> 16)));
+        } else if constexpr (FMT == SCONE_FMT_I8) {
+#pragma unroll
+          for (int b = 0; b < 4; ++b) {
+            const int q = (int)(w << (24 - 8 * b)) >> 24;
+            acc[4 * i + b] = fmaf(sc, (float)q, acc[4 * i + b]);
+          }
+        } else {
+#pragma unroll
+          for (int b = 0; b < 8; ++b) {
+            const int q = (int)((w >> (4 * b)) & 0xFu) - 8;
+            acc[b] = fmaf(sc, (float)q, acc[b]);
+          }
+        }
+      }
+    }
+    if constexpr (PARTIAL) {
+      uint32_t *po = reinterpret_cast<uint32_t *>(out_row) + (size_t)u * U;
+#pragma unroll
+      for (int e = 0; e < U; ++e) po[e] = __float_as_uint(acc[e]);
+    } else {
+      if (do_mean) {
+#pragma unroll
+        for (int e = 0; e < U; ++e) {  // correctly rounded x / K (Markstein, see embed_token)
+          const float q0 = acc[e] * y;
+          const float r = fmaf(-kf, q0, acc[e]);
+          acc[e] = fmaf(r, y, q0);
+        }
+      }
+      uint32_t *po = reinterpret_cast<uint32_t *>(out_row) + (size_t)u * OW;
+#pragma unroll
+      for (int w = 0; w < OW; ++w) {
+        float b[OPW], c[OPW], v[OPW];
+        pack_io<OutT>::unpack(bw[w], b);
+        pack_io<OutT>::unpack(bp[w], c);
+#pragma unroll
+        for (int k = 0; k < OPW; ++k) v[k] = (b[k] + acc[w * OPW + k]) + c[k];
+        __builtin_nontemporal_store(pack_io<OutT>::pack(v), po + w);
+      }
+    }
+  }
+}
+
+template <int FMT, typename OutT, int MAXN, bool PARTIAL>
+__global__ __launch_bounds__(256) void k_embed_wave_any(const scone_row_store rows, const void *__restrict__ scales_v,
+                                                        const int32_t *__restrict__ ell, const int32_t *__restrict__ tok,
+                                                        const int32_t *__restrict__ pos, const OutT *__restrict__ wte,
+                                                        const OutT *__restrict__ wpe, const uint8_t *__restrict__ zero_row,
+                                                        OutT *__restrict__ out, int32_t *__restrict__ counts,
+                                                        uint32_t *__restrict__ status, const wave_params q, int d) {
+  constexpr int NC = MAXN * (MAXN + 1) / 2;
+  constexpr int W = MAXN <= 3 ? 8 : 16;
+  const uint32_t lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int pg = (int)(blockIdx.x % (unsigned)q.pos_groups);
+  const int chunk = (int)(blockIdx.x / (unsigned)q.pos_groups);
+  const int i = pg * 4 + wave;
+  if (i >= q.T) return;
+  const int b0 = chunk * q.seqs_per_block;
+  int b1 = b0 + q.seqs_per_block;
+  if (b1 > q.B) b1 = q.B;
+  for (int b = b0; b < b1; ++b) {
+    const long long p = (long long)b * q.T + i;
+    int32_t rec[W];
+#pragma unroll
+    for (int j = 0; j < W; ++j) rec[j] = ell[p * W + j];
+    const int kown = rec[W - 2] & 0xFF, kfull = rec[W - 2] >> 8;
+    const uint8_t *wte_row = zero_row, *wpe_row = zero_row;
+    if constexpr (PARTIAL) {
+      if (lane == 0) counts[p] = kfull;
+    } else {
+      const int32_t tokv = wte ? tok[p] : 0;
+      const int32_t posv = wpe ? (pos ? pos[p] : i) : 0;
+      const bool tok_ok = wte && tokv >= 0 && (long long)tokv < q.vocab;
+      const bool pos_ok = wpe && posv >= 0 && (long long)posv < q.n_pos;
+      if ((wte && !tok_ok) || (wpe && !pos_ok)) {
+        if (lane == 0) atomicOr(status, SCONE_ST_BAD_TOKEN);
+      }
+      if (tok_ok && !(q.mode == SCONE_MODE_LONGEST_SUFFIX && kfull > 0))
+        wte_row = reinterpret_cast<const uint8_t *>(wte + (long long)tokv * d);
+      if (pos_ok) wpe_row = reinterpret_cast<const uint8_t *>(wpe + (long long)posv * d);
+    }
+    uint8_t *out_row = reinterpret_cast<uint8_t *>(out + p * d);
+#define SCONE_CASE(K)                                                                                              \
+  case K:                                                                                                          \
+    if constexpr (K <= NC)                                                                                         \
+      embed_units<FMT, OutT, K, PARTIAL>(rows, scales_v, rec, q.row_begin, d, kfull, q.reduce, wte_row, wpe_row, out_row, \
+                                         lane);                                                                    \
+    break;
+    switch (kown) {
+      SCONE_CASE(0) SCONE_CASE(1) SCONE_CASE(2) SCONE_CASE(3) SCONE_CASE(4) SCONE_CASE(5) SCONE_CASE(6)
+      SCONE_CASE(7) SCONE_CASE(8) SCONE_CASE(9) SCONE_CASE(10)
+      default: break;
+    }
+#undef SCONE_CASE
+  }
+}
+
+template <int FMT, typename OutT, int MAXN>
+int launch_wave_any(scone_handle *h, const embed_args &a, hipStream_t s) {
+  wave_params q;
+  q.BT = a.BT, q.T = a.T, q.max_n = a.max_n;
+  q.row_begin = a.tv.row_begin, q.row_end = a.tv.row_end;
+  q.vocab = a.vocab, q.n_pos = a.n_pos, q.reduce = a.reduce, q.mode = a.mode;
+  q.B = (int)(a.BT / a.T);
+  q.pos_groups = (a.T + 3) / 4;
+  long long chunks = SCONE_WAVE_BLOCKS / q.pos_groups;
+  if (chunks < 1) chunks = 1;
+  if (chunks > q.B) chunks = q.B;
+  q.seqs_per_block = (int)((q.B + chunks - 1) / chunks);
+  chunks = (q.B + q.seqs_per_block - 1) / q.seqs_per_block;
+  const long long blocks = chunks * q.pos_groups;
+  if (blocks > 0x7FFFFFFFll) return scone_fail(h, SCONE_EINVAL, "scone_embed: too many tokens for one launch");
+  if constexpr (std::is_same<OutT, float>::value) {
+    if (a.partial) {
+      hipLaunchKernelGGL((k_embed_wave_any<FMT, float, MAXN, true>), dim3((unsigned)blocks), dim3(256), 0, s, a.tv.st,
+                         (const void *)a.tv.scales, a.ell, a.tok, (const int32_t *)nullptr, (const float *)nullptr,
+                         (const float *)nullptr, (const uint8_t *)a.zero_row, a.partial, a.counts, a.status, q, a.tv.d);
+      SCONE_HIP(h, hipGetLastError());
+      return SCONE_OK;
+    }
+  }
+  hipLaunchKernelGGL((k_embed_wave_any<FMT, OutT, MAXN, false>), dim3((unsigned)blocks), dim3(256), 0, s, a.tv.st,
+                     (const void *)a.tv.scales, a.ell, a.tok, a.pos, (const OutT *)a.wte, (const OutT *)a.wpe,
+                     (const uint8_t *)a.zero_row, (OutT *)a.out, (int32_t *)nullptr, a.status, q, a.tv.d);
   SCONE_HIP(h, hipGetLastError());
   return SCONE_OK;
 }
@@ -489,6 +685,8 @@ int try_launch_wave(scone_handle *h, const embed_args &a, hipStream_t s) {
   if constexpr (wave_geom<FMT, 1280>::OK) {  // gpt2-large (configs/large_config.yaml:16)
     if (a.tv.d == 1280) return a.max_n <= 3 ? launch_wave<FMT, OutT, 1280, 3>(h, a, s) : launch_wave<FMT, OutT, 1280, 4>(h, a, s);
   }
+  if (a.tv.d % 8 == 0)  // any other dim: unit-walking kernel
+    return a.max_n <= 3 ? launch_wave_any<FMT, OutT, 3>(h, a, s) : launch_wave_any<FMT, OutT, 4>(h, a, s);
   return -1;
 }
 

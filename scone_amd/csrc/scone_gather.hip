@@ -33,8 +33,8 @@ int launch_fmt(scone_handle *h, const embed_args &a, int src, int mode, int out_
 }
 // formats / dims served by k_embed_wave (scone_embed_wave.h: wave_geom<>::OK)
 bool scone_wave_kernel_covers(int fmt, int d) {
-  if (d != 768 && d != 1024 && d != 1280) return false;
-  return !(fmt == SCONE_FMT_I4 && d != 1024);  // INT4 needs whole 512-element segments
+  (void)fmt;
+  return d % 8 == 0;  // specialised kernels for 768 / 1024 / 1280, the unit-walking kernel otherwise
 }
 
 void fill_table_view(const scone_handle *h, table_view &tv) {
@@ -147,13 +147,13 @@ extern "C" int scone_embed(scone_handle *h, const int32_t *d_tok, int32_t B, int
   a.BT = BT, a.T = T, a.max_n = h->cfg.max_n;
   a.tok_begin = 0, a.ntok = BT;
   a.zero_row = h->d_zero_row, a.mode = (int)h->cfg.lookup_mode;
-  rc = check_mode(h, "scone_embed: lookup_mode longest_suffix needs d = 768 / 1024 / 1280");
+  rc = check_mode(h, "scone_embed: lookup_mode longest_suffix needs d % 8 == 0");
   if (rc) return rc;
   a.tok = d_tok, a.pos = d_pos, a.wte = d_wte, a.vocab = vocab, a.wpe = d_wpe, a.n_pos = n_pos;
   a.reduce = reduce, a.out = d_out, a.status = h->d_status;
   if (h->cfg.stage_tokens && h->rows_host) {
     if (!scone_wave_kernel_covers(h->cfg.table_fmt, h->cfg.dim))
-      return scone_fail(h, SCONE_EINVAL, "scone_embed: staged prefetch needs d = 768 / 1024 / 1280");
+      return scone_fail(h, SCONE_EINVAL, "scone_embed: staged prefetch needs d % 8 == 0");
     return embed_staged(h, a, B, T, out_dtype, s);
   }
   if (scone_wave_kernel_covers(h->cfg.table_fmt, h->cfg.dim)) {
@@ -191,7 +191,7 @@ extern "C" int scone_shard_embed(scone_handle *h, const int32_t *d_tok, int32_t 
   if (B < 0 || T <= 0 || world < 1 || rank < 0 || rank >= world || (n_recv && !d_recv_buf))
     return scone_fail(h, SCONE_EINVAL, "scone_shard_embed: bad argument");
   if (!scone_wave_kernel_covers(h->cfg.table_fmt, h->cfg.dim))
-    return scone_fail(h, SCONE_EINVAL, "scone_shard_embed: the row exchange needs d = 768 / 1024 / 1280");
+    return scone_fail(h, SCONE_EINVAL, "scone_shard_embed: the row exchange needs d % 8 == 0");
   if (reduce != SCONE_REDUCE_MEAN && reduce != SCONE_REDUCE_SUM)
     return scone_fail(h, SCONE_EINVAL, "scone_shard_embed: bad reduce");
   SCONE_HIP(h, hipSetDevice(h->device));
@@ -234,7 +234,7 @@ extern "C" int scone_embed_partial(scone_handle *h, const int32_t *d_tok, int32_
   a.BT = BT, a.T = T, a.max_n = h->cfg.max_n;
   a.tok_begin = 0, a.ntok = BT;
   a.zero_row = h->d_zero_row, a.tok = d_tok, a.mode = (int)h->cfg.lookup_mode;
-  rc = check_mode(h, "scone_embed_partial: lookup_mode longest_suffix needs d = 768 / 1024 / 1280");
+  rc = check_mode(h, "scone_embed_partial: lookup_mode longest_suffix needs d % 8 == 0");
   if (rc) return rc;
   if (scone_wave_kernel_covers(h->cfg.table_fmt, h->cfg.dim)) {
     rc = scone_ensure_ell(h, BT);

@@ -497,7 +497,8 @@ def test_pinned_host_placement_matches_hbm(fmt, hot_rows):
 
 @pytest.mark.parametrize("fmt,d,max_n", [("int8", 768, 3), ("int8", 1024, 4), ("int4", 1024, 3), ("fp16", 768, 4),
                                          ("fp32", 1024, 3), ("int8", 768, 4), ("int8", 1280, 4), ("fp16", 1280, 3),
-                                         ("int4", 1280, 3), ("int8", 2048, 3)])
+                                         ("int4", 1280, 3), ("int8", 2048, 3), ("fp16", 4096, 4), ("int4", 2048, 3),
+                                         ("fp32", 136, 3), ("int8", 48, 4), ("fp32", 100, 2)])
 def test_wave_kernel_shape_sweep(fmt, d, max_n):
     """Every (B, T) geometry of the wave kernel -- T not a multiple of 4, T < max_n, one sequence, many short
     sequences, explicit and default position ids, all output dtypes -- bit-exact in fp32 against the oracle."""
@@ -617,8 +618,8 @@ def test_paper_mode_longest_suffix_vs_oracle(fmt, d, max_n):
         only = cache.embed_tokens(torch.from_numpy(tok), out_dtype=torch.float32).cpu().numpy()
         assert np.array_equal(only, R.paper_embed(f2id, max_n, tok, deq))
     # the mode needs the wave kernel's dims
-    bad = EmbeddingCache(ex, 128, table_format="fp32", lookup_mode="longest_suffix")
-    bad.cache_embeddings(list(range(n)), torch.zeros(n, 128), verbose=False)
+    bad = EmbeddingCache(ex, 100, table_format="fp32", lookup_mode="longest_suffix")      # needs d % 8 == 0
+    bad.cache_embeddings(list(range(n)), torch.zeros(n, 100), verbose=False)
     with pytest.raises(ValueError):
         bad.embed_tokens(torch.zeros((1, 4), dtype=torch.int64))
 

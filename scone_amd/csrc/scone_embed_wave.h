@@ -30,6 +30,7 @@ struct wave_params {
   int mode;            // SCONE_MODE_*
   int pos_groups;      // ceil(T / 4): a workgroup's 4 waves own 4 consecutive positions
   int seqs_per_block;  // sequences walked by one workgroup
+  unsigned n_blocks;   // workgroups with work (the grid is rounded up to a multiple of 8)
 };
 
 template <typename T> struct pack_io;
@@ -276,8 +277,18 @@ __global__ __launch_bounds__(256, (wave_occupancy<FMT, OutT, D, MAXN, FIXED_POS>
   constexpr int NWO = wave_geom<FMT, D>::EPL * (int)sizeof(OutT) / 4;
   const uint32_t lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int pg = (int)(blockIdx.x % (unsigned)q.pos_groups);
-  const int chunk = (int)(blockIdx.x / (unsigned)q.pos_groups);
+  // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs (b and b+8 share one), so
+  // logical id = (b % 8) * (grid / 8) + b / 8 puts NEIGHBOURING position groups of a sequence run on
+  // one XCD: the f-gram rows that straddle a group boundary are then served by the same L2.
+#ifndef SCONE_NO_XCD_REMAP
+  const unsigned per_xcd = gridDim.x >> 3;  // the grid is a multiple of 8
+  const unsigned logical = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+#else
+  const unsigned logical = blockIdx.x;
+#endif
+  if (logical >= q.n_blocks) return;
+  const int pg = (int)(logical % (unsigned)q.pos_groups);
+  const int chunk = (int)(logical / (unsigned)q.pos_groups);
   const int i = pg * 4 + wave;  // position inside the sequence (wave-constant)
   if (i >= q.T) return;
   const int b0 = chunk * q.seqs_per_block;
@@ -375,8 +386,10 @@ int launch_wave(scone_handle *h, const embed_args &a, hipStream_t s) {
   if (chunks > q.B) chunks = q.B;
   q.seqs_per_block = (int)((q.B + chunks - 1) / chunks);
   chunks = (q.B + q.seqs_per_block - 1) / q.seqs_per_block;
-  const long long blocks = chunks * q.pos_groups;
-  if (blocks > 0x7FFFFFFFll) return scone_fail(h, SCONE_EINVAL, "scone_embed: too many tokens for one launch");
+  long long blocks = chunks * q.pos_groups;
+  if (blocks > 0x7FFFFFF0ll) return scone_fail(h, SCONE_EINVAL, "scone_embed: too many tokens for one launch");
+  q.n_blocks = (unsigned)blocks;
+  blocks = (blocks + 7) / 8 * 8;
   if constexpr (std::is_same<OutT, float>::value) {
     if (a.partial) {  // shard mode: fp32 partial sums + full hit counts
       hipLaunchKernelGGL((k_embed_wave<FMT, float, D, MAXN, true, true>), dim3((unsigned)blocks), dim3(256), 0, s,

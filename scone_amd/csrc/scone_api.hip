@@ -182,8 +182,8 @@ extern "C" int scone_create(const scone_cfg *cfg, scone_handle **out) {
     h->bloom_mask = bits - 1;
   }
   if (cfg->dim > 0) {  // a row of zeros: stands in for wte / wpe when the caller passes none
-    CREATE_HIP(hipMalloc(&h->d_zero_row, (size_t)cfg->dim * 4));
-    CREATE_HIP(hipMemset(h->d_zero_row, 0, (size_t)cfg->dim * 4));
+    CREATE_HIP(hipMalloc(&h->d_zero_row, (size_t)cfg->dim * 4 + 64));  // + room for a record's scales / header
+    CREATE_HIP(hipMemset(h->d_zero_row, 0, (size_t)cfg->dim * 4 + 64));
   }
   if (cfg->dim > 0) {
     if (!payload_geometry(h->cfg, &h->row_payload_bytes, &h->scale_bytes_per_row)) {

@@ -206,7 +206,8 @@ extern "C" int scone_shard_embed(scone_handle *h, const int32_t *d_tok, int32_t 
   embed_args a = {};
   fill_table_view(h, a.tv);
   a.tv.st.hot = nullptr, a.tv.st.n_hot = 0;  // every row of this slice is a received record
-  a.tv.st.cold = reinterpret_cast<uint8_t *>(const_cast<void *>(d_recv_buf));
+  // nothing received: any (erroneous) reference is already redirected to record 0 -> give it the zero row
+  a.tv.st.cold = n_recv ? reinterpret_cast<uint8_t *>(const_cast<void *>(d_recv_buf)) : reinterpret_cast<uint8_t *>(h->d_zero_row);
   a.tv.st.row_bytes = (unsigned int)scone_shard_rec_bytes(h);
   a.tv.scales = reinterpret_cast<const __half *>(scales);
   a.tv.row_begin = 0, a.tv.row_end = (long long)(n_recv ? n_recv : 1);

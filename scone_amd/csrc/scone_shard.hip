@@ -134,14 +134,23 @@ __global__ __launch_bounds__(256) void k_shard_unpack(const uint8_t *__restrict_
     reinterpret_cast<unsigned short *>(scales + p * scale_bytes)[b] = reinterpret_cast<const unsigned short *>(rec + row_bytes)[b];
 }
 
+// A reference whose record did not arrive (the peers disagree about the batch: a caller error) is
+// pointed at record 0 -- or at the zero row when nothing arrived -- and reported through the status
+// word, so the lookup kernel never reads outside the receive buffer.
 __global__ __launch_bounds__(256) void k_shard_remap(int32_t *__restrict__ ell, long long ntok, int W, int NC,
-                                                     const uint32_t *__restrict__ slot_of_ref) {
+                                                     const uint32_t *__restrict__ slot_of_ref, unsigned long long n_recv,
+                                                     uint32_t *__restrict__ status) {
   const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long t = gid / NC;
   const int j = (int)(gid - t * NC);
   if (t >= ntok) return;
   if (j >= (ell[t * W + W - 2] & 0xFF)) return;
-  ell[t * W + j] = (int32_t)slot_of_ref[t * NC + j];
+  uint32_t p = slot_of_ref[t * NC + j];
+  if (p >= n_recv) {
+    atomicOr(status, SCONE_ST_BAD_ID);
+    p = 0;
+  }
+  ell[t * W + j] = (int32_t)p;
 }
 
 template <typename T>
@@ -287,6 +296,7 @@ int scone_shard_prepare_embed(scone_handle *h, int32_t B, int32_t T, int32_t wor
     st->scales = p, st->cap_recv = cap;
     if (rc) return rc;
   }
+  SCONE_HIP(h, hipMemsetAsync(st->slot_of_ref, 0xFF, (size_t)slice_tokens * NC * sizeof(uint32_t), s));
   if (n_recv) {
     hipLaunchKernelGGL(k_shard_unpack, dim3((unsigned)((n_recv + 255) / 256)), dim3(256), 0, s, (const uint8_t *)d_recv,
                        (unsigned long long)n_recv, scone_shard_rec_bytes(h), (int)h->row_payload_bytes, (int)sb, NC,
@@ -294,7 +304,7 @@ int scone_shard_prepare_embed(scone_handle *h, int32_t B, int32_t T, int32_t wor
   }
   if (my_tokens > 0)
     hipLaunchKernelGGL(k_shard_remap, dim3((unsigned)((my_tokens * NC + 255) / 256)), dim3(256), 0, s, st->ell_slice,
-                       my_tokens, W, NC, st->slot_of_ref);
+                       my_tokens, W, NC, st->slot_of_ref, (unsigned long long)n_recv, h->d_status);
   SCONE_HIP(h, hipGetLastError());
   *ell = st->ell_slice;
   *scales = st->scales;

@@ -876,3 +876,24 @@ def test_integration_stub_from_the_docs():
     ref = R.combine(tok.cpu().long(), fg, wte.float().cpu(), wpe.float().cpu()).numpy()
     assert _rel(out.float().cpu().numpy(), ref) < REL_TOL
     lib.scone_destroy(h)
+
+
+def test_row_exchange_missing_records_are_reported_not_read_out_of_bounds():
+    from scone_amd.hip_backend import SconeTable
+    rng = np.random.default_rng(2)
+    vocab, n, d = 11, 300, 768
+    lens = rng.integers(1, 4, size=n).astype(np.uint8)
+    keys = rng.integers(0, vocab, size=(n, 3)).astype(np.uint32)
+    keys[np.arange(3)[None, :] >= lens[:, None]] = 0
+    t = SconeTable(3, n, d, "int8")
+    t.index_build(keys, lens)
+    t.store_f32(torch.from_numpy(rng.standard_normal((n, d)).astype(np.float32)))
+    tok = torch.from_numpy(rng.integers(0, vocab, size=(4, 16)))
+    send_counts, recv_counts = t.shard_plan(tok, 1, 0)
+    send = t.shard_pack(4, 16, 1, send_counts)
+    assert t.status() == 0
+    t.shard_embed(tok, 1, 0, send[: send.shape[0] // 2].contiguous())       # half of the records withheld
+    assert t.status() & 2
+    t.shard_plan(tok, 1, 0)
+    t.shard_embed(tok, 1, 0, send[:0].contiguous())                          # nothing arrived
+    assert t.status() & 2

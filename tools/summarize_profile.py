@@ -24,6 +24,13 @@ def main(tag):
     shutil.copy(os.path.join(src, "kernel_stats.csv"), os.path.join(dst, "kernel_stats.csv"))
     bench = json.loads(open(os.path.join(src, "bench.json")).read().strip().splitlines()[-1])
     json.dump(bench, open(os.path.join(dst, "bench.json"), "w"), indent=1)
+    # the bench line printed INSIDE the rocprofv3 --kernel-trace run: its HIP-event average of the gather
+    # kernel is the one to compare with kernel_stats.csv (the profiler lowers the clock by a few percent)
+    tl = os.path.join(src, "trace.log")
+    if os.path.exists(tl):
+        lines = [l for l in open(tl) if l.startswith('{"metric"')]
+        if lines:
+            json.dump(json.loads(lines[-1]), open(os.path.join(dst, "bench_under_rocprof.json"), "w"), indent=1)
     out = {}
     for d in sorted(glob.glob(os.path.join(src, "pmc_*/"))):
         f = glob.glob(d + "*/*counter_collection.csv")

@@ -897,3 +897,49 @@ def test_row_exchange_missing_records_are_reported_not_read_out_of_bounds():
     t.shard_plan(tok, 1, 0)
     t.shard_embed(tok, 1, 0, send[:0].contiguous())                          # nothing arrived
     assert t.status() & 2
+
+
+# ------------------------------------------------------------------ BASELINE.json configs at their named sizes
+def test_config_c1_100k_fp32_table_from_fit():
+    """configs[0]: 100K f-grams fp32 d=768, vocabulary from fit on a 1M-token Zipf corpus (the reference's own
+    CPU-runnable case), 8 x 512 Zipf tokens: ids bit-exact, fp32 mean bit-exact against the oracle."""
+    from scone_amd import EmbeddingCache, NGramExtractor
+    from scone_amd import synthetic as S
+    rng = np.random.default_rng(1234)
+    cdf = S.zipf_cdf(S.GPT2_VOCAB)
+    corpus = [S.zipf_tokens(rng, cdf, 1000).tolist() for _ in range(1000)]
+    ex = NGramExtractor(max_n=3, min_freq=1, max_f_grams=100_000).fit_gpu(corpus, verbose=False)
+    assert len(ex) == 100_000
+    keys, lens = ex.key_arrays()
+    d = 768
+    table = rng.standard_normal((len(ex), d)).astype(np.float32)
+    cache = EmbeddingCache(ex, d, table_format="fp32", keep_host_copy=False)
+    cache.cache_embeddings(np.arange(len(ex)), torch.from_numpy(table), verbose=False)
+    tok = S.zipf_tokens(rng, cdf, (8, 512))
+    off, ids = cache.match(torch.from_numpy(tok))
+    ro, ri = R.hits_to_csr(R.match_hits(keys, lens, tok, 3))
+    assert np.array_equal(off.cpu().numpy(), ro) and np.array_equal(ids.cpu().numpy(), ri)
+    assert 2.0 < len(ri) / tok.size < 3.2                      # the survey measured 2.59 hits per token on this setup
+    out = cache.embed_tokens(torch.from_numpy(tok), out_dtype=torch.float32).cpu().numpy()
+    assert np.array_equal(out, R.embed_numpy(table, ro, ri, "mean").reshape(8, 512, d))
+    # the reference's per-position API on one sequence
+    te = cache.get_token_embeddings(tok[0].tolist())
+    assert all(np.array_equal(te[p].numpy(), table[ri[ro[p]:ro[p + 1]]]) for p in te)
+
+
+def test_config_c3_10m_int8_d1024():
+    """configs[2]: 10M f-grams INT8 d=1024 in HBM: index of 1e7 exact keys, spot check against the oracle."""
+    from scone_amd import EmbeddingCache
+    from scone_amd import synthetic as S
+    n, d = 10_000_000, 1024
+    keys, lens = S.make_keys_structured(n)
+    cache = EmbeddingCache.from_synthetic(_extractor(keys, lens, 3), d, table_format="int8", seed=7, base_scale=0.02 / 127)
+    assert cache.table.index_stats()[0] == n
+    tok = S.stream_uniform_ids(keys, lens, 4, 512, 3)
+    off, ids = cache.match(torch.from_numpy(tok))
+    ro, ri = R.hits_to_csr(R.match_hits(keys, lens, tok, 3))
+    assert np.array_equal(off.cpu().numpy(), ro) and np.array_equal(ids.cpu().numpy(), ri)
+    uniq, inv = np.unique(ri, return_inverse=True)
+    rows = R.synth_rows_i8(7, uniq, d).astype(np.float32) * R.synth_scale_f16(7, uniq, 0.02 / 127).astype(np.float32)[:, None]
+    out = cache.embed_tokens(torch.from_numpy(tok), out_dtype=torch.float32).cpu().numpy()
+    assert np.array_equal(out, R.embed_numpy(rows, ro, inv, "mean").reshape(4, 512, d))

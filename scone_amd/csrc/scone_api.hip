@@ -164,6 +164,11 @@ extern "C" int scone_create(const scone_cfg *cfg, scone_handle **out) {
     }                                            \
   } while (0)
   CREATE_HIP(hipSetDevice(h->device));
+  {
+    int cus = 0;
+    CREATE_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device));
+    h->n_cus = cus > 0 ? cus : 256;
+  }
   CREATE_HIP(hipMalloc(&h->slots, cap * sizeof(scone_slot)));
   CREATE_HIP(hipMemset(h->slots, 0, cap * sizeof(scone_slot)));
   CREATE_HIP(hipMalloc(&h->d_counters, 2 * sizeof(unsigned long long)));

@@ -105,6 +105,7 @@ struct scone_shard_state;
 struct scone_handle {
   scone_cfg cfg;
   int device;
+  int n_cus;  // compute units of the device (256 on MI355X)
   // index
   scone_slot *slots;
   uint64_t cap;  // power of two

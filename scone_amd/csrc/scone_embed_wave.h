@@ -380,8 +380,15 @@ int launch_wave(scone_handle *h, const embed_args &a, hipStream_t s) {
   q.vocab = a.vocab, q.n_pos = a.n_pos, q.reduce = a.reduce, q.mode = a.mode;
   q.B = (int)(a.BT / a.T);
   q.pos_groups = (a.T + 3) / 4;
-  // ~4096 workgroups (256 CUs x 8 resident x 2 rounds) when the batch allows it
-  long long chunks = SCONE_WAVE_BLOCKS / q.pos_groups;
+  // Grid = a whole number of residency rounds: a workgroup is one wave per SIMD, so WAVES of them fit a
+  // CU; with e.g. 4096 workgroups on 256 x 7 slots the third round is a quarter full and the chip idles
+  // (measured: 3 full rounds -3.7 % kernel time vs 4096 workgroups; 1, 2 and 4 rounds within 1 % of 3).
+#ifdef SCONE_WAVE_BLOCKS_FIXED
+  const long long target = SCONE_WAVE_BLOCKS_FIXED;
+#else
+  const long long target = 3ll * h->n_cus * wave_occupancy<FMT, OutT, D, MAXN, true>::WAVES;
+#endif
+  long long chunks = (target + q.pos_groups / 2) / q.pos_groups;
   if (chunks < 1) chunks = 1;
   if (chunks > q.B) chunks = q.B;
   q.seqs_per_block = (int)((q.B + chunks - 1) / chunks);

@@ -109,6 +109,25 @@ def cpu_baseline(args, keys, lens, tok, seed, base_scale, gpu_out, wte, wpe):
         done += len(seqs)
         dt = time.perf_counter() - t0
     nseq = done
+    # courtesy upper bound: the plain-C oracle (oracle/oracle.c), OpenMP over independent sequences on all host
+    # cores, on the same sample (vocabulary and table restricted to the f-grams the sample references)
+    c_line = None
+    try:
+        from oracle.c_oracle import COracle
+        refs = np.asarray(sorted(cache.embeddings.keys()), dtype=np.int64)
+        sub = np.stack([cache.embeddings[int(i)] for i in refs])
+        co = COracle(keys[refs], lens[refs], 3)
+        tok_s = np.asarray(seqs, dtype=np.int64)
+        nthr = min(os.cpu_count() or 1, 64)
+        co.embed(sub, tok_s[:8], "mean", nthr)
+        reps, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < 3.0:
+            co.embed(sub, tok_s, "mean", nthr)
+            reps += 1
+        c_line = {"value": reps * tok_s.size / (time.perf_counter() - t0), "unit": "tokens/s", "cores": nthr,
+                  "kind": "port (plain C, OpenMP over sequences; oracle/oracle.c)"}
+    except Exception as e:
+        c_line = {"value": None, "error": repr(e)}
     # parity spot check of the GPU output (first sequence) against the oracle
     ref = R.combine(torch.from_numpy(tok[:1]), first, wte.float().cpu(), wpe.float().cpu()).numpy()
     err = float(np.abs(gpu_out[:1].float().cpu().numpy() - ref).max() / np.abs(ref).max())
@@ -118,6 +137,7 @@ def cpu_baseline(args, keys, lens, tok, seed, base_scale, gpu_out, wte, wpe):
                   f"({dt:.1f} s; oracle/ref_port.py aggregate(), python {sys.version_info.major}.{sys.version_info.minor}, "
                   f"torch {torch.__version__}, host cpus {os.cpu_count()})",
         "gpu_vs_oracle_max_rel_err_seq0": err,
+        "c_oracle_all_cores": c_line,
     }
 
 

@@ -154,3 +154,20 @@ def test_paper_lookup_known_answers():
     wte = 100 + np.arange(10 * 4, dtype=np.float32).reshape(10, 4)
     e = R.paper_embed(d, 3, np.array([[4, 5, 6, 7]]), table, wte=wte)
     assert np.array_equal(e[0, 0], wte[4]) and np.array_equal(e[0, 2], table[2]) and np.array_equal(e[0, 3], table[3])
+
+
+def test_c_oracle_bit_exact_vs_golden(golden_dir):
+    """oracle/oracle.c (second, independent restatement): ids and fp32 means equal the reference's."""
+    from oracle.c_oracle import COracle
+    z = _load(golden_dir, "match.npz")
+    for c in z["cases"]:
+        co = COracle(z[f"{c}_keys"], z[f"{c}_lens"], int(z[f"{c}_max_n"]))
+        for si in range(int(z["n_streams"])):
+            off, ids = co.match_csr(z[f"{c}_s{si}_tok"])
+            assert np.array_equal(off, z[f"{c}_s{si}_off"]) and np.array_equal(ids, z[f"{c}_s{si}_ids"]), (c, si)
+    z = _load(golden_dir, "lookup.npz")
+    for c in z["cases"]:
+        co = COracle(z[f"{c}_keys"], z[f"{c}_lens"], int(z[f"{c}_max_n"]))
+        out, total = co.embed(z[f"{c}_table"], z[f"{c}_tok"], "mean", nthreads=2)
+        assert total == len(z[f"{c}_ids"])
+        assert np.array_equal(out, z[f"{c}_agg_f32"]), c

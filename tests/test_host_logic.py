@@ -121,3 +121,37 @@ def test_key_packing_twin_is_injective():
             p = pack(t, max_n)
             assert seen.setdefault(p, t) == t
             assert p != (0, 0)
+
+
+def test_product_never_imports_the_oracle():
+    """oracle/ is test infrastructure: nothing under scone_amd/ may import, load or execute it."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    bad = []
+    for dirpath, _, files in os.walk(os.path.join(root, "scone_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".c", ".cpp")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                if re.search(r"^\s*(from|import)\s+oracle\b|liboracle|oracle/oracle\.c|ref_port", text, flags=re.M):
+                    bad.append(os.path.join(dirpath, f))
+    assert not bad, bad
+
+
+def test_committed_bench_line_follows_the_contract():
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prof = os.path.join(root, "profiles")
+    rounds = sorted(d for d in os.listdir(prof) if os.path.exists(os.path.join(prof, d, "bench.json")))
+    r = json.load(open(os.path.join(prof, rounds[-1], "bench.json")))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in r, k
+    assert r["unit"] == "tokens/s" and r["higher_is_better"] is True and r["vs_baseline"] is None and r["data"] == "synthetic"
+    assert "workload" in r["config"] and "model" not in r["config"]
+    rf = r["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and "traffic" in rf
+    cb = r["cpu_baseline"]
+    assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["unit"] == "tokens/s" and cb["sample"]
+    # value = tokens of all ranks / time
+    assert abs(r["value"] - r["config"]["tokens_per_step_per_rank"] * r["n_gpus"] / (r["ms_per_step"] * 1e-3)) / r["value"] < 1e-6

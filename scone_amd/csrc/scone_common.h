@@ -145,6 +145,8 @@ struct scone_handle {
 int scone_fail(scone_handle *h, int code, const char *what);
 int scone_hip_fail(scone_handle *h, hipError_t e, const char *what);
 scone_row_store scone_store_of(const scone_handle *h);
+struct scone_index_view;
+void scone_index_view_of(const scone_handle *h, scone_index_view *v);  // scone_index.hip
 int scone_ensure_hits(scone_handle *h, int64_t ntok);
 int scone_ensure_ell(scone_handle *h, int64_t ntok);
 int scone_prof_begin(scone_handle *h, hipStream_t s);  // no-ops unless profiling is enabled

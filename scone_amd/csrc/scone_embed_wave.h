@@ -16,6 +16,7 @@
 #pragma once
 
 #include "scone_gather_impl.h"
+#include "scone_probe.h"
 
 namespace scone_gather {
 
@@ -370,6 +371,115 @@ __global__ __launch_bounds__(256, (wave_occupancy<FMT, OutT, D, MAXN, FIXED_POS>
     tokv = tokn;
     posv = posn;
   }
+}
+
+// Decode-size batches (a few thousand tokens at most) are launch-bound: match and gather in ONE launch.
+// One wave per token.  Lane c < NC probes candidate window c of the token (n = 1..MAXN, start ascending --
+// the reference's append order is the lane order); a wavefront ballot of the hits gives K and, bit by
+// bit, the compacted id list as scalars; from there on it is the same K-way body as k_embed_wave.
+template <int FMT, typename OutT, int D, int MAXN>
+__global__ __launch_bounds__(256) void k_embed_fused(const scone_row_store rows, const void *__restrict__ scales_v,
+                                                     const scone_index_view ix, const int32_t *__restrict__ tok,
+                                                     const int32_t *__restrict__ pos, const OutT *__restrict__ wte,
+                                                     const OutT *__restrict__ wpe, const uint8_t *__restrict__ zero_row,
+                                                     OutT *__restrict__ out, uint32_t *__restrict__ status,
+                                                     const wave_params q) {
+  constexpr int NC = MAXN * (MAXN + 1) / 2;
+  constexpr int NWO = wave_geom<FMT, D>::EPL * (int)sizeof(OutT) / 4;
+  const uint32_t lane = threadIdx.x & 63;
+  const long long p = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  if (p >= q.BT) return;
+  const int i = (int)(p % q.T);
+
+  // ---- match: lane c probes candidate c ------------------------------------------------------------
+  int32_t my_id = -1;
+  if ((int)lane < NC) {
+    int n, s;
+    cand_ns((int)lane, n, s);
+    if (n <= q.max_n && i - s >= 0 && i - s + n <= q.T) {
+      uint32_t k[SCONE_MAX_N] = {0u, 0u, 0u, 0u};
+      bool ok = true;
+#pragma unroll
+      for (int j = 0; j < MAXN; ++j) {
+        if (j < n) {
+          const int32_t v = tok[p - s + j];
+          ok = ok && v >= 0;
+          k[j] = (uint32_t)v;
+        }
+      }
+      if (ok) my_id = scone_lookup_key(ix, k, n);
+    }
+  }
+  const unsigned long long hit = __ballot(my_id >= 0);
+  unsigned long long own = __ballot(my_id >= 0 && (long long)my_id >= q.row_begin && (long long)my_id < q.row_end);
+  const int kfull = __popcll(hit), kown = __popcll(own);
+  int32_t rec[NC];
+#pragma unroll
+  for (int k = 0; k < NC; ++k) {
+    const int l = own ? __builtin_ctzll(own) : 0;
+    rec[k] = __builtin_amdgcn_readlane(my_id, l);
+    own &= own - 1;
+  }
+
+  // ---- gather + reduce + combine: as k_embed_wave ----------------------------------------------------
+  const int32_t tokv = wte ? tok[p] : 0;
+  const int32_t posv = wpe ? (pos ? pos[p] : i) : 0;
+  const bool tok_ok = wte && tokv >= 0 && (long long)tokv < q.vocab;
+  const bool pos_ok = wpe && posv >= 0 && (long long)posv < q.n_pos;
+  if ((wte && !tok_ok) || (wpe && !pos_ok)) {
+    if (lane == 0) atomicOr(status, SCONE_ST_BAD_TOKEN);
+  }
+  const uint8_t *wte_row = tok_ok ? reinterpret_cast<const uint8_t *>(wte + (long long)tokv * D) : zero_row;
+  const uint8_t *wpe_row = pos_ok ? reinterpret_cast<const uint8_t *>(wpe + (long long)posv * D) : zero_row;
+  uint8_t *out_row = reinterpret_cast<uint8_t *>(out + p * D);
+  uint32_t wpe_words[NWO];
+#pragma unroll
+  for (int w = 0; w < NWO; ++w) wpe_words[w] = 0u;
+#define SCONE_CASE(K)                                                                                            \
+  case K:                                                                                                        \
+    if constexpr (K <= NC)                                                                                       \
+      embed_token<FMT, OutT, D, K, false, false>(rows, scales_v, rec, q.row_begin, kfull, q.reduce, wte_row, wpe_row, \
+                                                 wpe_words, out_row, lane);                                      \
+    break;
+  switch (kown) {
+    SCONE_CASE(0) SCONE_CASE(1) SCONE_CASE(2) SCONE_CASE(3) SCONE_CASE(4) SCONE_CASE(5) SCONE_CASE(6)
+    SCONE_CASE(7) SCONE_CASE(8) SCONE_CASE(9) SCONE_CASE(10)
+    default: break;
+  }
+#undef SCONE_CASE
+}
+
+// returns -1 if the fused kernel does not apply
+template <int FMT, typename OutT>
+int try_launch_fused(scone_handle *h, const embed_args &a, hipStream_t s) {
+  if (a.mode != SCONE_MODE_COVER || a.partial) return -1;
+  wave_params q = {};
+  q.BT = a.BT, q.T = a.T, q.max_n = a.max_n;
+  q.row_begin = a.tv.row_begin, q.row_end = a.tv.row_end;
+  q.vocab = a.vocab, q.n_pos = a.n_pos, q.reduce = a.reduce, q.mode = a.mode;
+  scone_index_view ix;
+  scone_index_view_of(h, &ix);
+  const unsigned blocks = (unsigned)((a.BT + 3) / 4);
+#define SCONE_FUSED(DD, NN)                                                                                       \
+  hipLaunchKernelGGL((k_embed_fused<FMT, OutT, DD, NN>), dim3(blocks), dim3(256), 0, s, a.tv.st,                  \
+                     (const void *)a.tv.scales, ix, a.tok, a.pos, (const OutT *)a.wte, (const OutT *)a.wpe,       \
+                     (const uint8_t *)a.zero_row, (OutT *)a.out, a.status, q)
+  if constexpr (wave_geom<FMT, 768>::OK) {
+    if (a.tv.d == 768) {
+      if (a.max_n <= 3) SCONE_FUSED(768, 3); else SCONE_FUSED(768, 4);
+      SCONE_HIP(h, hipGetLastError());
+      return SCONE_OK;
+    }
+  }
+  if constexpr (wave_geom<FMT, 1024>::OK) {
+    if (a.tv.d == 1024) {
+      if (a.max_n <= 3) SCONE_FUSED(1024, 3); else SCONE_FUSED(1024, 4);
+      SCONE_HIP(h, hipGetLastError());
+      return SCONE_OK;
+    }
+  }
+#undef SCONE_FUSED
+  return -1;
 }
 
 template <int FMT, typename OutT, int D, int MAXN>
@@ -729,6 +839,15 @@ int launch_table_fmt(scone_handle *h, const embed_args &a, int src, int mode, in
       return rc != -1 ? rc : launch_dtype<FMT, SRC_HITS, MODE_FINALIZE>(h, a, out_dtype, s);
     } else {
       return scone_fail(h, SCONE_EINVAL, "finalize runs on fp32 sums");
+    }
+  }
+  // decode-size batch: match + gather in one launch (scone_embed sets a.fused and skips the match kernel)
+  if (a.fused) {
+    switch (out_dtype) {
+      case SCONE_DT_F32: return try_launch_fused<FMT, float>(h, a, s);
+      case SCONE_DT_F16: return try_launch_fused<FMT, __half>(h, a, s);
+      case SCONE_DT_BF16: return try_launch_fused<FMT, __hip_bfloat16>(h, a, s);
+      default: return scone_fail(h, SCONE_EINVAL, "unknown out_dtype");
     }
   }
   // fused full lookup: wave-per-token kernel where it applies, lane-group kernel otherwise

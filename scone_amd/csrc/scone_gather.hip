@@ -19,6 +19,10 @@
 
 using namespace scone_gather;
 
+#ifndef SCONE_FUSED_MAX_TOKENS
+#define SCONE_FUSED_MAX_TOKENS 2048  // above this the two-kernel form (one probe per window, not per covered token) wins
+#endif
+
 namespace {
 
 int launch_fmt(scone_handle *h, const embed_args &a, int src, int mode, int out_dtype, hipStream_t s) {
@@ -155,6 +159,16 @@ extern "C" int scone_embed(scone_handle *h, const int32_t *d_tok, int32_t B, int
     if (!scone_wave_kernel_covers(h->cfg.table_fmt, h->cfg.dim))
       return scone_fail(h, SCONE_EINVAL, "scone_embed: staged prefetch needs d % 8 == 0");
     return embed_staged(h, a, B, T, out_dtype, s);
+  }
+  // decode-size batches are launch-bound: one fused launch (k_embed_fused) instead of match + gather
+  if (BT <= SCONE_FUSED_MAX_TOKENS && h->cfg.lookup_mode == SCONE_MODE_COVER && (h->cfg.dim == 768 || h->cfg.dim == 1024) &&
+      !(h->cfg.table_fmt == SCONE_FMT_I4 && h->cfg.dim == 768)) {
+    a.fused = 1;
+    rc = scone_prof_begin(h, s);
+    if (rc) return rc;
+    rc = launch_fmt(h, a, SRC_HITS, MODE_FULL, out_dtype, s);
+    if (rc) return rc;
+    return scone_prof_end(h, s);
   }
   if (scone_wave_kernel_covers(h->cfg.table_fmt, h->cfg.dim)) {
     // fast path: per-token id records (one scalar load per token in the gather kernel)

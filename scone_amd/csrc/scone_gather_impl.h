@@ -179,6 +179,7 @@ struct embed_args {
   const void *base;  // gather_reduce: [ntok, d] added after the reduce, or null
   int reduce;
   int mode;           // SCONE_MODE_* (honoured by the wave kernels)
+  int fused;          // decode-size batch: match inside the lookup kernel (k_embed_fused)
   void *out;          // OutT [ntok, d]       (MODE_FULL / MODE_FINALIZE)
   float *partial;     // fp32 [ntok, d]       (MODE_PARTIAL)
   int32_t *counts;    // [ntok] full K        (MODE_PARTIAL out / MODE_FINALIZE in)

@@ -6,6 +6,7 @@
 //   NGramExtractor.get_token_f_grams                 scone/tokenization/n_gram_extractor.py:106-126
 //   [f_gram_to_id[g] for g in f_grams]               scone/inference/embedding_cache.py:173
 #include "scone_common.h"
+#include "scone_probe.h"
 
 namespace {
 
@@ -67,21 +68,6 @@ __global__ __launch_bounds__(256) void k_index_insert(scone_slot *__restrict__ s
   atomicOr(status, SCONE_ST_INDEX_FULL);
 }
 
-// ------------------------------------------------------------------ probe
-__device__ __forceinline__ int32_t probe_index(const scone_slot *__restrict__ slots,
-                                               unsigned long long mask, unsigned long long lo,
-                                               uint32_t ext) {
-  unsigned long long s = scone_hash_key(lo, ext) & mask;
-  for (unsigned long long probe = 0; probe <= mask; ++probe) {
-    // one 16-byte load per probe
-    const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(&slots[s]);
-    if (v.x == lo && (uint32_t)(v.y >> 32) == ext) return (int32_t)((uint32_t)v.y - 1u);
-    if (v.x == 0ull) return -1;
-    s = (s + 1ull) & mask;
-  }
-  return -1;
-}
-
 // One thread per (n, position): hits[(n-1)*BT + p] = id of tok[p .. p+n-1] or -1.
 // Windows never cross a sequence boundary (callers pass one sequence at a time,
 // f_gram_tokenizer.py:77) and must fit in T (n_gram_extractor.py:118).
@@ -124,18 +110,6 @@ __global__ __launch_bounds__(256) void k_match(const scone_slot *__restrict__ sl
 // (plus the max_n-1 halo starts in front of the tile), the per-window ids are staged in LDS
 // ("index buckets"), then one thread per position compacts its candidates.
 #define ELL_TILE 256
-
-// Resolve one probe whose first slot has already been fetched (v = slots[s]).
-__device__ __forceinline__ int32_t probe_finish(const scone_slot *__restrict__ slots, unsigned long long mask,
-                                                unsigned long long lo, uint32_t ext, unsigned long long s, ulonglong2 v) {
-  for (unsigned long long probe = 0; probe <= mask; ++probe) {
-    if (v.x == lo && (uint32_t)(v.y >> 32) == ext) return (int32_t)((uint32_t)v.y - 1u);
-    if (v.x == 0ull) return -1;
-    s = (s + 1ull) & mask;
-    v = *reinterpret_cast<const ulonglong2 *>(&slots[s]);
-  }
-  return -1;
-}
 
 // All windows (n = 1..MAXN) that START at position `start`: the MAXN first-slot loads are
 // issued back to back (memory-level parallelism inside one lane), unigrams come from the
@@ -393,6 +367,11 @@ int scone_launch_match(scone_handle *h, const int32_t *d_tok, int32_t B, int32_t
                      h->cfg.max_n, d_hits);
   SCONE_HIP(h, hipGetLastError());
   return SCONE_OK;
+}
+
+void scone_index_view_of(const scone_handle *h, scone_index_view *v) {
+  v->slots = h->slots, v->mask = h->cap - 1, v->uni = h->d_uni, v->uni_cap = SCONE_UNI_CAP;
+  v->bloom = h->d_bloom, v->bloom_mask = h->bloom_mask, v->max_n = h->cfg.max_n;
 }
 
 int scone_launch_match_ell(scone_handle *h, const int32_t *d_tok, int32_t B, int32_t T, int32_t *d_ell, hipStream_t s) {

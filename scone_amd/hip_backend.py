@@ -119,6 +119,7 @@ class SconeTable:
         if rc != L.OK:
             _raise(rc, "scone_create: " + lib.scone_last_error(None).decode())
         self._h = h
+        self._embed_fn = lib.scone_embed
 
     # -- plumbing ---------------------------------------------------------------
     def _check(self, rc: int, who: str) -> None:
@@ -282,7 +283,8 @@ class SconeTable:
               position_ids: Optional[torch.Tensor] = None, reduce: str = "mean",
               out_dtype: Optional[torch.dtype] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Fused match + gather + dequantise + reduce (+ wte[tok] + wpe[pos]) -> [B, T, d]."""
-        tok = self._tok(tok)
+        if not (tok.dim() == 2 and tok.dtype == torch.int32 and tok.is_cuda and tok.is_contiguous()):
+            tok = self._tok(tok)          # decode-size calls are host-bound: skip conversions that are no-ops
         B, T = tok.shape
         if out_dtype is None:
             out_dtype = wte.dtype if wte is not None else (wpe.dtype if wpe is not None else torch.float32)
@@ -297,11 +299,14 @@ class SconeTable:
             out = torch.empty((B, T, self.dim), dtype=out_dtype, device=self.device)
         else:
             assert out.is_cuda and out.is_contiguous() and out.dtype == out_dtype and out.numel() == B * T * self.dim
-        with torch.cuda.device(self.device):
-            rc = L.lib().scone_embed(self._h, _ptr(tok), B, T, _ptr(wte), 0 if wte is None else wte.shape[0],
-                                     _ptr(wpe), 0 if wpe is None else wpe.shape[0], _ptr(position_ids),
-                                     _REDUCE[reduce], _ptr(out), _DT[out_dtype], _stream())
-        self._check(rc, "scone_embed")
+        # the library selects its device itself (hipSetDevice); torch's current stream of THAT device is the launch stream
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        rc = self._embed_fn(self._h, tok.data_ptr(), B, T, None if wte is None else wte.data_ptr(),
+                            0 if wte is None else wte.shape[0], None if wpe is None else wpe.data_ptr(),
+                            0 if wpe is None else wpe.shape[0], None if position_ids is None else position_ids.data_ptr(),
+                            _REDUCE[reduce], out.data_ptr(), _DT[out_dtype], stream)
+        if rc != L.OK:
+            self._check(rc, "scone_embed")
         return out
 
     def reserve(self, max_tokens: int) -> None:

@@ -164,6 +164,12 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no HIP device visible)")
+    # Rehearsal knobs (never set by the driver): SCONE_DIST_BACKEND=gloo + SCONE_ONE_DEVICE=1 let several
+    # ranks share ONE GPU so that the N > 1 code path can be exercised on a 1-GPU box (RCCL refuses two
+    # ranks on one device).  Numbers from such a run are not scaling results.
+    backend = os.environ.get("SCONE_DIST_BACKEND", "nccl")
+    if os.environ.get("SCONE_ONE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1 or args.force_dist:
@@ -173,7 +179,10 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     from scone_amd import EmbeddingCache, NGramExtractor
     from scone_amd import synthetic as S
@@ -259,7 +268,7 @@ def main():
     n_launch, kern_ms = table.profile_read(reset=True)
     table.profile_enable(False)
     if dist is not None:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
@@ -280,8 +289,8 @@ def main():
             "value": value, "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "strong" if sharded else "weak", "vs_baseline": None,
-            "dtype": {"int8": "i8->f32 accumulate, f16 out", "int4": "i4->f32 accumulate, f16 out",
-                      "fp16": "f16->f32 accumulate, f16 out", "fp32": "f32, f16 out"}[args.format],
+            "dtype": "f32",       # the arithmetic type of the path: rows dequantised, summed and combined in fp32
+            "table_format": args.format, "out_dtype": "f16",
             "data": "synthetic", "workload_sig": sig,
             "config": {
                 "workload": f"{N}-row {args.format} f-gram table d={d} max_n={max_n} vocab={vocab} in "
@@ -300,6 +309,10 @@ def main():
                 "algorithmic_bytes_per_launch": bytes_per_launch, "avg_kernel_ms": avg_ms, "timed_launches": n_launch,
                 "traffic": None if tr is None else tr.get("hbm_bytes_per_launch"),
                 "traffic_source": None if tr is None else tr.get("source"),
+                # the same launch priced by the bytes that actually left L2 (PMC), not by the algorithmic bytes:
+                # adjacent tokens share f-gram rows and hot wte rows hit L2, so this is the lower figure
+                "traffic_GBps": None if tr is None else tr["hbm_bytes_per_launch"] / (avg_ms * 1e-3) / 1e9,
+                "traffic_frac": None if tr is None else tr["hbm_bytes_per_launch"] / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
             },
         }
         if not args.no_cpu_baseline and world == 1 and not sharded:

@@ -33,6 +33,41 @@ import torch.distributed as dist
 from scone_amd.tokenization.n_gram_extractor import NGramExtractor
 
 
+def _host_staged(group) -> bool:
+    """True when the group's backend cannot carry device tensors (gloo): the collectives below then go
+    through host copies.  RCCL ("nccl") moves device buffers directly over xGMI; the staged form exists
+    so that the whole sharded path -- real kernels, real process separation -- can be rehearsed with
+    several ranks sharing ONE GPU, which RCCL refuses."""
+    return dist.get_backend(group) == "gloo"
+
+
+def _reduce_scatter_sum(out: torch.Tensor, inp: torch.Tensor, group) -> None:
+    if _host_staged(group) and inp.is_cuda:
+        o = torch.empty(out.shape, dtype=out.dtype)
+        dist.reduce_scatter_tensor(o, inp.cpu(), op=dist.ReduceOp.SUM, group=group)
+        out.copy_(o)
+    else:
+        dist.reduce_scatter_tensor(out, inp, op=dist.ReduceOp.SUM, group=group)
+
+
+def _all_gather(out: torch.Tensor, inp: torch.Tensor, group) -> None:
+    if _host_staged(group) and inp.is_cuda:
+        o = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(o, inp.cpu(), group=group)
+        out.copy_(o)
+    else:
+        dist.all_gather_into_tensor(out, inp, group=group)
+
+
+def _all_to_all(out: torch.Tensor, inp: torch.Tensor, out_splits, in_splits, group) -> None:
+    if _host_staged(group) and inp.is_cuda:
+        o = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_to_all_single(o, inp.cpu(), output_split_sizes=out_splits, input_split_sizes=in_splits, group=group)
+        out.copy_(o)
+    else:
+        dist.all_to_all_single(out, inp, output_split_sizes=out_splits, input_split_sizes=in_splits, group=group)
+
+
 def shard_range(n_rows: int, rank: int, world: int) -> Tuple[int, int]:
     """Contiguous row range owned by ``rank``: ``[rank*N//W, (rank+1)*N//W)``."""
     return (rank * n_rows) // world, ((rank + 1) * n_rows) // world
@@ -115,7 +150,7 @@ class ShardedEmbeddingCache:
             if pad:
                 partial = torch.cat([partial, partial.new_zeros((pad, d))])
             mine = torch.empty((per, d), dtype=torch.float32, device=partial.device)
-            dist.reduce_scatter_tensor(mine, partial, op=dist.ReduceOp.SUM, group=self.group)
+            _reduce_scatter_sum(mine, partial, self.group)
         else:
             mine = partial                                                    # one shard: nothing to exchange
         if b - a == per:
@@ -129,7 +164,7 @@ class ShardedEmbeddingCache:
             return out_slice
         if W > 1:
             full = torch.empty((per * W, d), dtype=out_dtype, device=partial.device)
-            dist.all_gather_into_tensor(full, out_slice, group=self.group)
+            _all_gather(full, out_slice, self.group)
         else:
             full = out_slice
         return full[:ntok].reshape(B, T, d)
@@ -143,8 +178,7 @@ class ShardedEmbeddingCache:
         rec = send.shape[1]
         if W > 1:
             recv = torch.empty((int(sum(recv_counts)), rec), dtype=torch.uint8, device=send.device)
-            dist.all_to_all_single(recv, send, output_split_sizes=[int(c) for c in recv_counts],
-                                   input_split_sizes=[int(c) for c in send_counts], group=self.group)
+            _all_to_all(recv, send, [int(c) for c in recv_counts], [int(c) for c in send_counts], self.group)
         else:
             recv = send
         b0, b1 = min(r * bper, B), min(r * bper + bper, B)
@@ -157,7 +191,7 @@ class ShardedEmbeddingCache:
             return out_slice
         if W > 1:
             full = torch.empty((bper * T * W, d), dtype=out_dtype, device=send.device)
-            dist.all_gather_into_tensor(full, out_slice, group=self.group)
+            _all_gather(full, out_slice, self.group)
         else:
             full = out_slice
         return full[:B * T].reshape(B, T, d)

@@ -1,0 +1,121 @@
+"""GPU, several PROCESSES sharing the one card: the row-sharded path with real device shards
+(``hip_backend.SconeTable`` with row_begin/row_end), real process separation and a real
+``torch.distributed`` group.  RCCL refuses two ranks on one device, so the group is gloo and
+``scone_amd.distributed`` stages the collectives through the host; everything else -- plan,
+pack, the fused kernel reading the received records in place, finalise, the output all-gather
+-- is the code an 8-GPU RCCL run executes.  Also launches ``bench.py --gpus 2`` the way the
+driver does (``python -m torch.distributed.run``) and checks its JSON line.
+
+At most 3 ranks touch the GPU at once (the box allows 6)."""
+
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _problem(fmt, d, max_n, seed=5):
+    rng = np.random.default_rng(seed)
+    vocab, n = 23, 700
+    lens = rng.integers(1, max_n + 1, size=n).astype(np.uint8)
+    keys = rng.integers(0, vocab, size=(n, max_n)).astype(np.uint32)
+    keys[np.arange(max_n)[None, :] >= lens[:, None]] = 0
+    table = rng.standard_normal((n, d)).astype(np.float32)
+    B, T = 5, 33                                   # B not a multiple of the world size: padded tail slice
+    tok = rng.integers(0, vocab + 1, size=(B, T))  # id `vocab` never matches
+    wte = (rng.standard_normal((vocab + 1, d)) * 0.1).astype(np.float32)
+    wpe = (rng.standard_normal((T, d)) * 0.1).astype(np.float32)
+    return keys, lens, table, tok, wte, wpe
+
+
+def _worker(rank, world, port, fmt, d, max_n, exchange, q):
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        torch.cuda.set_device(0)
+        from scone_amd import EmbeddingCache, NGramExtractor
+        from scone_amd.distributed import ShardedEmbeddingCache
+        keys, lens, table, tok, wte, wpe = _problem(fmt, d, max_n)
+        ex = NGramExtractor.from_arrays(keys, lens, max_n=max_n)
+        sh = ShardedEmbeddingCache(ex, d, table_format=fmt, rank=rank, world=world)
+        sh.load_rows(torch.from_numpy(table), 0)
+        wte_d, wpe_d = torch.from_numpy(wte).half().cuda(), torch.from_numpy(wpe).half().cuda()
+        got = sh.embed_tokens(torch.from_numpy(tok), wte=wte_d, wpe=wpe_d, exchange=exchange)
+        # the unsharded table on the same GPU
+        full = EmbeddingCache(ex, d, table_format=fmt)
+        full.cache_embeddings(list(range(len(lens))), torch.from_numpy(table), verbose=False)
+        ref = full.embed_tokens(torch.from_numpy(tok), wte=wte_d, wpe=wpe_d)
+        same = bool(torch.equal(got, ref))
+        err = float((got.float() - ref.float()).abs().max() / ref.float().abs().max())
+        sl = sh.embed_tokens(torch.from_numpy(tok), wte=wte_d, wpe=wpe_d, exchange=exchange, gather_output=False)
+        q.put((rank, same, err, tuple(got.shape), tuple(sl.shape)))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:                          # surface the failure in the parent
+        import traceback
+        q.put((rank, False, repr(e) + traceback.format_exc(), None, None))
+
+
+@pytest.mark.parametrize("fmt,d,max_n,world,exchange", [("int8", 768, 3, 2, "rows"), ("int4", 1024, 4, 3, "rows"),
+                                                        ("int8", 768, 3, 2, "partial_sums")])
+def test_sharded_cache_across_processes_on_one_gpu(fmt, d, max_n, world, exchange):
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, fmt, d, max_n, exchange, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, same, err, shape, sl_shape in results:
+        assert shape is not None, f"rank {rank} failed: {err}"
+        assert shape == (5, 33, d)
+        if exchange == "rows":
+            assert same, f"rank {rank}: row exchange must be bit-identical to the unsharded table (rel err {err})"
+        else:
+            assert err < 1e-3, (rank, err)          # fp32 partial sums are added in shard order, not list order
+
+
+@pytest.mark.parametrize("mode", ["replicated", "sharded"])
+def test_bench_two_ranks_launched_like_the_driver(mode):
+    """`python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2` with the rehearsal knobs
+    (gloo, both ranks on device 0): one JSON line, n_gpus 2, value = tokens of BOTH ranks / max time."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    env = dict(os.environ, SCONE_DIST_BACKEND="gloo", SCONE_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
+           "--gpus", "2", "--steps", "5", "--warmup", "2", "--rows", "200000", "--batch", "256", "--table-mode", mode]
+    p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["steps"] == 5 and "cpu_baseline" not in r
+    ranks_counted = 2 if mode == "replicated" else 1      # sharded: every rank embeds the SAME batch (strong scaling)
+    assert r["scaling"] == ("weak" if mode == "replicated" else "strong")
+    assert abs(r["value"] - ranks_counted * 256 * 512 * 5 / (r["ms_per_step"] * 5e-3)) / r["value"] < 1e-6
+    if mode == "replicated":
+        assert r["roofline"]["timed_launches"] == 5

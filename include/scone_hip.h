@@ -80,7 +80,7 @@ typedef struct scone_cfg {
   uint64_t n_rows;         /* N = number of f-grams (global)                               */
   uint64_t row_begin;      /* rows owned by this handle: [row_begin, row_end); the whole   */
   uint64_t row_end;        /* table is 0..N (row_end = 0 means N)                          */
-  uint64_t index_capacity; /* hash slots; 0 = smallest power of two >= 2*N                 */
+  uint64_t index_capacity; /* hash slots (power of two >= 4); 0 = smallest power of two >= 2*N */
   uint64_t hot_rows;       /* SCONE_PLACE_PINNED_HOST only: global rows [0, hot_rows) stay in HBM, the
                               rest in pinned host DRAM.  f-gram ids are frequency-ordered
                               (Counter.most_common, n_gram_extractor.py:91-99), so the head of

@@ -146,8 +146,8 @@ extern "C" int scone_create(const scone_cfg *cfg, scone_handle **out) {
     cap = 64;
     while (cap < 2 * cfg->n_rows) cap <<= 1;
   }
-  if (cap & (cap - 1)) {
-    g_create_err = "scone_create: index_capacity must be a power of two";
+  if ((cap & (cap - 1)) || cap < SCONE_BUCKET) {
+    g_create_err = "scone_create: index_capacity must be a power of two >= 4";
     delete h;
     return SCONE_EINVAL;
   }

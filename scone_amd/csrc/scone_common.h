@@ -70,6 +70,21 @@ __host__ __device__ inline unsigned long long scone_hash_key(unsigned long long 
   return x;
 }
 
+// Probe sequence.  The table is cut into buckets of SCONE_BUCKET consecutive slots (4 x 16 B = one 64-B
+// sector, so a probe step costs the memory system the same as a single-slot read).  A key's home bucket is
+// hash & (buckets - 1); when a bucket is full the sequence continues at bucket + step (step odd -> visits every
+// bucket of the power-of-two table; taken from the high hash bits, so keys that collide on a bucket part again).
+// Inside a bucket slots fill front to back, and a key only ever moves past FULL buckets, so a lookup stops at
+// the first empty slot it sees.  Compared with slot-by-slot linear probing this bounds the dependent-load
+// chain: at load 0.5 a bucket overflows with p ~ 0.05, so the longest chain over 10^6 lookups is ~5 steps
+// where linear probing's longest cluster costs 30-40 dependent L2 misses and sets the match kernel's tail.
+#define SCONE_BUCKET 4
+#define SCONE_BUCKET_SHIFT 2
+__host__ __device__ inline unsigned long long scone_bucket_home(unsigned long long hash, unsigned long long slot_mask) {
+  return hash & (slot_mask >> SCONE_BUCKET_SHIFT);
+}
+__host__ __device__ inline unsigned long long scone_bucket_step(unsigned long long hash) { return (hash >> 32) | 1ull; }
+
 // Presence filter in front of the hash probes of the fused match: bit (hash >> 20) & mask is set for
 // every inserted key, so a clear bit proves the window is not an f-gram without touching the table
 // (most bigram / trigram windows are misses, and every table probe costs a 128-B line).

@@ -48,22 +48,27 @@ __global__ __launch_bounds__(256) void k_index_insert(scone_slot *__restrict__ s
     const unsigned long long bit = scone_bloom_bit(hash, bloom_mask);
     atomicOr(&bloom[bit >> 5], 1u << (bit & 31));
   }
-  unsigned long long s = hash & mask;
-  for (unsigned long long probe = 0; probe <= mask; ++probe) {
-    unsigned long long old = atomicCAS(&slots[s].lo, 0ull, key.lo);
-    if (old == 0ull || old == key.lo) {
-      unsigned long long prev = atomicCAS(&slots[s].hi, 0ull, myhi);
-      if (prev == 0ull) {
-        atomicAdd(&counters[0], 1ull);
-        return;
-      }
-      if ((uint32_t)(prev >> 32) == key.ext) {
-        atomicMin(&slots[s].hi, myhi);
-        atomicAdd(&counters[1], 1ull);
-        return;
+  // bucket sequence of scone_common.h: slots of a bucket front to back, then the next bucket
+  const unsigned long long nbm = mask >> SCONE_BUCKET_SHIFT, step = scone_bucket_step(hash);
+  unsigned long long b = scone_bucket_home(hash, mask);
+  for (unsigned long long probe = 0; probe <= nbm; ++probe) {
+    for (int j = 0; j < SCONE_BUCKET; ++j) {
+      const unsigned long long s = (b << SCONE_BUCKET_SHIFT) + j;
+      unsigned long long old = atomicCAS(&slots[s].lo, 0ull, key.lo);
+      if (old == 0ull || old == key.lo) {
+        unsigned long long prev = atomicCAS(&slots[s].hi, 0ull, myhi);
+        if (prev == 0ull) {
+          atomicAdd(&counters[0], 1ull);
+          return;
+        }
+        if ((uint32_t)(prev >> 32) == key.ext) {
+          atomicMin(&slots[s].hi, myhi);
+          atomicAdd(&counters[1], 1ull);
+          return;
+        }
       }
     }
-    s = (s + 1ull) & mask;
+    b = (b + step) & nbm;
   }
   atomicOr(status, SCONE_ST_INDEX_FULL);
 }
@@ -111,7 +116,7 @@ __global__ __launch_bounds__(256) void k_match(const scone_slot *__restrict__ sl
 // ("index buckets"), then one thread per position compacts its candidates.
 #define ELL_TILE 256
 
-// All windows (n = 1..MAXN) that START at position `start`: the MAXN first-slot loads are
+// All windows (n = 1..MAXN) that START at position `start`: the MAXN home-bucket loads are
 // issued back to back (memory-level parallelism inside one lane), unigrams come from the
 // direct table when it covers the token.
 template <int MAXN>
@@ -136,9 +141,9 @@ __device__ __forceinline__ void probe_starts(const scone_slot *__restrict__ slot
       }
     }
   }
-  unsigned long long lo[MAXN], sl[MAXN];
+  unsigned long long lo[MAXN], hs[MAXN], bk[MAXN];
   uint32_t ext[MAXN];
-  ulonglong2 first[MAXN];
+  scone_bucket_regs first[MAXN];
   bool live[MAXN];
 #pragma unroll
   for (int n = 1; n <= MAXN; ++n) {
@@ -152,7 +157,7 @@ __device__ __forceinline__ void probe_starts(const scone_slot *__restrict__ slot
     if (!key.ok) continue;
     lo[n - 1] = key.lo, ext[n - 1] = key.ext;
     const unsigned long long hash = scone_hash_key(key.lo, key.ext);
-    sl[n - 1] = hash & mask;
+    hs[n - 1] = hash, bk[n - 1] = scone_bucket_home(hash, mask);
     live[n - 1] = true;
     if (bloom) {  // a clear presence bit proves a miss (the bitmap is small enough to live in L2)
       const unsigned long long bit = scone_bloom_bit(hash, bloom_mask);
@@ -161,10 +166,10 @@ __device__ __forceinline__ void probe_starts(const scone_slot *__restrict__ slot
   }
 #pragma unroll
   for (int n = 0; n < MAXN; ++n)
-    if (live[n]) first[n] = *reinterpret_cast<const ulonglong2 *>(&slots[sl[n]]);
+    if (live[n]) load_bucket(slots, bk[n], first[n]);
 #pragma unroll
   for (int n = 0; n < MAXN; ++n)
-    if (live[n]) res[n] = probe_finish(slots, mask, lo[n], ext[n], sl[n], first[n]);
+    if (live[n]) res[n] = probe_finish(slots, mask, lo[n], ext[n], hs[n], bk[n], first[n]);
 }
 
 template <int MAXN>

@@ -111,9 +111,9 @@ __global__ __launch_bounds__(256) void k_match(const scone_slot *__restrict__ sl
 //   ell[p*W + W-2]          = K_own | (K_full << 8)      (K_full: all hits, the mean's divisor)
 // W = 8 (max_n <= 3, <= 6 ids) or 16 (max_n = 4, <= 10 ids), so the gather kernel fetches a
 // token's whole list with ONE aligned scalar load.  A workgroup owns ELL_TILE consecutive
-// positions: thread (n, t) probes the window of length n starting at position t of the tile
-// (plus the max_n-1 halo starts in front of the tile), the per-window ids are staged in LDS
-// ("index buckets"), then one thread per position compacts its candidates.
+// positions: thread t probes the windows (n = 1..MAXN) starting at its position, the per-window
+// ids are staged in LDS ("index buckets"), then every thread compacts the candidates covering its
+// position (the first max_n-1 threads only supply the window starts in front of the tile).
 #define ELL_TILE 256
 
 // All windows (n = 1..MAXN) that START at position `start`: the MAXN home-bucket loads are
@@ -181,23 +181,22 @@ __global__ __launch_bounds__(ELL_TILE) void k_match_ell(const scone_slot *__rest
                                                         int keep_pos, int32_t *__restrict__ ell) {
   constexpr int HALO = MAXN - 1;
   constexpr int W = MAXN <= 3 ? 8 : 16;
-  __shared__ int32_t win[MAXN][ELL_TILE + HALO];
+  constexpr int TILE = ELL_TILE - HALO;  // positions per workgroup
+  __shared__ int32_t win[MAXN][ELL_TILE];
   const int t = threadIdx.x;
-  const long long tile0 = (long long)blockIdx.x * ELL_TILE;
+  // Thread t probes the windows that START at position p = tile0 - HALO + t and later compacts the
+  // candidates covering p; the first HALO threads only supply the starts in front of the tile.  ONE
+  // probe pass per thread: a second, 2-lane pass for the halo would double the dependent-load chain of
+  // wave 0 and with it, through the barrier, of the whole workgroup.
+  const long long p = (long long)blockIdx.x * TILE - HALO + t;
 
   int32_t r[MAXN];
-  probe_starts<MAXN>(slots, mask, uni, uni_cap, bloom, bloom_mask, tok, BT, T, max_n, tile0 + t, r);
+  probe_starts<MAXN>(slots, mask, uni, uni_cap, bloom, bloom_mask, tok, BT, T, max_n, p, r);
 #pragma unroll
-  for (int n = 0; n < MAXN; ++n) win[n][t + HALO] = r[n];
-  if (t < HALO) {  // the max_n-1 starts in front of the tile
-    probe_starts<MAXN>(slots, mask, uni, uni_cap, bloom, bloom_mask, tok, BT, T, max_n, tile0 - HALO + t, r);
-#pragma unroll
-    for (int n = 0; n < MAXN; ++n) win[n][t] = r[n];
-  }
+  for (int n = 0; n < MAXN; ++n) win[n][t] = r[n];
   __syncthreads();
 
-  const long long p = tile0 + t;
-  if (p >= BT) return;
+  if (t < HALO || p >= BT) return;
   const int i = BT <= 0x7FFFFFFFll ? (int)((unsigned)p % (unsigned)T) : (int)(p % T);
   int32_t rec[W];
 #pragma unroll
@@ -209,7 +208,7 @@ __global__ __launch_bounds__(ELL_TILE) void k_match_ell(const scone_slot *__rest
 #pragma unroll
     for (int nn = MAXN; nn >= 2; --nn) {
       if (kfull == 0 && nn <= max_n && i - (nn - 1) >= 0) {
-        const int32_t id = win[nn - 1][t + HALO - (nn - 1)];
+        const int32_t id = win[nn - 1][t - (nn - 1)];
         if (id >= 0) {
           kfull = 1;
           if (id >= row_begin && id < row_end) rec[0] = id, kown = 1;
@@ -222,7 +221,7 @@ __global__ __launch_bounds__(ELL_TILE) void k_match_ell(const scone_slot *__rest
 #pragma unroll
     for (int s = nn - 1; s >= 0; --s) {
       if (mode == SCONE_MODE_COVER && nn <= max_n && i - s >= 0) {
-        const int32_t id = win[nn - 1][t + HALO - s];
+        const int32_t id = win[nn - 1][t - s];
         if (id >= 0) {
           // keep_pos (row exchange between shards): an owned id stays at its index in the FULL list,
           // ids of other shards leave a hole (-1); otherwise owned ids are compacted
@@ -387,7 +386,8 @@ int scone_launch_match_ell_ex(scone_handle *h, const int32_t *d_tok, int32_t B, 
                               long long re, int keep_pos, hipStream_t s) {
   const long long BT = (long long)B * T;
   if (BT == 0) return SCONE_OK;
-  const long long blocks = (BT + ELL_TILE - 1) / ELL_TILE;
+  const long long tile = ELL_TILE - (h->cfg.max_n <= 3 ? 2 : 3);  // k_match_ell<MAXN>::TILE
+  const long long blocks = (BT + tile - 1) / tile;
   if (blocks > 0x7FFFFFFFll) return scone_fail(h, SCONE_EINVAL, "scone_embed: too many tokens for one launch");
   if (h->cfg.max_n <= 3)
     hipLaunchKernelGGL((k_match_ell<3>), dim3((unsigned)blocks), dim3(ELL_TILE), 0, s, h->slots, h->cap - 1, h->d_uni,

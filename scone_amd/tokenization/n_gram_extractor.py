@@ -218,6 +218,28 @@ class NGramExtractor:
             result[pos] = [id_to[int(i)] for i in ids[offsets[pos]:offsets[pos + 1]]]
         return result
 
+    def get_token_f_grams_batch(self, input_ids) -> List[Dict[int, List[Tuple[int, ...]]]]:
+        """:meth:`get_token_f_grams` for every row of ``input_ids [B, T]`` with ONE GPU match
+        (the reference loops over sequences, f_gram_tokenizer.py:121-123)."""
+        import torch
+        ids = torch.as_tensor(input_ids)
+        if ids.dim() != 2:
+            raise ValueError("input_ids must be [B, T]")
+        B, T = ids.shape
+        if B == 0 or T == 0:
+            return [{} for _ in range(B)]
+        index = self.device_index()
+        offsets, flat = index.match_csr(ids.clamp(-1, 2**31 - 1).to(torch.int32))
+        offsets = offsets.cpu().numpy()
+        flat = flat.cpu().numpy()
+        id_to = self.id_to_f_gram
+        out = []
+        for b in range(B):
+            base = b * T
+            out.append({pos: [id_to[int(i)] for i in flat[offsets[base + pos]:offsets[base + pos + 1]]]
+                        for pos in range(T)})
+        return out
+
     # ------------------------------------------------------------------ persistence
     def save(self, path: str) -> None:
         """Same on-disk format as the reference (n_gram_extractor.py:128-141)."""

@@ -240,11 +240,72 @@ def make_combine(SconeLanguageModel):
     print("combine.npz:", len(cases), "cases")
 
 
+CALLER_WORDS = ("the of and to in a is that for it as was with be by on not he this are or his from at which "
+                "but have an had they you were their one all we can her has there been if more when will would who so no").split()
+
+
+def caller_texts(rng, n, lo, hi):
+    return [" ".join(rng.choice(CALLER_WORDS, size=int(rng.integers(lo, hi)), p=None).tolist()) for _ in range(n)]
+
+
+def make_callers(NGramExtractor):
+    """The two callers of the match step, driven with a deterministic stub tokenizer (tests/stub_tokenizer.py):
+    FGramTokenizer.tokenize / batch_tokenize (scone/tokenization/f_gram_tokenizer.py:38-126) and the f-gram id
+    vector of SconeDataset.__getitem__ (scone/data/dataset.py:117-147)."""
+    sys.path.insert(0, os.path.dirname(HERE))
+    from stub_tokenizer import StubTokenizer
+    from scone.tokenization.f_gram_tokenizer import FGramTokenizer
+    from scone.data.dataset import SconeDataset
+    rng = np.random.default_rng(77)
+    tok = StubTokenizer()
+    corpus_texts = caller_texts(rng, 60, 5, 60)
+    ex = NGramExtractor(max_n=3, min_freq=2, max_f_grams=400)
+    ex.fit([tok.encode(t) for t in corpus_texts], verbose=False)
+    ft = FGramTokenizer(tok, ex)
+    keys, lens = keys_arrays(ex.f_gram_to_id, 3)
+    out = {"keys": keys, "lens": lens, "max_n": np.int64(3)}
+    texts = caller_texts(rng, 6, 1, 40) + ["the of and to", "zzz qqq"]      # the last one has no f-gram words in the corpus
+    out["texts"] = np.asarray(texts)
+
+    def csr_of(tfg, n):
+        offsets, ids = [0], []
+        for pos in range(n):
+            ids.extend(ex.f_gram_to_id[g] for g in tfg[pos])
+            offsets.append(len(ids))
+        return np.asarray(offsets, dtype=np.int64), np.asarray(ids, dtype=np.int64)
+
+    for i, t in enumerate(texts):                                              # tokenize, one text at a time
+        for tag, kw in (("plain", {}), ("trunc", {"max_length": 8, "truncation": True})):
+            r = ft.tokenize(t, **kw)
+            out[f"tok{i}_{tag}_input_ids"] = np.asarray(r["input_ids"], dtype=np.int64)
+            out[f"tok{i}_{tag}_mask"] = np.asarray(r["attention_mask"], dtype=np.int64)
+            out[f"tok{i}_{tag}_off"], out[f"tok{i}_{tag}_ids"] = csr_of(r["token_f_grams"], len(r["input_ids"]))
+    r = ft.batch_tokenize(texts, max_length=24)                                 # padded + truncated batch
+    ids = r["input_ids"].numpy()
+    out["batch_input_ids"], out["batch_mask"] = ids, r["attention_mask"].numpy()
+    offs, flat = [], []
+    for b in range(ids.shape[0]):
+        o, f = csr_of(r["token_f_grams"][b], ids.shape[1])
+        offs.append(o)
+        flat.append(f)
+    out["batch_off"] = np.stack(offs)
+    out["batch_ids_flat"] = np.concatenate(flat)
+    for max_length in (16, 4):                                                  # dataset items (causal_lm)
+        ds = SconeDataset(texts, tok, ft, max_length=max_length, task="causal_lm")
+        items = [ds[i] for i in range(len(texts))]
+        out[f"ds{max_length}_input_ids"] = np.stack([it["input_ids"].numpy() for it in items])
+        out[f"ds{max_length}_f_gram_ids"] = np.stack([it["f_gram_ids"].numpy() for it in items])
+        out[f"ds{max_length}_f_gram_mask"] = np.stack([it["f_gram_attention_mask"].numpy() for it in items])
+    np.savez_compressed(os.path.join(HERE, "callers.npz"), **out)
+    print("callers.npz:", len(texts), "texts,", len(lens), "f-grams")
+
+
 def main():
     NGramExtractor, EmbeddingCache, SconeLanguageModel = import_reference()
     make_match(NGramExtractor)
     make_lookup(NGramExtractor, EmbeddingCache)
     make_combine(SconeLanguageModel)
+    make_callers(NGramExtractor)
 
 
 if __name__ == "__main__":

@@ -943,3 +943,57 @@ def test_config_c3_10m_int8_d1024():
     rows = R.synth_rows_i8(7, uniq, d).astype(np.float32) * R.synth_scale_f16(7, uniq, 0.02 / 127).astype(np.float32)[:, None]
     out = cache.embed_tokens(torch.from_numpy(tok), out_dtype=torch.float32).cpu().numpy()
     assert np.array_equal(out, R.embed_numpy(rows, ro, inv, "mean").reshape(4, 512, d))
+
+
+# ------------------------------------------------------------------ callers of the match step
+def test_fgram_tokenizer_and_dataset_ids_match_the_reference(golden_dir, tmp_path):
+    """FGramTokenizer.tokenize / batch_tokenize (f_gram_tokenizer.py:38-126) and the f-gram id vector of
+    SconeDataset.__getitem__ (dataset.py:117-147) against outputs captured from the reference."""
+    import sys
+    sys.path.insert(0, os.path.dirname(golden_dir))
+    from stub_tokenizer import StubTokenizer
+    from scone_amd import FGramTokenizer
+    z = np.load(os.path.join(golden_dir, "callers.npz"))
+    ex = _extractor(z["keys"], z["lens"], int(z["max_n"]))
+    ft = FGramTokenizer(StubTokenizer(), ex)
+    assert FGramTokenizer(tokenizer=ft.base_tokenizer, n_gram_extractor=ex).n_gram_extractor is ex   # train.py:290-293
+    texts = [str(t) for t in z["texts"]]
+    f2id = ex.f_gram_to_id
+
+    def csr_of(tfg, n):
+        off, ids = [0], []
+        for pos in range(n):
+            ids.extend(f2id[g] for g in tfg[pos])
+            off.append(len(ids))
+        return np.asarray(off), np.asarray(ids, dtype=np.int64)
+
+    for i, t in enumerate(texts):
+        for tag, kw in (("plain", {}), ("trunc", {"max_length": 8, "truncation": True})):
+            r = ft.tokenize(t, **kw)
+            assert r["input_ids"] == z[f"tok{i}_{tag}_input_ids"].tolist()
+            assert r["attention_mask"] == z[f"tok{i}_{tag}_mask"].tolist()
+            off, ids = csr_of(r["token_f_grams"], len(r["input_ids"]))
+            assert np.array_equal(off, z[f"tok{i}_{tag}_off"]) and np.array_equal(ids, z[f"tok{i}_{tag}_ids"])
+        assert "token_f_grams" not in ft.tokenize(t, return_f_grams=False)
+    r = ft.batch_tokenize(texts, max_length=24)
+    assert np.array_equal(r["input_ids"].numpy(), z["batch_input_ids"])
+    T = r["input_ids"].shape[1]
+    flat = []
+    for b in range(len(texts)):
+        off, ids = csr_of(r["token_f_grams"][b], T)
+        assert np.array_equal(off, z["batch_off"][b])
+        flat.append(ids)
+    assert np.array_equal(np.concatenate(flat), z["batch_ids_flat"])
+    off_d, ids_d = ft.batch_f_gram_ids(r["input_ids"])                      # device CSR form, no tuples
+    assert np.array_equal(ids_d.cpu().numpy(), z["batch_ids_flat"]) and int(off_d[-1]) == len(z["batch_ids_flat"])
+    for max_length in (16, 4):
+        for i, t in enumerate(texts):
+            ids = ft.base_tokenizer(t, max_length=max_length, truncation=True, return_tensors="pt")["input_ids"].squeeze(0)
+            got_ids, got_mask = ft.flat_f_gram_ids(ids.tolist(), max_length=max_length)
+            assert np.array_equal(got_ids.numpy(), z[f"ds{max_length}_f_gram_ids"][i])
+            assert np.array_equal(got_mask.numpy(), z[f"ds{max_length}_f_gram_mask"][i])
+    # save_pretrained / from_pretrained round trip (n_gram_extractor.npy in the reference's format)
+    ft.save_pretrained(str(tmp_path / "ft"))
+    back = FGramTokenizer.from_pretrained(str(tmp_path / "ft"), base_tokenizer=StubTokenizer())
+    assert back.n_gram_extractor.f_gram_to_id == f2id
+    assert back.tokenize(texts[0])["token_f_grams"] == ft.tokenize(texts[0])["token_f_grams"]

@@ -171,3 +171,39 @@ def test_c_oracle_bit_exact_vs_golden(golden_dir):
         out, total = co.embed(z[f"{c}_table"], z[f"{c}_tok"], "mean", nthreads=2)
         assert total == len(z[f"{c}_ids"])
         assert np.array_equal(out, z[f"{c}_agg_f32"]), c
+
+
+def test_callers_fixture_is_reproduced_by_the_oracle(golden_dir):
+    """callers.npz (FGramTokenizer.tokenize / batch_tokenize and SconeDataset's id vector, captured from the
+    reference with tests/stub_tokenizer.py): the stub still produces the recorded token ids and the oracle's
+    match reproduces every recorded id list."""
+    import sys
+    sys.path.insert(0, os.path.dirname(golden_dir))
+    from stub_tokenizer import StubTokenizer
+    z = _load(golden_dir, "callers.npz")
+    keys, lens, max_n = z["keys"], z["lens"], int(z["max_n"])
+    f2id = R._key_dict(keys, lens)
+    tok = StubTokenizer()
+    texts = [str(t) for t in z["texts"]]
+    for i, t in enumerate(texts):
+        for tag, kw in (("plain", {}), ("trunc", {"max_length": 8, "truncation": True})):
+            ids = tok(t, return_tensors="pt", **kw)["input_ids"].squeeze(0).tolist()
+            assert ids == z[f"tok{i}_{tag}_input_ids"].tolist()
+            off, flat = R.match_csr_python(f2id, max_n, ids)
+            assert np.array_equal(off, z[f"tok{i}_{tag}_off"]) and np.array_equal(flat, z[f"tok{i}_{tag}_ids"])
+    enc = tok(texts, max_length=24, padding=True, truncation=True, return_tensors="pt")
+    assert np.array_equal(enc["input_ids"].numpy(), z["batch_input_ids"])
+    assert np.array_equal(enc["attention_mask"].numpy(), z["batch_mask"])
+    ro, ri = R.hits_to_csr(R.match_hits(keys, lens, z["batch_input_ids"], max_n))
+    T = z["batch_input_ids"].shape[1]
+    assert np.array_equal(ri, z["batch_ids_flat"])
+    for b in range(len(texts)):
+        assert np.array_equal(ro[b * T:(b + 1) * T + 1] - ro[b * T], z["batch_off"][b])
+    for max_length in (16, 4):
+        for i, t in enumerate(texts):
+            ids = tok(t, max_length=max_length, truncation=True, return_tensors="pt")["input_ids"].squeeze(0).tolist()
+            _, flat = R.match_csr_python(f2id, max_n, ids)
+            want = np.zeros(10, dtype=np.int64)
+            want[:min(10, len(flat))] = flat[:10]
+            assert np.array_equal(want, z[f"ds{max_length}_f_gram_ids"][i])
+            assert int(z[f"ds{max_length}_f_gram_mask"][i].sum()) == min(10, len(flat))

@@ -64,12 +64,12 @@ def parse():
 
 
 def cpu_baseline(args, keys, lens, tok, seed, base_scale, gpu_out, wte, wpe):
-    if keys.shape[0] > 20_000_000:
-        raise RuntimeError("cpu baseline skipped: a Python dict of > 2e7 f-grams does not fit the time budget")
     """Time the reference loop (set-of-tuples match -> dict id map -> torch.stack of fp32 rows
     -> mean -> zero-filled [1,T,d]; n_gram_extractor.py:106-126, embedding_cache.py:113-181,
     engine.py:234-266) on a bounded sample of the same stream, 1 core, and use its output to
     sanity-check the GPU result for the first sequence."""
+    if keys.shape[0] > 20_000_000:
+        raise RuntimeError("cpu baseline skipped: a Python dict of > 2e7 f-grams does not fit the time budget")
     from oracle import ref_port as R
     torch.set_num_threads(1)
     d = args.dim

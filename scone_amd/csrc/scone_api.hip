@@ -122,7 +122,10 @@ extern "C" int scone_create(const scone_cfg *cfg, scone_handle **out) {
     return SCONE_EINVAL;
   }
   scone_handle *h = new (std::nothrow) scone_handle();
-  if (!h) return SCONE_ENOMEM;
+  if (!h) {
+    g_create_err = "scone_create: out of host memory";
+    return SCONE_ENOMEM;
+  }
   h->cfg = *cfg;
   h->device = cfg->device;
   if (h->cfg.row_end == 0) h->cfg.row_end = h->cfg.n_rows;
@@ -245,7 +248,8 @@ extern "C" void scone_destroy(scone_handle *h) {
   scone_stage_destroy(h);
   scone_shard_destroy(h);
   if (h->prof_ev) {
-    for (int i = 0; i < 2 * SCONE_PROF_RING; ++i) (void)hipEventDestroy(h->prof_ev[i]);
+    for (int i = 0; i < 2 * SCONE_PROF_RING; ++i)
+      if (h->prof_ev[i]) (void)hipEventDestroy(h->prof_ev[i]);
     delete[] h->prof_ev;
   }
   delete h;
@@ -303,7 +307,7 @@ extern "C" int scone_profile_enable(scone_handle *h, int enable) {
   if (!h) return SCONE_EINVAL;
   SCONE_HIP(h, hipSetDevice(h->device));
   if (enable && !h->prof_ev) {
-    h->prof_ev = new (std::nothrow) hipEvent_t[2 * SCONE_PROF_RING];
+    h->prof_ev = new (std::nothrow) hipEvent_t[2 * SCONE_PROF_RING]();  // null handles: destroy skips them
     if (!h->prof_ev) return scone_fail(h, SCONE_ENOMEM, "scone_profile_enable: out of memory");
     for (int i = 0; i < 2 * SCONE_PROF_RING; ++i) SCONE_HIP(h, hipEventCreate(&h->prof_ev[i]));
   }

@@ -74,6 +74,7 @@ static int embed_staged(scone_handle *h, const embed_args &full, int32_t B, int3
   int rc = scone_stage_prepare(h, seqs * T);
   if (rc) return rc;
   seqs = scone_stage_chunk_tokens(h) / T;
+  if (seqs < 1) return scone_fail(h, SCONE_EINVAL, "scone_embed(staged): sequence too long for one staging chunk");
   if (seqs > B) seqs = B;
   const size_t esz = out_dtype == SCONE_DT_F32 ? 4 : 2;
   const long long nchunks = (B + seqs - 1) / seqs;

@@ -80,7 +80,8 @@ __global__ __launch_bounds__(256) void k_stage_copy(const uint32_t *__restrict__
 }  // namespace
 
 struct scone_stage_state {
-  long long chunk_tokens = 0;
+  long long chunk_tokens = 0;     // tokens per chunk actually provisioned
+  long long requested_tokens = 0; // what the caller asked for (may exceed chunk_tokens, see prepare)
   uint32_t cap = 0;  // staged rows per buffer
   hipStream_t side = nullptr;
   hipEvent_t staged[2] = {nullptr, nullptr}, consumed[2] = {nullptr, nullptr}, start = nullptr;
@@ -114,17 +115,21 @@ void scone_stage_destroy(scone_handle *h) {
 }
 
 int scone_stage_prepare(scone_handle *h, long long chunk_tokens) {
-  if (h->stage && h->stage->chunk_tokens >= chunk_tokens) return SCONE_OK;
+  if (h->stage && h->stage->requested_tokens >= chunk_tokens) return SCONE_OK;
+  const long long requested = chunk_tokens;
   scone_stage_destroy(h);
   scone_stage_state *st = new (std::nothrow) scone_stage_state();
   if (!st) return scone_fail(h, SCONE_ENOMEM, "scone_embed(staged): out of memory");
   h->stage = st;
   const int W = SCONE_ELL_W(h->cfg.max_n), NC = h->cfg.max_n * (h->cfg.max_n + 1) / 2;
   const long long n_cold = (long long)(h->local_rows - h->hot_local);
+  // 24-bit slot numbers: a chunk may reference chunk_tokens * NC distinct cold rows, and every one of them
+  // must get a slot (an unclaimed reference would be remapped outside the staging buffer) -> bound the chunk
+  if (chunk_tokens * NC > 0xFFFFFEll && n_cold > 0xFFFFFEll) chunk_tokens = 0xFFFFFEll / NC;
   long long cap = chunk_tokens * NC;
   if (cap > n_cold) cap = n_cold;
-  if (cap > 0xFFFFFEll) cap = 0xFFFFFEll;  // 24-bit slot numbers
   st->chunk_tokens = chunk_tokens;
+  st->requested_tokens = requested;
   st->cap = (uint32_t)cap;
   SCONE_HIP(h, hipStreamCreateWithFlags(&st->side, hipStreamNonBlocking));
   SCONE_HIP(h, hipEventCreateWithFlags(&st->start, hipEventDisableTiming));

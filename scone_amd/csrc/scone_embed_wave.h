@@ -63,6 +63,24 @@ template <> struct pack_io<__hip_bfloat16> {
   }
 };
 
+// acc[e] = fma(sc, q_e, acc[e]) for the 8 offset-binary nibbles of w, in 2.5 instead of 4 VALU ops per element:
+// w ^ 0x88888888 turns every nibble into two's complement; with a nibble in the HIGH half of a byte the
+// sign-extending byte convert (v_cvt_f32_i32 sext(BYTE_k), one SDWA instruction) yields 16 q, and
+// fma(sc / 16, 16 q, acc) equals fma(sc, q, acc) bit for bit (sc / 16 and the product are exact).
+__device__ __forceinline__ void i4_accumulate(uint32_t w, float sc, float *acc) {
+  const uint32_t t = w ^ 0x88888888u;
+  const uint32_t ev = (t << 4) & 0xF0F0F0F0u;  // elements 0, 2, 4, 6 in bytes 0..3
+  const uint32_t od = t & 0xF0F0F0F0u;         // elements 1, 3, 5, 7
+  const float sc16 = sc * 0.0625f;
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    const int qe = (int)(ev << (24 - 8 * b)) >> 24;
+    const int qo = (int)(od << (24 - 8 * b)) >> 24;
+    acc[2 * b] = fmaf(sc16, (float)qe, acc[2 * b]);
+    acc[2 * b + 1] = fmaf(sc16, (float)qo, acc[2 * b + 1]);
+  }
+}
+
 // Lane <-> element map.  A row is cut into segments of 512 elements; inside a segment lane l owns
 // 8 consecutive elements (4 in a trailing 256-element segment).  With this map every wave
 // instruction -- INT8 row loads (8 or 4 B/lane), fp16 wte / wpe loads and output stores
@@ -219,11 +237,7 @@ __device__ __forceinline__ void embed_token(const scone_row_store &rows, const v
             acc[G::seg_acc(s) + 4 * i + b] = fmaf(sc, (float)q, acc[G::seg_acc(s) + 4 * i + b]);
           }
         } else {
-#pragma unroll
-          for (int b = 0; b < 8; ++b) {
-            const int q = (int)((w >> (4 * b)) & 0xFu) - 8;
-            acc[G::seg_acc(s) + 8 * i + b] = fmaf(sc, (float)q, acc[G::seg_acc(s) + 8 * i + b]);
-          }
+          i4_accumulate(w, sc, &acc[G::seg_acc(s) + 8 * i]);
         }
       }
     }
@@ -604,11 +618,7 @@ __device__ __forceinline__ void embed_units(const scone_row_store &rows, const v
             acc[4 * i + b] = fmaf(sc, (float)q, acc[4 * i + b]);
           }
         } else {
-#pragma unroll
-          for (int b = 0; b < 8; ++b) {
-            const int q = (int)((w >> (4 * b)) & 0xFu) - 8;
-            acc[b] = fmaf(sc, (float)q, acc[b]);
-          }
+          i4_accumulate(w, sc, acc);
         }
       }
     }

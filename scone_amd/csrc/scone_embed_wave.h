@@ -103,7 +103,9 @@ template <int FMT, int D> struct wave_geom {
 };
 
 // waves per SIMD to ask of the register allocator: rows in flight (NC x NBR/4) + wte/wpe/out words +
-// accumulators + addressing, rounded to the 8-register allocation granule (512 registers per SIMD lane)
+// accumulators + addressing, rounded to the 8-register allocation granule (512 registers per SIMD lane).
+// The estimate must not undershoot: a kernel squeezed below its need spills to scratch INSIDE the token loop
+// (INT4 d = 1024 at 6 waves/SIMD: 44 B/lane of scratch, +2 % WRITE_SIZE, 5 % slower than at 5 waves without spills).
 #ifndef SCONE_WAVE_SLACK
 #define SCONE_WAVE_SLACK 14
 #endif
@@ -113,8 +115,11 @@ template <int FMT, int D> struct wave_geom {
 template <int FMT, typename OutT, int D, int MAXN, bool FIXED_POS> struct wave_occupancy {
   static constexpr int NC = MAXN * (MAXN + 1) / 2;
   static constexpr int NWO = wave_geom<FMT, D>::EPL * (int)sizeof(OutT) / 4;
-  static constexpr int EST = NC * (wave_geom<FMT, D>::NBR / 4) + (FIXED_POS ? 4 : 3) * NWO + wave_geom<FMT, D>::EPL +
-                             SCONE_WAVE_SLACK;
+  // INT4 also holds one group-scale word per (row, segment) in flight
+  static constexpr int EST = NC * (wave_geom<FMT, D>::NBR / 4) + (FMT == SCONE_FMT_I4 ? NC * wave_geom<FMT, D>::NSEG : 0) +
+                             (FIXED_POS ? 4 : 3) * NWO + wave_geom<FMT, D>::EPL + SCONE_WAVE_SLACK +
+                             (MAXN >= 4 ? (FMT == SCONE_FMT_I4 ? 24 : 8) : 0) +  // the 10-way switch keeps more addresses live
+                             (std::is_same<OutT, __hip_bfloat16>::value ? 4 : 0);  // round-to-nearest-even by hand
   static constexpr int ALLOC = (EST + 7) / 8 * 8;
   static constexpr int WAVES = 512 / ALLOC >= 8 ? 8 : (512 / ALLOC < 1 ? 1 : 512 / ALLOC);
 };

@@ -32,4 +32,5 @@ run int4_1M_d1024 --steps 30 --warmup 3 --format int4 --dim 1024 || exit 1
 run int8_1M_d1280 --steps 30 --warmup 3 --dim 1280 || exit 1
 run C4_int4_100M_d1024_hbm --steps 20 --warmup 3 --rows 100000000 --format int4 --dim 1024 --keygen structured || exit 1
 run C4_int4_100M_d1024_pinned --steps 10 --warmup 2 --rows 100000000 --format int4 --dim 1024 --keygen structured --placement pinned_host --hot-rows 1000000 --stage-tokens 131072 || exit 1
+run C4_int4_100M_d1024_pinned_zero_copy --steps 10 --warmup 2 --rows 100000000 --format int4 --dim 1024 --keygen structured --placement pinned_host --hot-rows 1000000 --stage-tokens 0 || exit 1
 run C5_shard0of8_int4_1B_d1024 --steps 10 --warmup 2 --rows 1000000000 --format int4 --dim 1024 --keygen structured --shard-of 0/8 || exit 1

@@ -191,6 +191,7 @@ int scone_shard_prepare_embed(scone_handle *h, int32_t B, int32_t T, int32_t wor
                               hipStream_t s);
 
 // staged prefetch of host-resident rows (scone_stage.hip)
+#define SCONE_STAGE_NBUF 3
 void scone_stage_destroy(scone_handle *h);
 int scone_stage_prepare(scone_handle *h, long long chunk_tokens);
 int scone_stage_chunk(scone_handle *h, int buf, const int32_t *d_tok, int32_t Bc, int32_t T);

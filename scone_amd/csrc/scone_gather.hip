@@ -65,8 +65,8 @@ int need_table(scone_handle *h, const char *who) {
 
 }  // namespace
 
-// Pinned-host table, staged prefetch (scone_stage.hip): chunks of whole sequences; the side stream
-// matches + stages chunk c+1 while the caller's stream reduces chunk c out of the HBM staging buffer.
+// Pinned-host table, staged prefetch (scone_stage.hip): chunks of whole sequences; side streams prepare
+// chunk c+2 and copy chunk c+1 while the caller's stream reduces chunk c out of the HBM staging buffer.
 static int embed_staged(scone_handle *h, const embed_args &full, int32_t B, int32_t T, int32_t out_dtype, hipStream_t s) {
   long long seqs = (long long)h->cfg.stage_tokens / T;
   if (seqs < 1) seqs = 1;
@@ -82,12 +82,16 @@ static int embed_staged(scone_handle *h, const embed_args &full, int32_t B, int3
   SCONE_HIP(h, hipEventRecord(scone_stage_start_event(h), s));
   SCONE_HIP(h, hipStreamWaitEvent(scone_stage_side(h), scone_stage_start_event(h), 0));
   auto chunk_b = [&](long long c) { return (int32_t)((c + 1) * seqs <= B ? seqs : B - c * seqs); };
-  rc = scone_stage_chunk(h, 0, full.tok, chunk_b(0), T);
-  if (rc) return rc;
+  // chunks 0 .. NBUF-2 are staged ahead; inside the loop chunk c + NBUF - 1 is queued before chunk c is reduced
+  for (long long c = 0; c < nchunks && c < SCONE_STAGE_NBUF - 1; ++c) {
+    rc = scone_stage_chunk(h, (int)(c % SCONE_STAGE_NBUF), full.tok + c * seqs * T, chunk_b(c), T);
+    if (rc) return rc;
+  }
   for (long long c = 0; c < nchunks; ++c) {
-    const int buf = (int)(c & 1);
-    if (c + 1 < nchunks) {  // prefetch the next chunk while this one is reduced
-      rc = scone_stage_chunk(h, buf ^ 1, full.tok + (c + 1) * seqs * T, chunk_b(c + 1), T);
+    const int buf = (int)(c % SCONE_STAGE_NBUF);
+    const long long ahead = c + SCONE_STAGE_NBUF - 1;
+    if (ahead < nchunks) {  // its buffer was last used by chunk c - 1, whose "consumed" event is already recorded
+      rc = scone_stage_chunk(h, (int)(ahead % SCONE_STAGE_NBUF), full.tok + ahead * seqs * T, chunk_b(ahead), T);
       if (rc) return rc;
     }
     const long long t0 = c * seqs * T;

@@ -9,9 +9,12 @@
 //   3. k_stage_remap          ids in the records -> n_hot + slot
 //   4. k_stage_copy           one wave per listed row: mapped host DRAM -> HBM staging (+ its scales)
 // and on the MAIN stream, after the "staged" event: the ordinary fused lookup kernel with the staging
-// buffer as the cold half of the row store.  Two staging buffers: chunk c+1 is matched and copied
-// over PCIe while chunk c is reduced, and a row referenced by several tokens of a chunk (an n-gram
+// buffer as the cold half of the row store.  A row referenced by several tokens of a chunk (an n-gram
 // covers n positions; hot f-grams recur) crosses PCIe once per chunk instead of once per reference.
+// Steps 1-3 run on a PREP stream and step 4 on a COPY stream, with SCONE_STAGE_NBUF = 3 buffer sets:
+// while chunk c is reduced and chunk c+1 crosses the link, chunk c+2 is already being matched and
+// claimed, so the link never waits for a match -> claim -> remap chain (with one side stream and two
+// buffers it idled for that chain once per chunk: ~40 GB/s instead of ~50 GB/s over Gen5 x16).
 #include "scone_common.h"
 
 #include <new>
@@ -57,7 +60,9 @@ __global__ __launch_bounds__(256) void k_stage_remap(int32_t *__restrict__ ell, 
   ell[t * W + j] = (int32_t)(n_hot + (slot_of[id - n_hot] & 0xFFFFFFu));
 }
 
-// one wave per staged row; 16 bytes per lane per step from mapped host memory
+// one wave per staged row; 16 bytes per lane per step from mapped host memory.  (Tried: two 512-B rows per
+// wave and a 2048-block grid to double the row reads in flight -- 10 % SLOWER, 199 -> 181 M tok/s at C4 size:
+// the link is already saturated by 4096 waves, more of them only take CUs from the lookup kernel.)
 __global__ __launch_bounds__(256) void k_stage_copy(const uint32_t *__restrict__ count, const int32_t *__restrict__ list,
                                                     scone_row_store host, uint8_t *__restrict__ stage_rows,
                                                     const uint8_t *__restrict__ scales, uint8_t *__restrict__ stage_scales,
@@ -83,23 +88,25 @@ struct scone_stage_state {
   long long chunk_tokens = 0;     // tokens per chunk actually provisioned
   long long requested_tokens = 0; // what the caller asked for (may exceed chunk_tokens, see prepare)
   uint32_t cap = 0;  // staged rows per buffer
-  hipStream_t side = nullptr;
-  hipEvent_t staged[2] = {nullptr, nullptr}, consumed[2] = {nullptr, nullptr}, start = nullptr;
-  bool consumed_valid[2] = {false, false};
+  hipStream_t prep = nullptr, copy = nullptr;
+  hipEvent_t prepped[SCONE_STAGE_NBUF] = {}, staged[SCONE_STAGE_NBUF] = {}, consumed[SCONE_STAGE_NBUF] = {}, start = nullptr;
+  bool consumed_valid[SCONE_STAGE_NBUF] = {};
   uint32_t *slot_of = nullptr;
   uint32_t gen = 0;
-  int32_t *ell[2] = {nullptr, nullptr};
-  int32_t *list[2] = {nullptr, nullptr};
-  uint32_t *count[2] = {nullptr, nullptr};
-  uint8_t *rows[2] = {nullptr, nullptr};
-  uint8_t *scales[2] = {nullptr, nullptr};
+  int32_t *ell[SCONE_STAGE_NBUF] = {};
+  int32_t *list[SCONE_STAGE_NBUF] = {};
+  uint32_t *count[SCONE_STAGE_NBUF] = {};
+  uint8_t *rows[SCONE_STAGE_NBUF] = {};
+  uint8_t *scales[SCONE_STAGE_NBUF] = {};
 };
 
 void scone_stage_destroy(scone_handle *h) {
   scone_stage_state *st = h->stage;
   if (!st) return;
-  if (st->side) (void)hipStreamDestroy(st->side);
-  for (int b = 0; b < 2; ++b) {
+  if (st->prep) (void)hipStreamDestroy(st->prep);
+  if (st->copy) (void)hipStreamDestroy(st->copy);
+  for (int b = 0; b < SCONE_STAGE_NBUF; ++b) {
+    if (st->prepped[b]) (void)hipEventDestroy(st->prepped[b]);
     if (st->staged[b]) (void)hipEventDestroy(st->staged[b]);
     if (st->consumed[b]) (void)hipEventDestroy(st->consumed[b]);
     if (st->ell[b]) (void)hipFree(st->ell[b]);
@@ -131,12 +138,14 @@ int scone_stage_prepare(scone_handle *h, long long chunk_tokens) {
   st->chunk_tokens = chunk_tokens;
   st->requested_tokens = requested;
   st->cap = (uint32_t)cap;
-  SCONE_HIP(h, hipStreamCreateWithFlags(&st->side, hipStreamNonBlocking));
+  SCONE_HIP(h, hipStreamCreateWithFlags(&st->prep, hipStreamNonBlocking));
+  SCONE_HIP(h, hipStreamCreateWithFlags(&st->copy, hipStreamNonBlocking));
   SCONE_HIP(h, hipEventCreateWithFlags(&st->start, hipEventDisableTiming));
   SCONE_HIP(h, hipMalloc(&st->slot_of, (size_t)(n_cold > 0 ? n_cold : 1) * 4));
   SCONE_HIP(h, hipMemset(st->slot_of, 0, (size_t)(n_cold > 0 ? n_cold : 1) * 4));
   const size_t sb = h->scale_bytes_per_row;
-  for (int b = 0; b < 2; ++b) {
+  for (int b = 0; b < SCONE_STAGE_NBUF; ++b) {
+    SCONE_HIP(h, hipEventCreateWithFlags(&st->prepped[b], hipEventDisableTiming));
     SCONE_HIP(h, hipEventCreateWithFlags(&st->staged[b], hipEventDisableTiming));
     SCONE_HIP(h, hipEventCreateWithFlags(&st->consumed[b], hipEventDisableTiming));
     SCONE_HIP(h, hipMalloc(&st->ell[b], (size_t)chunk_tokens * W * 4));
@@ -157,7 +166,7 @@ int scone_stage_chunk(scone_handle *h, int buf, const int32_t *d_tok, int32_t Bc
   scone_stage_state *st = h->stage;
   const int W = SCONE_ELL_W(h->cfg.max_n), NC = h->cfg.max_n * (h->cfg.max_n + 1) / 2;
   const long long ntok = (long long)Bc * T;
-  hipStream_t s = st->side;
+  hipStream_t s = st->prep;
   if (st->consumed_valid[buf]) SCONE_HIP(h, hipStreamWaitEvent(s, st->consumed[buf], 0));
   st->gen += 1;
   if (st->gen > 255) {  // 8-bit generation tags wrapped: forget every old claim
@@ -173,15 +182,19 @@ int scone_stage_chunk(scone_handle *h, int buf, const int32_t *d_tok, int32_t Bc
                      st->slot_of, st->gen, st->count[buf], st->list[buf], st->cap);
   hipLaunchKernelGGL(k_stage_remap, dim3(blocks), dim3(256), 0, s, st->ell[buf], ntok, W, NC, (long long)h->hot_local,
                      st->slot_of);
-  hipLaunchKernelGGL(k_stage_copy, dim3(1024), dim3(256), 0, s, st->count[buf], st->list[buf], scone_store_of(h),
+  SCONE_HIP(h, hipGetLastError());
+  SCONE_HIP(h, hipEventRecord(st->prepped[buf], s));
+  // the copy stream only ever waits for the list of THIS chunk, never for the preparation of the next one
+  SCONE_HIP(h, hipStreamWaitEvent(st->copy, st->prepped[buf], 0));
+  hipLaunchKernelGGL(k_stage_copy, dim3(1024), dim3(256), 0, st->copy, st->count[buf], st->list[buf], scone_store_of(h),
                      st->rows[buf], (const uint8_t *)h->scales, st->scales[buf], (int)h->scale_bytes_per_row,
                      (long long)h->hot_local, st->cap);
   SCONE_HIP(h, hipGetLastError());
-  SCONE_HIP(h, hipEventRecord(st->staged[buf], s));
+  SCONE_HIP(h, hipEventRecord(st->staged[buf], st->copy));
   return SCONE_OK;
 }
 
-hipStream_t scone_stage_side(scone_handle *h) { return h->stage->side; }
+hipStream_t scone_stage_side(scone_handle *h) { return h->stage->prep; }
 hipEvent_t scone_stage_start_event(scone_handle *h) { return h->stage->start; }
 hipEvent_t scone_stage_staged_event(scone_handle *h, int buf) { return h->stage->staged[buf]; }
 int scone_stage_mark_consumed(scone_handle *h, int buf, hipStream_t main_stream) {

@@ -248,7 +248,7 @@ def match_hits(keys: np.ndarray, lens: np.ndarray, tok: np.ndarray, max_n: int) 
     Same membership test as n_gram_extractor.py:119-121, one entry per (n, start).
     """
     B, T = tok.shape
-    kd = _key_dict(keys, lens)
+    kd = None                        # python dict of all keys: only built if the packed-u64 path cannot be used
     hits = np.full((max_n, B, T), -1, dtype=np.int32)
     # per-length sorted key arrays -> searchsorted on packed python-int-free keys
     for n in range(1, max_n + 1):
@@ -261,6 +261,8 @@ def match_hits(keys: np.ndarray, lens: np.ndarray, tok: np.ndarray, max_n: int) 
         kn = keys[sel, :n].astype(np.uint64)
         bits = 64 // n
         if int(kn.max(initial=0)) >= (1 << bits) or int(tok.max(initial=0)) >= (1 << bits) or tok.min(initial=0) < 0:
+            if kd is None:
+                kd = _key_dict(keys, lens)
             for b in range(B):
                 for i in range(T - n + 1):
                     hits[n - 1, b, i] = kd.get(tuple(int(x) for x in tok[b, i:i + n]), -1)
@@ -398,6 +400,23 @@ def synth_rows_i8(seed: int, row_ids: np.ndarray, d: int) -> np.ndarray:
         w = np.arange(d // 4, dtype=np.uint32)
         words = hash32(base[:, None] + w[None, :])
     return words.view(np.uint8).reshape(len(row_ids), d).view(np.int8)
+
+
+def synth_rows_i4(seed: int, row_ids: np.ndarray, d: int, base_scale: float) -> Tuple[np.ndarray, np.ndarray]:
+    """INT4 form of the synthetic fill (k_fill_synth<I4> in csrc/scone_table.hip): payload word w of row i =
+    hash32(row_base(i) + w) for w < d/8 (eight offset-binary nibbles per word, element 8w+b in bits 4b..4b+3),
+    group scale g = synth_scale_f16(counter = i * (d/128) + g).  Returns (packed [n, d/2] uint8, scales [n, d/128] f16)."""
+    row_ids = np.asarray(row_ids, dtype=np.uint64)
+    lo = (row_ids & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+    hi = (row_ids >> np.uint64(32)).astype(np.uint32)
+    ng = d // I4_GROUP
+    with np.errstate(over="ignore"):
+        base = hash32(lo + np.uint32(0x9E3779B9) * hi) ^ np.uint32(seed)
+        words = hash32(base[:, None] + np.arange(d // 8, dtype=np.uint32)[None, :])
+    packed = np.ascontiguousarray(words).view(np.uint8).reshape(len(row_ids), d // 2)
+    counters = row_ids[:, None] * np.uint64(ng) + np.arange(ng, dtype=np.uint64)[None, :]
+    scales = synth_scale_f16(seed, counters.reshape(-1), base_scale).reshape(len(row_ids), ng)
+    return packed, scales
 
 
 def synth_scale_f16(seed: int, row_ids: np.ndarray, base_scale: float) -> np.ndarray:

@@ -167,6 +167,16 @@ int scone_ensure_ell(scone_handle *h, int64_t ntok);
 int scone_prof_begin(scone_handle *h, hipStream_t s);  // no-ops unless profiling is enabled
 int scone_prof_end(scone_handle *h, hipStream_t s);
 
+// A dispatch carries its size in WORK-ITEMS in a 32-bit field: blocks x threads must stay below 2^32, beyond that
+// the grid silently wraps (found by a 100M-row table whose one-wave-per-row synthetic fill stopped at row 33.5M
+// without any error).  Row- and key-parallel kernels therefore walk their items with a grid-stride loop over a
+// capped grid (SCONE_MAX_BLOCKS); token-parallel launches check scone_grid_fits().
+#define SCONE_MAX_BLOCKS (1u << 20)
+static inline bool scone_grid_fits(unsigned long long blocks, unsigned threads) { return blocks * threads < (1ull << 32); }
+static inline unsigned scone_capped_blocks(unsigned long long blocks) {
+  return (unsigned)(blocks < SCONE_MAX_BLOCKS ? (blocks ? blocks : 1) : SCONE_MAX_BLOCKS);
+}
+
 #define SCONE_HIP(h, call)                                       \
   do {                                                           \
     hipError_t e__ = (call);                                     \

@@ -523,7 +523,7 @@ int launch_wave(scone_handle *h, const embed_args &a, hipStream_t s) {
   q.seqs_per_block = (int)((q.B + chunks - 1) / chunks);
   chunks = (q.B + q.seqs_per_block - 1) / q.seqs_per_block;
   long long blocks = chunks * q.pos_groups;
-  if (blocks > 0x7FFFFFF0ll) return scone_fail(h, SCONE_EINVAL, "scone_embed: too many tokens for one launch");
+  if (!scone_grid_fits((unsigned long long)blocks + 8, 256)) return scone_fail(h, SCONE_EINVAL, "scone_embed: too many tokens for one launch");
   q.n_blocks = (unsigned)blocks;
   blocks = (blocks + 7) / 8 * 8;
   if constexpr (std::is_same<OutT, float>::value) {
@@ -723,7 +723,7 @@ int launch_wave_any(scone_handle *h, const embed_args &a, hipStream_t s) {
   q.seqs_per_block = (int)((q.B + chunks - 1) / chunks);
   chunks = (q.B + q.seqs_per_block - 1) / q.seqs_per_block;
   const long long blocks = chunks * q.pos_groups;
-  if (blocks > 0x7FFFFFFFll) return scone_fail(h, SCONE_EINVAL, "scone_embed: too many tokens for one launch");
+  if (!scone_grid_fits((unsigned long long)blocks, 256)) return scone_fail(h, SCONE_EINVAL, "scone_embed: too many tokens for one launch");
   if constexpr (std::is_same<OutT, float>::value) {
     if (a.partial) {
       hipLaunchKernelGGL((k_embed_wave_any<FMT, float, MAXN, true>), dim3((unsigned)blocks), dim3(256), 0, s, a.tv.st,

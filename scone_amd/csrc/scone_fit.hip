@@ -202,7 +202,7 @@ extern "C" int scone_fit(int32_t device, const int32_t *d_tokens, int64_t n_toke
                                   (size_t)n_texts, rocprim::plus<unsigned long long>(), s));
 
   const unsigned long long work = max_occ;
-  if ((work + 255) / 256 > 0x7FFFFFFFull) return SCONE_EINVAL;
+  if (!scone_grid_fits((work + 255) / 256, 256)) return SCONE_EINVAL;  // corpus too large for one launch
   hipLaunchKernelGGL(k_fit_count, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, s, slots.as<scone_slot>(), cap - 1,
                      cnt.as<unsigned int>(), first.as<unsigned long long>(), d_tokens, (long long)n_tokens,
                      (const long long *)d_text_offsets, (long long)n_texts, base.as<unsigned long long>(), max_n,
@@ -212,7 +212,7 @@ extern "C" int scone_fit(int32_t device, const int32_t *d_tokens, int64_t n_toke
   // eligible entries (count >= min_freq); their number bounds the sort buffers, so count first
   FIT_HIP(sel_first.alloc(max_occ * 8));
   FIT_HIP(sel_slot.alloc(max_occ * 8));
-  if ((cap + 255) / 256 > 0x7FFFFFFFull) return SCONE_EINVAL;
+  if (!scone_grid_fits((cap + 255) / 256, 256)) return SCONE_EINVAL;
   hipLaunchKernelGGL(k_fit_compact, dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, s, cnt.as<unsigned int>(),
                      first.as<unsigned long long>(), cap, min_freq, counters.as<unsigned long long>(),
                      counters.as<unsigned long long>() + 1, sel_first.as<unsigned long long>(),

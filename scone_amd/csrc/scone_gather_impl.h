@@ -350,7 +350,7 @@ int launch_one(scone_handle *h, const embed_args &a, hipStream_t s) {
   constexpr int GROUPS = 64 / LPT;
   const long long groups_per_block = 4 * GROUPS;
   const long long blocks = (a.ntok + groups_per_block - 1) / groups_per_block;
-  if (blocks > 0x7FFFFFFFll) return scone_fail(h, SCONE_EINVAL, "scone_embed: too many tokens for one launch");
+  if (!scone_grid_fits((unsigned long long)blocks, 256)) return scone_fail(h, SCONE_EINVAL, "scone_embed: too many tokens for one launch");
   hipLaunchKernelGGL((k_embed<FMT, OutT, D, LPT, NCAND, SRC, MODE>), dim3((unsigned)blocks), dim3(256), 0, s, a);
   SCONE_HIP(h, hipGetLastError());
   return SCONE_OK;

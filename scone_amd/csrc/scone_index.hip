@@ -414,7 +414,7 @@ int scone_launch_match(scone_handle *h, const int32_t *d_tok, int32_t B, int32_t
   long long total = BT * h->cfg.max_n;
   if (total == 0) return SCONE_OK;
   long long blocks = (total + 255) / 256;
-  if (blocks > 0x7FFFFFFFll) return scone_fail(h, SCONE_EINVAL, "scone_match: too many tokens for one launch");
+  if (!scone_grid_fits((unsigned long long)blocks, 256)) return scone_fail(h, SCONE_EINVAL, "scone_match: too many tokens for one launch");
   hipLaunchKernelGGL(k_match, dim3((unsigned)blocks), dim3(256), 0, s, h->slots, h->cap - 1, d_tok, BT, T,
                      h->cfg.max_n, d_hits);
   SCONE_HIP(h, hipGetLastError());
@@ -436,7 +436,7 @@ int scone_launch_match_ell_ex(scone_handle *h, const int32_t *d_tok, int32_t B, 
   if (BT == 0) return SCONE_OK;
   const long long tile = ELL_TILE - (h->cfg.max_n <= 3 ? 2 : 3);  // k_match_ell<MAXN>::TILE
   const long long blocks = (BT + tile - 1) / tile;
-  if (blocks > 0x7FFFFFFFll) return scone_fail(h, SCONE_EINVAL, "scone_embed: too many tokens for one launch");
+  if (!scone_grid_fits((unsigned long long)blocks, ELL_TILE)) return scone_fail(h, SCONE_EINVAL, "scone_embed: too many tokens for one launch");
   if (h->cfg.max_n <= 3)
     hipLaunchKernelGGL((k_match_ell<3>), dim3((unsigned)blocks), dim3(ELL_TILE), 0, s, h->slots, h->cap - 1, h->d_uni,
                        SCONE_UNI_CAP, h->d_bloom, h->bloom_mask, d_tok, BT, T, h->cfg.max_n, rb, re, (int)h->cfg.lookup_mode, keep_pos, d_ell);
@@ -455,7 +455,7 @@ extern "C" int scone_index_build_device(scone_handle *h, const uint32_t *d_keys,
   if (id0 + n > 0xFFFFFFFEull) return scone_fail(h, SCONE_ERANGE, "scone_index_build: ids must be < 2^32-2");
   SCONE_HIP(h, hipSetDevice(h->device));
   unsigned long long blocks = (n + 255) / 256;
-  if (blocks > 0x7FFFFFFFull) return scone_fail(h, SCONE_EINVAL, "scone_index_build: chunk too large");
+  if (!scone_grid_fits(blocks, 256)) return scone_fail(h, SCONE_EINVAL, "scone_index_build: chunk too large");
   hipLaunchKernelGGL(k_index_insert, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, h->slots,
                      h->cap - 1, d_keys, d_lens, (unsigned long long)n, (unsigned long long)id0, h->cfg.max_n,
                      h->d_counters, h->d_status, h->d_uni, SCONE_UNI_CAP, h->d_bloom, h->bloom_mask);

@@ -225,6 +225,8 @@ extern "C" int scone_shard_plan(scone_handle *h, const int32_t *d_tok, int32_t B
   SCONE_HIP(h, hipMemsetAsync(st->counters, 0, 3 * 64 * sizeof(uint32_t), s));
   for (int q = 0; q < world; ++q) h_send_counts[q] = h_recv_counts[q] = 0;
   if (ntok == 0) return SCONE_OK;
+  if (!scone_grid_fits((unsigned long long)(ntok * NC + 255) / 256, 256))
+    return scone_fail(h, SCONE_EINVAL, "scone_shard_plan: too many tokens for one launch");
   // what I send: the whole batch against my rows, ids at their index in the full list
   rc = scone_launch_match_ell_ex(h, d_tok, B, T, st->ell_send, (long long)h->cfg.row_begin, (long long)h->cfg.row_end, 1, s);
   if (rc) return rc;

@@ -177,6 +177,8 @@ int scone_stage_chunk(scone_handle *h, int buf, const int32_t *d_tok, int32_t Bc
   if (rc) return rc;
   SCONE_HIP(h, hipMemsetAsync(st->count[buf], 0, 4, s));
   const long long work = ntok * NC;
+  if (!scone_grid_fits((unsigned long long)(work + 255) / 256, 256))
+    return scone_fail(h, SCONE_EINVAL, "scone_embed(staged): chunk too large for one launch (lower stage_tokens)");
   const unsigned blocks = (unsigned)((work + 255) / 256);
   hipLaunchKernelGGL(k_stage_claim, dim3(blocks), dim3(256), 0, s, st->ell[buf], ntok, W, NC, (long long)h->hot_local,
                      st->slot_of, st->gen, st->count[buf], st->list[buf], st->cap);

@@ -27,12 +27,12 @@ __global__ __launch_bounds__(256) void k_store_f32(const float *__restrict__ src
                                                    int d, scone_row_store st, __half *__restrict__ scales,
                                                    uint32_t *__restrict__ status) {
   const int lane = threadIdx.x & 63;
-  unsigned long long r = (unsigned long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (r >= nrows) return;
+  const unsigned long long nwaves = (unsigned long long)gridDim.x * (blockDim.x >> 6);
+  for (unsigned long long r = (unsigned long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); r < nrows; r += nwaves) {
   unsigned long long g = ids ? (unsigned long long)ids[r] : row0 + r;
   if (g < row_begin || g >= row_end) {  // wave-uniform
     if (lane == 0) atomicOr(status, SCONE_ST_BAD_ID);
-    return;
+    continue;
   }
   const unsigned long long lr = g - row_begin;
   const float *x = src + r * (unsigned long long)d;
@@ -73,6 +73,7 @@ __global__ __launch_bounds__(256) void k_store_f32(const float *__restrict__ src
       if (lane == 0) scales[lr * ng + grp] = sh;
     }
   }
+  }  // grid-stride loop over rows
 }
 
 // hipcc selects v_fma_mixlo_f16 for "convert(a * b)" even with -ffp-contract=off: one rounding of
@@ -99,8 +100,8 @@ __global__ __launch_bounds__(256) void k_fill_synth(unsigned long long row_begin
                                                     uint32_t seed, float base_scale, scone_row_store st,
                                                     __half *__restrict__ scales) {
   const int lane = threadIdx.x & 63;
-  unsigned long long lr = (unsigned long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (lr >= local_rows) return;
+  const unsigned long long nwaves = (unsigned long long)gridDim.x * (blockDim.x >> 6);
+  for (unsigned long long lr = (unsigned long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); lr < local_rows; lr += nwaves) {
   const unsigned long long g = row_begin + lr;
   const uint32_t base = synth_row_base(seed, g);
   if (FMT == SCONE_FMT_I4) {
@@ -109,7 +110,7 @@ __global__ __launch_bounds__(256) void k_fill_synth(unsigned long long row_begin
     for (int w = lane; w < nw; w += 64) o[w] = scone_hash32(base + (uint32_t)w);
     for (int grp = lane; grp < ng; grp += 64)
       scales[lr * ng + grp] = synth_scale(seed, g * (unsigned long long)ng + grp, base_scale);
-    return;
+    continue;
   }
   const int nw = d / 4;
   const __half sh = synth_scale(seed, g, base_scale);
@@ -130,6 +131,7 @@ __global__ __launch_bounds__(256) void k_fill_synth(unsigned long long row_begin
     }
   }
   if (FMT == SCONE_FMT_I8 && lane == 0) scales[lr] = sh;
+  }  // grid-stride loop over rows
 }
 
 // out[i, :] = dequantised row ids[i]; one wave per output row.
@@ -139,14 +141,14 @@ __global__ __launch_bounds__(256) void k_gather_rows(scone_row_store st, const _
                                                      unsigned long long row_begin, unsigned long long row_end, int d,
                                                      float *__restrict__ out, uint32_t *__restrict__ status) {
   const int lane = threadIdx.x & 63;
-  unsigned long long i = (unsigned long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (i >= n) return;
+  const unsigned long long nwaves = (unsigned long long)gridDim.x * (blockDim.x >> 6);
+  for (unsigned long long i = (unsigned long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); i < n; i += nwaves) {
   const long long id = ids[i];
   float *o = out + i * (unsigned long long)d;
   if (id < (long long)row_begin || id >= (long long)row_end) {
     if (lane == 0) atomicOr(status, SCONE_ST_BAD_ID);
     for (int e = lane; e < d; e += 64) o[e] = 0.f;
-    return;
+    continue;
   }
   const unsigned long long lr = (unsigned long long)id - row_begin;
   if (FMT == SCONE_FMT_F32) {
@@ -169,6 +171,7 @@ __global__ __launch_bounds__(256) void k_gather_rows(scone_row_store st, const _
       o[2 * b + 1] = (float)((int)(v >> 4) - 8) * sf;
     }
   }
+  }  // grid-stride loop over ids
 }
 
 template <typename F>
@@ -260,7 +263,7 @@ static int store_f32_common(scone_handle *h, const float *d_src, const int64_t *
   if (!d_src) return scone_fail(h, SCONE_EINVAL, "scone_table_store_f32: null rows");
   SCONE_HIP(h, hipSetDevice(h->device));
   table_modified(h);
-  const unsigned blocks = (unsigned)((nrows + 3) / 4);
+  const unsigned blocks = scone_capped_blocks((nrows + 3) / 4);
   int bad = dispatch_fmt(h->cfg.table_fmt, [&](auto F) {
     hipLaunchKernelGGL((k_store_f32<decltype(F)::value>), dim3(blocks), dim3(256), 0, s, d_src, d_ids,
                        (unsigned long long)row0, (unsigned long long)nrows, (unsigned long long)h->cfg.row_begin,
@@ -294,10 +297,9 @@ extern "C" int scone_table_fill_synthetic(scone_handle *h, uint32_t seed, float 
   if (h->local_rows == 0) return SCONE_OK;
   SCONE_HIP(h, hipSetDevice(h->device));
   table_modified(h);
-  const unsigned long long blocks = (h->local_rows + 3) / 4;
-  if (blocks > 0x7FFFFFFFull) return scone_fail(h, SCONE_EINVAL, "scone_table_fill_synthetic: too many rows per launch");
+  const unsigned blocks = scone_capped_blocks((h->local_rows + 3) / 4);
   int bad = dispatch_fmt(h->cfg.table_fmt, [&](auto F) {
-    hipLaunchKernelGGL((k_fill_synth<decltype(F)::value>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL((k_fill_synth<decltype(F)::value>), dim3(blocks), dim3(256), 0, (hipStream_t)stream,
                        (unsigned long long)h->cfg.row_begin, (unsigned long long)h->local_rows, h->cfg.dim, seed,
                        base_scale, scone_store_of(h), (__half *)h->scales);
   });
@@ -313,9 +315,9 @@ extern "C" int scone_table_gather_rows(scone_handle *h, const int64_t *d_ids, ui
   if (n == 0) return SCONE_OK;
   if (!d_ids || !d_out) return scone_fail(h, SCONE_EINVAL, "scone_table_gather_rows: null pointer");
   SCONE_HIP(h, hipSetDevice(h->device));
-  const unsigned long long blocks = (n + 3) / 4;
+  const unsigned blocks = scone_capped_blocks((n + 3) / 4);
   int bad = dispatch_fmt(h->cfg.table_fmt, [&](auto F) {
-    hipLaunchKernelGGL((k_gather_rows<decltype(F)::value>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL((k_gather_rows<decltype(F)::value>), dim3(blocks), dim3(256), 0, (hipStream_t)stream,
                        scone_store_of(h), (const __half *)h->scales, d_ids, (unsigned long long)n,
                        (unsigned long long)h->cfg.row_begin, (unsigned long long)h->cfg.row_end, h->cfg.dim, d_out,
                        h->d_status);

@@ -366,6 +366,19 @@ def test_row_sharded_partial_sums_equal_full():
 
 
 # ------------------------------------------------------------------ synthetic table (full-size property)
+def test_synthetic_int4_table_matches_host_generator():
+    from scone_amd.hip_backend import SconeTable
+    n, d = 50_000, 1024
+    t = SconeTable(3, n, d, "int4")
+    t.fill_synthetic(7, 0.02 / 127)
+    ids = np.array([0, 1, 2, 777, n - 1], dtype=np.int64)
+    got = t.gather_rows(torch.from_numpy(ids)).cpu().numpy()
+    assert np.array_equal(got, R.dequantize_i4(*R.synth_rows_i4(7, ids, d, 0.02 / 127)))
+    rows, scales = t.download(0, 3)
+    p, s = R.synth_rows_i4(7, np.arange(3), d, 0.02 / 127)
+    assert np.array_equal(rows, p) and np.array_equal(scales, s)
+
+
 @pytest.mark.parametrize("fmt", ["int8", "fp16", "fp32"])
 def test_synthetic_table_matches_host_generator(fmt):
     from scone_amd.hip_backend import SconeTable
@@ -943,6 +956,53 @@ def test_config_c3_10m_int8_d1024():
     rows = R.synth_rows_i8(7, uniq, d).astype(np.float32) * R.synth_scale_f16(7, uniq, 0.02 / 127).astype(np.float32)[:, None]
     out = cache.embed_tokens(torch.from_numpy(tok), out_dtype=torch.float32).cpu().numpy()
     assert np.array_equal(out, R.embed_numpy(rows, ro, inv, "mean").reshape(4, 512, d))
+
+
+def test_config_c4_100m_int4_d1024_at_its_named_size():
+    """configs[3] at its named size: 100M f-grams INT4 d=1024 (52.8 GB of rows, 4.3 GB index).  Rows at both ends,
+    in the middle and around row 2^25 equal the host generator -- a one-wave-per-row fill of this table once
+    stopped at row 33.5M because blocks x threads wrapped at 2^32 work-items, silently -- and lookups over the
+    whole id range equal the oracle (ids bit-exact, fp32 result bit-exact on recomputed rows)."""
+    from scone_amd import EmbeddingCache
+    from scone_amd import synthetic as S
+    n, d = 100_000_000, 1024
+    free, _ = torch.cuda.mem_get_info()
+    if free < 70e9:
+        pytest.skip("needs 70 GB of free HBM")
+    keys, lens = S.make_keys_structured(n)
+    cache = EmbeddingCache.from_synthetic(_extractor(keys, lens, 3), d, table_format="int4", seed=7, base_scale=0.02 / 127)
+    table = cache.table
+    assert table.index_stats()[0] == n
+    ids = np.array([0, 1, 2**25 - 1, 2**25, 2**25 + 1, n // 2, 2**26 + 12345, n - 2, n - 1], dtype=np.int64)
+    got = table.gather_rows(torch.from_numpy(ids)).cpu().numpy()
+    assert np.array_equal(got, R.dequantize_i4(*R.synth_rows_i4(7, ids, d, 0.02 / 127)))
+    tok = S.stream_uniform_ids(keys, lens, 4, 512, 3)
+    off, mids = cache.match(torch.from_numpy(tok))
+    ro, ri = R.hits_to_csr(R.match_hits(keys, lens, tok, 3))
+    assert np.array_equal(off.cpu().numpy(), ro) and np.array_equal(mids.cpu().numpy(), ri)
+    assert ri.max() > 0.9 * n                                   # the stream does reach the end of the table
+    uniq, inv = np.unique(ri, return_inverse=True)
+    rows = R.dequantize_i4(*R.synth_rows_i4(7, uniq, d, 0.02 / 127))
+    out = cache.embed_tokens(torch.from_numpy(tok), out_dtype=torch.float32).cpu().numpy()
+    assert np.array_equal(out, R.embed_numpy(rows, ro, inv, "mean").reshape(4, 512, d))
+
+
+def test_config_c5_shard_rows_at_its_named_size():
+    """configs[4]: the last of 8 shards of the 1e9-row INT4 d=1024 table (125M rows = 66 GB on this GPU; the index
+    is left empty here): the shard's first, middle and last rows equal the host generator."""
+    from scone_amd.hip_backend import SconeTable
+    n, d, world = 1_000_000_000, 1024, 8
+    free, _ = torch.cuda.mem_get_info()
+    if free < 80e9:
+        pytest.skip("needs 80 GB of free HBM")
+    lo, hi = (world - 1) * n // world, n
+    t = SconeTable(3, n, d, "int4", row_begin=lo, row_end=hi, index_capacity=64)
+    t.fill_synthetic(7, 0.02 / 127)
+    ids = np.array([lo, lo + 1, lo + 2**25, lo + 2**26 + 7, (lo + hi) // 2, hi - 2, hi - 1], dtype=np.int64)
+    got = t.gather_rows(torch.from_numpy(ids)).cpu().numpy()
+    assert np.array_equal(got, R.dequantize_i4(*R.synth_rows_i4(7, ids, d, 0.02 / 127)))
+    z = t.gather_rows(torch.tensor([lo - 1]))                   # not this shard's row: zeros + status bit, no fault
+    assert not bool(z.any()) and t.status() & 2
 
 
 # ------------------------------------------------------------------ callers of the match step

@@ -1,0 +1,122 @@
+#!/usr/bin/env python3
+"""The W-way row exchange at scale on ONE GPU: W real shards of a table that fits one GPU only in total
+(default: 100M INT4 rows d = 1024 = 52.8 GB over 8 handles, each with its own replicated index), a 1M-token
+batch, the all-to-all done by hand (device copies, not timed).  Measures what one GPU can measure of the
+8-GPU step: every rank's LOCAL phases (plan = 2 matches + counts, pack, embed of its slice) with HIP events,
+the record counts per (source, destination) pair and the wire bytes; checks the assembled output against
+the unsharded lookup of the same tokens when the table also fits as ONE handle (--check).
+
+    python tools/shard_emulate.py [--rows 100000000] [--world 8] [--check]
+
+The xGMI time itself cannot be measured here; DESIGN.md prices it from the printed byte counts.
+"""
+import argparse
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+from scone_amd import synthetic as S
+from scone_amd.distributed import shard_range
+from scone_amd.hip_backend import SconeTable
+
+
+def timed(fn):
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    a.record()
+    out = fn()
+    b.record()
+    torch.cuda.synchronize()
+    return out, a.elapsed_time(b)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rows", type=int, default=100_000_000)
+    ap.add_argument("--world", type=int, default=8)
+    ap.add_argument("--dim", type=int, default=1024)
+    ap.add_argument("--format", default="int4")
+    ap.add_argument("--batch", type=int, default=2048)
+    ap.add_argument("--seq", type=int, default=512)
+    ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--check", action="store_true")
+    a = ap.parse_args()
+    N, W, d, B, T = a.rows, a.world, a.dim, a.batch, a.seq
+    keys, lens = S.make_keys_structured(N, S.GPT2_VOCAB, 3) if N >= 20_000_000 else S.make_keys(N, S.GPT2_VOCAB, 3, seed=11)
+    tok_np = S.stream_uniform_ids(keys, lens, B, T, 1234)
+    tok = torch.from_numpy(tok_np).to("cuda", torch.int32)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    wte = (torch.randn(S.GPT2_VOCAB, d, generator=g, device="cuda") * 0.02).half()
+    wpe = (torch.randn(1024, d, generator=g, device="cuda") * 0.01).half()
+    shards = []
+    for r in range(W):
+        lo, hi = shard_range(N, r, W)
+        s = SconeTable(3, N, d, a.format, row_begin=lo, row_end=hi)
+        s.index_build(keys, lens)
+        s.fill_synthetic(7, 0.02 / 127)
+        shards.append(s)
+    rec = shards[0].shard_record_bytes()
+    bper = (B + W - 1) // W
+    res = {"rows": N, "world": W, "format": a.format, "dim": d, "tokens": B * T, "record_bytes": rec, "ranks": []}
+    out = torch.empty(B * T, d, dtype=torch.float16, device="cuda")
+    for rep in range(a.reps):
+        plans, t_plan = [], []
+        for r, s in enumerate(shards):
+            p, ms = timed(lambda: s.shard_plan(tok, W, r))
+            plans.append(p)
+            t_plan.append(ms)
+        sends, t_pack = [], []
+        for r, s in enumerate(shards):
+            buf, ms = timed(lambda: s.shard_pack(B, T, W, plans[r][0]))
+            sends.append(buf)
+            t_pack.append(ms)
+        t_embed = []
+        for q in range(W):
+            parts = []
+            for r in range(W):
+                o = sum(plans[r][0][:q])
+                parts.append(sends[r][o:o + plans[r][0][q]])
+            recv = torch.cat(parts).contiguous()                      # the all-to-all, by hand
+            b0, b1 = min(q * bper, B), min(q * bper + bper, B)
+            _, ms = timed(lambda: shards[q].shard_embed(tok, W, q, recv, wte=wte, wpe=wpe, out_dtype=torch.float16,
+                                                        out=out[b0 * T:b1 * T]))
+            t_embed.append(ms)
+            del recv
+        if rep == a.reps - 1:
+            for r in range(W):
+                res["ranks"].append({"rank": r, "plan_ms": t_plan[r], "pack_ms": t_pack[r], "embed_ms": t_embed[r],
+                                     "send_records": int(sum(plans[r][0])), "recv_records": int(sum(plans[r][1])),
+                                     "send_off_rank_bytes": int((sum(plans[r][0]) - plans[r][0][r]) * rec),
+                                     "recv_off_rank_bytes": int((sum(plans[r][1]) - plans[r][1][r]) * rec)})
+        del sends
+    loc = [x["plan_ms"] + x["pack_ms"] + x["embed_ms"] for x in res["ranks"]]
+    res["local_ms_max"] = max(loc)
+    res["local_ms_mean"] = sum(loc) / len(loc)
+    res["wire_bytes_all_ranks"] = sum(x["send_off_rank_bytes"] for x in res["ranks"])
+    res["all_gather_bytes_per_rank"] = (W - 1) * bper * T * d * 2
+    if a.check:
+        full = SconeTable(3, N, d, a.format)
+        full.index_build(keys, lens)
+        full.fill_synthetic(7, 0.02 / 127)
+        want = full.embed(tok, wte=wte, wpe=wpe).reshape(B * T, d)
+        res["bit_identical_to_unsharded"] = bool(torch.equal(out, want))
+        if not res["bit_identical_to_unsharded"]:
+            bad = (out != want).any(dim=1)
+            res["mismatching_tokens"] = int(bad.sum())
+            res["mismatching_tokens_per_slice"] = [int(bad[q * bper * T:(q + 1) * bper * T].sum()) for q in range(W)]
+            res["max_abs_diff"] = float((out.float() - want.float()).abs().max())
+            first = int(torch.nonzero(bad)[0])
+            res["first_bad_token"] = first
+            res["status_bits"] = [s.status() for s in shards]
+            off, ids = full.match_csr(tok.view(-1)[first - first % T:first - first % T + T].view(1, T))
+            i = first % T
+            res["first_bad_ids"] = ids[int(off[i]):int(off[i + 1])].tolist()
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()

@@ -54,6 +54,8 @@ def parse():
     ap.add_argument("--table-mode", default="replicated", choices=["replicated", "sharded"])
     ap.add_argument("--exchange", default="rows", choices=["rows", "partial_sums"],
                     help="sharded mode: all-to-all of quantised rows (default) or reduce-scatter of fp32 partial sums")
+    ap.add_argument("--replicated-rows", type=int, default=50257,
+                    help="sharded mode: head of the table kept on every rank (default: the unigram rows)")
     ap.add_argument("--shard-of", default="", help="R/W: build only shard R of a W-way row-sharded table on this one GPU "
                     "and time its local work (partial sums + finalise of its 1/W token slice); no exchange -- "
                     "capacity / kernel check for tables that need W GPUs (C5)")
@@ -207,7 +209,8 @@ def main():
     elif sharded:
         from scone_amd.distributed import ShardedEmbeddingCache
         cache = ShardedEmbeddingCache.from_synthetic(ex, d, table_format=args.format, seed=seed,
-                                                     base_scale=base_scale, rank=rank, world=world)
+                                                     base_scale=base_scale, rank=rank, world=world,
+                                                     replicated_rows=args.replicated_rows)
         stream_seed = 1234            # every rank embeds the same batch; rows are sharded
     else:
         cache = EmbeddingCache.from_synthetic(ex, d, table_format=args.format, seed=seed, base_scale=base_scale,

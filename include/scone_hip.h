@@ -220,6 +220,16 @@ int scone_finalize(scone_handle *h, const float *d_sum, const int32_t *d_counts,
  *      [r*ceil(B/world), (r+1)*ceil(B/world)).  Tokens and index are replicated, so both ends of a transfer
  *      derive what is sent; the caller only moves the record buffers (one all_to_all_single). -------------- */
 int scone_shard_record_bytes(scone_handle *h, uint64_t *bytes);
+/* Replicated head (optional; call once after scone_create, before rows are stored).  Global rows [0, n_head) are
+ * kept on EVERY shard in addition to the rows it owns and never cross xGMI.  f-gram ids are frequency-ordered
+ * (Counter.most_common, n_gram_extractor.py:91-99): the head holds every unigram and the most frequent f-grams,
+ * i.e. about half of all row references (every token has its unigram), and without it the rank that owns the head
+ * sends ten times what the others send.  scone_table_fill_synthetic fills the head as well;
+ * scone_shard_head_store_f32 quantises fp32 rows into it exactly as scone_table_store_f32 does (rows must lie in
+ * [0, n_head); every rank stores the same rows). */
+int scone_shard_set_head(scone_handle *h, uint64_t n_head);
+int scone_shard_head_store_f32(scone_handle *h, const float *d_rows_f32, uint64_t row0, uint64_t nrows,
+                               scone_stream_t stream);
 /* Matches the batch, fills h_send_counts[q] (records this rank sends to rank q) and h_recv_counts[q]
  * (records it receives from rank q); synchronises.  world <= 64. */
 int scone_shard_plan(scone_handle *h, const int32_t *d_tok, int32_t B, int32_t T, int32_t world, int32_t rank,

@@ -193,9 +193,16 @@ int scone_launch_match_ell_ex(scone_handle *h, const int32_t *d_tok, int32_t B, 
                               long long row_begin, long long row_end, int keep_pos, hipStream_t s);
 #define SCONE_ELL_W(max_n) ((max_n) <= 3 ? 8 : 16)
 
+// table kernels on an arbitrary row store (scone_table.hip); used for the replicated head of a shard
+int scone_store_f32_into(scone_handle *h, const scone_row_store &st, void *scales, uint64_t row_begin, uint64_t row_end,
+                         const float *d_src, const int64_t *d_ids, uint64_t row0, uint64_t nrows, hipStream_t s);
+int scone_fill_synth_into(scone_handle *h, const scone_row_store &st, void *scales, uint64_t row_begin, uint64_t nrows,
+                          uint32_t seed, float base_scale, hipStream_t s);
 // row exchange between shards (scone_shard.hip)
+int scone_shard_fill_head_synth(scone_handle *h, uint32_t seed, float base_scale, hipStream_t s);  // no-op without a head
 void scone_shard_destroy(scone_handle *h);
 int scone_shard_rec_bytes(const scone_handle *h);
+uint8_t *scone_shard_head(const scone_handle *h, unsigned long long *n_head);  // replicated head rows (record layout) or null
 int scone_shard_prepare_embed(scone_handle *h, int32_t B, int32_t T, int32_t world, int32_t rank, const void *d_recv,
                               uint64_t n_recv, const int32_t **ell, const void **scales, int32_t *b0, int32_t *b1,
                               hipStream_t s);

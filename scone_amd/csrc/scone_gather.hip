@@ -224,12 +224,15 @@ extern "C" int scone_shard_embed(scone_handle *h, const int32_t *d_tok, int32_t 
   if (!d_tok || !d_out_slice) return scone_fail(h, SCONE_EINVAL, "scone_shard_embed: null pointer");
   embed_args a = {};
   fill_table_view(h, a.tv);
-  a.tv.st.hot = nullptr, a.tv.st.n_hot = 0;  // every row of this slice is a received record
+  // row store of this lookup: [replicated head | received records], both in record layout
+  unsigned long long n_head = 0;
+  a.tv.st.hot = scone_shard_head(h, &n_head);
+  a.tv.st.n_hot = n_head;
   // nothing received: any (erroneous) reference is already redirected to record 0 -> give it the zero row
   a.tv.st.cold = n_recv ? reinterpret_cast<uint8_t *>(const_cast<void *>(d_recv_buf)) : reinterpret_cast<uint8_t *>(h->d_zero_row);
   a.tv.st.row_bytes = (unsigned int)scone_shard_rec_bytes(h);
   a.tv.scales = reinterpret_cast<const __half *>(scales);
-  a.tv.row_begin = 0, a.tv.row_end = (long long)(n_recv ? n_recv : 1);
+  a.tv.row_begin = 0, a.tv.row_end = (long long)(n_head + (n_recv ? n_recv : 1));
   a.BT = (long long)(b1 - b0) * T, a.ntok = a.BT, a.T = T, a.max_n = h->cfg.max_n;
   a.ell = ell, a.zero_row = h->d_zero_row, a.mode = (int)h->cfg.lookup_mode;
   a.tok = d_tok + (long long)b0 * T;

@@ -16,6 +16,11 @@
 //   embed   received records -> slot map (by the header), scales unpacked, ids of my slice remapped to
 //           record numbers, then the ordinary fused lookup kernel reads the rows straight out of the
 //           receive buffer (row store stride = record size)
+//
+// Replicated head (scone_shard_set_head): global rows [0, n_head) -- the unigrams and the most frequent f-grams of
+// the frequency-ordered table -- are kept on every shard in record layout and are neither counted, packed nor
+// sent; the lookup kernel reads them as the "hot" part of its row store, the received records as the "cold" part.
+// On the C5-shaped workload that removes half of all records and the 10x send imbalance of the rank owning the head.
 #include "scone_common.h"
 
 #include <new>
@@ -28,8 +33,11 @@ struct scone_shard_state {
   unsigned long long *send_off = nullptr;  // [64] record offsets per destination
   uint32_t *send_src = nullptr;  // [total_send] packed (token, list index) per record
   uint32_t *slot_of_ref = nullptr;  // [slice tokens * NC]
-  uint8_t *scales = nullptr;     // unpacked scales of the received records
+  uint8_t *scales = nullptr;     // [n_head + received records] scales: the head's, then the unpacked ones
   long long cap_send = 0;
+  unsigned long long n_head = 0; // replicated head: global rows [0, n_head) live on every shard
+  uint8_t *head_rows = nullptr;  // [n_head, rec_bytes]: payload at the start of every record-sized slot
+  uint8_t *head_scales = nullptr;  // [n_head, scale_bytes_per_row]
 };
 
 namespace {
@@ -55,14 +63,16 @@ __global__ __launch_bounds__(256) void k_shard_count_send(const int32_t *__restr
 }
 
 __global__ __launch_bounds__(256) void k_shard_count_recv(const int32_t *__restrict__ ell, long long ntok, int W, int NC,
-                                                          long long n_rows, int world, uint32_t *__restrict__ recv_cnt) {
+                                                          long long n_rows, int world, long long n_head,
+                                                          uint32_t *__restrict__ recv_cnt) {
   __shared__ uint32_t bins[64];
   if (threadIdx.x < 64) bins[threadIdx.x] = 0;
   __syncthreads();
   const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long t = gid / NC;
   const int j = (int)(gid - t * NC);
-  if (t < ntok && j < (ell[t * W + W - 2] & 0xFF)) atomicAdd(&bins[owner_of(ell[t * W + j], n_rows, world)], 1u);
+  if (t < ntok && j < (ell[t * W + W - 2] & 0xFF) && ell[t * W + j] >= n_head)  // head rows are local everywhere
+    atomicAdd(&bins[owner_of(ell[t * W + j], n_rows, world)], 1u);
   __syncthreads();
   if (threadIdx.x < 64 && bins[threadIdx.x]) atomicAdd(&recv_cnt[threadIdx.x], bins[threadIdx.x]);
 }
@@ -139,18 +149,19 @@ __global__ __launch_bounds__(256) void k_shard_unpack(const uint8_t *__restrict_
 // word, so the lookup kernel never reads outside the receive buffer.
 __global__ __launch_bounds__(256) void k_shard_remap(int32_t *__restrict__ ell, long long ntok, int W, int NC,
                                                      const uint32_t *__restrict__ slot_of_ref, unsigned long long n_recv,
-                                                     uint32_t *__restrict__ status) {
+                                                     long long n_head, uint32_t *__restrict__ status) {
   const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long t = gid / NC;
   const int j = (int)(gid - t * NC);
   if (t >= ntok) return;
   if (j >= (ell[t * W + W - 2] & 0xFF)) return;
+  if (ell[t * W + j] < n_head) return;  // a head row: its id IS its row number in the lookup's row store
   uint32_t p = slot_of_ref[t * NC + j];
   if (p >= n_recv) {
     atomicOr(status, SCONE_ST_BAD_ID);
     p = 0;
   }
-  ell[t * W + j] = (int32_t)p;
+  ell[t * W + j] = (int32_t)(n_head + p);  // received records follow the head
 }
 
 template <typename T>
@@ -169,11 +180,17 @@ int grow(scone_handle *h, T **p, long long *cap, long long need, size_t elems_pe
 void scone_shard_destroy(scone_handle *h) {
   scone_shard_state *st = h->shard;
   if (!st) return;
-  void *ptrs[] = {st->ell_send, st->ell_slice, st->counters, st->send_off, st->send_src, st->slot_of_ref, st->scales};
+  void *ptrs[] = {st->ell_send, st->ell_slice, st->counters, st->send_off, st->send_src, st->slot_of_ref, st->scales,
+                  st->head_rows, st->head_scales};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   delete st;
   h->shard = nullptr;
+}
+
+uint8_t *scone_shard_head(const scone_handle *h, unsigned long long *n_head) {
+  *n_head = h->shard ? h->shard->n_head : 0;
+  return h->shard ? h->shard->head_rows : nullptr;
 }
 
 int scone_shard_rec_bytes(const scone_handle *h) {
@@ -228,7 +245,9 @@ extern "C" int scone_shard_plan(scone_handle *h, const int32_t *d_tok, int32_t B
   if (!scone_grid_fits((unsigned long long)(ntok * NC + 255) / 256, 256))
     return scone_fail(h, SCONE_EINVAL, "scone_shard_plan: too many tokens for one launch");
   // what I send: the whole batch against my rows, ids at their index in the full list
-  rc = scone_launch_match_ell_ex(h, d_tok, B, T, st->ell_send, (long long)h->cfg.row_begin, (long long)h->cfg.row_end, 1, s);
+  const long long n_head = (long long)st->n_head;
+  const long long send_begin = (long long)h->cfg.row_begin > n_head ? (long long)h->cfg.row_begin : n_head;  // head rows are never sent
+  rc = scone_launch_match_ell_ex(h, d_tok, B, T, st->ell_send, send_begin, (long long)h->cfg.row_end, 1, s);
   if (rc) return rc;
   const unsigned blocks = (unsigned)((ntok * NC + 255) / 256);
   hipLaunchKernelGGL(k_shard_count_send, dim3(blocks), dim3(256), 0, s, st->ell_send, ntok, W, NC, slice_tokens, st->counters);
@@ -238,7 +257,7 @@ extern "C" int scone_shard_plan(scone_handle *h, const int32_t *d_tok, int32_t B
     if (rc) return rc;
     const unsigned blocks2 = (unsigned)((my_tokens * NC + 255) / 256);
     hipLaunchKernelGGL(k_shard_count_recv, dim3(blocks2), dim3(256), 0, s, st->ell_slice, my_tokens, W, NC,
-                       (long long)h->cfg.n_rows, world, st->counters + 64);
+                       (long long)h->cfg.n_rows, world, n_head, st->counters + 64);
   }
   SCONE_HIP(h, hipGetLastError());
   uint32_t host[128];
@@ -291,24 +310,81 @@ int scone_shard_prepare_embed(scone_handle *h, int32_t B, int32_t T, int32_t wor
   *b0_out = b0, *b1_out = b1;
   const long long my_tokens = (long long)(b1 - b0) * T, slice_tokens = (long long)bper * T;
   const size_t sb = h->scale_bytes_per_row;
+  const unsigned long long n_head = st->n_head;
   if (sb) {
     long long cap = st->cap_recv;
     uint8_t *p = st->scales;
-    int rc = grow(h, &p, &cap, (long long)n_recv, sb);
+    int rc = grow(h, &p, &cap, (long long)(n_head + n_recv), sb);
     st->scales = p, st->cap_recv = cap;
     if (rc) return rc;
+    if (n_head)  // [head scales | scales of the received records]
+      SCONE_HIP(h, hipMemcpyAsync(st->scales, st->head_scales, (size_t)n_head * sb, hipMemcpyDeviceToDevice, s));
   }
   SCONE_HIP(h, hipMemsetAsync(st->slot_of_ref, 0xFF, (size_t)slice_tokens * NC * sizeof(uint32_t), s));
   if (n_recv) {
     hipLaunchKernelGGL(k_shard_unpack, dim3((unsigned)((n_recv + 255) / 256)), dim3(256), 0, s, (const uint8_t *)d_recv,
                        (unsigned long long)n_recv, scone_shard_rec_bytes(h), (int)h->row_payload_bytes, (int)sb, NC,
-                       slice_tokens, st->slot_of_ref, st->scales, h->d_status);
+                       slice_tokens, st->slot_of_ref, st->scales ? st->scales + (size_t)n_head * sb : nullptr, h->d_status);
   }
   if (my_tokens > 0)
     hipLaunchKernelGGL(k_shard_remap, dim3((unsigned)((my_tokens * NC + 255) / 256)), dim3(256), 0, s, st->ell_slice,
-                       my_tokens, W, NC, st->slot_of_ref, (unsigned long long)n_recv, h->d_status);
+                       my_tokens, W, NC, st->slot_of_ref, (unsigned long long)n_recv, (long long)n_head, h->d_status);
   SCONE_HIP(h, hipGetLastError());
   *ell = st->ell_slice;
   *scales = st->scales;
   return SCONE_OK;
+}
+
+// ---------------------------------------------------------------- replicated head
+static scone_row_store head_store(const scone_handle *h) {
+  scone_row_store st;
+  st.hot = h->shard->head_rows, st.cold = nullptr;
+  st.n_hot = h->shard->n_head;
+  st.row_bytes = (unsigned int)scone_shard_rec_bytes(h);
+  return st;
+}
+
+extern "C" int scone_shard_set_head(scone_handle *h, uint64_t n_head) {
+  if (!h) return SCONE_EINVAL;
+  if (h->cfg.dim <= 0 || !h->rows) return scone_fail(h, SCONE_ESTATE, "scone_shard_set_head: handle has no table");
+  if (h->cfg.placement != SCONE_PLACE_HBM) return scone_fail(h, SCONE_EINVAL, "scone_shard_set_head: HBM tables only");
+  if (n_head > h->cfg.n_rows) n_head = h->cfg.n_rows;
+  if (n_head > 0x7FFFFFFFull) return scone_fail(h, SCONE_EINVAL, "scone_shard_set_head: head too large");
+  SCONE_HIP(h, hipSetDevice(h->device));
+  if (!h->shard) {
+    h->shard = new (std::nothrow) scone_shard_state();
+    if (!h->shard) return scone_fail(h, SCONE_ENOMEM, "scone_shard_set_head: out of memory");
+  }
+  scone_shard_state *st = h->shard;
+  if (st->head_rows) SCONE_HIP(h, hipFree(st->head_rows));
+  if (st->head_scales) SCONE_HIP(h, hipFree(st->head_scales));
+  st->head_rows = st->head_scales = nullptr;
+  st->n_head = 0;
+  if (n_head == 0) return SCONE_OK;
+  const size_t rec = (size_t)scone_shard_rec_bytes(h);
+  SCONE_HIP(h, hipMalloc(&st->head_rows, n_head * rec));
+  SCONE_HIP(h, hipMemset(st->head_rows, 0, n_head * rec));
+  if (h->scale_bytes_per_row) {
+    SCONE_HIP(h, hipMalloc(&st->head_scales, n_head * h->scale_bytes_per_row + 4));
+    SCONE_HIP(h, hipMemset(st->head_scales, 0, n_head * h->scale_bytes_per_row + 4));
+  }
+  st->n_head = n_head;
+  return SCONE_OK;
+}
+
+extern "C" int scone_shard_head_store_f32(scone_handle *h, const float *d_rows_f32, uint64_t row0, uint64_t nrows,
+                                          scone_stream_t stream) {
+  if (!h) return SCONE_EINVAL;
+  if (!h->shard || !h->shard->n_head) return scone_fail(h, SCONE_ESTATE, "scone_shard_head_store_f32: call scone_shard_set_head first");
+  if (nrows == 0) return SCONE_OK;
+  if (!d_rows_f32) return scone_fail(h, SCONE_EINVAL, "scone_shard_head_store_f32: null rows");
+  if (row0 + nrows > h->shard->n_head) return scone_fail(h, SCONE_ERANGE, "scone_shard_head_store_f32: rows outside [0, n_head)");
+  SCONE_HIP(h, hipSetDevice(h->device));
+  return scone_store_f32_into(h, head_store(h), h->shard->head_scales, 0, h->shard->n_head, d_rows_f32, nullptr, row0, nrows,
+                              (hipStream_t)stream);
+}
+
+int scone_shard_fill_head_synth(scone_handle *h, uint32_t seed, float base_scale, hipStream_t s) {
+  if (!h->shard || !h->shard->n_head) return SCONE_OK;
+  return scone_fill_synth_into(h, head_store(h), h->shard->head_scales, 0, h->shard->n_head, seed, base_scale, s);
 }

@@ -257,21 +257,39 @@ extern "C" int scone_table_download(scone_handle *h, void *rows, void *scales, u
   return SCONE_OK;
 }
 
+int scone_store_f32_into(scone_handle *h, const scone_row_store &st, void *scales, uint64_t row_begin, uint64_t row_end,
+                         const float *d_src, const int64_t *d_ids, uint64_t row0, uint64_t nrows, hipStream_t s) {
+  const unsigned blocks = scone_capped_blocks((nrows + 3) / 4);
+  int bad = dispatch_fmt(h->cfg.table_fmt, [&](auto F) {
+    hipLaunchKernelGGL((k_store_f32<decltype(F)::value>), dim3(blocks), dim3(256), 0, s, d_src, d_ids,
+                       (unsigned long long)row0, (unsigned long long)nrows, (unsigned long long)row_begin,
+                       (unsigned long long)row_end, h->cfg.dim, st, (__half *)scales, h->d_status);
+  });
+  if (bad) return scone_fail(h, SCONE_EINVAL, "scone_table_store_f32: bad format");
+  SCONE_HIP(h, hipGetLastError());
+  return SCONE_OK;
+}
+
+int scone_fill_synth_into(scone_handle *h, const scone_row_store &st, void *scales, uint64_t row_begin, uint64_t nrows,
+                          uint32_t seed, float base_scale, hipStream_t s) {
+  if (nrows == 0) return SCONE_OK;
+  const unsigned blocks = scone_capped_blocks((nrows + 3) / 4);
+  int bad = dispatch_fmt(h->cfg.table_fmt, [&](auto F) {
+    hipLaunchKernelGGL((k_fill_synth<decltype(F)::value>), dim3(blocks), dim3(256), 0, s, (unsigned long long)row_begin,
+                       (unsigned long long)nrows, h->cfg.dim, seed, base_scale, st, (__half *)scales);
+  });
+  if (bad) return scone_fail(h, SCONE_EINVAL, "scone_table_fill_synthetic: bad format");
+  SCONE_HIP(h, hipGetLastError());
+  return SCONE_OK;
+}
+
 static int store_f32_common(scone_handle *h, const float *d_src, const int64_t *d_ids, uint64_t row0, uint64_t nrows,
                             hipStream_t s) {
   if (nrows == 0) return SCONE_OK;
   if (!d_src) return scone_fail(h, SCONE_EINVAL, "scone_table_store_f32: null rows");
   SCONE_HIP(h, hipSetDevice(h->device));
   table_modified(h);
-  const unsigned blocks = scone_capped_blocks((nrows + 3) / 4);
-  int bad = dispatch_fmt(h->cfg.table_fmt, [&](auto F) {
-    hipLaunchKernelGGL((k_store_f32<decltype(F)::value>), dim3(blocks), dim3(256), 0, s, d_src, d_ids,
-                       (unsigned long long)row0, (unsigned long long)nrows, (unsigned long long)h->cfg.row_begin,
-                       (unsigned long long)h->cfg.row_end, h->cfg.dim, scone_store_of(h), (__half *)h->scales, h->d_status);
-  });
-  if (bad) return scone_fail(h, SCONE_EINVAL, "scone_table_store_f32: bad format");
-  SCONE_HIP(h, hipGetLastError());
-  return SCONE_OK;
+  return scone_store_f32_into(h, scone_store_of(h), h->scales, h->cfg.row_begin, h->cfg.row_end, d_src, d_ids, row0, nrows, s);
 }
 
 extern "C" int scone_table_store_f32(scone_handle *h, const float *d_rows_f32, uint64_t row0, uint64_t nrows,
@@ -294,18 +312,12 @@ extern "C" int scone_table_store_f32_ids(scone_handle *h, const float *d_rows_f3
 extern "C" int scone_table_fill_synthetic(scone_handle *h, uint32_t seed, float base_scale, scone_stream_t stream) {
   int rc = check_table(h, "scone_table_fill_synthetic: handle has no table (dim == 0)");
   if (rc) return rc;
-  if (h->local_rows == 0) return SCONE_OK;
   SCONE_HIP(h, hipSetDevice(h->device));
   table_modified(h);
-  const unsigned blocks = scone_capped_blocks((h->local_rows + 3) / 4);
-  int bad = dispatch_fmt(h->cfg.table_fmt, [&](auto F) {
-    hipLaunchKernelGGL((k_fill_synth<decltype(F)::value>), dim3(blocks), dim3(256), 0, (hipStream_t)stream,
-                       (unsigned long long)h->cfg.row_begin, (unsigned long long)h->local_rows, h->cfg.dim, seed,
-                       base_scale, scone_store_of(h), (__half *)h->scales);
-  });
-  if (bad) return scone_fail(h, SCONE_EINVAL, "scone_table_fill_synthetic: bad format");
-  SCONE_HIP(h, hipGetLastError());
-  return SCONE_OK;
+  rc = scone_fill_synth_into(h, scone_store_of(h), h->scales, h->cfg.row_begin, h->local_rows, seed, base_scale,
+                             (hipStream_t)stream);
+  if (rc) return rc;
+  return scone_shard_fill_head_synth(h, seed, base_scale, (hipStream_t)stream);  // the replicated head of a shard, if any
 }
 
 extern "C" int scone_table_gather_rows(scone_handle *h, const int64_t *d_ids, uint64_t n, float *d_out,

@@ -16,6 +16,11 @@ here and only needed when the table does not fit one GPU's 288 GB (BASELINE conf
   row is 544 B on the wire where an fp32 partial sum is 4096 B per token AND rank: for the C5
   workload about 0.2 GB per rank and step instead of 3.7 GB, spread over all 7 xGMI links by the
   all-to-all, and the result is bit-identical to the unsharded table (same reduction order);
+* ``replicated_rows=H``: the head of the table, global rows ``[0, H)``, is kept on every rank and never sent.
+  f-gram ids are frequency-ordered (``Counter.most_common``), so the head holds every unigram and the most
+  frequent f-grams -- about half of all row references on the C5-shaped workload, all of which would otherwise
+  leave the one rank that owns them (measured on one GPU with 8 shards of a 100M-row table,
+  ``tools/shard_emulate.py``: rank 0 sends 550 MB per 1M-token step, the others 52-75 MB);
 * exchange ``"partial_sums"`` (kept for comparison): every rank sums the rows it owns
   (``scone_embed_partial``) -> ``reduce_scatter`` -> ``scone_finalize``;
 * finally an ``all_gather`` of the finished vectors in the output dtype (skippable when the
@@ -88,7 +93,7 @@ class ShardedEmbeddingCache:
 
     def __init__(self, n_gram_extractor: NGramExtractor, embedding_dim: int, *, table_format: str = "int8",
                  rank: Optional[int] = None, world: Optional[int] = None, group=None, device=None,
-                 n_rows: Optional[int] = None, placement: str = "hbm", table=None) -> None:
+                 n_rows: Optional[int] = None, placement: str = "hbm", table=None, replicated_rows: int = 0) -> None:
         self.group = group
         self.rank = dist.get_rank(group) if rank is None else int(rank)
         self.world = dist.get_world_size(group) if world is None else int(world)
@@ -101,7 +106,10 @@ class ShardedEmbeddingCache:
             table = SconeTable(n_gram_extractor.max_n, self.n_rows, dim=self.embedding_dim, table_format=table_format,
                                placement=placement, device=device, row_begin=self.row_begin, row_end=self.row_end)
             n_gram_extractor.build_index(table)          # replicated index
+            if replicated_rows:
+                table.shard_set_head(replicated_rows)
         self.table = table
+        self.replicated_rows = min(int(replicated_rows), self.n_rows)
 
     @classmethod
     def from_synthetic(cls, n_gram_extractor: NGramExtractor, embedding_dim: int, *, table_format: str = "int8",
@@ -118,6 +126,9 @@ class ShardedEmbeddingCache:
         b = min(row0 + rows_f32.shape[0], self.row_end)
         if b > a:
             self.table.store_f32(rows_f32[a - row0:b - row0], row0=a)
+        hb = min(row0 + rows_f32.shape[0], self.replicated_rows)     # the replicated head: every rank keeps it
+        if hb > row0:
+            self.table.shard_head_store_f32(rows_f32[:hb - row0], row0=row0)
 
     # ------------------------------------------------------------------
     def embed_tokens(self, input_ids: torch.Tensor, *, reduce: str = "mean", wte: Optional[torch.Tensor] = None,

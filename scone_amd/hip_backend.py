@@ -333,6 +333,21 @@ class SconeTable:
         return partial, counts
 
     # -- row exchange between shards (scone_shard_*) ---------------------------------
+    def shard_set_head(self, n_head: int) -> None:
+        """Keep global rows ``[0, n_head)`` on this shard as well (replicated head: never sent between shards)."""
+        with torch.cuda.device(self.device):
+            self._check(L.lib().scone_shard_set_head(self._h, int(n_head)), "scone_shard_set_head")
+        self.n_head = min(int(n_head), self.n_rows)
+
+    def shard_head_store_f32(self, rows: torch.Tensor, row0: int = 0) -> None:
+        rows = rows.to(device=self.device, dtype=torch.float32).contiguous()
+        if rows.dim() != 2 or rows.shape[1] != self.dim:
+            raise ValueError(f"rows must be [n, {self.dim}], got {tuple(rows.shape)}")
+        with torch.cuda.device(self.device):
+            rc = L.lib().scone_shard_head_store_f32(self._h, _ptr(rows), int(row0), rows.shape[0], _stream())
+            torch.cuda.current_stream().synchronize()          # `rows` may be a temporary
+        self._check(rc, "scone_shard_head_store_f32")
+
     def shard_record_bytes(self) -> int:
         n = C.c_uint64(0)
         self._check(L.lib().scone_shard_record_bytes(self._h, C.byref(n)), "scone_shard_record_bytes")

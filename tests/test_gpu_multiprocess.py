@@ -46,7 +46,7 @@ def _problem(fmt, d, max_n, seed=5):
     return keys, lens, table, tok, wte, wpe
 
 
-def _worker(rank, world, port, fmt, d, max_n, exchange, q):
+def _worker(rank, world, port, fmt, d, max_n, exchange, head, q):
     try:
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         import torch.distributed as dist
@@ -56,7 +56,7 @@ def _worker(rank, world, port, fmt, d, max_n, exchange, q):
         from scone_amd.distributed import ShardedEmbeddingCache
         keys, lens, table, tok, wte, wpe = _problem(fmt, d, max_n)
         ex = NGramExtractor.from_arrays(keys, lens, max_n=max_n)
-        sh = ShardedEmbeddingCache(ex, d, table_format=fmt, rank=rank, world=world)
+        sh = ShardedEmbeddingCache(ex, d, table_format=fmt, rank=rank, world=world, replicated_rows=head)
         sh.load_rows(torch.from_numpy(table), 0)
         wte_d, wpe_d = torch.from_numpy(wte).half().cuda(), torch.from_numpy(wpe).half().cuda()
         got = sh.embed_tokens(torch.from_numpy(tok), wte=wte_d, wpe=wpe_d, exchange=exchange)
@@ -75,15 +75,15 @@ def _worker(rank, world, port, fmt, d, max_n, exchange, q):
         q.put((rank, False, repr(e) + traceback.format_exc(), None, None))
 
 
-@pytest.mark.parametrize("fmt,d,max_n,world,exchange", [("int8", 768, 3, 2, "rows"), ("int4", 1024, 4, 3, "rows"),
-                                                        ("int8", 768, 3, 2, "partial_sums")])
-def test_sharded_cache_across_processes_on_one_gpu(fmt, d, max_n, world, exchange):
+@pytest.mark.parametrize("fmt,d,max_n,world,exchange,head", [("int8", 768, 3, 2, "rows", 0), ("int4", 1024, 4, 3, "rows", 100),
+                                                             ("int8", 768, 3, 2, "partial_sums", 0)])
+def test_sharded_cache_across_processes_on_one_gpu(fmt, d, max_n, world, exchange, head):
     if not torch.cuda.is_available():
         pytest.skip("needs an MI355X")
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, fmt, d, max_n, exchange, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, fmt, d, max_n, exchange, head, q)) for r in range(world)]
     for p in procs:
         p.start()
     results = [q.get(timeout=300) for _ in procs]

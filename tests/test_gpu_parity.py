@@ -770,11 +770,13 @@ def test_abi_argument_errors():
     assert t.status() == 0
 
 
+@pytest.mark.parametrize("head", [0, 37, 1200])
 @pytest.mark.parametrize("fmt,d,max_n,world", [("int8", 768, 3, 3), ("int4", 1024, 4, 8), ("fp16", 1280, 3, 2)])
-def test_row_exchange_between_shards_is_bit_exact(fmt, d, max_n, world):
+def test_row_exchange_between_shards_is_bit_exact(fmt, d, max_n, world, head):
     """The row exchange for row-sharded tables (plan -> pack -> all-to-all of quantised rows -> embed), with the
     W shards living on one GPU and the all-to-all done by hand: every slice equals the unsharded table BIT FOR
-    BIT (the receiver reduces the rows in the reference's order), and the wire carries sum(K) records."""
+    BIT (the receiver reduces the rows in the reference's order), and the wire carries one record per reference
+    to a row outside the replicated head (`head` rows kept on every shard; 1200 spans more than one shard)."""
     from scone_amd.hip_backend import SconeTable
     from scone_amd.distributed import shard_range
     rng = np.random.default_rng(90 + world)
@@ -792,6 +794,10 @@ def test_row_exchange_between_shards_is_bit_exact(fmt, d, max_n, world):
         s = SconeTable(max_n, n, d, fmt, row_begin=a, row_end=b)
         s.index_build(keys, lens)
         s.store_f32(torch.from_numpy(table[a:b]), row0=a)
+        if head:
+            s.shard_set_head(head)
+            s.shard_head_store_f32(torch.from_numpy(table[:head // 2]), row0=0)      # in two calls
+            s.shard_head_store_f32(torch.from_numpy(table[head // 2:head]), row0=head // 2)
         shards.append(s)
     wte = torch.from_numpy(rng.standard_normal((vocab, d)).astype(np.float32)).half().cuda()
     wpe = torch.from_numpy(rng.standard_normal((40, d)).astype(np.float32)).half().cuda()
@@ -805,7 +811,7 @@ def test_row_exchange_between_shards_is_bit_exact(fmt, d, max_n, world):
                 for q in range(world):
                     assert plans[r][0][q] == plans[q][1][r]
             off, ids = full.match_csr(tok)
-            assert sum(sum(p[0]) for p in plans) == ids.numel()       # one record per (token, f-gram) reference
+            assert sum(sum(p[0]) for p in plans) == int((ids >= head).sum())   # one record per reference outside the head
             sends = [s.shard_pack(B, T, world, plans[r][0]) for r, s in enumerate(shards)]
             bper = (B + world - 1) // world
             for q in range(world):

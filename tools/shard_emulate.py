@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--seq", type=int, default=512)
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--check", action="store_true")
+    ap.add_argument("--head", type=int, default=0, help="replicated head: global rows [0, head) kept on every shard")
     a = ap.parse_args()
     N, W, d, B, T = a.rows, a.world, a.dim, a.batch, a.seq
     keys, lens = S.make_keys_structured(N, S.GPT2_VOCAB, 3) if N >= 20_000_000 else S.make_keys(N, S.GPT2_VOCAB, 3, seed=11)
@@ -57,11 +58,14 @@ def main():
         lo, hi = shard_range(N, r, W)
         s = SconeTable(3, N, d, a.format, row_begin=lo, row_end=hi)
         s.index_build(keys, lens)
-        s.fill_synthetic(7, 0.02 / 127)
+        if a.head:
+            s.shard_set_head(a.head)
+        s.fill_synthetic(7, 0.02 / 127)                                  # fills the head as well
         shards.append(s)
     rec = shards[0].shard_record_bytes()
     bper = (B + W - 1) // W
-    res = {"rows": N, "world": W, "format": a.format, "dim": d, "tokens": B * T, "record_bytes": rec, "ranks": []}
+    res = {"rows": N, "world": W, "format": a.format, "dim": d, "tokens": B * T, "record_bytes": rec,
+           "replicated_head_rows": a.head, "ranks": []}
     out = torch.empty(B * T, d, dtype=torch.float16, device="cuda")
     for rep in range(a.reps):
         plans, t_plan = [], []

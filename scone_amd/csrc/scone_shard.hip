@@ -46,18 +46,57 @@ __device__ __forceinline__ int owner_of(long long id, long long n_rows, int worl
   return (int)((((unsigned long long)id + 1ull) * (unsigned long long)world - 1ull) / (unsigned long long)n_rows);
 }
 
-// Counting / claiming use per-workgroup LDS bins and ONE global atomic per bin and workgroup: slices
-// are contiguous token ranges, so a workgroup's references go to one or two destinations, and
-// millions of global atomics on one counter would serialise (~90 atomics per microsecond per address).
+// Counting / claiming.  One thread per TOKEN (its 32/64-B record holds all its references), a persistent grid of at
+// most SHARD_BLOCKS workgroups each owning one contiguous run of tokens, per-workgroup LDS bins filled through a
+// wavefront scan (slices are contiguous token ranges, so a wave's references almost always go to ONE destination:
+// one LDS atomic per wave), and ONE global atomic per bin and WORKGROUP at the end.  A global atomic on one address
+// retires at ~90 per microsecond: the first version (a workgroup per 256 references -> 24.6k workgroups all adding
+// to the same per-destination counter) spent 256 us per kernel on that alone.
+#define SHARD_BLOCKS 1024
+
+// slots for `cnt` items in bin q; returns this lane's first slot (relative to the bin's value before the call)
+__device__ __forceinline__ uint32_t wave_bin_alloc(uint32_t *bins, uint32_t cnt, int q) {
+  const unsigned long long act = __ballot(cnt != 0);
+  if (!act) return 0;
+  const int lane = threadIdx.x & 63;
+  const int leader = __builtin_ctzll(act);
+  const int q0 = __shfl(q, leader, 64);
+  if (__ballot(cnt != 0 && q != q0) == 0ull) {  // one destination for the whole wave: inclusive scan of cnt
+    uint32_t inc = cnt;
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t u = __shfl_up(inc, d, 64);
+      if (lane >= d) inc += u;
+    }
+    const uint32_t total = __shfl(inc, 63, 64);
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(&bins[q0], total);
+    base = __shfl(base, leader, 64);
+    return base + inc - cnt;
+  }
+  return cnt ? atomicAdd(&bins[q], cnt) : 0;  // a wave straddling a slice boundary
+}
+
+// references of token t that this shard sends: entries j < K_full of its keep-position record that hold an id
+__device__ __forceinline__ uint32_t send_mask(const int32_t *__restrict__ ell, long long t, int W, int NC) {
+  const int kfull = ell[t * W + W - 2] >> 8;
+  uint32_t m = 0;
+  for (int j = 0; j < NC; ++j)
+    if (j < kfull && ell[t * W + j] >= 0) m |= 1u << j;
+  return m;
+}
+
 __global__ __launch_bounds__(256) void k_shard_count_send(const int32_t *__restrict__ ell, long long ntok, int W, int NC,
                                                           long long slice_tokens, uint32_t *__restrict__ send_cnt) {
   __shared__ uint32_t bins[64];
   if (threadIdx.x < 64) bins[threadIdx.x] = 0;
   __syncthreads();
-  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long long t = gid / NC;
-  const int j = (int)(gid - t * NC);
-  if (t < ntok && j < (ell[t * W + W - 2] >> 8) && ell[t * W + j] >= 0) atomicAdd(&bins[t / slice_tokens], 1u);
+  const long long per = (ntok + gridDim.x - 1) / gridDim.x;
+  const long long t0 = (long long)blockIdx.x * per, t1 = t0 + per < ntok ? t0 + per : ntok;
+  for (long long base = t0; base < t1; base += blockDim.x) {  // uniform trip count inside the workgroup
+    const long long t = base + threadIdx.x;
+    const uint32_t cnt = t < t1 ? (uint32_t)__popc(send_mask(ell, t, W, NC)) : 0u;
+    wave_bin_alloc(bins, cnt, cnt ? (int)(t / slice_tokens) : 0);
+  }
   __syncthreads();
   if (threadIdx.x < 64 && bins[threadIdx.x]) atomicAdd(&send_cnt[threadIdx.x], bins[threadIdx.x]);
 }
@@ -71,34 +110,47 @@ __global__ __launch_bounds__(256) void k_shard_count_recv(const int32_t *__restr
   const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long t = gid / NC;
   const int j = (int)(gid - t * NC);
-  if (t < ntok && j < (ell[t * W + W - 2] & 0xFF) && ell[t * W + j] >= n_head)  // head rows are local everywhere
-    atomicAdd(&bins[owner_of(ell[t * W + j], n_rows, world)], 1u);
+  const bool need = t < ntok && j < (ell[t * W + W - 2] & 0xFF) && ell[t * W + j] >= n_head;  // head rows are local everywhere
+  if (need) atomicAdd(&bins[owner_of(ell[t * W + j], n_rows, world)], 1u);  // owners are scattered: per-lane atomics
   __syncthreads();
   if (threadIdx.x < 64 && bins[threadIdx.x]) atomicAdd(&recv_cnt[threadIdx.x], bins[threadIdx.x]);
 }
 
-// claim a record number for every (token, list index) I own: position = destination's offset +
-// workgroup's reserved range + index inside the workgroup
+// claim a record number for every (token, list index) I own: position = destination's offset + the workgroup's
+// reserved range (one global atomic per destination and workgroup, after a counting pass over the workgroup's run of
+// tokens) + the slot handed out inside the workgroup
 __global__ __launch_bounds__(256) void k_shard_claim(const int32_t *__restrict__ ell, long long ntok, int W, int NC,
                                                      long long slice_tokens, const unsigned long long *__restrict__ send_off,
                                                      uint32_t *__restrict__ cursor, uint32_t *__restrict__ send_src) {
   __shared__ uint32_t bins[64], base[64];
   if (threadIdx.x < 64) bins[threadIdx.x] = 0;
   __syncthreads();
-  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long long t = gid / NC;
-  const int j = (int)(gid - t * NC);
-  const bool mine = t < ntok && j < (ell[t * W + W - 2] >> 8) && ell[t * W + j] >= 0;
-  const int q = mine ? (int)(t / slice_tokens) : 0;
-  uint32_t local = 0;
-  if (mine) local = atomicAdd(&bins[q], 1u);
+  const long long per = (ntok + gridDim.x - 1) / gridDim.x;
+  const long long t0 = (long long)blockIdx.x * per, t1 = t0 + per < ntok ? t0 + per : ntok;
+  for (long long b0 = t0; b0 < t1; b0 += blockDim.x) {
+    const long long t = b0 + threadIdx.x;
+    const uint32_t cnt = t < t1 ? (uint32_t)__popc(send_mask(ell, t, W, NC)) : 0u;
+    wave_bin_alloc(bins, cnt, cnt ? (int)(t / slice_tokens) : 0);
+  }
   __syncthreads();
-  if (threadIdx.x < 64 && bins[threadIdx.x]) base[threadIdx.x] = atomicAdd(&cursor[threadIdx.x], bins[threadIdx.x]);
+  if (threadIdx.x < 64) {
+    base[threadIdx.x] = bins[threadIdx.x] ? atomicAdd(&cursor[threadIdx.x], bins[threadIdx.x]) : 0u;
+    bins[threadIdx.x] = 0;  // reused as the running offset inside the reserved range
+  }
   __syncthreads();
-  if (!mine) return;
-  const unsigned long long p = send_off[q] + base[q] + local;
-  send_src[2 * p] = (uint32_t)t;
-  send_src[2 * p + 1] = (uint32_t)j;
+  for (long long b0 = t0; b0 < t1; b0 += blockDim.x) {
+    const long long t = b0 + threadIdx.x;
+    uint32_t m = t < t1 ? send_mask(ell, t, W, NC) : 0u;
+    const int q = m ? (int)(t / slice_tokens) : 0;
+    uint32_t slot = wave_bin_alloc(bins, (uint32_t)__popc(m), q);
+    while (m) {
+      const int j = __builtin_ctz(m);
+      m &= m - 1;
+      const unsigned long long p = send_off[q] + base[q] + slot++;
+      send_src[2 * p] = (uint32_t)t;
+      send_src[2 * p + 1] = (uint32_t)j;
+    }
+  }
 }
 
 // one wave per record: row payload + scales + header
@@ -249,7 +301,7 @@ extern "C" int scone_shard_plan(scone_handle *h, const int32_t *d_tok, int32_t B
   const long long send_begin = (long long)h->cfg.row_begin > n_head ? (long long)h->cfg.row_begin : n_head;  // head rows are never sent
   rc = scone_launch_match_ell_ex(h, d_tok, B, T, st->ell_send, send_begin, (long long)h->cfg.row_end, 1, s);
   if (rc) return rc;
-  const unsigned blocks = (unsigned)((ntok * NC + 255) / 256);
+  const unsigned blocks = (unsigned)((ntok + 255) / 256 < SHARD_BLOCKS ? (ntok + 255) / 256 : SHARD_BLOCKS);
   hipLaunchKernelGGL(k_shard_count_send, dim3(blocks), dim3(256), 0, s, st->ell_send, ntok, W, NC, slice_tokens, st->counters);
   // what I need: my slice against every row
   if (my_tokens > 0) {
@@ -286,7 +338,7 @@ extern "C" int scone_shard_pack(scone_handle *h, int32_t B, int32_t T, int32_t w
   if (rc) return rc;
   st->cap_send = cap;
   SCONE_HIP(h, hipMemcpyAsync(st->send_off, off, world * sizeof(unsigned long long), hipMemcpyHostToDevice, s));
-  const unsigned blocks = (unsigned)((ntok * NC + 255) / 256);
+  const unsigned blocks = (unsigned)((ntok + 255) / 256 < SHARD_BLOCKS ? (ntok + 255) / 256 : SHARD_BLOCKS);
   hipLaunchKernelGGL(k_shard_claim, dim3(blocks), dim3(256), 0, s, st->ell_send, ntok, W, NC, slice_tokens, st->send_off,
                      st->counters + 128, st->send_src);
   unsigned pb = (unsigned)((total + 3) / 4);

@@ -993,6 +993,34 @@ def test_config_c4_100m_int4_d1024_at_its_named_size():
     assert np.array_equal(out, R.embed_numpy(rows, ro, inv, "mean").reshape(4, 512, d))
 
 
+def test_config_c4_pinned_host_at_its_named_size():
+    """configs[3] as BASELINE words it: the 100M-row INT4 d=1024 table in PINNED HOST DRAM (52.8 GB mapped into the
+    GPU, 1M hot rows in HBM), read in place (zero-copy) and through the staged prefetch: rows at large offsets equal
+    the host generator and both lookups equal the oracle on recomputed rows, bit for bit."""
+    from scone_amd import EmbeddingCache
+    from scone_amd import synthetic as S
+    n, d = 100_000_000, 1024
+    keys, lens = S.make_keys_structured(n)
+    ex = _extractor(keys, lens, 3)
+    tok = S.stream_uniform_ids(keys, lens, 4, 512, 5)
+    ro, ri = R.hits_to_csr(R.match_hits(keys, lens, tok, 3))
+    uniq, inv = np.unique(ri, return_inverse=True)
+    want = R.embed_numpy(R.dequantize_i4(*R.synth_rows_i4(7, uniq, d, 0.02 / 127)), ro, inv, "mean").reshape(4, 512, d)
+    ids = np.array([0, 999_999, 1_000_000, 2**25 + 3, n // 2, n - 1], dtype=np.int64)
+    for stage_tokens in (0, 1024):
+        try:
+            cache = EmbeddingCache.from_synthetic(ex, d, table_format="int4", seed=7, base_scale=0.02 / 127,
+                                                  placement="pinned_host", hot_rows=1_000_000, stage_tokens=stage_tokens)
+        except MemoryError:
+            pytest.skip("needs 52.8 GB of pinned host memory")
+        got = cache.table.gather_rows(torch.from_numpy(ids)).cpu().numpy()
+        assert np.array_equal(got, R.dequantize_i4(*R.synth_rows_i4(7, ids, d, 0.02 / 127))), stage_tokens
+        out = cache.embed_tokens(torch.from_numpy(tok), out_dtype=torch.float32).cpu().numpy()
+        assert np.array_equal(out, want), stage_tokens
+        del cache
+        torch.cuda.empty_cache()
+
+
 def test_config_c5_shard_rows_at_its_named_size():
     """configs[4]: the last of 8 shards of the 1e9-row INT4 d=1024 table (125M rows = 66 GB on this GPU; the index
     is left empty here): the shard's first, middle and last rows equal the host generator."""

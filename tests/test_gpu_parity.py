@@ -1039,6 +1039,46 @@ def test_config_c5_shard_rows_at_its_named_size():
     assert not bool(z.any()) and t.status() & 2
 
 
+def test_config_c5_last_shard_lookup_at_its_named_size():
+    """configs[4]: the LAST of 8 shards of the 1e9-row INT4 d=1024 table with the full replicated index (2^31 slots,
+    34 GB; ids up to 1e9 - 1).  A stream laid out from f-grams of this shard must match to exactly those ids at their
+    first positions (the index is exact, so any other hit there would be a wrong id), and the shard's partial sums
+    equal the rows recomputed on the host."""
+    from scone_amd import synthetic as S
+    from scone_amd.hip_backend import SconeTable
+    n, d, world = 1_000_000_000, 1024, 8
+    free, _ = torch.cuda.mem_get_info()
+    if free < 120e9:
+        pytest.skip("needs 120 GB of free HBM")
+    import psutil
+    if psutil.virtual_memory().available < 60e9:
+        pytest.skip("needs 60 GB of host memory for the 1e9 keys")
+    keys, lens = S.make_keys_structured(n)
+    lo, hi = (world - 1) * n // world, n
+    t = SconeTable(3, n, d, "int4", row_begin=lo, row_end=hi)
+    t.index_build(keys, lens)
+    assert t.index_stats()[0] == n
+    t.fill_synthetic(7, 0.02 / 127)
+    rng = np.random.default_rng(8)
+    pick = np.concatenate([rng.integers(lo, hi, size=60), [lo, hi - 1, hi - 2]]).astype(np.int64)
+    T = 4                                                        # one f-gram per sequence, padded with a token outside the vocabulary
+    tok = np.full((len(pick), T), S.GPT2_VOCAB + 5, dtype=np.int64)
+    for r, i in enumerate(pick):
+        tok[r, :lens[i]] = keys[i, :lens[i]]
+    hits = t.match(torch.from_numpy(tok)).cpu().numpy()          # [max_n, B, T]
+    for r, i in enumerate(pick):
+        assert hits[lens[i] - 1, r, 0] == i, (r, i)
+    partial, counts = t.embed_partial(torch.from_numpy(tok))
+    partial = partial.cpu().numpy().reshape(len(pick), T, d)
+    rows = R.dequantize_i4(*R.synth_rows_i4(7, pick, d, 0.02 / 127))
+    for r, i in enumerate(pick):
+        # position 0 is covered by f-gram i (owned by this shard) and by f-grams of other shards (unigram, prefixes):
+        # the shard's partial sum there is exactly row i
+        own = [h for h in (hits[0, r, 0], hits[1, r, 0], hits[2, r, 0]) if lo <= h < hi]
+        assert own == [i]
+        assert np.array_equal(partial[r, 0], rows[r]), (r, i)
+
+
 # ------------------------------------------------------------------ callers of the match step
 def test_fgram_tokenizer_and_dataset_ids_match_the_reference(golden_dir, tmp_path):
     """FGramTokenizer.tokenize / batch_tokenize (f_gram_tokenizer.py:38-126) and the f-gram id vector of

@@ -234,7 +234,7 @@ int scone_shard_head_store_f32(scone_handle *h, const float *d_rows_f32, uint64_
  * (records it receives from rank q); synchronises.  world <= 64. */
 int scone_shard_plan(scone_handle *h, const int32_t *d_tok, int32_t B, int32_t T, int32_t world, int32_t rank,
                      uint32_t *h_send_counts, uint32_t *h_recv_counts, scone_stream_t stream);
-/* Writes sum(h_send_counts) records to d_send_buf, grouped by destination in rank order; synchronises. */
+/* Writes sum(h_send_counts) records to d_send_buf, grouped by destination in rank order; stream-ordered. */
 int scone_shard_pack(scone_handle *h, int32_t B, int32_t T, int32_t world, const uint32_t *h_send_counts,
                      void *d_send_buf, scone_stream_t stream);
 /* d_recv_buf: the n_recv records received (any order within a source).  Writes this rank's slice of the output,

@@ -30,7 +30,6 @@ struct scone_shard_state {
   int32_t *ell_send = nullptr;   // [ntok, W] my rows at their index in the full list
   int32_t *ell_slice = nullptr;  // [slice tokens, W] all rows, compacted; remapped in place by embed
   uint32_t *counters = nullptr;  // [3 * 64]: send counts, recv counts, pack cursors
-  unsigned long long *send_off = nullptr;  // [64] record offsets per destination
   uint32_t *send_src = nullptr;  // [total_send] packed (token, list index) per record
   uint32_t *slot_of_ref = nullptr;  // [slice tokens * NC]
   uint8_t *scales = nullptr;     // [n_head + received records] scales: the head's, then the unpacked ones
@@ -119,8 +118,12 @@ __global__ __launch_bounds__(256) void k_shard_count_recv(const int32_t *__restr
 // claim a record number for every (token, list index) I own: position = destination's offset + the workgroup's
 // reserved range (one global atomic per destination and workgroup, after a counting pass over the workgroup's run of
 // tokens) + the slot handed out inside the workgroup
+struct shard_offsets {  // record offset of every destination's run in the send buffer; a kernel ARGUMENT (no copy, no sync)
+  unsigned long long v[64];
+};
+
 __global__ __launch_bounds__(256) void k_shard_claim(const int32_t *__restrict__ ell, long long ntok, int W, int NC,
-                                                     long long slice_tokens, const unsigned long long *__restrict__ send_off,
+                                                     long long slice_tokens, const shard_offsets send_off,
                                                      uint32_t *__restrict__ cursor, uint32_t *__restrict__ send_src) {
   __shared__ uint32_t bins[64], base[64];
   if (threadIdx.x < 64) bins[threadIdx.x] = 0;
@@ -146,7 +149,7 @@ __global__ __launch_bounds__(256) void k_shard_claim(const int32_t *__restrict__
     while (m) {
       const int j = __builtin_ctz(m);
       m &= m - 1;
-      const unsigned long long p = send_off[q] + base[q] + slot++;
+      const unsigned long long p = send_off.v[q] + base[q] + slot++;
       send_src[2 * p] = (uint32_t)t;
       send_src[2 * p + 1] = (uint32_t)j;
     }
@@ -232,7 +235,7 @@ int grow(scone_handle *h, T **p, long long *cap, long long need, size_t elems_pe
 void scone_shard_destroy(scone_handle *h) {
   scone_shard_state *st = h->shard;
   if (!st) return;
-  void *ptrs[] = {st->ell_send, st->ell_slice, st->counters, st->send_off, st->send_src, st->slot_of_ref, st->scales,
+  void *ptrs[] = {st->ell_send, st->ell_slice, st->counters, st->send_src, st->slot_of_ref, st->scales,
                   st->head_rows, st->head_scales};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
@@ -290,7 +293,6 @@ extern "C" int scone_shard_plan(scone_handle *h, const int32_t *d_tok, int32_t B
   if (rc) return rc;
   st->cap_slice = cs;
   if (!st->counters) SCONE_HIP(h, hipMalloc(&st->counters, 3 * 64 * sizeof(uint32_t)));
-  if (!st->send_off) SCONE_HIP(h, hipMalloc(&st->send_off, 64 * sizeof(unsigned long long)));
   SCONE_HIP(h, hipMemsetAsync(st->counters, 0, 3 * 64 * sizeof(uint32_t), s));
   for (int q = 0; q < world; ++q) h_send_counts[q] = h_recv_counts[q] = 0;
   if (ntok == 0) return SCONE_OK;
@@ -329,17 +331,17 @@ extern "C" int scone_shard_pack(scone_handle *h, int32_t B, int32_t T, int32_t w
   const int W = SCONE_ELL_W(h->cfg.max_n), NC = h->cfg.max_n * (h->cfg.max_n + 1) / 2;
   const int32_t bper = (B + world - 1) / world;
   const long long ntok = (long long)B * T, slice_tokens = (long long)bper * T;
-  unsigned long long off[64], total = 0;
-  for (int q = 0; q < world; ++q) off[q] = total, total += h_send_counts[q];
+  shard_offsets off = {};
+  unsigned long long total = 0;
+  for (int q = 0; q < world; ++q) off.v[q] = total, total += h_send_counts[q];
   if (total == 0) return SCONE_OK;
   if (!d_send_buf) return scone_fail(h, SCONE_EINVAL, "scone_shard_pack: null send buffer");
   long long cap = st->cap_send;
   int rc = grow(h, &st->send_src, &cap, (long long)total, 2);
   if (rc) return rc;
   st->cap_send = cap;
-  SCONE_HIP(h, hipMemcpyAsync(st->send_off, off, world * sizeof(unsigned long long), hipMemcpyHostToDevice, s));
   const unsigned blocks = (unsigned)((ntok + 255) / 256 < SHARD_BLOCKS ? (ntok + 255) / 256 : SHARD_BLOCKS);
-  hipLaunchKernelGGL(k_shard_claim, dim3(blocks), dim3(256), 0, s, st->ell_send, ntok, W, NC, slice_tokens, st->send_off,
+  hipLaunchKernelGGL(k_shard_claim, dim3(blocks), dim3(256), 0, s, st->ell_send, ntok, W, NC, slice_tokens, off,
                      st->counters + 128, st->send_src);
   unsigned pb = (unsigned)((total + 3) / 4);
   if (pb > 4096) pb = 4096;
@@ -347,7 +349,6 @@ extern "C" int scone_shard_pack(scone_handle *h, int32_t B, int32_t T, int32_t w
                      scone_store_of(h), (long long)h->cfg.row_begin, (const uint8_t *)h->scales, (int)h->scale_bytes_per_row,
                      scone_shard_rec_bytes(h), (uint8_t *)d_send_buf);
   SCONE_HIP(h, hipGetLastError());
-  SCONE_HIP(h, hipStreamSynchronize(s));  // `off` lives on this stack frame
   return SCONE_OK;
 }
 

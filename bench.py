@@ -56,6 +56,9 @@ def parse():
                     help="sharded mode: all-to-all of quantised rows (default) or reduce-scatter of fp32 partial sums")
     ap.add_argument("--replicated-rows", type=int, default=50257,
                     help="sharded mode: head of the table kept on every rank (default: the unigram rows)")
+    ap.add_argument("--no-gather-output", action="store_true",
+                    help="sharded mode: stop after every rank has finished its own slice of the batch (a consumer that is "
+                         "data-parallel over the same slices needs no all-gather of the [B, T, d] output)")
     ap.add_argument("--shard-of", default="", help="R/W: build only shard R of a W-way row-sharded table on this one GPU "
                     "and time its local work (partial sums + finalise of its 1/W token slice); no exchange -- "
                     "capacity / kernel check for tables that need W GPUs (C5)")
@@ -248,7 +251,7 @@ def main():
             table.finalize(partial[a0:b0], counts[a0:b0], tok, a0, b0, wte=wte, wpe=wpe, out_dtype=torch.float16,
                            out=out.view(-1, d)[a0:b0])
         elif sharded:
-            cache.embed_tokens(tok, wte=wte, wpe=wpe, exchange=args.exchange)
+            cache.embed_tokens(tok, wte=wte, wpe=wpe, exchange=args.exchange, gather_output=not args.no_gather_output)
         else:
             cache.embed_tokens(tok, wte=wte, wpe=wpe, out=out)
 
@@ -301,8 +304,10 @@ def main():
                             f"{B}x{T} tokens/step/rank; fused match+gather+dequant+mean+wte+wpe, fp16 out",
                 "tokens_per_step_per_rank": ntok, "mean_hits_per_token": sum_k / ntok, "hits_histogram_K0_6": k_hist[:7],
                 "parallelism": (f"shard {args.shard_of} of a row-sharded table, local work only (no exchange)" if emu else
-                                ("row-sharded table, RCCL all-to-all of quantised rows + all-gather" if args.exchange == "rows" else
-                                 "row-sharded table, RCCL reduce-scatter of fp32 partial sums + all-gather") if sharded
+                                (("row-sharded table, RCCL all-to-all of quantised rows" if args.exchange == "rows" else
+                                  "row-sharded table, RCCL reduce-scatter of fp32 partial sums")
+                                 + (", every rank keeps its slice" if args.no_gather_output else " + all-gather of the output")
+                                 + f", replicated head {args.replicated_rows} rows") if sharded
                                 else f"replicated table, tokens sharded over {world} rank(s), no collective"),
             },
             "roofline": {

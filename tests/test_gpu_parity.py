@@ -1131,3 +1131,41 @@ def test_fgram_tokenizer_and_dataset_ids_match_the_reference(golden_dir, tmp_pat
     back = FGramTokenizer.from_pretrained(str(tmp_path / "ft"), base_tokenizer=StubTokenizer())
     assert back.n_gram_extractor.f_gram_to_id == f2id
     assert back.tokenize(texts[0])["token_f_grams"] == ft.tokenize(texts[0])["token_f_grams"]
+
+
+def test_interleaved_handles_streams_and_growing_batches():
+    """Two handles on two HIP streams, batch sizes that grow and shrink (workspaces are re-allocated on the way), fused
+    small-batch and two-kernel paths interleaved with match_csr and get_token_embeddings: every result equals the
+    result of the same call made alone."""
+    rng = np.random.default_rng(123)
+    vocab, d = 41, 768
+    caches, refs = [], []
+    for seed, fmt, max_n in ((1, "int8", 3), (2, "fp16", 4)):
+        r = np.random.default_rng(seed)
+        n = 900
+        lens = r.integers(1, max_n + 1, size=n).astype(np.uint8)
+        keys = r.integers(0, vocab, size=(n, max_n)).astype(np.uint32)
+        keys[np.arange(max_n)[None, :] >= lens[:, None]] = 0
+        table = r.standard_normal((n, d)).astype(np.float32)
+        caches.append(_cache(keys, lens, max_n, table, fmt))
+    wte = torch.from_numpy(rng.standard_normal((vocab, d)).astype(np.float32)).half().cuda()
+    wpe = torch.from_numpy(rng.standard_normal((64, d)).astype(np.float32)).half().cuda()
+    shapes = [(1, 5), (3, 64), (70, 64), (2, 9), (300, 64), (1, 1), (40, 64), (8, 3), (500, 64), (2, 64)]
+    toks = [torch.from_numpy(rng.integers(0, vocab, size=s)).to("cuda", torch.int32) for s in shapes]
+    alone = [[c.embed_tokens(t, wte=wte, wpe=wpe).clone() for t in toks] for c in caches]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    for rep in range(3):
+        outs = [[None] * len(toks) for _ in caches]
+        for k in rng.permutation(len(toks)):
+            for ci, c in enumerate(caches):
+                with torch.cuda.stream(streams[ci]):
+                    outs[ci][k] = c.embed_tokens(toks[k], wte=wte, wpe=wpe)
+                    if k % 3 == 0:
+                        c.match(toks[k])                             # uses the same handle's workspaces in between
+            if k % 4 == 1:
+                caches[0].get_token_embeddings(toks[k][0].tolist())
+        torch.cuda.synchronize()
+        for ci in range(len(caches)):
+            for k in range(len(toks)):
+                assert torch.equal(outs[ci][k], alone[ci][k]), (rep, ci, k)

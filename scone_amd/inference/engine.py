@@ -14,7 +14,9 @@ reference does around the lookup path:
 * with the paper's causal lookup (``lookup_mode="longest_suffix"``) decoding is incremental: a new
   token only needs its own embedding (computed from the last ``max_n`` tokens) and the KV cache.
   With the reference code's covering lookup (``"cover"``) a new token changes the f-gram sets of
-  the ``max_n - 1`` positions before it, so the prefix is re-embedded every step (exact, O(T^2)).
+  the ``max_n - 1`` positions before it: the KV cache is rolled back over those positions and the last
+  ``max_n`` positions are recomputed from a lookup over the last ``2 max_n - 1`` tokens (O(1) positions per
+  step; the reference would re-run everything).
 
 The transformer itself is any HF-style causal LM (``.transformer``, ``.lm_head``); tokenisation is
 delegated to the tokenizer object the caller passes (``encode`` / ``decode``).
@@ -97,12 +99,25 @@ class SconeInferenceEngine:
                 x = self.embed(tail, position_ids=pos)[:, -1:, :]
                 out = self.base.transformer(inputs_embeds=x, past_key_values=past, position_ids=pos[:, -1:],
                                             use_cache=True, return_dict=True)
+            elif past is not None and hasattr(past, "crop"):
+                # covering lookup (the reference code): the new token joins f-grams that also cover the max_n - 1
+                # positions before it, so THEIR input embeddings change -- roll the KV cache back over them and
+                # recompute the last max_n positions; every f-gram covering one of those lies inside the last
+                # 2 max_n - 1 tokens, so that window is all the lookup needs.  O(1) positions per step instead of T.
+                redo = min(self.max_n, T)
+                if redo > 1:
+                    past.crop(-(redo - 1))
+                win = min(T, 2 * self.max_n - 1)
+                pos = torch.arange(T - win, T, device=self.device).unsqueeze(0).expand(B, -1)
+                x = self.embed(ids[:, -win:], position_ids=pos)[:, -redo:, :]
+                out = self.base.transformer(inputs_embeds=x, past_key_values=past, position_ids=pos[:, -redo:],
+                                            use_cache=True, return_dict=True)
             else:
                 pos = torch.arange(T, device=self.device).unsqueeze(0).expand(B, -1)
                 x = self.embed(ids, position_ids=pos)
                 # the same call SconeLanguageModel.forward makes (language_model.py:257-264)
-                out = self.base.transformer(inputs_embeds=x, position_ids=pos, use_cache=self.causal, return_dict=True)
-            past = out.past_key_values if self.causal else None
+                out = self.base.transformer(inputs_embeds=x, position_ids=pos, use_cache=True, return_dict=True)
+            past = out.past_key_values
             logits = self.base.lm_head(out.last_hidden_state[:, -1, :]).float()
             if eos_token_id is not None and T < min_length:
                 logits[:, eos_token_id] = -float("inf")

@@ -296,6 +296,12 @@ def make_callers(NGramExtractor):
         out[f"ds{max_length}_input_ids"] = np.stack([it["input_ids"].numpy() for it in items])
         out[f"ds{max_length}_f_gram_ids"] = np.stack([it["f_gram_ids"].numpy() for it in items])
         out[f"ds{max_length}_f_gram_mask"] = np.stack([it["f_gram_attention_mask"].numpy() for it in items])
+    # extract_f_grams (scone/data/preprocessing.py:12-50): tokenise + fit, driven with the same stub
+    from scone.data.preprocessing import extract_f_grams
+    xf = extract_f_grams(corpus_texts, tok, max_n=3, min_freq=3, max_f_grams=250, verbose=False)
+    out["xf_texts"] = np.asarray(corpus_texts)
+    out["xf_keys"], out["xf_lens"] = keys_arrays(xf.f_gram_to_id, 3)
+    out["xf_args"] = np.asarray([3, 3, 250], dtype=np.int64)
     np.savez_compressed(os.path.join(HERE, "callers.npz"), **out)
     print("callers.npz:", len(texts), "texts,", len(lens), "f-grams")
 

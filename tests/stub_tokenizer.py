@@ -21,7 +21,7 @@ class StubTokenizer:
     def encode(self, text):
         return self._ids(text)
 
-    def __call__(self, text, max_length=None, padding=False, truncation=False, return_tensors=None):
+    def __call__(self, text, max_length=None, padding=False, truncation=False, return_tensors=None, add_special_tokens=True):
         single = isinstance(text, str)
         seqs = [self._ids(t) for t in ([text] if single else text)]
         if truncation and max_length is not None:
@@ -38,6 +38,8 @@ class StubTokenizer:
         if width is not None:
             mask = [m + [0] * (width - len(m)) for m in mask]
             seqs = [s + [self.pad_token_id] * (width - len(s)) for s in seqs]
+        if return_tensors is None:          # HF returns plain lists (flat for a single text) without return_tensors
+            return {"input_ids": seqs[0] if single else seqs, "attention_mask": mask[0] if single else mask}
         return {"input_ids": torch.tensor(seqs, dtype=torch.long), "attention_mask": torch.tensor(mask, dtype=torch.long)}
 
     def save_pretrained(self, directory):

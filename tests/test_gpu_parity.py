@@ -1126,6 +1126,13 @@ def test_fgram_tokenizer_and_dataset_ids_match_the_reference(golden_dir, tmp_pat
             got_ids, got_mask = ft.flat_f_gram_ids(ids.tolist(), max_length=max_length)
             assert np.array_equal(got_ids.numpy(), z[f"ds{max_length}_f_gram_ids"][i])
             assert np.array_equal(got_mask.numpy(), z[f"ds{max_length}_f_gram_mask"][i])
+    # extract_f_grams (preprocessing.py:12-50): tokenise + fit on the GPU, same f-grams and ids as the reference
+    from scone_amd.data import extract_f_grams
+    max_n, min_freq, max_f = (int(x) for x in z["xf_args"])
+    xf = extract_f_grams([str(t) for t in z["xf_texts"]], StubTokenizer(), max_n=max_n, min_freq=min_freq,
+                         max_f_grams=max_f, verbose=False)
+    k2, l2 = xf.key_arrays()
+    assert np.array_equal(l2, z["xf_lens"]) and np.array_equal(k2, z["xf_keys"])
     # save_pretrained / from_pretrained round trip (n_gram_extractor.npy in the reference's format)
     ft.save_pretrained(str(tmp_path / "ft"))
     back = FGramTokenizer.from_pretrained(str(tmp_path / "ft"), base_tokenizer=StubTokenizer())

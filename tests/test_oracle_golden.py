@@ -207,3 +207,21 @@ def test_callers_fixture_is_reproduced_by_the_oracle(golden_dir):
             want[:min(10, len(flat))] = flat[:10]
             assert np.array_equal(want, z[f"ds{max_length}_f_gram_ids"][i])
             assert int(z[f"ds{max_length}_f_gram_mask"][i].sum()) == min(10, len(flat))
+
+
+def test_extract_f_grams_fixture_is_reproduced_by_the_oracle(golden_dir):
+    """extract_f_grams (preprocessing.py:12-50) captured from the reference with the stub tokenizer: the oracle's fit
+    on the stub's token ids gives the same f-grams in the same id order, and so does the product's host fit."""
+    import sys
+    sys.path.insert(0, os.path.dirname(golden_dir))
+    from stub_tokenizer import StubTokenizer
+    from scone_amd.data import extract_f_grams
+    z = _load(golden_dir, "callers.npz")
+    max_n, min_freq, max_f = (int(x) for x in z["xf_args"])
+    tok = StubTokenizer()
+    texts = [str(t) for t in z["xf_texts"]]
+    grams = R.fit([tok(t, add_special_tokens=False)["input_ids"] for t in texts], max_n, min_freq, max_f)
+    want = [tuple(int(x) for x in z["xf_keys"][i, :z["xf_lens"][i]]) for i in range(len(z["xf_lens"]))]
+    assert grams == want
+    ex = extract_f_grams(texts, tok, max_n=max_n, min_freq=min_freq, max_f_grams=max_f, verbose=False, use_gpu=False)
+    assert [ex.id_to_f_gram[i] for i in range(len(want))] == want

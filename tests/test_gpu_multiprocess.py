@@ -98,7 +98,7 @@ def test_sharded_cache_across_processes_on_one_gpu(fmt, d, max_n, world, exchang
             assert err < 1e-3, (rank, err)          # fp32 partial sums are added in shard order, not list order
 
 
-@pytest.mark.parametrize("mode", ["replicated", "sharded"])
+@pytest.mark.parametrize("mode", ["replicated", "sharded", "sharded-slices"])
 def test_bench_two_ranks_launched_like_the_driver(mode):
     """`python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2` with the rehearsal knobs
     (gloo, both ranks on device 0): one JSON line, n_gpus 2, value = tokens of BOTH ranks / max time."""
@@ -107,7 +107,9 @@ def test_bench_two_ranks_launched_like_the_driver(mode):
     env = dict(os.environ, SCONE_DIST_BACKEND="gloo", SCONE_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
-           "--gpus", "2", "--steps", "5", "--warmup", "2", "--rows", "200000", "--batch", "256", "--table-mode", mode]
+           "--gpus", "2", "--steps", "5", "--warmup", "2", "--rows", "200000", "--batch", "256", "--table-mode", mode.split("-")[0]]
+    if mode == "sharded-slices":
+        cmd.append("--no-gather-output")
     p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]

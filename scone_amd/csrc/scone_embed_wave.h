@@ -109,6 +109,15 @@ template <int FMT, int D> struct wave_geom {
 #ifndef SCONE_WAVE_SLACK
 #define SCONE_WAVE_SLACK 14
 #endif
+// Rows at or beyond this (local) row number are fetched with streaming ("nt") loads: f-gram ids are frequency-ordered
+// (Counter.most_common), so the head of the table -- every GPT-2 unigram and the hottest f-grams -- is what far-apart
+// tokens re-reference and what is worth keeping in the 4 MB L2 next to the hot wte rows; a row of the tail is shared by
+// the 2-3 adjacent tokens it covers (still an L2 hit: they are in flight together) and then dead.  Measured, gather
+// kernel, alternating runs on one box: S_uniform 0.690 -> 0.681 ms (thresholds 4K / 64K / 256K: 0.681 / 0.681 / 0.677),
+// Zipf stream 0.584 -> 0.569 ms; streaming loads for EVERY row: 0.69 -> 0.75 ms (the unigram rows are evicted too).
+#ifndef SCONE_NT_FROM_ROW
+#define SCONE_NT_FROM_ROW 65536
+#endif
 #ifndef SCONE_WAVE_BLOCKS
 #define SCONE_WAVE_BLOCKS 4096  // ~256 CUs x 8 resident workgroups x 2 rounds
 #endif
@@ -200,7 +209,8 @@ __device__ __forceinline__ void embed_token(const scone_row_store &rows, const v
       const uint32_t *p = reinterpret_cast<const uint32_t *>(rp + G::seg_first(s) / 4 * G::BPE4 +
                                                               lane * (uint32_t)(G::seg_elems(s) * G::BPE4 / 4));
 #pragma unroll
-      for (int i = 0; i < G::seg_row_words(s); ++i) raw[k][G::seg_row_word0(s) + i] = p[i];
+      for (int i = 0; i < G::seg_row_words(s); ++i)  // wave-uniform choice between a plain and a streaming load
+        raw[k][G::seg_row_word0(s) + i] = lr >= SCONE_NT_FROM_ROW ? __builtin_nontemporal_load(p + i) : p[i];
       if constexpr (FMT == SCONE_FMT_I8) {
         scw[k][s] = s == 0 ? reinterpret_cast<const uint32_t *>(scales_v)[lr >> 1] : 0u;  // two half scales per word (scalar load)
       } else if constexpr (FMT == SCONE_FMT_I4) {

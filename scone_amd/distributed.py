@@ -148,6 +148,10 @@ class ShardedEmbeddingCache:
         ntok, d, W = B * T, self.embedding_dim, self.world
         if out_dtype is None:
             out_dtype = wte.dtype if wte is not None else (wpe.dtype if wpe is not None else torch.float32)
+        if W == 1 and exchange == "rows" and hasattr(self.table, "embed"):
+            # one shard owns every row: the plain fused lookup, nothing to exchange
+            out = self.table.embed(tok, wte=wte, wpe=wpe, position_ids=position_ids, reduce=reduce, out_dtype=out_dtype)
+            return out if gather_output else out.reshape(ntok, d)
         if exchange == "rows":
             return self._embed_row_exchange(tok, reduce, wte, wpe, position_ids, out_dtype, gather_output)
         if exchange != "partial_sums":

@@ -841,7 +841,8 @@ def test_sharded_cache_world1_row_exchange():
     wte = torch.from_numpy(rng.standard_normal((vocab, d)).astype(np.float32)).half().cuda()
     wpe = torch.from_numpy(rng.standard_normal((41, d)).astype(np.float32)).half().cuda()
     a = plain.embed_tokens(tok, wte=wte, wpe=wpe)
-    assert torch.equal(a, sharded.embed_tokens(tok, wte=wte, wpe=wpe, exchange="rows"))
+    assert torch.equal(a, sharded.embed_tokens(tok, wte=wte, wpe=wpe, exchange="rows"))      # one shard: plain lookup
+    assert torch.equal(a, sharded._embed_row_exchange(tok, "mean", wte, wpe, None, torch.float16, True))   # plan/pack/embed with itself
     assert torch.equal(a, sharded.embed_tokens(tok, wte=wte, wpe=wpe, exchange="partial_sums"))
 
 

@@ -20,7 +20,7 @@
 using namespace scone_gather;
 
 #ifndef SCONE_FUSED_MAX_TOKENS
-#define SCONE_FUSED_MAX_TOKENS 2048  // above this the two-kernel form (one probe per window, not per covered token) wins
+#define SCONE_FUSED_MAX_TOKENS 32768  // measured crossover (tools/latency.py): 8K tokens 15.5 -> 9.9 us, 16K 20.5 -> 16.8, 32K 30.2 -> 29.3, 64K 45.7 -> 53.7 (two-kernel form wins: one probe per window, not per covered token)
 #endif
 
 namespace {

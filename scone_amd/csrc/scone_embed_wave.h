@@ -507,6 +507,13 @@ int try_launch_fused(scone_handle *h, const embed_args &a, hipStream_t s) {
       return SCONE_OK;
     }
   }
+  if constexpr (wave_geom<FMT, 1280>::OK) {  // gpt2-large (configs/large_config.yaml:16)
+    if (a.tv.d == 1280) {
+      if (a.max_n <= 3) SCONE_FUSED(1280, 3); else SCONE_FUSED(1280, 4);
+      SCONE_HIP(h, hipGetLastError());
+      return SCONE_OK;
+    }
+  }
 #undef SCONE_FUSED
   return -1;
 }

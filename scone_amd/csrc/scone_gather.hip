@@ -166,8 +166,10 @@ extern "C" int scone_embed(scone_handle *h, const int32_t *d_tok, int32_t B, int
     return embed_staged(h, a, B, T, out_dtype, s);
   }
   // decode-size batches are launch-bound: one fused launch (k_embed_fused) instead of match + gather
-  if (BT <= SCONE_FUSED_MAX_TOKENS && h->cfg.lookup_mode == SCONE_MODE_COVER && (h->cfg.dim == 768 || h->cfg.dim == 1024) &&
-      !(h->cfg.table_fmt == SCONE_FMT_I4 && h->cfg.dim == 768)) {
+  // (INT4 has no specialised kernel at d = 768 / 1280: a row segment would be narrower than one 16-B access)
+  if (BT <= SCONE_FUSED_MAX_TOKENS && h->cfg.lookup_mode == SCONE_MODE_COVER &&
+      (h->cfg.dim == 768 || h->cfg.dim == 1024 || h->cfg.dim == 1280) &&
+      !(h->cfg.table_fmt == SCONE_FMT_I4 && h->cfg.dim != 1024)) {
     a.fused = 1;
     rc = scone_prof_begin(h, s);
     if (rc) return rc;

@@ -425,7 +425,9 @@ __global__ __launch_bounds__(256) void k_embed_fused(const scone_row_store rows,
   if ((int)lane < NC) {
     int n, s;
     cand_ns((int)lane, n, s);
-    if (n <= q.max_n && i - s >= 0 && i - s + n <= q.T) {
+    // the paper's lookup only asks for windows that END at this token (s = n - 1) and have n >= 2
+    const bool wanted = q.mode == SCONE_MODE_COVER || (s == n - 1 && n >= 2);
+    if (wanted && n <= q.max_n && i - s >= 0 && i - s + n <= q.T) {
       uint32_t k[SCONE_MAX_N] = {0u, 0u, 0u, 0u};
       bool ok = true;
 #pragma unroll
@@ -439,7 +441,12 @@ __global__ __launch_bounds__(256) void k_embed_fused(const scone_row_store rows,
       if (ok) my_id = scone_lookup_key(ix, k, n);
     }
   }
-  const unsigned long long hit = __ballot(my_id >= 0);
+  unsigned long long hit = __ballot(my_id >= 0);
+  if (q.mode == SCONE_MODE_LONGEST_SUFFIX && hit) {
+    // Algorithm 2: the LONGEST f-gram ending here.  Candidates are ordered n ascending, so it is the highest hit lane.
+    hit = 1ull << (63 - __builtin_clzll(hit));
+    if (!((hit >> lane) & 1ull)) my_id = -1;
+  }
   unsigned long long own = __ballot(my_id >= 0 && (long long)my_id >= q.row_begin && (long long)my_id < q.row_end);
   const int kfull = __popcll(hit), kown = __popcll(own);
   int32_t rec[NC];
@@ -458,7 +465,9 @@ __global__ __launch_bounds__(256) void k_embed_fused(const scone_row_store rows,
   if ((wte && !tok_ok) || (wpe && !pos_ok)) {
     if (lane == 0) atomicOr(status, SCONE_ST_BAD_TOKEN);
   }
-  const uint8_t *wte_row = tok_ok ? reinterpret_cast<const uint8_t *>(wte + (long long)tokv * D) : zero_row;
+  // paper mode: a matched f-gram REPLACES the token embedding (Algorithm 2), so wte is skipped
+  const bool use_wte = tok_ok && !(q.mode == SCONE_MODE_LONGEST_SUFFIX && kfull > 0);
+  const uint8_t *wte_row = use_wte ? reinterpret_cast<const uint8_t *>(wte + (long long)tokv * D) : zero_row;
   const uint8_t *wpe_row = pos_ok ? reinterpret_cast<const uint8_t *>(wpe + (long long)posv * D) : zero_row;
   uint8_t *out_row = reinterpret_cast<uint8_t *>(out + p * D);
   uint32_t wpe_words[NWO];
@@ -481,7 +490,7 @@ __global__ __launch_bounds__(256) void k_embed_fused(const scone_row_store rows,
 // returns -1 if the fused kernel does not apply
 template <int FMT, typename OutT>
 int try_launch_fused(scone_handle *h, const embed_args &a, hipStream_t s) {
-  if (a.mode != SCONE_MODE_COVER || a.partial) return -1;
+  if (a.partial) return -1;
   wave_params q = {};
   q.BT = a.BT, q.T = a.T, q.max_n = a.max_n;
   q.row_begin = a.tv.row_begin, q.row_end = a.tv.row_end;

@@ -167,7 +167,7 @@ extern "C" int scone_embed(scone_handle *h, const int32_t *d_tok, int32_t B, int
   }
   // decode-size batches are launch-bound: one fused launch (k_embed_fused) instead of match + gather
   // (INT4 has no specialised kernel at d = 768 / 1280: a row segment would be narrower than one 16-B access)
-  if (BT <= SCONE_FUSED_MAX_TOKENS && h->cfg.lookup_mode == SCONE_MODE_COVER &&
+  if (BT <= SCONE_FUSED_MAX_TOKENS &&
       (h->cfg.dim == 768 || h->cfg.dim == 1024 || h->cfg.dim == 1280) &&
       !(h->cfg.table_fmt == SCONE_FMT_I4 && h->cfg.dim != 1024)) {
     a.fused = 1;

@@ -2,6 +2,7 @@
 #include "scone_common.h"
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -171,6 +172,11 @@ extern "C" int scone_create(const scone_cfg *cfg, scone_handle **out) {
     int cus = 0;
     CREATE_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device));
     h->n_cus = cus > 0 ? cus : 256;
+  }
+  {  // one-launch limit: default = the measured crossover; the environment can move it (tests run both forms, A/B runs)
+    h->fused_max_tokens = 32768;
+    const char *ev = getenv("SCONE_FUSED_MAX_TOKENS");
+    if (ev && *ev) h->fused_max_tokens = atoll(ev);
   }
   CREATE_HIP(hipMalloc(&h->slots, cap * sizeof(scone_slot)));
   CREATE_HIP(hipMemset(h->slots, 0, cap * sizeof(scone_slot)));

@@ -121,6 +121,7 @@ struct scone_handle {
   scone_cfg cfg;
   int device;
   int n_cus;  // compute units of the device (256 on MI355X)
+  long long fused_max_tokens;  // batches up to this many tokens take the one-launch kernel (env SCONE_FUSED_MAX_TOKENS overrides)
   // index
   scone_slot *slots;
   uint64_t cap;  // power of two

@@ -19,9 +19,9 @@
 
 using namespace scone_gather;
 
-#ifndef SCONE_FUSED_MAX_TOKENS
-#define SCONE_FUSED_MAX_TOKENS 32768  // measured crossover (tools/latency.py): 8K tokens 15.5 -> 9.9 us, 16K 20.5 -> 16.8, 32K 30.2 -> 29.3, 64K 45.7 -> 53.7 (two-kernel form wins: one probe per window, not per covered token)
-#endif
+// One-launch limit (scone_handle::fused_max_tokens, default 32768): measured crossover (tools/latency.py) -- 8K tokens
+// 15.5 -> 9.9 us, 16K 20.5 -> 16.8, 32K 30.2 -> 29.3, 64K 45.7 -> 53.7: above it the two-kernel form wins (one probe per
+// window, not per covered token).
 
 namespace {
 
@@ -167,7 +167,7 @@ extern "C" int scone_embed(scone_handle *h, const int32_t *d_tok, int32_t B, int
   }
   // decode-size batches are launch-bound: one fused launch (k_embed_fused) instead of match + gather
   // (INT4 has no specialised kernel at d = 768 / 1280: a row segment would be narrower than one 16-B access)
-  if (BT <= SCONE_FUSED_MAX_TOKENS &&
+  if (BT <= h->fused_max_tokens &&
       (h->cfg.dim == 768 || h->cfg.dim == 1024 || h->cfg.dim == 1280) &&
       !(h->cfg.table_fmt == SCONE_FMT_I4 && h->cfg.dim != 1024)) {
     a.fused = 1;

@@ -27,6 +27,18 @@ def _need_gpu():
     _lib.lib()          # fail loudly if the extension is missing
 
 
+@pytest.fixture(params=["one_launch", "two_kernels"])
+def lookup_form(request, monkeypatch):
+    """Both forms of the fused lookup on the same inputs: batches up to 32768 tokens normally take the one-launch kernel
+    (k_embed_fused); SCONE_FUSED_MAX_TOKENS=0 (read when a handle is created) sends every batch through
+    k_match_ell + k_embed_wave."""
+    if request.param == "two_kernels":
+        monkeypatch.setenv("SCONE_FUSED_MAX_TOKENS", "0")
+    else:
+        monkeypatch.delenv("SCONE_FUSED_MAX_TOKENS", raising=False)
+    return request.param
+
+
 def _extractor(keys, lens, max_n):
     from scone_amd import NGramExtractor
     return NGramExtractor.from_arrays(keys, lens, max_n=max_n)
@@ -187,7 +199,7 @@ def test_missing_rows_and_bad_ids_raise(golden_dir):
 @pytest.mark.parametrize("fmt", ["fp32", "fp16", "int8", "int4"])
 @pytest.mark.parametrize("d", [128, 768, 1024])
 @pytest.mark.parametrize("max_n", [3, 4])
-def test_embed_formats_vs_oracle(fmt, d, max_n):
+def test_embed_formats_vs_oracle(fmt, d, max_n, lookup_form):
     """Quantise on the GPU, read the dequantised table back, run the oracle on it."""
     rng = np.random.default_rng(sum(map(ord, fmt)) * 10007 + d * 13 + max_n)
     vocab, n = 31, 900
@@ -223,7 +235,7 @@ def test_embed_formats_vs_oracle(fmt, d, max_n):
 
 # ------------------------------------------------------------------ a7: combine
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
-def test_fused_combine_vs_oracle(dtype):
+def test_fused_combine_vs_oracle(dtype, lookup_form):
     rng = np.random.default_rng(77)
     vocab, n, d, max_n, B, T = 50, 700, 768, 3, 3, 40
     lens = rng.integers(1, max_n + 1, size=n).astype(np.uint8)
@@ -290,7 +302,7 @@ def test_scone_embedding_module_paths(golden_dir):
 
 
 # ------------------------------------------------------------------ edge cases
-def test_empty_and_short_inputs():
+def test_empty_and_short_inputs(lookup_form):
     rng = np.random.default_rng(1)
     keys = np.array([[1, 0, 0], [1, 2, 0], [1, 2, 3]], dtype=np.uint32)
     lens = np.array([1, 2, 3], dtype=np.uint8)
@@ -315,7 +327,7 @@ def test_empty_and_short_inputs():
     assert (off[3] - off[2]).item() == 6 and ids[off[2]:off[3]].cpu().tolist() == [0, 1, 1, 2, 2, 2]
 
 
-def test_results_independent_of_batch_shape():
+def test_results_independent_of_batch_shape(lookup_form):
     """Idempotence / shape independence: the same sequence gives identical bits alone or inside a batch."""
     rng = np.random.default_rng(2)
     vocab, n, d = 17, 400, 256
@@ -512,7 +524,7 @@ def test_pinned_host_placement_matches_hbm(fmt, hot_rows):
                                          ("fp32", 1024, 3), ("int8", 768, 4), ("int8", 1280, 4), ("fp16", 1280, 3),
                                          ("int4", 1280, 3), ("int8", 2048, 3), ("fp16", 4096, 4), ("int4", 2048, 3),
                                          ("fp32", 136, 3), ("int8", 48, 4), ("fp32", 100, 2)])
-def test_wave_kernel_shape_sweep(fmt, d, max_n):
+def test_wave_kernel_shape_sweep(fmt, d, max_n, lookup_form):
     """Every (B, T) geometry of the wave kernel -- T not a multiple of 4, T < max_n, one sequence, many short
     sequences, explicit and default position ids, all output dtypes -- bit-exact in fp32 against the oracle."""
     rng = np.random.default_rng(1000 + d + max_n)
@@ -605,7 +617,7 @@ def test_fit_gpu_large_corpus_vs_host_fit():
 
 # ------------------------------------------------------------------ the paper's lookup
 @pytest.mark.parametrize("fmt,d,max_n", [("fp32", 768, 3), ("int8", 1024, 4), ("int8", 768, 2)])
-def test_paper_mode_longest_suffix_vs_oracle(fmt, d, max_n):
+def test_paper_mode_longest_suffix_vs_oracle(fmt, d, max_n, lookup_form):
     """lookup_mode='longest_suffix' (paper, Algorithm 2): the longest f-gram of length >= 2 ending at the token
     replaces the token embedding; otherwise wte; + wpe.  Bit-exact in fp32 against oracle.paper_embed."""
     from scone_amd import EmbeddingCache
@@ -947,7 +959,7 @@ def test_config_c1_100k_fp32_table_from_fit():
     assert all(np.array_equal(te[p].numpy(), table[ri[ro[p]:ro[p + 1]]]) for p in te)
 
 
-def test_config_c3_10m_int8_d1024():
+def test_config_c3_10m_int8_d1024(lookup_form):
     """configs[2]: 10M f-grams INT8 d=1024 in HBM: index of 1e7 exact keys, spot check against the oracle."""
     from scone_amd import EmbeddingCache
     from scone_amd import synthetic as S
@@ -965,7 +977,7 @@ def test_config_c3_10m_int8_d1024():
     assert np.array_equal(out, R.embed_numpy(rows, ro, inv, "mean").reshape(4, 512, d))
 
 
-def test_config_c4_100m_int4_d1024_at_its_named_size():
+def test_config_c4_100m_int4_d1024_at_its_named_size(lookup_form):
     """configs[3] at its named size: 100M f-grams INT4 d=1024 (52.8 GB of rows, 4.3 GB index).  Rows at both ends,
     in the middle and around row 2^25 equal the host generator -- a one-wave-per-row fill of this table once
     stopped at row 33.5M because blocks x threads wrapped at 2^32 work-items, silently -- and lookups over the

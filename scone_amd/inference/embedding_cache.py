@@ -256,7 +256,7 @@ class EmbeddingCache:
         for pos in range(len(token_ids)):
             a, b = int(off[pos]), int(off[pos + 1])
             if b > a:
-                result[pos] = rows[a:b].clone()
+                result[pos] = rows[a:b]          # disjoint slices of a tensor made for this call: fresh, as in the reference
         return result
 
     # ------------------------------------------------------------------ additive fused API

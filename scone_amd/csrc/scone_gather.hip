@@ -133,6 +133,7 @@ extern "C" int scone_gather_reduce(scone_handle *h, const int32_t *d_offsets, co
   a.BT = ntok, a.T = (int)(ntok > 0x7FFFFFFF ? 0x7FFFFFFF : ntok), a.max_n = h->cfg.max_n;
   a.tok_begin = 0, a.ntok = ntok;
   a.base = d_base, a.reduce = reduce, a.out = d_out, a.status = h->d_status;
+  a.zero_row = h->d_zero_row;
   return launch_fmt(h, a, SRC_CSR, MODE_FULL, out_dtype, (hipStream_t)stream);
 }
 

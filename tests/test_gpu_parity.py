@@ -1189,3 +1189,55 @@ def test_interleaved_handles_streams_and_growing_batches():
         for ci in range(len(caches)):
             for k in range(len(toks)):
                 assert torch.equal(outs[ci][k], alone[ci][k]), (rep, ci, k)
+
+
+@pytest.mark.parametrize("fmt,d", [("int8", 768), ("int4", 1024), ("fp16", 1280), ("fp32", 768), ("int8", 256)])
+def test_gather_reduce_csr_entry_point(fmt, d):
+    """scone_gather_reduce: caller-supplied per-token id lists (empty, short, exactly 10, longer than any list the
+    reference can produce), optional base rows, mean / sum, a shard that owns only part of the ids, an id outside the
+    table (status bit, skipped, still counted in K).  fp32 out bit-exact against the oracle on the dequantised table."""
+    from scone_amd.hip_backend import SconeTable
+    rng = np.random.default_rng(77)
+    n = 3000
+    table = rng.standard_normal((n, d)).astype(np.float32)
+    keys = np.zeros((n, 3), dtype=np.uint32)
+    keys[:, 0] = np.arange(n)
+    lens = np.ones(n, dtype=np.uint8)
+    ks = [0, 1, 2, 3, 6, 10, 11, 17, 40, 5, 0, 10, 1]
+    ks = ks + rng.integers(0, 13, size=500).tolist()
+    off = np.zeros(len(ks) + 1, dtype=np.int64)
+    np.cumsum(ks, out=off[1:])
+    ids = rng.integers(0, n, size=int(off[-1])).astype(np.int64)
+    deq = {"fp32": table, "fp16": table.astype(np.float16).astype(np.float32),
+           "int8": R.dequantize_i8(*R.quantize_i8(table)), "int4": R.dequantize_i4(*R.quantize_i4(table))}[fmt]
+    base = rng.standard_normal((len(ks), d)).astype(np.float32)
+    for lo, hi in ((0, n), (1000, 2200)):
+        t = SconeTable(3, n, d, fmt, row_begin=lo, row_end=hi)
+        t.index_build(keys, lens)
+        t.store_f32(torch.from_numpy(table[lo:hi]), row0=lo)
+        own = (ids >= lo) & (ids < hi)
+        seg = np.repeat(np.arange(len(ks)), ks)
+        off_own = np.zeros(len(ks) + 1, dtype=np.int64)
+        np.cumsum(np.bincount(seg[own], minlength=len(ks)), out=off_own[1:])
+        sums = R.embed_numpy(deq, off_own, ids[own], "sum")
+        kf = np.asarray(ks, dtype=np.float32)[:, None]
+        mean = np.where(kf > 1, sums / np.maximum(kf, 1), sums).astype(np.float32)       # K counts every listed id
+        for reduce, want in (("sum", sums), ("mean", mean)):
+            got = t.gather_reduce(torch.from_numpy(off), torch.from_numpy(ids), reduce).cpu().numpy()
+            assert np.array_equal(got, want), (fmt, d, lo, reduce)
+        got = t.gather_reduce(torch.from_numpy(off), torch.from_numpy(ids), "mean", base=torch.from_numpy(base)).cpu().numpy()
+        assert np.array_equal(got, base + mean)
+        got16 = t.gather_reduce(torch.from_numpy(off), torch.from_numpy(ids), "mean", base=torch.from_numpy(base),
+                                out_dtype=torch.float16).float().cpu().numpy()
+        b16 = torch.from_numpy(base).half().float().numpy()
+        assert _rel(got16, b16 + mean) < REL_TOL
+        assert t.status() == 0
+        bad = ids.copy()
+        bad[off[5]] = n + 5                                        # token 5 (K = 10): one id outside the table
+        got = t.gather_reduce(torch.from_numpy(off), torch.from_numpy(bad), "sum").cpu().numpy()
+        assert t.status() & 2
+        keep = own.copy()
+        keep[off[5]] = False
+        off_b = np.zeros(len(ks) + 1, dtype=np.int64)
+        np.cumsum(np.bincount(seg[keep], minlength=len(ks)), out=off_b[1:])
+        assert np.array_equal(got, R.embed_numpy(deq, off_b, bad[keep], "sum"))

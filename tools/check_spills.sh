@@ -17,7 +17,7 @@ for line in open(sys.argv[1]):
         vg = int(line.split()[-1])
     elif "; ScratchSize:" in line:
         sc = int(line.split()[-1])
-        if sc and name and any(k in name for k in ("k_embed_wave", "k_embed_fused", "k_match_ell")):
+        if sc and name and any(k in name for k in ("k_embed_wave", "k_embed_fused", "k_embed_csr_wave", "k_match_ell")):
             print(f"{sys.argv[2]}: scratch {sc} B/lane, {vg} VGPRs: {name[:110]}")
             bad += 1
 sys.exit(1 if bad else 0)

@@ -211,11 +211,10 @@ class NGramExtractor:
         index = self.device_index()
         tok = torch.as_tensor(np.asarray(token_ids, dtype=np.int64).clip(-1, 2**31 - 1), dtype=torch.int32)
         offsets, ids = index.match_csr(tok)
-        offsets = offsets.cpu().numpy()
-        ids = ids.cpu().numpy()
-        id_to = self.id_to_f_gram
+        offsets = offsets.cpu().tolist()                      # plain Python ints: list slicing beats numpy scalar indexing
+        grams = list(map(self.id_to_f_gram.__getitem__, ids.cpu().tolist()))
         for pos in range(len(token_ids)):
-            result[pos] = [id_to[int(i)] for i in ids[offsets[pos]:offsets[pos + 1]]]
+            result[pos] = grams[offsets[pos]:offsets[pos + 1]]
         return result
 
     def get_token_f_grams_batch(self, input_ids) -> List[Dict[int, List[Tuple[int, ...]]]]:
@@ -230,14 +229,12 @@ class NGramExtractor:
             return [{} for _ in range(B)]
         index = self.device_index()
         offsets, flat = index.match_csr(ids.clamp(-1, 2**31 - 1).to(torch.int32))
-        offsets = offsets.cpu().numpy()
-        flat = flat.cpu().numpy()
-        id_to = self.id_to_f_gram
+        offsets = offsets.cpu().tolist()
+        grams = list(map(self.id_to_f_gram.__getitem__, flat.cpu().tolist()))
         out = []
         for b in range(B):
             base = b * T
-            out.append({pos: [id_to[int(i)] for i in flat[offsets[base + pos]:offsets[base + pos + 1]]]
-                        for pos in range(T)})
+            out.append({pos: grams[offsets[base + pos]:offsets[base + pos + 1]] for pos in range(T)})
         return out
 
     # ------------------------------------------------------------------ persistence

@@ -393,7 +393,9 @@ class SconeTable:
                                            _ptr(wte), 0 if wte is None else wte.shape[0], _ptr(wpe),
                                            0 if wpe is None else wpe.shape[0], _ptr(position_ids), _REDUCE[reduce],
                                            _ptr(out), _DT[out_dtype], _stream())
-            torch.cuda.current_stream().synchronize()      # recv / tok may be temporaries of the caller
+        # the kernel reads `recv` / `tok` / `position_ids` in place after this call returns: keep them alive until the
+        # next exchange on this handle instead of synchronising the host here
+        self._shard_keepalive = (recv, tok, position_ids, wte, wpe)
         self._check(rc, "scone_shard_embed")
         return out
 

@@ -100,17 +100,26 @@ __global__ __launch_bounds__(256) void k_shard_count_send(const int32_t *__restr
   if (threadIdx.x < 64 && bins[threadIdx.x]) atomicAdd(&send_cnt[threadIdx.x], bins[threadIdx.x]);
 }
 
+// what my slice needs from every owner: one thread per token of the slice, persistent grid, LDS bins (owners are
+// scattered over the ranks, so per-lane LDS atomics -- spread over `world` words -- it is), one global atomic per bin
+// and workgroup
 __global__ __launch_bounds__(256) void k_shard_count_recv(const int32_t *__restrict__ ell, long long ntok, int W, int NC,
                                                           long long n_rows, int world, long long n_head,
                                                           uint32_t *__restrict__ recv_cnt) {
   __shared__ uint32_t bins[64];
   if (threadIdx.x < 64) bins[threadIdx.x] = 0;
   __syncthreads();
-  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long long t = gid / NC;
-  const int j = (int)(gid - t * NC);
-  const bool need = t < ntok && j < (ell[t * W + W - 2] & 0xFF) && ell[t * W + j] >= n_head;  // head rows are local everywhere
-  if (need) atomicAdd(&bins[owner_of(ell[t * W + j], n_rows, world)], 1u);  // owners are scattered: per-lane atomics
+  const long long per = (ntok + gridDim.x - 1) / gridDim.x;
+  const long long t0 = (long long)blockIdx.x * per, t1 = t0 + per < ntok ? t0 + per : ntok;
+  for (long long t = t0 + threadIdx.x; t < t1; t += blockDim.x) {
+    const int kown = ell[t * W + W - 2] & 0xFF;
+    for (int j = 0; j < NC; ++j) {
+      if (j < kown) {
+        const long long id = ell[t * W + j];
+        if (id >= n_head) atomicAdd(&bins[owner_of(id, n_rows, world)], 1u);  // head rows are local everywhere
+      }
+    }
+  }
   __syncthreads();
   if (threadIdx.x < 64 && bins[threadIdx.x]) atomicAdd(&recv_cnt[threadIdx.x], bins[threadIdx.x]);
 }
@@ -309,7 +318,7 @@ extern "C" int scone_shard_plan(scone_handle *h, const int32_t *d_tok, int32_t B
   if (my_tokens > 0) {
     rc = scone_launch_match_ell_ex(h, d_tok + (long long)b0 * T, b1 - b0, T, st->ell_slice, 0, (long long)h->cfg.n_rows, 0, s);
     if (rc) return rc;
-    const unsigned blocks2 = (unsigned)((my_tokens * NC + 255) / 256);
+    const unsigned blocks2 = (unsigned)((my_tokens + 255) / 256 < SHARD_BLOCKS ? (my_tokens + 255) / 256 : SHARD_BLOCKS);
     hipLaunchKernelGGL(k_shard_count_recv, dim3(blocks2), dim3(256), 0, s, st->ell_slice, my_tokens, W, NC,
                        (long long)h->cfg.n_rows, world, n_head, st->counters + 64);
   }

@@ -27,6 +27,20 @@ class OracleShard:
         self.R, self.keys, self.lens, self.max_n = R, keys, lens, max_n
         self.table, self.row_begin, self.row_end = table, row_begin, row_end
         self.n_rows, self.dim = table.shape[0], table.shape[1]
+        self.n_head, self.stored = 0, []
+
+    # ---- ingestion stand-ins: record what ShardedEmbeddingCache.load_rows stores where
+    def store_f32(self, rows, row0=0, ids=None):
+        self.stored.append(("owned", int(row0), int(rows.shape[0])))
+        assert np.array_equal(rows.numpy(), self.table[row0:row0 + rows.shape[0]])
+
+    def shard_set_head(self, n_head):
+        self.n_head = int(n_head)
+
+    def shard_head_store_f32(self, rows, row0=0):
+        self.stored.append(("head", int(row0), int(rows.shape[0])))
+        assert row0 + rows.shape[0] <= self.n_head
+        assert np.array_equal(rows.numpy(), self.table[row0:row0 + rows.shape[0]])
 
     def embed_partial(self, tok):
         R = self.R
@@ -191,6 +205,30 @@ def test_sharded_exchange_world2_gloo(shape, dtype, exchange):
         assert out_shape == (shape[0], shape[1], 32)
         assert err < (1e-6 if dtype == "float32" else 2e-3), (rank, err)
         assert ok_slice
+
+
+def test_load_rows_stores_owned_range_and_replicated_head():
+    """ShardedEmbeddingCache.load_rows: every rank keeps its own row range and, with replicated_rows, the head of
+    the table, whatever chunking the rows arrive in (no process group needed: rank / world are given)."""
+    from scone_amd import NGramExtractor
+    from scone_amd.distributed import ShardedEmbeddingCache, shard_range
+    rng = np.random.default_rng(1)
+    n, d, world, head = 1000, 8, 4, 130
+    keys = np.zeros((n, 3), dtype=np.uint32)
+    keys[:, 0] = np.arange(n)
+    ex = NGramExtractor.from_arrays(keys, np.ones(n, dtype=np.uint8), max_n=3)
+    table = rng.standard_normal((n, d)).astype(np.float32)
+    for rank in range(world):
+        a, b = shard_range(n, rank, world)
+        shard = OracleShard(keys, np.ones(n, dtype=np.uint8), 3, table, a, b)
+        shard.shard_set_head(head)
+        cache = ShardedEmbeddingCache(ex, d, rank=rank, world=world, n_rows=n, table=shard, replicated_rows=head)
+        for r0 in range(0, n, 96):                                   # chunks that straddle the head and the shard edges
+            cache.load_rows(torch.from_numpy(table[r0:r0 + 96]), r0)
+        owned = sorted((r0, r0 + m) for kind, r0, m in shard.stored if kind == "owned")
+        heads = sorted((r0, r0 + m) for kind, r0, m in shard.stored if kind == "head")
+        assert owned[0][0] == a and owned[-1][1] == b and all(x[1] == y[0] for x, y in zip(owned, owned[1:]))
+        assert heads[0][0] == 0 and heads[-1][1] == head and all(x[1] == y[0] for x, y in zip(heads, heads[1:]))
 
 
 def test_shard_ranges_partition_and_owner():

@@ -17,9 +17,11 @@
  *     are host pointers; all device work is enqueued on the given stream
  *     (hipStream_t passed as void*; NULL = the default stream) and the call
  *     returns without synchronising unless documented otherwise
- *   - a handle is immutable on the lookup path: lookups from several host
- *     threads on different streams are safe as long as each thread uses its
- *     own workspace (see scone_embed's workspace note)
+ *   - index and table are immutable on the lookup path.  Batches that take the one-launch kernel (up to
+ *     32768 tokens at d = 768 / 1024 / 1280, see scone_embed) touch no other state: such lookups may run concurrently from several
+ *     host threads on different streams.  Larger batches, scone_match_csr, scone_embed_partial and the
+ *     scone_shard_* calls use workspaces owned by the handle: calls of those kinds on ONE handle must be
+ *     stream-ordered (one stream, or events between streams)
  */
 #ifndef SCONE_HIP_H
 #define SCONE_HIP_H
@@ -185,8 +187,9 @@ int scone_gather_reduce(scone_handle *h, const int32_t *d_offsets, const int32_t
  *   out[b,i,:] = cast( (wte[tok[b,i]] + reduce_k row_k) + wpe[pos[b,i]] )
  * d_wte / d_wpe: [vocab,d] / [n_pos,d] in out_dtype, or NULL (term omitted);
  * d_pos: int32 [B,T] or NULL (= arange(T), language_model.py:248-251).
- * Uses the handle's internal hit workspace (grown on first use / by scone_reserve),
- * so concurrent calls on one handle must be stream-ordered. */
+ * Batches of up to 32768 tokens (environment SCONE_FUSED_MAX_TOKENS, read by scone_create) at d = 768 / 1024 / 1280
+ * run as ONE launch without any workspace; larger ones use the handle's id-record workspace (grown on first use / by scone_reserve), so
+ * concurrent large calls on one handle must be stream-ordered. */
 int scone_embed(scone_handle *h, const int32_t *d_tok, int32_t B, int32_t T, const void *d_wte,
                 int64_t vocab, const void *d_wpe, int64_t n_pos, const int32_t *d_pos,
                 int32_t reduce, void *d_out, int32_t out_dtype, scone_stream_t stream);

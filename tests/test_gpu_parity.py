@@ -1241,3 +1241,44 @@ def test_gather_reduce_csr_entry_point(fmt, d):
         off_b = np.zeros(len(ks) + 1, dtype=np.int64)
         np.cumsum(np.bincount(seg[keep], minlength=len(ks)), out=off_b[1:])
         assert np.array_equal(got, R.embed_numpy(deq, off_b, bad[keep], "sum"))
+
+
+def test_one_handle_from_two_host_threads():
+    """Batches that take the one-launch kernel touch no handle state: two host threads, each on its own HIP stream,
+    hammer ONE handle concurrently; every result equals the single-threaded answer."""
+    import threading
+    rng = np.random.default_rng(31)
+    vocab, n, d = 53, 1500, 768
+    lens = rng.integers(1, 4, size=n).astype(np.uint8)
+    keys = rng.integers(0, vocab, size=(n, 3)).astype(np.uint32)
+    keys[np.arange(3)[None, :] >= lens[:, None]] = 0
+    cache = _cache(keys, lens, 3, rng.standard_normal((n, d)).astype(np.float32), "int8")
+    wte = torch.from_numpy(rng.standard_normal((vocab, d)).astype(np.float32)).half().cuda()
+    wpe = torch.from_numpy(rng.standard_normal((128, d)).astype(np.float32)).half().cuda()
+    toks = [torch.from_numpy(rng.integers(0, vocab, size=s)).to("cuda", torch.int32) for s in ((1, 7), (4, 128), (64, 128), (2, 33))]
+    want = [cache.embed_tokens(t, wte=wte, wpe=wpe).clone() for t in toks]
+    torch.cuda.synchronize()
+    errors = []
+
+    def worker(seed):
+        try:
+            r = np.random.default_rng(seed)
+            stream = torch.cuda.Stream()
+            with torch.cuda.stream(stream):
+                for it in range(300):
+                    k = int(r.integers(len(toks)))
+                    out = cache.embed_tokens(toks[k], wte=wte, wpe=wpe)
+                    if it % 25 == 0:
+                        stream.synchronize()
+                        if not torch.equal(out, want[k]):
+                            errors.append((seed, it, k))
+            stream.synchronize()
+        except Exception as e:          # surface in the main thread
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=worker, args=(s,)) for s in (1, 2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:3]

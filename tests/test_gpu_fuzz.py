@@ -1,0 +1,73 @@
+"""GPU parity fuzz: random vocabularies (tiny token alphabets -> overlapping, nested and duplicate f-grams), random batch
+shapes, every table format, both lookup forms, both lookup modes, optional position ids -- ids bit-exact and fp32 results
+bit-exact against the oracle on the dequantised table.  SCONE_FUZZ_CASES scales the number of cases (default 48)."""
+
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_port as R
+
+pytestmark = pytest.mark.gpu
+
+
+def _dequantised(fmt, table):
+    if fmt == "fp32":
+        return table
+    if fmt == "fp16":
+        return table.astype(np.float16).astype(np.float32)
+    if fmt == "int8":
+        return R.dequantize_i8(*R.quantize_i8(table))
+    return R.dequantize_i4(*R.quantize_i4(table))
+
+
+@pytest.mark.parametrize("form", ["one_launch", "two_kernels"])
+def test_fuzz_lookup_vs_oracle(form, monkeypatch):
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from scone_amd import EmbeddingCache, NGramExtractor
+    if form == "two_kernels":
+        monkeypatch.setenv("SCONE_FUSED_MAX_TOKENS", "0")
+    else:
+        monkeypatch.delenv("SCONE_FUSED_MAX_TOKENS", raising=False)
+    n_cases = int(os.environ.get("SCONE_FUZZ_CASES", "48"))
+    rng = np.random.default_rng(20260 + (form == "two_kernels"))
+    for case in range(n_cases):
+        max_n = int(rng.integers(1, 5))
+        vocab = int(rng.choice([2, 3, 5, 17, 300]))
+        fmt, d = [("fp32", 768), ("fp16", 768), ("int8", 768), ("int8", 1024), ("int4", 1024), ("fp16", 1280), ("int8", 64),
+                  ("fp32", 24), ("int4", 256)][int(rng.integers(9))]
+        n = int(rng.integers(1, 400))
+        lens = rng.integers(1, max_n + 1, size=n).astype(np.uint8)
+        keys = rng.integers(0, vocab, size=(n, max_n)).astype(np.uint32)
+        keys[np.arange(max_n)[None, :] >= lens[:, None]] = 0
+        table = (rng.standard_normal((n, d)) * rng.choice([1e-3, 1.0, 50.0])).astype(np.float32)
+        if rng.random() < 0.3:
+            table[rng.integers(0, n)] = 0.0                                   # an all-zero row (scale 0)
+        B, T = int(rng.integers(1, 40)), int(rng.integers(1, 70))
+        tok = rng.integers(-1 if rng.random() < 0.2 else 0, vocab + 1, size=(B, T))   # -1 and `vocab` never match
+        mode = "cover" if rng.random() < 0.7 else "longest_suffix"
+        ex = NGramExtractor.from_arrays(keys, lens, max_n=max_n)
+        cache = EmbeddingCache(ex, d, table_format=fmt, lookup_mode=mode)
+        cache.cache_embeddings(list(range(n)), torch.from_numpy(table), verbose=False)
+        off, ids = cache.match(torch.from_numpy(tok))
+        ro, ri = R.hits_to_csr(R.match_hits(keys, lens, tok, max_n))
+        tag = (form, case, max_n, vocab, fmt, d, n, B, T, mode)
+        assert np.array_equal(off.cpu().numpy(), ro) and np.array_equal(ids.cpu().numpy(), ri), tag
+        deq = _dequantised(fmt, table)
+        wte = (rng.standard_normal((vocab + 1, d)) * 0.1).astype(np.float32)
+        wpe = (rng.standard_normal((T + 3, d)) * 0.1).astype(np.float32)
+        pos = rng.integers(0, T + 3, size=(B, T)) if (rng.random() < 0.4 and mode == "cover") else None
+        tok_c = np.clip(tok, 0, vocab)                                        # wte rows exist for 0..vocab
+        got = cache.embed_tokens(torch.from_numpy(tok_c), wte=torch.from_numpy(wte).cuda(), wpe=torch.from_numpy(wpe).cuda(),
+                                 position_ids=None if pos is None else torch.from_numpy(pos),
+                                 out_dtype=torch.float32).cpu().numpy()
+        ro2, ri2 = R.hits_to_csr(R.match_hits(keys, lens, tok_c, max_n))
+        if mode == "cover":
+            fg = R.embed_numpy(deq, ro2, ri2, "mean").reshape(B, T, d)
+            want = (wte[tok_c] + fg) + wpe[np.arange(T)[None, :] if pos is None else pos]
+        else:
+            want = R.paper_embed(R._key_dict(keys, lens), max_n, tok_c, deq, wte, wpe)
+        assert np.array_equal(got, want.astype(np.float32)), tag

@@ -71,3 +71,58 @@ def test_fuzz_lookup_vs_oracle(form, monkeypatch):
         else:
             want = R.paper_embed(R._key_dict(keys, lens), max_n, tok_c, deq, wte, wpe)
         assert np.array_equal(got, want.astype(np.float32)), tag
+
+
+def test_fuzz_row_exchange_vs_unsharded():
+    """Random (world, replicated head, format, max_n, batch shape): the by-hand row exchange between W shards on one GPU
+    is bit-identical to the unsharded table, and the number of records equals the references outside the head."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from scone_amd.distributed import shard_range
+    from scone_amd.hip_backend import SconeTable
+    n_cases = max(4, int(os.environ.get("SCONE_FUZZ_CASES", "48")) // 4)
+    rng = np.random.default_rng(4711)
+    for case in range(n_cases):
+        world = int(rng.integers(1, 9))
+        max_n = int(rng.integers(1, 5))
+        fmt, d = [("int8", 768), ("int4", 1024), ("fp16", 1280), ("fp32", 768), ("int8", 1024)][int(rng.integers(5))]
+        vocab = int(rng.choice([3, 11, 200]))
+        n = int(rng.integers(world, 600))
+        head = int(rng.choice([0, 1, n // 3, n]))
+        lens = rng.integers(1, max_n + 1, size=n).astype(np.uint8)
+        keys = rng.integers(0, vocab, size=(n, max_n)).astype(np.uint32)
+        keys[np.arange(max_n)[None, :] >= lens[:, None]] = 0
+        table = rng.standard_normal((n, d)).astype(np.float32)
+        B, T = int(rng.integers(1, 30)), int(rng.integers(1, 50))
+        tok = torch.from_numpy(rng.integers(0, vocab + 1, size=(B, T)))
+        wte = torch.from_numpy(rng.standard_normal((vocab + 1, d)).astype(np.float32)).half().cuda()
+        wpe = torch.from_numpy(rng.standard_normal((T, d)).astype(np.float32)).half().cuda()
+        full = SconeTable(max_n, n, d, fmt)
+        full.index_build(keys, lens)
+        full.store_f32(torch.from_numpy(table))
+        want = full.embed(tok, wte=wte, wpe=wpe).reshape(B * T, d)
+        _, ids = full.match_csr(tok)
+        shards = []
+        for r in range(world):
+            a, b = shard_range(n, r, world)
+            s = SconeTable(max_n, n, d, fmt, row_begin=a, row_end=b)
+            s.index_build(keys, lens)
+            if b > a:
+                s.store_f32(torch.from_numpy(table[a:b]), row0=a)
+            if head:
+                s.shard_set_head(head)
+                s.shard_head_store_f32(torch.from_numpy(table[:head]), row0=0)
+            shards.append(s)
+        plans = [s.shard_plan(tok, world, r) for r, s in enumerate(shards)]
+        tag = (case, world, max_n, fmt, d, vocab, n, head, B, T)
+        assert sum(sum(p[0]) for p in plans) == int((ids >= head).sum()), tag
+        sends = [s.shard_pack(B, T, world, plans[r][0]) for r, s in enumerate(shards)]
+        bper = (B + world - 1) // world
+        for q in range(world):
+            parts = [sends[r][sum(plans[r][0][:q]):sum(plans[r][0][:q]) + plans[r][0][q]] for r in range(world)]
+            recv = torch.cat(parts).contiguous()
+            b0, b1 = min(q * bper, B), min(q * bper + bper, B)
+            if b1 > b0:
+                got = shards[q].shard_embed(tok, world, q, recv, wte=wte, wpe=wpe, out_dtype=torch.float16)
+                assert torch.equal(got, want[b0 * T:b1 * T]), tag + (q,)
+            assert shards[q].status() == 0, tag

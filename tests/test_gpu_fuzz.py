@@ -126,3 +126,63 @@ def test_fuzz_row_exchange_vs_unsharded():
                 got = shards[q].shard_embed(tok, world, q, recv, wte=wte, wpe=wpe, out_dtype=torch.float16)
                 assert torch.equal(got, want[b0 * T:b1 * T]), tag + (q,)
             assert shards[q].status() == 0, tag
+
+
+def test_fuzz_pinned_host_vs_hbm():
+    """Random (format, hot head, staging chunk, batch shape): rows in pinned host DRAM -- read in place or staged through
+    HBM in chunks -- give the bits the HBM-resident table gives."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from scone_amd import EmbeddingCache, NGramExtractor
+    n_cases = max(4, int(os.environ.get("SCONE_FUZZ_CASES", "48")) // 4)
+    rng = np.random.default_rng(99)
+    for case in range(n_cases):
+        max_n = int(rng.integers(1, 5))
+        fmt, d = [("int8", 768), ("int4", 1024), ("fp16", 1280), ("fp32", 768), ("int8", 2048)][int(rng.integers(5))]
+        vocab = int(rng.choice([5, 40]))
+        n = int(rng.integers(2, 500))
+        lens = rng.integers(1, max_n + 1, size=n).astype(np.uint8)
+        keys = rng.integers(0, vocab, size=(n, max_n)).astype(np.uint32)
+        keys[np.arange(max_n)[None, :] >= lens[:, None]] = 0
+        table = torch.from_numpy(rng.standard_normal((n, d)).astype(np.float32))
+        ex = NGramExtractor.from_arrays(keys, lens, max_n=max_n)
+        B, T = int(rng.integers(1, 60)), int(rng.integers(1, 40))
+        tok = torch.from_numpy(rng.integers(0, vocab, size=(B, T)))
+        wte = torch.from_numpy(rng.standard_normal((vocab, d)).astype(np.float32)).half().cuda()
+        wpe = torch.from_numpy(rng.standard_normal((T, d)).astype(np.float32)).half().cuda()
+        ref = EmbeddingCache(ex, d, table_format=fmt)
+        ref.cache_embeddings(list(range(n)), table, verbose=False)
+        want = ref.embed_tokens(tok, wte=wte, wpe=wpe)
+        hot = int(rng.choice([0, 1, n // 2, n - 1]))
+        stage = int(rng.choice([0, T, 3 * T, 100000]))
+        c = EmbeddingCache(ex, d, table_format=fmt, placement="pinned_host", hot_rows=hot, stage_tokens=stage)
+        c.cache_embeddings(list(range(n)), table, verbose=False)
+        for _ in range(2):                                                    # twice: staging buffers and generations are reused
+            assert torch.equal(c.embed_tokens(tok, wte=wte, wpe=wpe), want), (case, max_n, fmt, d, n, B, T, hot, stage)
+
+
+def test_staged_prefetch_generation_wrap():
+    """The staging slot map tags claims with an 8-bit generation; more than 255 chunks on one handle wrap it (the map is
+    cleared and generations restart): results stay bit-identical across the wrap."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from scone_amd import EmbeddingCache, NGramExtractor
+    rng = np.random.default_rng(5)
+    vocab, n, d, T = 30, 400, 768, 16
+    lens = rng.integers(1, 4, size=n).astype(np.uint8)
+    keys = rng.integers(0, vocab, size=(n, 3)).astype(np.uint32)
+    keys[np.arange(3)[None, :] >= lens[:, None]] = 0
+    table = torch.from_numpy(rng.standard_normal((n, d)).astype(np.float32))
+    ex = NGramExtractor.from_arrays(keys, lens, max_n=3)
+    ref = EmbeddingCache(ex, d, table_format="int8")
+    ref.cache_embeddings(list(range(n)), table, verbose=False)
+    c = EmbeddingCache(ex, d, table_format="int8", placement="pinned_host", hot_rows=10, stage_tokens=T)   # one sequence per chunk
+    c.cache_embeddings(list(range(n)), table, verbose=False)
+    wte = torch.from_numpy(rng.standard_normal((vocab, d)).astype(np.float32)).half().cuda()
+    chunks = 0
+    for it in range(12):
+        B = int(rng.integers(20, 40))
+        tok = torch.from_numpy(rng.integers(0, vocab, size=(B, T)))
+        assert torch.equal(c.embed_tokens(tok, wte=wte), ref.embed_tokens(tok, wte=wte)), it
+        chunks += B
+    assert chunks > 255 + 40

@@ -186,3 +186,24 @@ def test_staged_prefetch_generation_wrap():
         assert torch.equal(c.embed_tokens(tok, wte=wte), ref.embed_tokens(tok, wte=wte)), it
         chunks += B
     assert chunks > 255 + 40
+
+
+def test_fuzz_fit_gpu_vs_host_fit():
+    """Random corpora over tiny alphabets (many count ties, first-seen order decides): scone_fit gives the f-grams and ids of
+    the host fit (= the reference's Counter.most_common order) for random max_n / min_freq / max_f_grams."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from scone_amd import NGramExtractor
+    n_cases = max(6, int(os.environ.get("SCONE_FUZZ_CASES", "48")) // 2)
+    rng = np.random.default_rng(808)
+    for case in range(n_cases):
+        max_n = int(rng.integers(1, 5))
+        vocab = int(rng.choice([2, 4, 30]))
+        texts = [rng.integers(0, vocab, size=int(rng.integers(0, 60))).tolist() for _ in range(int(rng.integers(1, 25)))]
+        min_freq = int(rng.integers(1, 4))
+        max_f = int(rng.choice([1, 5, 50, 10_000]))
+        host = NGramExtractor(max_n=max_n, min_freq=min_freq, max_f_grams=max_f).fit(texts, verbose=False)
+        gpu = NGramExtractor(max_n=max_n, min_freq=min_freq, max_f_grams=max_f).fit_gpu(texts, verbose=False)
+        hk, hl = host.key_arrays()
+        gk, gl = gpu.key_arrays()
+        assert np.array_equal(hl, gl) and np.array_equal(hk, gk), (case, max_n, vocab, min_freq, max_f, len(texts))

@@ -1,6 +1,12 @@
-"""Mirror of ``scone.tokenization`` (the f-gram vocabulary, the match step and its caller)."""
+"""The f-gram vocabulary (index + GPU match, GPU ``fit``) and the tokenizer wrapper that calls it.
 
-from scone_amd.tokenization.n_gram_extractor import NGramExtractor
-from scone_amd.tokenization.f_gram_tokenizer import FGramTokenizer
+Same public names as ``scone.tokenization``; matching runs on the device index behind ``include/scone_hip.h``.
+"""
+
+from scone_amd.tokenization import f_gram_tokenizer as _ft
+from scone_amd.tokenization import n_gram_extractor as _ng
+
+NGramExtractor = _ng.NGramExtractor
+FGramTokenizer = _ft.FGramTokenizer
 
 __all__ = ["NGramExtractor", "FGramTokenizer"]

@@ -21,6 +21,12 @@ here and only needed when the table does not fit one GPU's 288 GB (BASELINE conf
   frequent f-grams -- about half of all row references on the C5-shaped workload, all of which would otherwise
   leave the one rank that owns them (measured on one GPU with 8 shards of a 100M-row table,
   ``tools/shard_emulate.py``: rank 0 sends 550 MB per 1M-token step, the others 52-75 MB);
+* exchange ``"gather_rows"``: when EVERY rank needs the whole ``[B, T, d]`` output (the north-star's all-gather of the
+  aggregated vectors), gathering the 2 KB fp16 vector of every token costs four times the bytes of gathering the
+  quantised ROWS the batch references: every rank packs the records of the rows it owns (the same plan / pack with
+  "one destination"), ONE all-gather of records (padded to the largest contribution), and every rank reduces the whole
+  batch itself out of ``[replicated head | gathered records]`` -- bit-identical again, ~0.5 GB on the wire per 1M-token
+  step instead of ~1.9 GB into every rank;
 * exchange ``"partial_sums"`` (kept for comparison): every rank sums the rows it owns
   (``scone_embed_partial``) -> ``reduce_scatter`` -> ``scone_finalize``;
 * finally an ``all_gather`` of the finished vectors in the output dtype (skippable when the
@@ -154,8 +160,17 @@ class ShardedEmbeddingCache:
             return out if gather_output else out.reshape(ntok, d)
         if exchange == "rows":
             return self._embed_row_exchange(tok, reduce, wte, wpe, position_ids, out_dtype, gather_output)
+        if exchange == "gather_rows":
+            out = self._embed_gather_rows(tok, reduce, wte, wpe, position_ids, out_dtype)
+            if gather_output:
+                return out.reshape(B, T, d)
+            bper = (B + W - 1) // W                                          # same slice convention as "rows"
+            b0, b1 = min(self.rank * bper, B), min(self.rank * bper + bper, B)
+            sl = out.new_zeros((bper * T, d))
+            sl[:(b1 - b0) * T] = out[b0 * T:b1 * T]
+            return sl
         if exchange != "partial_sums":
-            raise ValueError("exchange must be 'rows' or 'partial_sums'")
+            raise ValueError("exchange must be 'rows', 'gather_rows' or 'partial_sums'")
         partial, counts = self.table.embed_partial(tok)                      # [ntok, d] fp32, [ntok] int32
         per = (ntok + W - 1) // W                                             # tokens per rank (last slices padded)
         a = min(self.rank * per, ntok)
@@ -183,6 +198,34 @@ class ShardedEmbeddingCache:
         else:
             full = out_slice
         return full[:ntok].reshape(B, T, d)
+
+    def _embed_gather_rows(self, tok, reduce, wte, wpe, position_ids, out_dtype):
+        """All-gather of the quantised rows the batch references; every rank then embeds the whole batch."""
+        B, T = tok.shape
+        W = self.world
+        # plan / pack with ONE destination (world = 1 semantics of the kernels): every reference of the batch to a row
+        # I own (outside the replicated head), headers = (token in batch, index in its list)
+        send_counts, _ = self.table.shard_plan(tok, 1, 0)
+        send = self.table.shard_pack(B, T, 1, send_counts)                   # uint8 [c_me, record_bytes]
+        rec = send.shape[1]
+        if W > 1:
+            mine = torch.tensor([send.shape[0]], dtype=torch.int64, device=send.device)
+            allc = torch.empty(W, dtype=torch.int64, device=send.device)
+            _all_gather(allc, mine, self.group)
+            counts = [int(c) for c in allc.tolist()]
+            maxc = max(counts)
+            if maxc:
+                padded = torch.empty((maxc, rec), dtype=torch.uint8, device=send.device)
+                padded[:send.shape[0]] = send
+                full = torch.empty((W * maxc, rec), dtype=torch.uint8, device=send.device)
+                _all_gather(full, padded, self.group)
+                recv = torch.cat([full[r * maxc:r * maxc + counts[r]] for r in range(W)])
+            else:
+                recv = send
+        else:
+            recv = send
+        return self.table.shard_embed(tok, 1, 0, recv, wte=wte, wpe=wpe, position_ids=position_ids, reduce=reduce,
+                                      out_dtype=out_dtype)
 
     def _embed_row_exchange(self, tok, reduce, wte, wpe, position_ids, out_dtype, gather_output):
         B, T = tok.shape

@@ -188,7 +188,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("exchange", ["rows", "partial_sums"])
+@pytest.mark.parametrize("exchange", ["rows", "gather_rows", "partial_sums"])
 @pytest.mark.parametrize("shape,dtype", [((3, 17), "float32"), ((2, 8), "float16"), ((1, 5), "float32")])
 def test_sharded_exchange_world2_gloo(shape, dtype, exchange):
     ctx = mp.get_context("spawn")

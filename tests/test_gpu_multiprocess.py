@@ -76,6 +76,8 @@ def _worker(rank, world, port, fmt, d, max_n, exchange, head, q):
 
 
 @pytest.mark.parametrize("fmt,d,max_n,world,exchange,head", [("int8", 768, 3, 2, "rows", 0), ("int4", 1024, 4, 3, "rows", 100),
+                                                             ("int8", 768, 3, 3, "gather_rows", 0),
+                                                             ("int4", 1024, 4, 2, "gather_rows", 100),
                                                              ("int8", 768, 3, 2, "partial_sums", 0)])
 def test_sharded_cache_across_processes_on_one_gpu(fmt, d, max_n, world, exchange, head):
     if not torch.cuda.is_available():
@@ -92,7 +94,7 @@ def test_sharded_cache_across_processes_on_one_gpu(fmt, d, max_n, world, exchang
     for rank, same, err, shape, sl_shape in results:
         assert shape is not None, f"rank {rank} failed: {err}"
         assert shape == (5, 33, d)
-        if exchange == "rows":
+        if exchange in ("rows", "gather_rows"):
             assert same, f"rank {rank}: row exchange must be bit-identical to the unsharded table (rel err {err})"
         else:
             assert err < 1e-3, (rank, err)          # fp32 partial sums are added in shard order, not list order

@@ -45,6 +45,9 @@ def main():
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--check", action="store_true")
     ap.add_argument("--head", type=int, default=0, help="replicated head: global rows [0, head) kept on every shard")
+    ap.add_argument("--mode", default="rows", choices=["rows", "gather_rows"],
+                    help="rows: all-to-all of records, every rank reduces its slice; gather_rows: all-gather of records, "
+                         "every rank reduces the whole batch")
     a = ap.parse_args()
     N, W, d, B, T = a.rows, a.world, a.dim, a.batch, a.seq
     keys, lens = S.make_keys_structured(N, S.GPT2_VOCAB, 3) if N >= 20_000_000 else S.make_keys(N, S.GPT2_VOCAB, 3, seed=11)
@@ -68,6 +71,9 @@ def main():
            "replicated_head_rows": a.head, "ranks": []}
     out = torch.empty(B * T, d, dtype=torch.float16, device="cuda")
     best = None
+    if a.mode == "gather_rows":
+        gather_rows_mode(a, shards, tok, wte, wpe, out, res, keys, lens)
+        return
     for rep in range(a.reps):
         plans, t_plan = [], []
         for r, s in enumerate(shards):
@@ -123,6 +129,45 @@ def main():
             off, ids = full.match_csr(tok.view(-1)[first - first % T:first - first % T + T].view(1, T))
             i = first % T
             res["first_bad_ids"] = ids[int(off[i]):int(off[i + 1])].tolist()
+    print(json.dumps(res))
+
+
+def gather_rows_mode(a, shards, tok, wte, wpe, out, res, keys, lens):
+    """Every rank packs the records of the rows it owns for the WHOLE batch (plan / pack with one destination), the records
+    are all-gathered (here: concatenated), every rank reduces the whole batch."""
+    N, W, d, B, T = a.rows, a.world, a.dim, a.batch, a.seq
+    rec = res["record_bytes"]
+    best = None
+    for rep in range(a.reps):
+        sends, t_plan, t_pack, t_embed = [], [], [], []
+        for r, s in enumerate(shards):
+            p, ms = timed(lambda: s.shard_plan(tok, 1, 0))
+            t_plan.append(ms)
+            buf, ms = timed(lambda: s.shard_pack(B, T, 1, p[0]))
+            sends.append(buf)
+            t_pack.append(ms)
+        recv = torch.cat(sends).contiguous()                              # the all-gather of records, by hand
+        for q in range(W):
+            _, ms = timed(lambda: shards[q].shard_embed(tok, 1, 0, recv, wte=wte, wpe=wpe, out_dtype=torch.float16, out=out))
+            t_embed.append(ms)
+        cur = [t_plan, t_pack, t_embed]
+        best = cur if best is None else [[min(x, y) for x, y in zip(b, c)] for b, c in zip(best, cur)]
+        counts = [int(x.shape[0]) for x in sends]
+        del sends
+    for r in range(W):
+        res["ranks"].append({"rank": r, "plan_ms": best[0][r], "pack_ms": best[1][r], "embed_ms": best[2][r],
+                             "records_contributed": counts[r]})
+    loc = [x["plan_ms"] + x["pack_ms"] + x["embed_ms"] for x in res["ranks"]]
+    res["mode"] = "gather_rows"
+    res["local_ms_max"], res["local_ms_mean"] = max(loc), sum(loc) / len(loc)
+    res["all_gather_bytes_into_each_rank"] = int((sum(counts) - min(counts)) * rec)
+    res["all_gather_padded_bytes_total"] = int(max(counts) * rec * W)
+    if a.check:
+        full = SconeTable(3, N, d, a.format)
+        full.index_build(keys, lens)
+        full.fill_synthetic(7, 0.02 / 127)
+        want = full.embed(tok, wte=wte, wpe=wpe).reshape(B * T, d)
+        res["bit_identical_to_unsharded"] = bool(torch.equal(out, want))
     print(json.dumps(res))
 
 

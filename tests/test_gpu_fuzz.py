@@ -126,6 +126,17 @@ def test_fuzz_row_exchange_vs_unsharded():
                 got = shards[q].shard_embed(tok, world, q, recv, wte=wte, wpe=wpe, out_dtype=torch.float16)
                 assert torch.equal(got, want[b0 * T:b1 * T]), tag + (q,)
             assert shards[q].status() == 0, tag
+        # the all-gather form: every shard packs what it owns for the WHOLE batch, any shard reduces the whole batch
+        sends = []
+        for s_ in shards:
+            p1, _ = s_.shard_plan(tok, 1, 0)
+            sends.append(s_.shard_pack(B, T, 1, p1))
+        recv = torch.cat(sends).contiguous()
+        assert recv.shape[0] == int((ids >= head).sum()), tag
+        q = int(rng.integers(world))
+        got = shards[q].shard_embed(tok, 1, 0, recv, wte=wte, wpe=wpe, out_dtype=torch.float16)
+        assert torch.equal(got, want), tag + ("gather_rows", q)
+        assert shards[q].status() == 0, tag
 
 
 def test_fuzz_pinned_host_vs_hbm():

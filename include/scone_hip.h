@@ -248,6 +248,20 @@ int scone_shard_embed(scone_handle *h, const int32_t *d_tok, int32_t B, int32_t 
                       int64_t n_pos, const int32_t *d_pos, int32_t reduce, void *d_out_slice, int32_t out_dtype,
                       scone_stream_t stream);
 
+/* ---- row-sharded tables, all-gather form: EVERY rank ends up with the whole [B, T, d] output.  Gathering the rows the
+ *      batch references costs a quarter of the bytes of gathering the finished 2 KB vectors, and here every DISTINCT row
+ *      crosses once however many tokens reference it: scone_shard_gather_plan claims the distinct rows this shard owns
+ *      (outside the replicated head) that the batch references and returns their number (synchronises);
+ *      scone_shard_gather_pack writes one record [row payload | scales | row id] per claimed row; the caller all-gathers
+ *      the record buffers of all ranks (any order); scone_shard_gather_embed indexes the records by row id and reduces
+ *      the whole batch out of [replicated head | records] -- bit-identical to the unsharded table. -------------------- */
+int scone_shard_gather_plan(scone_handle *h, const int32_t *d_tok, int32_t B, int32_t T, uint64_t *h_n_records,
+                            scone_stream_t stream);
+int scone_shard_gather_pack(scone_handle *h, void *d_send_buf, scone_stream_t stream);
+int scone_shard_gather_embed(scone_handle *h, const int32_t *d_tok, int32_t B, int32_t T, const void *d_records,
+                             uint64_t n_records, const void *d_wte, int64_t vocab, const void *d_wpe, int64_t n_pos,
+                             const int32_t *d_pos, int32_t reduce, void *d_out, int32_t out_dtype, scone_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

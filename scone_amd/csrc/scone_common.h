@@ -204,6 +204,8 @@ int scone_shard_fill_head_synth(scone_handle *h, uint32_t seed, float base_scale
 void scone_shard_destroy(scone_handle *h);
 int scone_shard_rec_bytes(const scone_handle *h);
 uint8_t *scone_shard_head(const scone_handle *h, unsigned long long *n_head);  // replicated head rows (record layout) or null
+int scone_shard_gather_prepare_embed(scone_handle *h, int32_t B, int32_t T, const void *d_recv, uint64_t n_recv,
+                                     const int32_t **ell, const void **scales, hipStream_t s);
 int scone_shard_prepare_embed(scone_handle *h, int32_t B, int32_t T, int32_t world, int32_t rank, const void *d_recv,
                               uint64_t n_recv, const int32_t **ell, const void **scales, int32_t *b0, int32_t *b1,
                               hipStream_t s);

@@ -245,6 +245,45 @@ extern "C" int scone_shard_embed(scone_handle *h, const int32_t *d_tok, int32_t 
   return launch_fmt(h, a, SRC_HITS, MODE_FULL, out_dtype, s);
 }
 
+// All-gather form: the records of EVERY shard have arrived (one per distinct row); reduce the whole batch.
+extern "C" int scone_shard_gather_embed(scone_handle *h, const int32_t *d_tok, int32_t B, int32_t T, const void *d_records,
+                                        uint64_t n_records, const void *d_wte, int64_t vocab, const void *d_wpe, int64_t n_pos,
+                                        const int32_t *d_pos, int32_t reduce, void *d_out, int32_t out_dtype,
+                                        scone_stream_t stream) {
+  int rc = need_table(h, "scone_shard_gather_embed: handle has no table (dim == 0)");
+  if (rc) return rc;
+  if (!h->shard) return scone_fail(h, SCONE_ESTATE, "scone_shard_gather_embed: call scone_shard_gather_plan first");
+  if (B < 0 || T <= 0 || (n_records && !d_records)) return scone_fail(h, SCONE_EINVAL, "scone_shard_gather_embed: bad argument");
+  if (!scone_wave_kernel_covers(h->cfg.table_fmt, h->cfg.dim))
+    return scone_fail(h, SCONE_EINVAL, "scone_shard_gather_embed: needs d % 8 == 0");
+  if (reduce != SCONE_REDUCE_MEAN && reduce != SCONE_REDUCE_SUM)
+    return scone_fail(h, SCONE_EINVAL, "scone_shard_gather_embed: bad reduce");
+  const long long BT = (long long)B * T;
+  if (BT == 0) return SCONE_OK;
+  if (!d_tok || !d_out) return scone_fail(h, SCONE_EINVAL, "scone_shard_gather_embed: null pointer");
+  SCONE_HIP(h, hipSetDevice(h->device));
+  hipStream_t s = (hipStream_t)stream;
+  const int32_t *ell = nullptr;
+  const void *scales = nullptr;
+  rc = scone_shard_gather_prepare_embed(h, B, T, d_records, n_records, &ell, &scales, s);
+  if (rc) return rc;
+  embed_args a = {};
+  fill_table_view(h, a.tv);
+  unsigned long long n_head = 0;
+  a.tv.st.hot = scone_shard_head(h, &n_head);  // row store: [replicated head | gathered records], both in record layout
+  a.tv.st.n_hot = n_head;
+  a.tv.st.cold = n_records ? reinterpret_cast<uint8_t *>(const_cast<void *>(d_records)) : reinterpret_cast<uint8_t *>(h->d_zero_row);
+  a.tv.st.row_bytes = (unsigned int)scone_shard_rec_bytes(h);
+  a.tv.scales = reinterpret_cast<const __half *>(scales);
+  a.tv.row_begin = 0, a.tv.row_end = (long long)(n_head + (n_records ? n_records : 1));
+  a.BT = BT, a.ntok = BT, a.T = T, a.max_n = h->cfg.max_n;
+  a.ell = ell, a.zero_row = h->d_zero_row, a.mode = (int)h->cfg.lookup_mode;
+  a.tok = d_tok, a.pos = d_pos;
+  a.wte = d_wte, a.vocab = vocab, a.wpe = d_wpe, a.n_pos = n_pos;
+  a.reduce = reduce, a.out = d_out, a.status = h->d_status;
+  return launch_fmt(h, a, SRC_HITS, MODE_FULL, out_dtype, s);
+}
+
 extern "C" int scone_embed_partial(scone_handle *h, const int32_t *d_tok, int32_t B, int32_t T, float *d_partial,
                                    int32_t *d_counts, scone_stream_t stream) {
   int rc = need_table(h, "scone_embed_partial: handle has no table (dim == 0)");

@@ -26,7 +26,7 @@
 #include <new>
 
 struct scone_shard_state {
-  long long cap_tok = 0, cap_slice = 0, cap_recv = 0;
+  long long cap_tok = 0, cap_slice = 0, cap_slot = 0, cap_recv = 0;
   int32_t *ell_send = nullptr;   // [ntok, W] my rows at their index in the full list
   int32_t *ell_slice = nullptr;  // [slice tokens, W] all rows, compacted; remapped in place by embed
   uint32_t *counters = nullptr;  // [3 * 64]: send counts, recv counts, pack cursors
@@ -37,6 +37,14 @@ struct scone_shard_state {
   unsigned long long n_head = 0; // replicated head: global rows [0, n_head) live on every shard
   uint8_t *head_rows = nullptr;  // [n_head, rec_bytes]: payload at the start of every record-sized slot
   uint8_t *head_scales = nullptr;  // [n_head, scale_bytes_per_row]
+  // all-gather form: distinct rows
+  uint32_t *uniq_claim = nullptr;  // [local rows]: generation of the last batch that claimed the row
+  uint32_t uniq_gen = 0;
+  int32_t *uniq_list = nullptr;    // [cap_uniq] claimed row ids
+  long long cap_uniq = 0;
+  unsigned long long n_uniq = 0;   // records of the current plan
+  unsigned long long *rhash = nullptr;  // receiver: open-addressing map row id -> record number
+  long long cap_rhash = 0;
 };
 
 namespace {
@@ -245,7 +253,7 @@ void scone_shard_destroy(scone_handle *h) {
   scone_shard_state *st = h->shard;
   if (!st) return;
   void *ptrs[] = {st->ell_send, st->ell_slice, st->counters, st->send_src, st->slot_of_ref, st->scales,
-                  st->head_rows, st->head_scales};
+                  st->head_rows, st->head_scales, st->uniq_claim, st->uniq_list, st->rhash};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   delete st;
@@ -297,8 +305,7 @@ extern "C" int scone_shard_plan(scone_handle *h, const int32_t *d_tok, int32_t B
   long long cs = st->cap_slice;
   rc = grow(h, &st->ell_slice, &cs, slice_tokens, (size_t)W);
   if (rc) return rc;
-  long long cs2 = st->cap_slice;
-  rc = grow(h, &st->slot_of_ref, &cs2, slice_tokens, (size_t)NC);
+  rc = grow(h, &st->slot_of_ref, &st->cap_slot, slice_tokens, (size_t)NC);
   if (rc) return rc;
   st->cap_slice = cs;
   if (!st->counters) SCONE_HIP(h, hipMalloc(&st->counters, 3 * 64 * sizeof(uint32_t)));
@@ -449,4 +456,238 @@ extern "C" int scone_shard_head_store_f32(scone_handle *h, const float *d_rows_f
 int scone_shard_fill_head_synth(scone_handle *h, uint32_t seed, float base_scale, hipStream_t s) {
   if (!h->shard || !h->shard->n_head) return SCONE_OK;
   return scone_fill_synth_into(h, head_store(h), h->shard->head_scales, 0, h->shard->n_head, seed, base_scale, s);
+}
+
+// ---------------------------------------------------------------- all-gather form: one record per distinct row
+namespace {
+
+// every reference of the batch to a row I own claims the row for this batch; the first claimer of a row appends it to
+// the list.  One CAS per reference at most, nobody waits.
+#define GATHER_STASH 2048
+__global__ __launch_bounds__(256) void k_gather_claim(const int32_t *__restrict__ ell, long long ntok, int W, int NC,
+                                                      long long row_begin, long long send_begin, long long row_end,
+                                                      uint32_t *__restrict__ claim, uint32_t gen,
+                                                      uint32_t *__restrict__ count, int32_t *__restrict__ list, long long cap) {
+  // the workgroup's claimed ids are stashed in LDS and appended to the list with ONE global atomic at the end (a global
+  // atomic per claimed row on the one counter would serialise: ~90 per microsecond); a stash overflow appends directly
+  __shared__ int32_t stash[GATHER_STASH];
+  __shared__ uint32_t n_stash, base;
+  if (threadIdx.x == 0) n_stash = 0;
+  __syncthreads();
+  const long long per = (ntok + gridDim.x - 1) / gridDim.x;
+  const long long t0 = (long long)blockIdx.x * per, t1 = t0 + per < ntok ? t0 + per : ntok;
+  for (long long t = t0 + threadIdx.x; t < t1; t += blockDim.x) {
+    const int kown = ell[t * W + W - 2] & 0xFF;  // the lists against ALL rows (compacted): pick the ids I own
+    for (int j = 0; j < NC; ++j) {
+      if (j >= kown) break;
+      const long long id = ell[t * W + j];
+      if (id < send_begin || id >= row_end) continue;  // another shard's row, or a row of the replicated head
+      uint32_t *e = &claim[id - row_begin];
+      const uint32_t v = *e;
+      if (v == gen) continue;  // already claimed for this batch
+      if (atomicCAS(e, v, gen) == v) {
+        const uint32_t k = atomicAdd(&n_stash, 1u);
+        if (k < GATHER_STASH) {
+          stash[k] = (int32_t)id;
+        } else {
+          const uint32_t s = atomicAdd(count, 1u);
+          if ((long long)s < cap) list[s] = (int32_t)id;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const uint32_t n = n_stash < GATHER_STASH ? n_stash : GATHER_STASH;
+  if (threadIdx.x == 0) base = n ? atomicAdd(count, n) : 0u;
+  __syncthreads();
+  for (uint32_t k = threadIdx.x; k < n; k += blockDim.x)
+    if ((long long)(base + k) < cap) list[base + k] = stash[k];
+}
+
+// one wave per claimed row: [payload | scales | row id, marker]
+__global__ __launch_bounds__(256) void k_gather_pack(const int32_t *__restrict__ list, unsigned long long n, scone_row_store st,
+                                                     long long row_begin, const uint8_t *__restrict__ scales, int scale_bytes,
+                                                     int rec_bytes, uint8_t *__restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const unsigned long long nwaves = (unsigned long long)gridDim.x * (blockDim.x >> 6);
+  for (unsigned long long p = (unsigned long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); p < n; p += nwaves) {
+    const long long id = list[p];
+    const unsigned long long lr = (unsigned long long)(id - row_begin);
+    const uint4 *src = reinterpret_cast<const uint4 *>(st.row(lr));
+    uint8_t *rec = out + p * (unsigned long long)rec_bytes;
+    uint4 *dst = reinterpret_cast<uint4 *>(rec);
+    for (unsigned v = lane; v < st.row_bytes / 16; v += 64) dst[v] = src[v];
+    if (lane < scale_bytes / 2)
+      reinterpret_cast<unsigned short *>(rec + st.row_bytes)[lane] =
+          reinterpret_cast<const unsigned short *>(scales + lr * scale_bytes)[lane];
+    if (lane == 0) {
+      uint32_t *hdr = reinterpret_cast<uint32_t *>(rec + rec_bytes - 8);
+      hdr[0] = (uint32_t)id;
+      hdr[1] = 0xFFFFFFFFu;
+    }
+  }
+}
+
+// receiver: record p holds row id hdr[0] -> hash map id -> p (key id + 1, empty 0; smallest p wins on a duplicate), scales
+__global__ __launch_bounds__(256) void k_gather_index(const uint8_t *__restrict__ recv, unsigned long long n_recv, int rec_bytes,
+                                                      int row_bytes, int scale_bytes, unsigned long long *__restrict__ rhash,
+                                                      unsigned long long hmask, uint8_t *__restrict__ scales) {
+  const unsigned long long p = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_recv) return;
+  const uint8_t *rec = recv + p * (unsigned long long)rec_bytes;
+  const uint32_t id = reinterpret_cast<const uint32_t *>(rec + rec_bytes - 8)[0];
+  for (int b = 0; b < scale_bytes / 2; ++b)
+    reinterpret_cast<unsigned short *>(scales + p * scale_bytes)[b] = reinterpret_cast<const unsigned short *>(rec + row_bytes)[b];
+  const unsigned long long key = (unsigned long long)id + 1ull, mine = (key << 32) | p;
+  unsigned long long s = scone_hash_key(key, 0u) & hmask;
+  for (unsigned long long probe = 0; probe <= hmask; ++probe) {
+    const unsigned long long old = atomicCAS(&rhash[s], 0ull, mine);
+    if (old == 0ull) return;
+    if ((old >> 32) == key) {
+      atomicMin(&rhash[s], mine);
+      return;
+    }
+    s = (s + 1ull) & hmask;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_gather_remap(int32_t *__restrict__ ell, long long ntok, int W, int NC,
+                                                      const unsigned long long *__restrict__ rhash, unsigned long long hmask,
+                                                      long long n_head, uint32_t *__restrict__ status) {
+  const long long per = (ntok + gridDim.x - 1) / gridDim.x;
+  const long long t0 = (long long)blockIdx.x * per, t1 = t0 + per < ntok ? t0 + per : ntok;
+  for (long long t = t0 + threadIdx.x; t < t1; t += blockDim.x) {
+    const int kown = ell[t * W + W - 2] & 0xFF;
+    for (int j = 0; j < NC; ++j) {
+      if (j >= kown) break;
+      const long long id = ell[t * W + j];
+      if (id < n_head) continue;  // a head row: its id is its row number in the lookup's row store
+      const unsigned long long key = (unsigned long long)id + 1ull;
+      unsigned long long s = scone_hash_key(key, 0u) & hmask;
+      long long slot = -1;
+      for (unsigned long long probe = 0; probe <= hmask; ++probe) {
+        const unsigned long long v = rhash[s];
+        if (v == 0ull) break;
+        if ((v >> 32) == key) {
+          slot = (long long)(v & 0xFFFFFFFFull);
+          break;
+        }
+        s = (s + 1ull) & hmask;
+      }
+      if (slot < 0) {  // the row did not arrive (the ranks disagree about the batch): report, never read out of bounds
+        atomicOr(status, SCONE_ST_BAD_ID);
+        slot = 0;
+      }
+      ell[t * W + j] = (int32_t)(n_head + slot);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int scone_shard_gather_plan(scone_handle *h, const int32_t *d_tok, int32_t B, int32_t T, uint64_t *h_n_records,
+                                       scone_stream_t stream) {
+  if (!h) return SCONE_EINVAL;
+  if (h->cfg.dim <= 0 || !h->rows) return scone_fail(h, SCONE_ESTATE, "scone_shard_gather_plan: handle has no table");
+  if (B < 0 || T <= 0 || !h_n_records || !d_tok) return scone_fail(h, SCONE_EINVAL, "scone_shard_gather_plan: bad argument");
+  if (h->cfg.placement != SCONE_PLACE_HBM) return scone_fail(h, SCONE_EINVAL, "scone_shard_gather_plan: HBM tables only");
+  SCONE_HIP(h, hipSetDevice(h->device));
+  hipStream_t s = (hipStream_t)stream;
+  if (!h->shard) {
+    h->shard = new (std::nothrow) scone_shard_state();
+    if (!h->shard) return scone_fail(h, SCONE_ENOMEM, "scone_shard_gather_plan: out of memory");
+  }
+  scone_shard_state *st = h->shard;
+  *h_n_records = 0;
+  st->n_uniq = 0;
+  const int W = SCONE_ELL_W(h->cfg.max_n), NC = h->cfg.max_n * (h->cfg.max_n + 1) / 2;
+  const long long ntok = (long long)B * T;
+  if (ntok == 0) return SCONE_OK;
+  if (!scone_grid_fits((unsigned long long)(ntok + 255) / 256, 256))
+    return scone_fail(h, SCONE_EINVAL, "scone_shard_gather_plan: too many tokens for one launch");
+  long long cs = st->cap_slice;
+  int rc = grow(h, &st->ell_slice, &cs, ntok, (size_t)W);
+  if (rc) return rc;
+  st->cap_slice = cs;
+  if (!st->counters) SCONE_HIP(h, hipMalloc(&st->counters, 3 * 64 * sizeof(uint32_t)));
+  if (!st->uniq_claim) {
+    SCONE_HIP(h, hipMalloc(&st->uniq_claim, (size_t)(h->local_rows ? h->local_rows : 1) * sizeof(uint32_t)));
+    SCONE_HIP(h, hipMemset(st->uniq_claim, 0, (size_t)(h->local_rows ? h->local_rows : 1) * sizeof(uint32_t)));
+    st->uniq_gen = 0;
+  }
+  st->uniq_gen += 1;
+  if (st->uniq_gen == 0) {  // 2^32 batches: forget every old claim
+    SCONE_HIP(h, hipMemsetAsync(st->uniq_claim, 0, (size_t)(h->local_rows ? h->local_rows : 1) * sizeof(uint32_t), s));
+    st->uniq_gen = 1;
+  }
+  long long need = ntok * NC < (long long)h->local_rows ? ntok * NC : (long long)h->local_rows;
+  rc = grow(h, &st->uniq_list, &st->cap_uniq, need, 1);
+  if (rc) return rc;
+  SCONE_HIP(h, hipMemsetAsync(st->counters, 0, 3 * 64 * sizeof(uint32_t), s));
+  const long long n_head = (long long)st->n_head;
+  const long long send_begin = (long long)h->cfg.row_begin > n_head ? (long long)h->cfg.row_begin : n_head;
+  // ONE match of the whole batch against ALL rows: the lists the lookup kernel will walk, and what the claim pass filters
+  rc = scone_launch_match_ell_ex(h, d_tok, B, T, st->ell_slice, 0, (long long)h->cfg.n_rows, 0, s);
+  if (rc) return rc;
+  const unsigned blocks = (unsigned)((ntok + 255) / 256 < SHARD_BLOCKS ? (ntok + 255) / 256 : SHARD_BLOCKS);
+  hipLaunchKernelGGL(k_gather_claim, dim3(blocks), dim3(256), 0, s, st->ell_slice, ntok, W, NC, (long long)h->cfg.row_begin,
+                     send_begin, (long long)h->cfg.row_end, st->uniq_claim, st->uniq_gen, st->counters, st->uniq_list,
+                     st->cap_uniq);
+  SCONE_HIP(h, hipGetLastError());
+  uint32_t cnt = 0;
+  SCONE_HIP(h, hipMemcpyAsync(&cnt, st->counters, sizeof(cnt), hipMemcpyDeviceToHost, s));
+  SCONE_HIP(h, hipStreamSynchronize(s));
+  st->n_uniq = cnt;
+  *h_n_records = cnt;
+  return SCONE_OK;
+}
+
+extern "C" int scone_shard_gather_pack(scone_handle *h, void *d_send_buf, scone_stream_t stream) {
+  if (!h || !h->shard) return h ? scone_fail(h, SCONE_ESTATE, "scone_shard_gather_pack: call scone_shard_gather_plan first") : SCONE_EINVAL;
+  scone_shard_state *st = h->shard;
+  if (st->n_uniq == 0) return SCONE_OK;
+  if (!d_send_buf) return scone_fail(h, SCONE_EINVAL, "scone_shard_gather_pack: null send buffer");
+  SCONE_HIP(h, hipSetDevice(h->device));
+  unsigned pb = (unsigned)((st->n_uniq + 3) / 4);
+  if (pb > 4096) pb = 4096;
+  hipLaunchKernelGGL(k_gather_pack, dim3(pb), dim3(256), 0, (hipStream_t)stream, st->uniq_list, st->n_uniq, scone_store_of(h),
+                     (long long)h->cfg.row_begin, (const uint8_t *)h->scales, (int)h->scale_bytes_per_row,
+                     scone_shard_rec_bytes(h), (uint8_t *)d_send_buf);
+  SCONE_HIP(h, hipGetLastError());
+  return SCONE_OK;
+}
+
+// index the gathered records by row id, unpack their scales behind the head's, remap the lists of the whole batch
+int scone_shard_gather_prepare_embed(scone_handle *h, int32_t B, int32_t T, const void *d_recv, uint64_t n_recv,
+                                     const int32_t **ell, const void **scales, hipStream_t s) {
+  scone_shard_state *st = h->shard;
+  const int W = SCONE_ELL_W(h->cfg.max_n), NC = h->cfg.max_n * (h->cfg.max_n + 1) / 2;
+  const long long ntok = (long long)B * T;
+  const size_t sb = h->scale_bytes_per_row;
+  const unsigned long long n_head = st->n_head;
+  if (n_recv > 0xFFFFFFF0ull) return scone_fail(h, SCONE_EINVAL, "scone_shard_gather_embed: too many records");
+  if (sb) {
+    long long cap = st->cap_recv;
+    uint8_t *p = st->scales;
+    int rc = grow(h, &p, &cap, (long long)(n_head + n_recv), sb);
+    st->scales = p, st->cap_recv = cap;
+    if (rc) return rc;
+    if (n_head) SCONE_HIP(h, hipMemcpyAsync(st->scales, st->head_scales, (size_t)n_head * sb, hipMemcpyDeviceToDevice, s));
+  }
+  long long hcap = 1024;
+  while (hcap < 2 * (long long)n_recv) hcap <<= 1;
+  int rc = grow(h, &st->rhash, &st->cap_rhash, hcap, 1);
+  if (rc) return rc;
+  SCONE_HIP(h, hipMemsetAsync(st->rhash, 0, (size_t)hcap * sizeof(unsigned long long), s));
+  if (n_recv)
+    hipLaunchKernelGGL(k_gather_index, dim3((unsigned)((n_recv + 255) / 256)), dim3(256), 0, s, (const uint8_t *)d_recv,
+                       (unsigned long long)n_recv, scone_shard_rec_bytes(h), (int)h->row_payload_bytes, (int)sb, st->rhash,
+                       (unsigned long long)hcap - 1, st->scales ? st->scales + (size_t)n_head * sb : nullptr);
+  const unsigned blocks = (unsigned)((ntok + 255) / 256 < SHARD_BLOCKS ? (ntok + 255) / 256 : SHARD_BLOCKS);
+  hipLaunchKernelGGL(k_gather_remap, dim3(blocks), dim3(256), 0, s, st->ell_slice, ntok, W, NC, st->rhash,
+                     (unsigned long long)hcap - 1, (long long)n_head, h->d_status);
+  SCONE_HIP(h, hipGetLastError());
+  *ell = st->ell_slice;
+  *scales = st->scales;
+  return SCONE_OK;
 }

@@ -23,10 +23,12 @@ here and only needed when the table does not fit one GPU's 288 GB (BASELINE conf
   ``tools/shard_emulate.py``: rank 0 sends 550 MB per 1M-token step, the others 52-75 MB);
 * exchange ``"gather_rows"``: when EVERY rank needs the whole ``[B, T, d]`` output (the north-star's all-gather of the
   aggregated vectors), gathering the 2 KB fp16 vector of every token costs four times the bytes of gathering the
-  quantised ROWS the batch references: every rank packs the records of the rows it owns (the same plan / pack with
-  "one destination"), ONE all-gather of records (padded to the largest contribution), and every rank reduces the whole
-  batch itself out of ``[replicated head | gathered records]`` -- bit-identical again, ~0.5 GB on the wire per 1M-token
-  step instead of ~1.9 GB into every rank;
+  quantised ROWS the batch references, and every DISTINCT row crosses once however many tokens reference it:
+  ``scone_shard_gather_plan`` claims the distinct rows this rank owns that the batch references, ``scone_shard_gather_pack``
+  writes one record ``[row | scales | row id]`` per claimed row, ONE all-gather of records (padded to the largest
+  contribution), and ``scone_shard_gather_embed`` indexes them by row id and reduces the whole batch out of
+  ``[replicated head | gathered records]`` -- bit-identical again, ~0.25 GB into every rank per 1M-token step instead
+  of ~1.9 GB;
 * exchange ``"partial_sums"`` (kept for comparison): every rank sums the rows it owns
   (``scone_embed_partial``) -> ``reduce_scatter`` -> ``scone_finalize``;
 * finally an ``all_gather`` of the finished vectors in the output dtype (skippable when the
@@ -203,10 +205,8 @@ class ShardedEmbeddingCache:
         """All-gather of the quantised rows the batch references; every rank then embeds the whole batch."""
         B, T = tok.shape
         W = self.world
-        # plan / pack with ONE destination (world = 1 semantics of the kernels): every reference of the batch to a row
-        # I own (outside the replicated head), headers = (token in batch, index in its list)
-        send_counts, _ = self.table.shard_plan(tok, 1, 0)
-        send = self.table.shard_pack(B, T, 1, send_counts)                   # uint8 [c_me, record_bytes]
+        # one record per DISTINCT row I own (outside the replicated head) that the batch references
+        send = self.table.shard_gather_pack(self.table.shard_gather_plan(tok))   # uint8 [c_me, record_bytes]
         rec = send.shape[1]
         if W > 1:
             mine = torch.tensor([send.shape[0]], dtype=torch.int64, device=send.device)
@@ -224,8 +224,8 @@ class ShardedEmbeddingCache:
                 recv = send
         else:
             recv = send
-        return self.table.shard_embed(tok, 1, 0, recv, wte=wte, wpe=wpe, position_ids=position_ids, reduce=reduce,
-                                      out_dtype=out_dtype)
+        return self.table.shard_gather_embed(tok, recv, wte=wte, wpe=wpe, position_ids=position_ids, reduce=reduce,
+                                             out_dtype=out_dtype)
 
     def _embed_row_exchange(self, tok, reduce, wte, wpe, position_ids, out_dtype, gather_output):
         B, T = tok.shape

@@ -399,6 +399,48 @@ class SconeTable:
         self._check(rc, "scone_shard_embed")
         return out
 
+    # -- all-gather form: one record per distinct row (scone_shard_gather_*) -------------
+    def shard_gather_plan(self, tok: torch.Tensor) -> int:
+        """Number of records this shard contributes: the distinct rows it owns (outside the replicated head) that
+        the batch references (synchronises)."""
+        tok = self._tok(tok)
+        B, T = tok.shape
+        n = C.c_uint64(0)
+        with torch.cuda.device(self.device):
+            rc = L.lib().scone_shard_gather_plan(self._h, _ptr(tok), B, T, C.byref(n), _stream())
+        self._check(rc, "scone_shard_gather_plan")
+        self._shard_keepalive = (tok,)
+        return n.value
+
+    def shard_gather_pack(self, n_records: int) -> torch.Tensor:
+        """uint8 ``[n_records, record_bytes]``: ``[row payload | scales | row id]`` per claimed row."""
+        buf = torch.empty((int(n_records), self.shard_record_bytes()), dtype=torch.uint8, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = L.lib().scone_shard_gather_pack(self._h, _ptr(buf), _stream())
+        self._check(rc, "scone_shard_gather_pack")
+        return buf
+
+    def shard_gather_embed(self, tok: torch.Tensor, records: torch.Tensor, wte: Optional[torch.Tensor] = None,
+                           wpe: Optional[torch.Tensor] = None, position_ids: Optional[torch.Tensor] = None,
+                           reduce: str = "mean", out_dtype: torch.dtype = torch.float32,
+                           out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """The whole batch ``[B*T, d]`` out of ``[replicated head | records of every shard]``."""
+        tok = self._tok(tok)
+        B, T = tok.shape
+        if position_ids is not None:
+            position_ids = position_ids.to(device=self.device, dtype=torch.int32).expand(B, T).contiguous()
+        if out is None:
+            out = torch.empty((B * T, self.dim), dtype=out_dtype, device=self.device)
+        assert records.is_cuda and records.is_contiguous() and records.dtype == torch.uint8
+        with torch.cuda.device(self.device):
+            rc = L.lib().scone_shard_gather_embed(self._h, _ptr(tok), B, T, _ptr(records), records.shape[0], _ptr(wte),
+                                                  0 if wte is None else wte.shape[0], _ptr(wpe),
+                                                  0 if wpe is None else wpe.shape[0], _ptr(position_ids), _REDUCE[reduce],
+                                                  _ptr(out), _DT[out_dtype], _stream())
+        self._shard_keepalive = (records, tok, position_ids, wte, wpe)       # read in place after the call returns
+        self._check(rc, "scone_shard_gather_embed")
+        return out
+
     def finalize(self, sums: torch.Tensor, counts: torch.Tensor, tok: torch.Tensor, tok_begin: int, tok_end: int,
                  wte: Optional[torch.Tensor] = None, wpe: Optional[torch.Tensor] = None,
                  position_ids: Optional[torch.Tensor] = None, reduce: str = "mean",

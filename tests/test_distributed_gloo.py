@@ -121,6 +121,40 @@ class OracleShard:
             return out
         return x
 
+    # ---- all-gather form stand-ins: a record = [fp32 row | int32 row id | int32 marker]
+    def shard_gather_plan(self, tok):
+        off, ids, tix, jix = self._refs(tok)
+        mine = np.unique(ids[(ids >= max(self.row_begin, self.n_head)) & (ids < self.row_end)])
+        self._uniq = mine
+        return len(mine)
+
+    def shard_gather_pack(self, n_records):
+        assert n_records == len(self._uniq)
+        n = self.dim * 4 + 8
+        recs = [np.concatenate([self.table[i].view(np.uint8), np.array([i, -1], dtype=np.int32).view(np.uint8)])
+                for i in self._uniq[::-1]]                           # any order is allowed
+        return torch.from_numpy(np.stack(recs) if recs else np.zeros((0, n), dtype=np.uint8))
+
+    def shard_gather_embed(self, tok, records, wte=None, wpe=None, position_ids=None, reduce="mean",
+                           out_dtype=torch.float32, out=None):
+        B, T = tok.shape
+        off, ids, tix, jix = self._refs(tok)
+        r = records.numpy()
+        by_id = {int(rec[self.dim * 4:].view(np.int32)[0]): rec[:self.dim * 4].view(np.float32) for rec in r}
+        assert len(by_id) == len(r), "a row arrived twice"
+        rows = np.zeros((len(ids), self.dim), dtype=np.float32)
+        for k, i in enumerate(ids.tolist()):
+            rows[k] = self.table[i] if i < self.n_head else by_id[i]   # head rows are local everywhere
+        assert np.array_equal(rows, self.table[ids])
+        x = torch.from_numpy(self.R.embed_numpy(rows, off, np.arange(len(ids)), reduce))
+        flat = tok.reshape(-1).long()
+        if wte is not None:
+            x = wte.float()[flat] + x
+        if wpe is not None:
+            pos = (torch.arange(flat.numel()) % T) if position_ids is None else position_ids.reshape(-1).long()
+            x = x + wpe.float()[pos]
+        return x.to(out_dtype)
+
     def finalize(self, sums, counts, tok, a, b, wte=None, wpe=None, position_ids=None, reduce="mean",
                  out_dtype=torch.float32, out=None):
         x = sums.clone()

@@ -126,17 +126,17 @@ def test_fuzz_row_exchange_vs_unsharded():
                 got = shards[q].shard_embed(tok, world, q, recv, wte=wte, wpe=wpe, out_dtype=torch.float16)
                 assert torch.equal(got, want[b0 * T:b1 * T]), tag + (q,)
             assert shards[q].status() == 0, tag
-        # the all-gather form: every shard packs what it owns for the WHOLE batch, any shard reduces the whole batch
-        sends = []
-        for s_ in shards:
-            p1, _ = s_.shard_plan(tok, 1, 0)
-            sends.append(s_.shard_pack(B, T, 1, p1))
-        recv = torch.cat(sends).contiguous()
-        assert recv.shape[0] == int((ids >= head).sum()), tag
-        q = int(rng.integers(world))
-        got = shards[q].shard_embed(tok, 1, 0, recv, wte=wte, wpe=wpe, out_dtype=torch.float16)
-        assert torch.equal(got, want), tag + ("gather_rows", q)
-        assert shards[q].status() == 0, tag
+        # the all-gather form: every shard packs one record per DISTINCT row it owns that the batch references, any shard
+        # reduces the whole batch out of [head | all records]
+        sends = [s_.shard_gather_pack(s_.shard_gather_plan(tok)) for s_ in shards]
+        order = rng.permutation(world)                                       # records may arrive in any order
+        recv = torch.cat([sends[r] for r in order]).contiguous()
+        assert recv.shape[0] == int(torch.unique(ids[ids >= head]).numel()), tag
+        for q in {int(rng.integers(world)), 0}:
+            shards[q].shard_gather_plan(tok)                                 # a rank embeds after ITS OWN plan of this batch
+            got = shards[q].shard_gather_embed(tok, recv, wte=wte, wpe=wpe, out_dtype=torch.float16)
+            assert torch.equal(got, want), tag + ("gather_rows", q)
+            assert shards[q].status() == 0, tag
 
 
 def test_fuzz_pinned_host_vs_hbm():
@@ -218,3 +218,50 @@ def test_fuzz_fit_gpu_vs_host_fit():
         hk, hl = host.key_arrays()
         gk, gl = gpu.key_arrays()
         assert np.array_equal(hl, gl) and np.array_equal(hk, gk), (case, max_n, vocab, min_freq, max_f, len(texts))
+
+
+def test_shard_workspaces_survive_mixed_modes_and_growing_batches():
+    """ONE set of shard handles, batches that grow and shrink, slice exchange and all-gather form interleaved: every
+    workspace of the shard state is sized for the call that uses it (each has its own capacity)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from scone_amd.distributed import shard_range
+    from scone_amd.hip_backend import SconeTable
+    rng = np.random.default_rng(2)
+    world, max_n, fmt, d, vocab, n, head = 4, 3, "int8", 768, 13, 900, 40
+    lens = rng.integers(1, max_n + 1, size=n).astype(np.uint8)
+    keys = rng.integers(0, vocab, size=(n, max_n)).astype(np.uint32)
+    keys[np.arange(max_n)[None, :] >= lens[:, None]] = 0
+    table = rng.standard_normal((n, d)).astype(np.float32)
+    full = SconeTable(max_n, n, d, fmt)
+    full.index_build(keys, lens)
+    full.store_f32(torch.from_numpy(table))
+    shards = []
+    for r in range(world):
+        a, b = shard_range(n, r, world)
+        s = SconeTable(max_n, n, d, fmt, row_begin=a, row_end=b)
+        s.index_build(keys, lens)
+        s.store_f32(torch.from_numpy(table[a:b]), row0=a)
+        s.shard_set_head(head)
+        s.shard_head_store_f32(torch.from_numpy(table[:head]), row0=0)
+        shards.append(s)
+    wte = torch.from_numpy(rng.standard_normal((vocab, d)).astype(np.float32)).half().cuda()
+    for step, (B, T, mode) in enumerate([(4, 8, "slice"), (60, 40, "gather"), (8, 16, "gather"), (96, 64, "slice"), (2, 5, "slice"),
+                                         (128, 64, "gather"), (100, 50, "slice")]):
+        tok = torch.from_numpy(rng.integers(0, vocab, size=(B, T)))
+        want = full.embed(tok, wte=wte).reshape(B * T, d)
+        if mode == "gather":
+            recv = torch.cat([s.shard_gather_pack(s.shard_gather_plan(tok)) for s in shards]).contiguous()
+            for q in range(world):
+                assert torch.equal(shards[q].shard_gather_embed(tok, recv, wte=wte, out_dtype=torch.float16), want), (step, q)
+        else:
+            plans = [s.shard_plan(tok, world, r) for r, s in enumerate(shards)]
+            sends = [s.shard_pack(B, T, world, plans[r][0]) for r, s in enumerate(shards)]
+            bper = (B + world - 1) // world
+            for q in range(world):
+                recv = torch.cat([sends[r][sum(plans[r][0][:q]):sum(plans[r][0][:q]) + plans[r][0][q]] for r in range(world)]).contiguous()
+                b0, b1 = min(q * bper, B), min(q * bper + bper, B)
+                if b1 > b0:
+                    got = shards[q].shard_embed(tok, world, q, recv, wte=wte, out_dtype=torch.float16)
+                    assert torch.equal(got, want[b0 * T:b1 * T]), (step, q)
+        assert all(s.status() == 0 for s in shards), step

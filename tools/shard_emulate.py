@@ -133,22 +133,22 @@ def main():
 
 
 def gather_rows_mode(a, shards, tok, wte, wpe, out, res, keys, lens):
-    """Every rank packs the records of the rows it owns for the WHOLE batch (plan / pack with one destination), the records
-    are all-gathered (here: concatenated), every rank reduces the whole batch."""
+    """Every rank packs one record per DISTINCT row it owns that the batch references, the records are all-gathered (here:
+    concatenated), every rank indexes them by row id and reduces the whole batch."""
     N, W, d, B, T = a.rows, a.world, a.dim, a.batch, a.seq
     rec = res["record_bytes"]
     best = None
     for rep in range(a.reps):
         sends, t_plan, t_pack, t_embed = [], [], [], []
         for r, s in enumerate(shards):
-            p, ms = timed(lambda: s.shard_plan(tok, 1, 0))
+            n_rec, ms = timed(lambda: s.shard_gather_plan(tok))
             t_plan.append(ms)
-            buf, ms = timed(lambda: s.shard_pack(B, T, 1, p[0]))
+            buf, ms = timed(lambda: s.shard_gather_pack(n_rec))
             sends.append(buf)
             t_pack.append(ms)
         recv = torch.cat(sends).contiguous()                              # the all-gather of records, by hand
         for q in range(W):
-            _, ms = timed(lambda: shards[q].shard_embed(tok, 1, 0, recv, wte=wte, wpe=wpe, out_dtype=torch.float16, out=out))
+            _, ms = timed(lambda: shards[q].shard_gather_embed(tok, recv, wte=wte, wpe=wpe, out_dtype=torch.float16, out=out))
             t_embed.append(ms)
         cur = [t_plan, t_pack, t_embed]
         best = cur if best is None else [[min(x, y) for x, y in zip(b, c)] for b, c in zip(best, cur)]

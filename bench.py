@@ -54,7 +54,7 @@ def parse():
     ap.add_argument("--hot-rows", type=int, default=0, help="pinned_host: leading rows kept in HBM")
     ap.add_argument("--stage-tokens", type=int, default=0, help="pinned_host: staged prefetch chunk size (0 = zero-copy)")
     ap.add_argument("--table-mode", default="replicated", choices=["replicated", "sharded"])
-    ap.add_argument("--exchange", default="rows", choices=["rows", "gather_rows", "partial_sums"],
+    ap.add_argument("--exchange", default="auto", choices=["auto", "rows", "gather_rows", "partial_sums"],
                     help="sharded mode: all-to-all of quantised rows + all-gather of the output (default), all-gather of the "
                          "quantised rows with every rank reducing the whole batch, or reduce-scatter of fp32 partial sums")
     ap.add_argument("--replicated-rows", type=int, default=50257,
@@ -309,11 +309,13 @@ def main():
                             f"{B}x{T} tokens/step/rank; fused match+gather+dequant+mean+wte+wpe, fp16 out",
                 "tokens_per_step_per_rank": ntok, "mean_hits_per_token": sum_k / ntok, "hits_histogram_K0_6": k_hist[:7],
                 "parallelism": (f"shard {args.shard_of} of a row-sharded table, local work only (no exchange)" if emu else
-                                (("row-sharded table, RCCL all-to-all of quantised rows" if args.exchange == "rows" else
-                                  "row-sharded table, RCCL all-gather of quantised rows, whole batch reduced on every rank"
-                                  if args.exchange == "gather_rows" else
+                                (("row-sharded table, RCCL all-to-all of quantised rows"
+                                  if (args.exchange == "rows" or (args.exchange == "auto" and args.no_gather_output)) else
+                                  "row-sharded table, RCCL all-gather of the distinct quantised rows, whole batch reduced on every rank"
+                                  if args.exchange in ("gather_rows", "auto") else
                                   "row-sharded table, RCCL reduce-scatter of fp32 partial sums")
-                                 + (", every rank keeps its slice" if args.no_gather_output else " + all-gather of the output")
+                                 + (", every rank keeps its slice" if args.no_gather_output else
+                                    ("" if args.exchange in ("gather_rows", "auto") else " + all-gather of the output"))
                                  + f", replicated head {args.replicated_rows} rows") if sharded
                                 else f"replicated table, tokens sharded over {world} rank(s), no collective"),
             },

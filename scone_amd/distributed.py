@@ -142,7 +142,7 @@ class ShardedEmbeddingCache:
     def embed_tokens(self, input_ids: torch.Tensor, *, reduce: str = "mean", wte: Optional[torch.Tensor] = None,
                      wpe: Optional[torch.Tensor] = None, position_ids: Optional[torch.Tensor] = None,
                      out_dtype: Optional[torch.dtype] = None, gather_output: bool = True,
-                     exchange: str = "rows") -> torch.Tensor:
+                     exchange: str = "auto") -> torch.Tensor:
         """Same result as ``EmbeddingCache.embed_tokens`` on the unsharded table (up to the fp32
         summation order across shards).  Every rank passes the SAME ``input_ids [B, T]``.
 
@@ -156,7 +156,11 @@ class ShardedEmbeddingCache:
         ntok, d, W = B * T, self.embedding_dim, self.world
         if out_dtype is None:
             out_dtype = wte.dtype if wte is not None else (wpe.dtype if wpe is not None else torch.float32)
-        if W == 1 and exchange == "rows" and hasattr(self.table, "embed"):
+        if exchange == "auto":
+            # the whole output on every rank: gather the distinct rows (a tenth of the bytes of gathering the finished
+            # vectors); every rank keeps its own slice: send each slice the rows it needs
+            exchange = "gather_rows" if gather_output else "rows"
+        if W == 1 and exchange in ("rows", "gather_rows") and hasattr(self.table, "embed"):
             # one shard owns every row: the plain fused lookup, nothing to exchange
             out = self.table.embed(tok, wte=wte, wpe=wpe, position_ids=position_ids, reduce=reduce, out_dtype=out_dtype)
             return out if gather_output else out.reshape(ntok, d)

@@ -143,12 +143,14 @@ class ShardedEmbeddingCache:
                      wpe: Optional[torch.Tensor] = None, position_ids: Optional[torch.Tensor] = None,
                      out_dtype: Optional[torch.dtype] = None, gather_output: bool = True,
                      exchange: str = "auto") -> torch.Tensor:
-        """Same result as ``EmbeddingCache.embed_tokens`` on the unsharded table (up to the fp32
-        summation order across shards).  Every rank passes the SAME ``input_ids [B, T]``.
+        """Same result as ``EmbeddingCache.embed_tokens`` on the unsharded table -- bit-identical with the row
+        exchanges, up to the fp32 summation order across shards with ``"partial_sums"``.  Every rank passes the SAME
+        ``input_ids [B, T]``.
 
-        ``gather_output=False`` stops after the reduce-scatter + finalise and returns only this
-        rank's ``[ntok/W (padded), d]`` slice (for consumers that are themselves data-parallel
-        over tokens)."""
+        ``gather_output=True``: every rank gets the whole ``[B, T, d]``; ``False``: only this rank's slice
+        ``[ceil(B/W)*T, d]`` (zero-padded at the tail; for consumers that are themselves data-parallel over the same
+        slices).  ``exchange``: ``"auto"`` (``"gather_rows"`` for the whole output, ``"rows"`` for slices), ``"rows"``,
+        ``"gather_rows"`` or ``"partial_sums"`` -- see the module docstring."""
         tok = torch.as_tensor(input_ids)
         if tok.dim() == 1:
             tok = tok.unsqueeze(0)

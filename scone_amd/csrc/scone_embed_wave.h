@@ -1,18 +1,26 @@
-// Wave-per-token form of the fused lookup kernel (the fast path for d = 768 / 1024).
+// Wave-per-token kernels of the fused lookup: every embedding dim that is a multiple of 8 runs here.
+//
+//   k_embed_wave      two-kernel form (after k_match_ell): d = 768 / 1024 / 1280 specialised, persistent grid, the wave's
+//                     wpe row in registers, the NEXT token's id record prefetched while the current one is reduced
+//   k_embed_fused     one launch, match inside (lane c probes candidate window c, wavefront ballot -> K and the id list):
+//                     batches up to 32768 tokens, both lookup modes
+//   k_embed_wave_any  any other d % 8 == 0: the row is walked in units of 8 elements
+//   k_embed_csr_wave  caller-supplied id lists (scone_gather_reduce)
+//   k_finalize_wave   second half of the partial-sum exchange of row-sharded tables
 //
 // One 64-lane wavefront owns one token at a time, so everything that steers the
 // gather is wave-uniform: the candidate f-gram ids, the token and position ids and
 // the row base addresses live in SGPRs (scalar loads through the constant cache,
 // counted by lgkmcnt -- independent of the vector-memory queue), every branch is a
-// scalar branch, and each row is fetched by ONE wave instruction reading
-// row_bytes contiguous bytes (12 or 16 bytes per lane for INT8 at d = 768 / 1024).
-// All K_t row loads plus the wte / wpe row loads of a token are issued back to
-// back before the first one is consumed; memory-level parallelism across tokens
-// comes from occupancy (<= 64 VGPRs -> 8 waves per SIMD), and the ids of the
-// wave's NEXT token are prefetched while the current one is reduced.
+// scalar branch, and each row is fetched by wave instructions that each cover a
+// contiguous run of bytes (segment lane map below).  All K_t row loads plus the wte
+// row load of a token are issued back to back before the first one is consumed (K is a
+// compile-time constant inside a K-way switch, so the waits are exact vmcnt counts);
+// memory-level parallelism across tokens comes from occupancy (5-7 waves per SIMD;
+// wave_occupancy<> keeps the register budget free of spills).
 //
 // Same arithmetic as k_embed (scone_gather_impl.h): sequential fp32 accumulation in
-// the reference's list order, IEEE sum / K, (wte + mean) + wpe, one rounding to OutT.
+// the reference's list order, correctly rounded sum / K, (wte + mean) + wpe, one rounding to OutT.
 #pragma once
 
 #include "scone_gather_impl.h"

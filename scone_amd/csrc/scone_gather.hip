@@ -7,14 +7,11 @@
 //   embeddings.mean(dim=0), zero-fill, .half()            scone/inference/engine.py:247-266
 //   wte(input_ids) + f_gram_embeddings + wpe(position_ids) scone/models/language_model.py:239-254
 //
-// Work decomposition (gfx950, 64-lane waves): a *group* of LPT lanes owns one
-// token; a wave therefore carries 64/LPT tokens.  Each lane owns 16-byte vectors
-// v = lane, lane+LPT, ... of every row (VEC elements each), so one wave
-// instruction reads LPT*16 contiguous bytes of 64/LPT different rows.  For every
-// token all K_t row vectors are requested before the first one is consumed
-// (K_t <= 10 independent 16-byte loads per lane per vector column); accumulation
-// is sequential in the reference's list order in fp32, so results do not depend
-// on the launch geometry.
+// This file holds the entry points (scone_embed, scone_gather_reduce, scone_embed_partial, scone_finalize, the embed
+// halves of the shard exchanges) and the staged-prefetch driver; the kernels are in scone_embed_wave.h (wave per token:
+// every d % 8 == 0) and scone_gather_impl.h (k_embed, the lane-group fallback for other dims: a group of LPT lanes owns
+// one token, each lane 16-byte vectors of every row).  Accumulation is sequential in the reference's list order in
+// fp32 everywhere, so results do not depend on the launch geometry.
 #include "scone_gather_impl.h"
 
 using namespace scone_gather;

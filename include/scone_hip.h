@@ -17,11 +17,15 @@
  *     are host pointers; all device work is enqueued on the given stream
  *     (hipStream_t passed as void*; NULL = the default stream) and the call
  *     returns without synchronising unless documented otherwise
- *   - index and table are immutable on the lookup path.  Batches that take the one-launch kernel (up to
- *     32768 tokens at d = 768 / 1024 / 1280, see scone_embed) touch no other state: such lookups may run concurrently from several
- *     host threads on different streams.  Larger batches, scone_match_csr, scone_embed_partial and the
- *     scone_shard_* calls use workspaces owned by the handle: calls of those kinds on ONE handle must be
- *     stream-ordered (one stream, or events between streams)
+ *   - index and table are immutable on the lookup path, and lookups are thread-safe and stream-ordered: scone_embed
+ *     (any batch size), scone_match, scone_match_csr, scone_gather_reduce, scone_embed_partial, scone_finalize and
+ *     scone_table_gather_rows may be called concurrently from several host threads on one handle, on the same or on
+ *     different streams.  Batches of up to 32768 tokens at d = 768 / 1024 / 1280 take one launch and no workspace; larger
+ *     ones use a workspace that belongs to the STREAM of the call (created on first use, grown on demand or by
+ *     scone_reserve) and is locked while the call enqueues its kernels.  Not concurrent on one handle: index / table
+ *     mutation against lookups, the scone_shard_* exchange calls, lookups on a table created with stage_tokens > 0
+ *     (one staging pipeline per handle), and scone_destroy against anything
+ *   - every entry point selects the handle's device and restores the caller's current device before it returns
  */
 #ifndef SCONE_HIP_H
 #define SCONE_HIP_H
@@ -188,11 +192,13 @@ int scone_gather_reduce(scone_handle *h, const int32_t *d_offsets, const int32_t
  * d_wte / d_wpe: [vocab,d] / [n_pos,d] in out_dtype, or NULL (term omitted);
  * d_pos: int32 [B,T] or NULL (= arange(T), language_model.py:248-251).
  * Batches of up to 32768 tokens (environment SCONE_FUSED_MAX_TOKENS, read by scone_create) at d = 768 / 1024 / 1280
- * run as ONE launch without any workspace; larger ones use the handle's id-record workspace (grown on first use / by scone_reserve), so
- * concurrent large calls on one handle must be stream-ordered. */
+ * run as ONE launch without any workspace; larger ones use the id-record workspace of the call's stream (grown on first
+ * use / by scone_reserve). */
 int scone_embed(scone_handle *h, const int32_t *d_tok, int32_t B, int32_t T, const void *d_wte,
                 int64_t vocab, const void *d_wpe, int64_t n_pos, const int32_t *d_pos,
                 int32_t reduce, void *d_out, int32_t out_dtype, scone_stream_t stream);
+/* Every per-stream workspace of the handle (those that exist, the default stream's -- created here -- and any created
+ * later) holds at least max_tokens tokens: nothing is allocated inside a timed region afterwards. */
 int scone_reserve(scone_handle *h, int64_t max_tokens);
 /* Optional timing of the gather/reduce kernel launched by scone_embed: while enabled, every
  * call brackets that kernel with HIP events on the launch stream (a ring of 1024 pairs).
@@ -200,6 +206,11 @@ int scone_reserve(scone_handle *h, int64_t max_tokens);
  * their summed duration in milliseconds since the last reset, and optionally resets. */
 int scone_profile_enable(scone_handle *h, int enable);
 int scone_profile_read(scone_handle *h, uint64_t *n_launches, double *total_ms, int reset);
+/* The individual launch times (milliseconds, launch order) behind scone_profile_read's sum since the last reset:
+ * writes min(*n, cap) of them to h_ms and the number available to *n (at most 65536 are kept).  Synchronises.
+ * bench.py reports their min / median / max: the same binary runs this kernel 5-10 % apart from process to
+ * process (placement of the big buffers), so a mean alone says little. */
+int scone_profile_samples(scone_handle *h, float *h_ms, uint64_t cap, uint64_t *n);
 
 /* ---- row-sharded tables (one handle per GPU; RCCL exchange is done by the
  *      caller between the two calls) ---------------------------------------- */
@@ -261,6 +272,29 @@ int scone_shard_gather_pack(scone_handle *h, void *d_send_buf, scone_stream_t st
 int scone_shard_gather_embed(scone_handle *h, const int32_t *d_tok, int32_t B, int32_t T, const void *d_records,
                              uint64_t n_records, const void *d_wte, int64_t vocab, const void *d_wpe, int64_t n_pos,
                              const int32_t *d_pos, int32_t reduce, void *d_out, int32_t out_dtype, scone_stream_t stream);
+/* The same exchange cut into n_chunks (<= 64) runs of sequences (chunk c = sequences [c * ceil(B / n_chunks), ...)) so that
+ * the all-gather of chunk c + 1 overlaps the reduction of chunk c:
+ *   scone_shard_gather_plan_chunks   one match of the batch, one claim pass per chunk in chunk order; a row claimed by an
+ *                                    earlier chunk is not claimed again.  h_chunk_end[c] = records claimed by chunks 0..c
+ *                                    (this shard's records of chunk c are [h_chunk_end[c-1], h_chunk_end[c])); synchronises
+ *   scone_shard_gather_pack_range    records [first, first + count) of the plan into d_send_buf, followed by `pad` padding
+ *                                    records (row id 0xFFFFFFFF: an all-gather wants equal contributions; receivers skip them)
+ *   scone_shard_gather_add_records   receiver: records [record0, record0 + n_records) of the gathered buffer
+ *                                    (d_records_base = record 0; the buffer will hold n_total records in all, padding
+ *                                    included) join the row map; record0 == 0 starts a new exchange
+ *   scone_shard_gather_embed_range   sequences [seq_begin, seq_end) of the planned batch out of [replicated head | records
+ *                                    added so far] into their place in d_out ([B, T, d]); every row they reference must
+ *                                    have been added.  B, T must be the planned batch's. */
+int scone_shard_gather_plan_chunks(scone_handle *h, const int32_t *d_tok, int32_t B, int32_t T, int32_t n_chunks,
+                                   uint64_t *h_chunk_end, scone_stream_t stream);
+int scone_shard_gather_pack_range(scone_handle *h, uint64_t first, uint64_t count, uint64_t pad, void *d_send_buf,
+                                  scone_stream_t stream);
+int scone_shard_gather_add_records(scone_handle *h, const void *d_records_base, uint64_t record0, uint64_t n_records,
+                                   uint64_t n_total, scone_stream_t stream);
+int scone_shard_gather_embed_range(scone_handle *h, const int32_t *d_tok, int32_t B, int32_t T, int32_t seq_begin,
+                                   int32_t seq_end, const void *d_records_base, uint64_t n_total, const void *d_wte,
+                                   int64_t vocab, const void *d_wpe, int64_t n_pos, const int32_t *d_pos, int32_t reduce,
+                                   void *d_out, int32_t out_dtype, scone_stream_t stream);
 
 #ifdef __cplusplus
 }

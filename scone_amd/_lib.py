@@ -74,10 +74,16 @@ SIGNATURES = {
     "scone_reserve": (C.c_int, [_P, _I64]),
     "scone_profile_enable": (C.c_int, [_P, C.c_int]),
     "scone_profile_read": (C.c_int, [_P, C.POINTER(_U64), C.POINTER(C.c_double), C.c_int]),
+    "scone_profile_samples": (C.c_int, [_P, C.POINTER(C.c_float), _U64, C.POINTER(_U64)]),
     "scone_embed_partial": (C.c_int, [_P, _P, _I32, _I32, _P, _P, _P]),
     "scone_shard_gather_plan": (C.c_int, [_P, _P, _I32, _I32, C.POINTER(_U64), _P]),
     "scone_shard_gather_pack": (C.c_int, [_P, _P, _P]),
     "scone_shard_gather_embed": (C.c_int, [_P, _P, _I32, _I32, _P, _U64, _P, _I64, _P, _I64, _P, _I32, _P, _I32, _P]),
+    "scone_shard_gather_plan_chunks": (C.c_int, [_P, _P, _I32, _I32, _I32, C.POINTER(_U64), _P]),
+    "scone_shard_gather_pack_range": (C.c_int, [_P, _U64, _U64, _U64, _P, _P]),
+    "scone_shard_gather_add_records": (C.c_int, [_P, _P, _U64, _U64, _U64, _P]),
+    "scone_shard_gather_embed_range": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _P, _U64, _P, _I64, _P, _I64, _P, _I32, _P,
+                                                 _I32, _P]),
     "scone_shard_set_head": (C.c_int, [_P, _U64]),
     "scone_shard_head_store_f32": (C.c_int, [_P, _P, _U64, _U64, _P]),
     "scone_shard_record_bytes": (C.c_int, [_P, C.POINTER(_U64)]),

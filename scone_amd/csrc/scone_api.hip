@@ -5,14 +5,22 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <thread>
+#include <vector>
 
+// The message of a handle's last failure; written under a lock so that concurrent lookups cannot corrupt the string
+// (scone_last_error returns a pointer into it: read it from the thread whose call failed, before its next call).
 int scone_fail(scone_handle *h, int code, const char *what) {
-  if (h) h->err = what ? what : "";
+  if (h) {
+    std::lock_guard<std::mutex> g(h->err_mu);
+    h->err = what ? what : "";
+  }
   return code;
 }
 
 int scone_hip_fail(scone_handle *h, hipError_t e, const char *what) {
   if (h) {
+    std::lock_guard<std::mutex> g(h->err_mu);
     h->err = std::string(what ? what : "HIP call") + ": " + hipGetErrorString(e);
   }
   (void)hipGetLastError();  // clear the sticky error
@@ -28,23 +36,43 @@ scone_row_store scone_store_of(const scone_handle *h) {
   return st;
 }
 
-int scone_ensure_hits(scone_handle *h, int64_t ntok) {
-  if (ntok <= h->hits_cap_tokens) return SCONE_OK;
-  if (h->d_hits) SCONE_HIP(h, hipFree(h->d_hits));
-  h->d_hits = nullptr;
-  h->hits_cap_tokens = 0;
-  SCONE_HIP(h, hipMalloc(&h->d_hits, (size_t)ntok * h->cfg.max_n * sizeof(int32_t)));
-  h->hits_cap_tokens = ntok;
+scone_ws *scone_ws_acquire(scone_handle *h, hipStream_t s) {
+  scone_ws *w = nullptr;
+  {
+    std::lock_guard<std::mutex> g(h->ws_mu);
+    for (scone_ws *c : h->ws)
+      if (c->stream == s) w = c;
+    if (!w) {
+      w = new (std::nothrow) scone_ws();
+      if (!w) return nullptr;
+      w->stream = s;
+      h->ws.push_back(w);
+    }
+  }
+  w->mu.lock();
+  return w;
+}
+
+// Growing frees the old buffer: hipFree synchronises the device, so no kernel still reads it.
+int scone_ensure_hits(scone_handle *h, scone_ws *w, int64_t ntok) {
+  if (ntok < h->reserve_tokens) ntok = h->reserve_tokens;
+  if (ntok <= w->hits_cap_tokens) return SCONE_OK;
+  if (w->d_hits) SCONE_HIP(h, hipFree(w->d_hits));
+  w->d_hits = nullptr;
+  w->hits_cap_tokens = 0;
+  SCONE_HIP(h, hipMalloc(&w->d_hits, (size_t)ntok * h->cfg.max_n * sizeof(int32_t)));
+  w->hits_cap_tokens = ntok;
   return SCONE_OK;
 }
 
-int scone_ensure_ell(scone_handle *h, int64_t ntok) {
-  if (ntok <= h->ell_cap_tokens) return SCONE_OK;
-  if (h->d_ell) SCONE_HIP(h, hipFree(h->d_ell));
-  h->d_ell = nullptr;
-  h->ell_cap_tokens = 0;
-  SCONE_HIP(h, hipMalloc(&h->d_ell, (size_t)ntok * SCONE_ELL_W(h->cfg.max_n) * sizeof(int32_t)));
-  h->ell_cap_tokens = ntok;
+int scone_ensure_ell(scone_handle *h, scone_ws *w, int64_t ntok) {
+  if (ntok < h->reserve_tokens) ntok = h->reserve_tokens;
+  if (ntok <= w->ell_cap_tokens) return SCONE_OK;
+  if (w->d_ell) SCONE_HIP(h, hipFree(w->d_ell));
+  w->d_ell = nullptr;
+  w->ell_cap_tokens = 0;
+  SCONE_HIP(h, hipMalloc(&w->d_ell, (size_t)ntok * SCONE_ELL_W(h->cfg.max_n) * sizeof(int32_t)));
+  w->ell_cap_tokens = ntok;
   return SCONE_OK;
 }
 
@@ -90,6 +118,25 @@ static bool payload_geometry(const scone_cfg &c, size_t *payload, size_t *scale_
       return true;
     default: return false;
   }
+}
+
+// memset of a (possibly tens of GB) pinned region, split over a few host threads
+static void zero_host(void *p, size_t bytes) {
+  const size_t chunk = (size_t)1 << 30;
+  if (bytes <= chunk) {
+    memset(p, 0, bytes);
+    return;
+  }
+  unsigned nthr = std::thread::hardware_concurrency();
+  if (nthr > 16) nthr = 16;
+  if (nthr < 1) nthr = 1;
+  std::vector<std::thread> pool;
+  const size_t per = (bytes + nthr - 1) / nthr;
+  for (unsigned t = 0; t < nthr; ++t) {
+    const size_t a = (size_t)t * per, b = a + per < bytes ? a + per : bytes;
+    if (a < b) pool.emplace_back([=] { memset(static_cast<char *>(p) + a, 0, b - a); });
+  }
+  for (auto &th : pool) th.join();
 }
 
 extern "C" int scone_create(const scone_cfg *cfg, scone_handle **out) {
@@ -138,9 +185,7 @@ extern "C" int scone_create(const scone_cfg *cfg, scone_handle **out) {
   h->local_rows = h->cfg.row_end - h->cfg.row_begin;
   h->slots = nullptr, h->d_counters = nullptr, h->d_status = nullptr, h->d_uni = nullptr, h->d_bloom = nullptr, h->bloom_mask = 0;
   h->rows = nullptr, h->rows_host = nullptr, h->scales = nullptr, h->hot_local = 0;
-  h->d_hits = nullptr, h->hits_cap_tokens = 0, h->d_block_sums = nullptr, h->block_sums_cap = 0;
-  h->d_ell = nullptr, h->ell_cap_tokens = 0, h->d_zero_row = nullptr;
-  h->d_total = nullptr;
+  h->d_zero_row = nullptr, h->reserve_tokens = 0;
   h->row_payload_bytes = 0, h->scale_bytes_per_row = 0;
   h->stage = nullptr, h->shard = nullptr;
   h->prof_on = false, h->prof_ev = nullptr, h->prof_head = 0, h->prof_n = 0, h->prof_ms = 0.0;
@@ -159,6 +204,7 @@ extern "C" int scone_create(const scone_cfg *cfg, scone_handle **out) {
 
   int rc = SCONE_OK;
   hipError_t e;
+  scone_device_guard dev_guard__(h->device);  // the caller's current device is restored on return
 #define CREATE_HIP(call)                         \
   do {                                           \
     e = (call);                                  \
@@ -167,7 +213,7 @@ extern "C" int scone_create(const scone_cfg *cfg, scone_handle **out) {
       goto fail;                                 \
     }                                            \
   } while (0)
-  CREATE_HIP(hipSetDevice(h->device));
+  CREATE_HIP(dev_guard__.err);
   {
     int cus = 0;
     CREATE_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device));
@@ -184,7 +230,6 @@ extern "C" int scone_create(const scone_cfg *cfg, scone_handle **out) {
   CREATE_HIP(hipMemset(h->d_counters, 0, 2 * sizeof(unsigned long long)));
   CREATE_HIP(hipMalloc(&h->d_status, sizeof(uint32_t)));
   CREATE_HIP(hipMemset(h->d_status, 0, sizeof(uint32_t)));
-  CREATE_HIP(hipMalloc(&h->d_total, sizeof(int64_t)));
   CREATE_HIP(hipMalloc(&h->d_uni, (size_t)SCONE_UNI_CAP * sizeof(int32_t)));
   CREATE_HIP(hipMemset(h->d_uni, 0xFF, (size_t)SCONE_UNI_CAP * sizeof(int32_t)));
   {  // presence bitmap: 8 bits of room per slot (16 per key at load 0.5), capped at 128 MB
@@ -219,12 +264,23 @@ extern "C" int scone_create(const scone_cfg *cfg, scone_handle **out) {
       goto fail;
     }
     {
+      // Rows and scales start as zeros: the index may name f-grams whose rows were never stored (the reference raises
+      // KeyError there, embedding_cache.py:139; EmbeddingCache.to_device / embed_tokens(check=True) report them) --
+      // a lookup must never sum uninitialised memory.  INT4 zero nibbles with a zero scale dequantise to -0.0 * 8 = 0.
       size_t hot_bytes = (size_t)h->hot_local * h->row_payload_bytes;
       size_t cold_bytes = (size_t)(h->local_rows - h->hot_local) * h->row_payload_bytes;
       CREATE_HIP(hipMalloc(&h->rows, hot_bytes ? hot_bytes : 16));
-      if (cold_bytes) CREATE_HIP(hipHostMalloc(&h->rows_host, cold_bytes, hipHostMallocMapped | hipHostMallocPortable));
+      CREATE_HIP(hipMemsetAsync(h->rows, 0, hot_bytes ? hot_bytes : 16, nullptr));
+      if (cold_bytes) {
+        CREATE_HIP(hipHostMalloc(&h->rows_host, cold_bytes, hipHostMallocMapped | hipHostMallocPortable));
+        zero_host(h->rows_host, cold_bytes);
+      }
     }
-    if (scales_bytes) CREATE_HIP(hipMalloc(&h->scales, scales_bytes + 4));  // +4: scales are also read as dword pairs
+    if (scales_bytes) {
+      CREATE_HIP(hipMalloc(&h->scales, scales_bytes + 4));  // +4: scales are also read as dword pairs
+      CREATE_HIP(hipMemsetAsync(h->scales, 0, scales_bytes + 4, nullptr));
+    }
+    CREATE_HIP(hipStreamSynchronize(nullptr));
   }
 #undef CREATE_HIP
   *out = h;
@@ -237,20 +293,24 @@ fail:
 
 extern "C" void scone_destroy(scone_handle *h) {
   if (!h) return;
-  (void)hipSetDevice(h->device);
+  scone_device_guard dev_guard__(h->device);  // e.g. a handle garbage-collected while another device is current
   if (h->slots) (void)hipFree(h->slots);
   if (h->d_counters) (void)hipFree(h->d_counters);
   if (h->d_status) (void)hipFree(h->d_status);
   if (h->d_uni) (void)hipFree(h->d_uni);
   if (h->d_bloom) (void)hipFree(h->d_bloom);
-  if (h->d_total) (void)hipFree(h->d_total);
   if (h->rows) (void)hipFree(h->rows);
   if (h->rows_host) (void)hipHostFree(h->rows_host);
   if (h->scales) (void)hipFree(h->scales);
-  if (h->d_hits) (void)hipFree(h->d_hits);
-  if (h->d_ell) (void)hipFree(h->d_ell);
+  for (scone_ws *w : h->ws) {
+    if (w->d_hits) (void)hipFree(w->d_hits);
+    if (w->d_ell) (void)hipFree(w->d_ell);
+    if (w->d_block_sums) (void)hipFree(w->d_block_sums);
+    if (w->d_total) (void)hipFree(w->d_total);
+    delete w;
+  }
+  h->ws.clear();
   if (h->d_zero_row) (void)hipFree(h->d_zero_row);
-  if (h->d_block_sums) (void)hipFree(h->d_block_sums);
   scone_stage_destroy(h);
   scone_shard_destroy(h);
   if (h->prof_ev) {
@@ -263,7 +323,7 @@ extern "C" void scone_destroy(scone_handle *h) {
 
 extern "C" int scone_status(scone_handle *h, uint32_t *bits, scone_stream_t stream) {
   if (!h || !bits) return SCONE_EINVAL;
-  SCONE_HIP(h, hipSetDevice(h->device));
+  SCONE_ON_DEVICE(h);
   hipStream_t s = (hipStream_t)stream;
   SCONE_HIP(h, hipMemcpyAsync(bits, h->d_status, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
   SCONE_HIP(h, hipMemsetAsync(h->d_status, 0, sizeof(uint32_t), s));
@@ -273,9 +333,28 @@ extern "C" int scone_status(scone_handle *h, uint32_t *bits, scone_stream_t stre
 
 extern "C" int scone_reserve(scone_handle *h, int64_t max_tokens) {
   if (!h || max_tokens < 0) return SCONE_EINVAL;
-  SCONE_HIP(h, hipSetDevice(h->device));
-  int rc = scone_ensure_hits(h, max_tokens);
-  return rc ? rc : scone_ensure_ell(h, max_tokens);
+  SCONE_ON_DEVICE(h);
+  // every workspace (existing ones now, later ones when they are created) holds at least max_tokens; the default
+  // stream's is created here so that a caller on that stream allocates nothing inside its timed region
+  {
+    std::lock_guard<std::mutex> g(h->ws_mu);
+    if (max_tokens > h->reserve_tokens) h->reserve_tokens = max_tokens;
+  }
+  scone_ws *w0 = scone_ws_acquire(h, nullptr);
+  if (!w0) return scone_fail(h, SCONE_ENOMEM, "scone_reserve: out of memory");
+  scone_ws_release(w0);
+  std::vector<scone_ws *> all;
+  {
+    std::lock_guard<std::mutex> g(h->ws_mu);
+    all = h->ws;
+  }
+  for (scone_ws *w : all) {
+    w->mu.lock();
+    scone_ws_lock lk(w);
+    int rc = h->cfg.dim > 0 && h->cfg.dim % 8 == 0 ? scone_ensure_ell(h, w, max_tokens) : scone_ensure_hits(h, w, max_tokens);
+    if (rc) return rc;
+  }
+  return SCONE_OK;
 }
 
 // ---------------------------------------------------------------- kernel timing
@@ -287,6 +366,7 @@ static int prof_drain(scone_handle *h) {
     SCONE_HIP(h, hipEventElapsedTime(&ms, h->prof_ev[2 * i], h->prof_ev[2 * i + 1]));
     h->prof_ms += ms;
     h->prof_n += 1;
+    if (h->prof_samples.size() < SCONE_PROF_MAX_SAMPLES) h->prof_samples.push_back(ms);
   }
   h->prof_head = 0;
   return SCONE_OK;
@@ -294,24 +374,38 @@ static int prof_drain(scone_handle *h) {
 
 int scone_prof_begin(scone_handle *h, hipStream_t s) {
   if (!h->prof_on) return SCONE_OK;
+  h->prof_mu.lock();  // until scone_prof_end / scone_prof_abort: the ring slot belongs to this launch
   if (h->prof_head == SCONE_PROF_RING) {
     int rc = prof_drain(h);
-    if (rc) return rc;
+    if (rc) {
+      h->prof_mu.unlock();
+      return rc;
+    }
   }
-  SCONE_HIP(h, hipEventRecord(h->prof_ev[2 * h->prof_head], s));
+  hipError_t e = hipEventRecord(h->prof_ev[2 * h->prof_head], s);
+  if (e != hipSuccess) {
+    h->prof_mu.unlock();
+    return scone_hip_fail(h, e, "hipEventRecord");
+  }
   return SCONE_OK;
 }
 
 int scone_prof_end(scone_handle *h, hipStream_t s) {
   if (!h->prof_on) return SCONE_OK;
-  SCONE_HIP(h, hipEventRecord(h->prof_ev[2 * h->prof_head + 1], s));
-  h->prof_head += 1;
-  return SCONE_OK;
+  hipError_t e = hipEventRecord(h->prof_ev[2 * h->prof_head + 1], s);
+  if (e == hipSuccess) h->prof_head += 1;
+  h->prof_mu.unlock();
+  return e == hipSuccess ? SCONE_OK : scone_hip_fail(h, e, "hipEventRecord");
+}
+
+void scone_prof_abort(scone_handle *h) {
+  if (h->prof_on) h->prof_mu.unlock();
 }
 
 extern "C" int scone_profile_enable(scone_handle *h, int enable) {
   if (!h) return SCONE_EINVAL;
-  SCONE_HIP(h, hipSetDevice(h->device));
+  SCONE_ON_DEVICE(h);
+  std::lock_guard<std::mutex> g(h->prof_mu);
   if (enable && !h->prof_ev) {
     h->prof_ev = new (std::nothrow) hipEvent_t[2 * SCONE_PROF_RING]();  // null handles: destroy skips them
     if (!h->prof_ev) return scone_fail(h, SCONE_ENOMEM, "scone_profile_enable: out of memory");
@@ -327,11 +421,23 @@ extern "C" int scone_profile_enable(scone_handle *h, int enable) {
 
 extern "C" int scone_profile_read(scone_handle *h, uint64_t *n_launches, double *total_ms, int reset) {
   if (!h) return SCONE_EINVAL;
-  SCONE_HIP(h, hipSetDevice(h->device));
+  SCONE_ON_DEVICE(h);
+  std::lock_guard<std::mutex> g(h->prof_mu);
   int rc = prof_drain(h);
   if (rc) return rc;
   if (n_launches) *n_launches = h->prof_n;
   if (total_ms) *total_ms = h->prof_ms;
-  if (reset) h->prof_n = 0, h->prof_ms = 0.0;
+  if (reset) h->prof_n = 0, h->prof_ms = 0.0, h->prof_samples.clear();
+  return SCONE_OK;
+}
+
+extern "C" int scone_profile_samples(scone_handle *h, float *h_ms, uint64_t cap, uint64_t *n) {
+  if (!h || !n || (cap && !h_ms)) return SCONE_EINVAL;
+  SCONE_ON_DEVICE(h);
+  std::lock_guard<std::mutex> g(h->prof_mu);
+  int rc = prof_drain(h);
+  if (rc) return rc;
+  *n = h->prof_samples.size();
+  for (uint64_t i = 0; i < *n && i < cap; ++i) h_ms[i] = h->prof_samples[i];
   return SCONE_OK;
 }

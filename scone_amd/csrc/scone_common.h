@@ -7,13 +7,16 @@
 #include <hip/hip_bf16.h>
 #include <stdint.h>
 
+#include <mutex>
 #include <string>
+#include <vector>
 
 #include "../../include/scone_hip.h"
 
 #define SCONE_I4_GROUP 128
 #define SCONE_MAX_N 4
 #define SCONE_PROF_RING 1024
+#define SCONE_PROF_MAX_SAMPLES 65536  // per-launch times kept between two resets
 #define SCONE_UNI_CAP (1 << 18)  // direct unigram table: token ids below this skip the hash probe
 #define SCONE_MAX_CAND 10  // max_n (max_n + 1) / 2 at max_n = 4
 
@@ -102,6 +105,13 @@ __host__ __device__ inline uint32_t scone_hash32(uint32_t x) {
   return x;
 }
 
+// INT4 group scales, physical order inside a row's scale array.  d = 1024: a lane of the wave-per-token kernel owns
+// elements of group g = lane / 16 (first 512-element segment) and of group g + 4 (second segment); stored next to
+// each other they are ONE dword load per row and lane instead of two 2-byte loads, and one VGPR instead of two
+// (slot = 2 (g mod 4) + g / 4).  Every other d: logical order.  The C ABI (scone_table_upload / _download) speaks the
+// logical order [N, d/128]; every kernel indexes through this function.
+__host__ __device__ inline int scone_i4_scale_slot(int g, int d) { return d == 1024 ? (((g & 3) << 1) | (g >> 2)) : g; }
+
 // Where a local row lives: rows [0, hot) in HBM, the rest (if any) in mapped pinned host memory.
 struct scone_row_store {
   uint8_t *hot;
@@ -115,6 +125,22 @@ struct scone_row_store {
 
 struct scone_stage_state;
 struct scone_shard_state;
+
+// Per-stream workspaces of the large-batch lookup (id records / dense hits / CSR scan sums).  A call takes the
+// workspace of ITS stream and holds its lock while it enqueues the kernels that write and then read it, so lookups of
+// any size may be issued concurrently from several host threads -- on different streams (different workspaces) or on
+// one (the enqueue sequences do not interleave, and the stream orders their execution).
+struct scone_ws {
+  hipStream_t stream = nullptr;
+  std::mutex mu;
+  int32_t *d_hits = nullptr;
+  int64_t hits_cap_tokens = 0;
+  int32_t *d_ell = nullptr;  // per-token id lists for the fused lookup, [tokens, SCONE_ELL_W(max_n)]
+  int64_t ell_cap_tokens = 0;
+  int32_t *d_block_sums = nullptr;
+  int64_t block_sums_cap = 0;
+  int64_t *d_total = nullptr;
+};
 
 // ---------------------------------------------------------------- handle
 struct scone_handle {
@@ -138,23 +164,22 @@ struct scone_handle {
   size_t row_payload_bytes;
   size_t scale_bytes_per_row;
   uint64_t local_rows;
-  // workspaces
-  int32_t *d_hits;
-  int64_t hits_cap_tokens;
-  int32_t *d_ell;  // per-token id lists for the fused lookup, [tokens, SCONE_ELL_W(max_n)]
-  int64_t ell_cap_tokens;
-  int32_t *d_block_sums;
-  int64_t block_sums_cap;
-  int64_t *d_total;
+  // workspaces: one set per stream that has issued a large lookup (scone_ws_acquire)
+  std::mutex ws_mu;             // guards the list
+  std::vector<scone_ws *> ws;
+  int64_t reserve_tokens;       // scone_reserve: every workspace holds at least this many tokens
   void *d_zero_row;  // dim * 4 zero bytes
   scone_stage_state *stage;  // staged host->HBM prefetch (scone_stage.hip), created on first use
   scone_shard_state *shard;  // row exchange between shards (scone_shard.hip), created on first use
-  // optional kernel timing (scone_profile_*)
+  // optional kernel timing (scone_profile_*); prof_mu is held from the begin event to the end event of a launch
+  std::mutex prof_mu;
+  std::mutex err_mu;
   bool prof_on;
   hipEvent_t *prof_ev;  // [2 * SCONE_PROF_RING]
   uint64_t prof_head;   // pairs recorded since the last drain
   uint64_t prof_n;      // launches accumulated
   double prof_ms;
+  std::vector<float> prof_samples;  // per-launch milliseconds since the last reset (scone_profile_samples)
   std::string err;
 };
 
@@ -163,10 +188,23 @@ int scone_hip_fail(scone_handle *h, hipError_t e, const char *what);
 scone_row_store scone_store_of(const scone_handle *h);
 struct scone_index_view;
 void scone_index_view_of(const scone_handle *h, scone_index_view *v);  // scone_index.hip
-int scone_ensure_hits(scone_handle *h, int64_t ntok);
-int scone_ensure_ell(scone_handle *h, int64_t ntok);
-int scone_prof_begin(scone_handle *h, hipStream_t s);  // no-ops unless profiling is enabled
+// The workspace of stream s, LOCKED (created on first use); release with scone_ws_release or hold it in a scone_ws_lock.
+scone_ws *scone_ws_acquire(scone_handle *h, hipStream_t s);
+inline void scone_ws_release(scone_ws *w) {
+  if (w) w->mu.unlock();
+}
+struct scone_ws_lock {
+  scone_ws *w;
+  explicit scone_ws_lock(scone_ws *ws) : w(ws) {}
+  ~scone_ws_lock() { scone_ws_release(w); }
+  scone_ws_lock(const scone_ws_lock &) = delete;
+  scone_ws_lock &operator=(const scone_ws_lock &) = delete;
+};
+int scone_ensure_hits(scone_handle *h, scone_ws *w, int64_t ntok);
+int scone_ensure_ell(scone_handle *h, scone_ws *w, int64_t ntok);
+int scone_prof_begin(scone_handle *h, hipStream_t s);  // no-ops unless profiling is enabled; begin takes prof_mu, end drops it
 int scone_prof_end(scone_handle *h, hipStream_t s);
+void scone_prof_abort(scone_handle *h);                // a launch failed between begin and end
 
 // A dispatch carries its size in WORK-ITEMS in a 32-bit field: blocks x threads must stay below 2^32, beyond that
 // the grid silently wraps (found by a 100M-row table whose one-wave-per-row synthetic fill stopped at row 33.5M
@@ -177,6 +215,29 @@ static inline bool scone_grid_fits(unsigned long long blocks, unsigned threads) 
 static inline unsigned scone_capped_blocks(unsigned long long blocks) {
   return (unsigned)(blocks < SCONE_MAX_BLOCKS ? (blocks ? blocks : 1) : SCONE_MAX_BLOCKS);
 }
+
+// Every entry point runs on the handle's device and leaves the CALLER's current device as it found it (a process
+// may hold tables on several GPUs, or have another device current when a handle is used or garbage-collected).
+struct scone_device_guard {
+  int prev = -1;
+  bool switched = false;
+  hipError_t err = hipSuccess;
+  explicit scone_device_guard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != dev) {
+      err = hipSetDevice(dev);
+      switched = err == hipSuccess;
+    }
+  }
+  ~scone_device_guard() {
+    if (switched && prev >= 0) (void)hipSetDevice(prev);
+  }
+  scone_device_guard(const scone_device_guard &) = delete;
+  scone_device_guard &operator=(const scone_device_guard &) = delete;
+};
+#define SCONE_ON_DEVICE(h)                                                                  \
+  scone_device_guard dev_guard__((h)->device);                                              \
+  if (dev_guard__.err != hipSuccess) return scone_hip_fail((h), dev_guard__.err, "hipSetDevice")
 
 #define SCONE_HIP(h, call)                                       \
   do {                                                           \
@@ -204,8 +265,10 @@ int scone_shard_fill_head_synth(scone_handle *h, uint32_t seed, float base_scale
 void scone_shard_destroy(scone_handle *h);
 int scone_shard_rec_bytes(const scone_handle *h);
 uint8_t *scone_shard_head(const scone_handle *h, unsigned long long *n_head);  // replicated head rows (record layout) or null
-int scone_shard_gather_prepare_embed(scone_handle *h, int32_t B, int32_t T, const void *d_recv, uint64_t n_recv,
-                                     const int32_t **ell, const void **scales, hipStream_t s);
+int scone_shard_gather_add(scone_handle *h, const void *d_records, uint64_t n, uint64_t record0, uint64_t n_total, hipStream_t s);
+int scone_shard_gather_remap(scone_handle *h, int32_t T, int32_t seq0, int32_t seq1, const int32_t **ell, const void **scales,
+                             hipStream_t s);
+int scone_shard_plan_shape(const scone_handle *h, int32_t *B, int32_t *T);
 int scone_shard_prepare_embed(scone_handle *h, int32_t B, int32_t T, int32_t world, int32_t rank, const void *d_recv,
                               uint64_t n_recv, const int32_t **ell, const void **scales, int32_t *b0, int32_t *b1,
                               hipStream_t s);

@@ -170,7 +170,8 @@ extern "C" int scone_fit(int32_t device, const int32_t *d_tokens, int64_t n_toke
   if (h_n_distinct) *h_n_distinct = 0;
   if (n_tokens == 0 || n_texts == 0 || max_f_grams == 0) return SCONE_OK;
   if (!d_tokens || !d_text_offsets || !d_keys_out || !d_lens_out) return SCONE_EINVAL;
-  FIT_HIP(hipSetDevice(device));
+  scone_device_guard dev_guard__(device);  // the caller's current device is restored on return
+  FIT_HIP(dev_guard__.err);
   hipStream_t s = (hipStream_t)stream;
 
   // table sized for the worst case: every occurrence distinct

@@ -104,7 +104,10 @@ static int embed_staged(scone_handle *h, const embed_args &full, int32_t B, int3
     rc = scone_prof_begin(h, s);
     if (rc) return rc;
     rc = launch_fmt(h, a, SRC_HITS, MODE_FULL, out_dtype, s);
-    if (rc) return rc;
+    if (rc) {
+      scone_prof_abort(h);
+      return rc;
+    }
     rc = scone_prof_end(h, s);
     if (rc) return rc;
     rc = scone_stage_mark_consumed(h, buf, s);
@@ -123,7 +126,7 @@ extern "C" int scone_gather_reduce(scone_handle *h, const int32_t *d_offsets, co
   if (!d_offsets || !d_out) return scone_fail(h, SCONE_EINVAL, "scone_gather_reduce: null pointer");
   if (reduce != SCONE_REDUCE_MEAN && reduce != SCONE_REDUCE_SUM)
     return scone_fail(h, SCONE_EINVAL, "scone_gather_reduce: bad reduce");
-  SCONE_HIP(h, hipSetDevice(h->device));
+  SCONE_ON_DEVICE(h);
   embed_args a = {};
   fill_table_view(h, a.tv);
   a.offsets = d_offsets, a.ids = d_ids;
@@ -147,7 +150,7 @@ extern "C" int scone_embed(scone_handle *h, const int32_t *d_tok, int32_t B, int
     return scone_fail(h, SCONE_EINVAL, "scone_embed: bad reduce");
   if ((d_wte && vocab <= 0) || (d_wpe && n_pos <= 0))
     return scone_fail(h, SCONE_EINVAL, "scone_embed: wte/wpe given without vocab/n_pos");
-  SCONE_HIP(h, hipSetDevice(h->device));
+  SCONE_ON_DEVICE(h);
   hipStream_t s = (hipStream_t)stream;
   embed_args a = {};
   fill_table_view(h, a.tv);
@@ -172,29 +175,38 @@ extern "C" int scone_embed(scone_handle *h, const int32_t *d_tok, int32_t B, int
     rc = scone_prof_begin(h, s);
     if (rc) return rc;
     rc = launch_fmt(h, a, SRC_HITS, MODE_FULL, out_dtype, s);
-    if (rc) return rc;
+    if (rc) {
+      scone_prof_abort(h);
+      return rc;
+    }
     return scone_prof_end(h, s);
   }
+  // the workspace of THIS stream, held while the match that writes it and the lookup that reads it are enqueued
+  scone_ws_lock ws(scone_ws_acquire(h, s));
+  if (!ws.w) return scone_fail(h, SCONE_ENOMEM, "scone_embed: out of memory");
   if (scone_wave_kernel_covers(h->cfg.table_fmt, h->cfg.dim)) {
     // fast path: per-token id records (one scalar load per token in the gather kernel)
-    rc = scone_ensure_ell(h, BT);
+    rc = scone_ensure_ell(h, ws.w, BT);
     if (rc) return rc;
-    rc = scone_launch_match_ell(h, d_tok, B, T, h->d_ell, s);
+    rc = scone_launch_match_ell(h, d_tok, B, T, ws.w->d_ell, s);
     if (rc) return rc;
-    a.ell = h->d_ell;
+    a.ell = ws.w->d_ell;
   } else {
-    rc = scone_ensure_hits(h, BT);
+    rc = scone_ensure_hits(h, ws.w, BT);
     if (rc) return rc;
-    rc = scone_launch_match(h, d_tok, B, T, h->d_hits, s);
+    rc = scone_launch_match(h, d_tok, B, T, ws.w->d_hits, s);
     if (rc) return rc;
-    a.hits = h->d_hits;
+    a.hits = ws.w->d_hits;
   }
   a.tok = d_tok, a.pos = d_pos, a.wte = d_wte, a.vocab = vocab, a.wpe = d_wpe, a.n_pos = n_pos;
   a.reduce = reduce, a.out = d_out, a.status = h->d_status;
   rc = scone_prof_begin(h, s);
   if (rc) return rc;
   rc = launch_fmt(h, a, SRC_HITS, MODE_FULL, out_dtype, s);
-  if (rc) return rc;
+  if (rc) {
+    scone_prof_abort(h);
+    return rc;
+  }
   return scone_prof_end(h, s);
 }
 
@@ -213,7 +225,7 @@ extern "C" int scone_shard_embed(scone_handle *h, const int32_t *d_tok, int32_t 
     return scone_fail(h, SCONE_EINVAL, "scone_shard_embed: the row exchange needs d % 8 == 0");
   if (reduce != SCONE_REDUCE_MEAN && reduce != SCONE_REDUCE_SUM)
     return scone_fail(h, SCONE_EINVAL, "scone_shard_embed: bad reduce");
-  SCONE_HIP(h, hipSetDevice(h->device));
+  SCONE_ON_DEVICE(h);
   hipStream_t s = (hipStream_t)stream;
   const int32_t *ell = nullptr;
   const void *scales = nullptr;
@@ -242,43 +254,73 @@ extern "C" int scone_shard_embed(scone_handle *h, const int32_t *d_tok, int32_t 
   return launch_fmt(h, a, SRC_HITS, MODE_FULL, out_dtype, s);
 }
 
-// All-gather form: the records of EVERY shard have arrived (one per distinct row); reduce the whole batch.
-extern "C" int scone_shard_gather_embed(scone_handle *h, const int32_t *d_tok, int32_t B, int32_t T, const void *d_records,
-                                        uint64_t n_records, const void *d_wte, int64_t vocab, const void *d_wpe, int64_t n_pos,
-                                        const int32_t *d_pos, int32_t reduce, void *d_out, int32_t out_dtype,
-                                        scone_stream_t stream) {
+// All-gather form.  The gathered records (one per distinct row, every shard's) join the handle's row map with
+// scone_shard_gather_add_records -- all at once, or chunk by chunk as the all-gathers of a pipelined exchange complete --
+// and scone_shard_gather_embed_range reduces a run of sequences of the planned batch out of
+// [replicated head | records received so far]; scone_shard_gather_embed is the two for a whole batch.
+extern "C" int scone_shard_gather_add_records(scone_handle *h, const void *d_records_base, uint64_t record0, uint64_t n_records,
+                                              uint64_t n_total, scone_stream_t stream) {
+  int rc = need_table(h, "scone_shard_gather_add_records: handle has no table (dim == 0)");
+  if (rc) return rc;
+  if (!h->shard) return scone_fail(h, SCONE_ESTATE, "scone_shard_gather_add_records: call scone_shard_gather_plan first");
+  if (n_records && !d_records_base) return scone_fail(h, SCONE_EINVAL, "scone_shard_gather_add_records: null records");
+  SCONE_ON_DEVICE(h);
+  const uint8_t *p = reinterpret_cast<const uint8_t *>(d_records_base) + (size_t)record0 * (size_t)scone_shard_rec_bytes(h);
+  return scone_shard_gather_add(h, p, n_records, record0, n_total, (hipStream_t)stream);
+}
+
+extern "C" int scone_shard_gather_embed_range(scone_handle *h, const int32_t *d_tok, int32_t B, int32_t T, int32_t seq_begin,
+                                              int32_t seq_end, const void *d_records_base, uint64_t n_total, const void *d_wte,
+                                              int64_t vocab, const void *d_wpe, int64_t n_pos, const int32_t *d_pos,
+                                              int32_t reduce, void *d_out, int32_t out_dtype, scone_stream_t stream) {
   int rc = need_table(h, "scone_shard_gather_embed: handle has no table (dim == 0)");
   if (rc) return rc;
   if (!h->shard) return scone_fail(h, SCONE_ESTATE, "scone_shard_gather_embed: call scone_shard_gather_plan first");
-  if (B < 0 || T <= 0 || (n_records && !d_records)) return scone_fail(h, SCONE_EINVAL, "scone_shard_gather_embed: bad argument");
+  int32_t pB = 0, pT = 0;
+  scone_shard_plan_shape(h, &pB, &pT);
+  if (B < 0 || T <= 0 || B != pB || T != pT || seq_begin < 0 || seq_end < seq_begin || seq_end > B || (n_total && !d_records_base))
+    return scone_fail(h, SCONE_EINVAL, "scone_shard_gather_embed: bad argument (B, T must be the planned batch's)");
   if (!scone_wave_kernel_covers(h->cfg.table_fmt, h->cfg.dim))
     return scone_fail(h, SCONE_EINVAL, "scone_shard_gather_embed: needs d % 8 == 0");
   if (reduce != SCONE_REDUCE_MEAN && reduce != SCONE_REDUCE_SUM)
     return scone_fail(h, SCONE_EINVAL, "scone_shard_gather_embed: bad reduce");
-  const long long BT = (long long)B * T;
-  if (BT == 0) return SCONE_OK;
+  const long long nt = (long long)(seq_end - seq_begin) * T;
+  if (nt == 0) return SCONE_OK;
   if (!d_tok || !d_out) return scone_fail(h, SCONE_EINVAL, "scone_shard_gather_embed: null pointer");
-  SCONE_HIP(h, hipSetDevice(h->device));
+  SCONE_ON_DEVICE(h);
   hipStream_t s = (hipStream_t)stream;
   const int32_t *ell = nullptr;
   const void *scales = nullptr;
-  rc = scone_shard_gather_prepare_embed(h, B, T, d_records, n_records, &ell, &scales, s);
+  rc = scone_shard_gather_remap(h, T, seq_begin, seq_end, &ell, &scales, s);
   if (rc) return rc;
   embed_args a = {};
   fill_table_view(h, a.tv);
   unsigned long long n_head = 0;
   a.tv.st.hot = scone_shard_head(h, &n_head);  // row store: [replicated head | gathered records], both in record layout
   a.tv.st.n_hot = n_head;
-  a.tv.st.cold = n_records ? reinterpret_cast<uint8_t *>(const_cast<void *>(d_records)) : reinterpret_cast<uint8_t *>(h->d_zero_row);
+  a.tv.st.cold = n_total ? reinterpret_cast<uint8_t *>(const_cast<void *>(d_records_base)) : reinterpret_cast<uint8_t *>(h->d_zero_row);
   a.tv.st.row_bytes = (unsigned int)scone_shard_rec_bytes(h);
   a.tv.scales = reinterpret_cast<const __half *>(scales);
-  a.tv.row_begin = 0, a.tv.row_end = (long long)(n_head + (n_records ? n_records : 1));
-  a.BT = BT, a.ntok = BT, a.T = T, a.max_n = h->cfg.max_n;
+  a.tv.row_begin = 0, a.tv.row_end = (long long)(n_head + (n_total ? n_total : 1));
+  const long long t0 = (long long)seq_begin * T;
+  const size_t esz = out_dtype == SCONE_DT_F32 ? 4 : 2;
+  a.BT = nt, a.ntok = nt, a.T = T, a.max_n = h->cfg.max_n;
   a.ell = ell, a.zero_row = h->d_zero_row, a.mode = (int)h->cfg.lookup_mode;
-  a.tok = d_tok, a.pos = d_pos;
+  a.tok = d_tok + t0, a.pos = d_pos ? d_pos + t0 : nullptr;
   a.wte = d_wte, a.vocab = vocab, a.wpe = d_wpe, a.n_pos = n_pos;
-  a.reduce = reduce, a.out = d_out, a.status = h->d_status;
+  a.reduce = reduce, a.out = reinterpret_cast<uint8_t *>(d_out) + (size_t)t0 * h->cfg.dim * esz, a.status = h->d_status;
   return launch_fmt(h, a, SRC_HITS, MODE_FULL, out_dtype, s);
+}
+
+extern "C" int scone_shard_gather_embed(scone_handle *h, const int32_t *d_tok, int32_t B, int32_t T, const void *d_records,
+                                        uint64_t n_records, const void *d_wte, int64_t vocab, const void *d_wpe, int64_t n_pos,
+                                        const int32_t *d_pos, int32_t reduce, void *d_out, int32_t out_dtype,
+                                        scone_stream_t stream) {
+  int rc = scone_shard_gather_add_records(h, d_records, 0, n_records, n_records, stream);
+  if (rc) return rc;
+  if ((long long)B * T == 0) return SCONE_OK;
+  return scone_shard_gather_embed_range(h, d_tok, B, T, 0, B, d_records, n_records, d_wte, vocab, d_wpe, n_pos, d_pos, reduce,
+                                        d_out, out_dtype, stream);
 }
 
 extern "C" int scone_embed_partial(scone_handle *h, const int32_t *d_tok, int32_t B, int32_t T, float *d_partial,
@@ -289,7 +331,7 @@ extern "C" int scone_embed_partial(scone_handle *h, const int32_t *d_tok, int32_
   const long long BT = (long long)B * T;
   if (BT == 0) return SCONE_OK;
   if (!d_tok || !d_partial || !d_counts) return scone_fail(h, SCONE_EINVAL, "scone_embed_partial: null pointer");
-  SCONE_HIP(h, hipSetDevice(h->device));
+  SCONE_ON_DEVICE(h);
   hipStream_t s = (hipStream_t)stream;
   embed_args a = {};
   fill_table_view(h, a.tv);
@@ -298,18 +340,20 @@ extern "C" int scone_embed_partial(scone_handle *h, const int32_t *d_tok, int32_
   a.zero_row = h->d_zero_row, a.tok = d_tok, a.mode = (int)h->cfg.lookup_mode;
   rc = check_mode(h, "scone_embed_partial: lookup_mode longest_suffix needs d % 8 == 0");
   if (rc) return rc;
+  scone_ws_lock ws(scone_ws_acquire(h, s));
+  if (!ws.w) return scone_fail(h, SCONE_ENOMEM, "scone_embed_partial: out of memory");
   if (scone_wave_kernel_covers(h->cfg.table_fmt, h->cfg.dim)) {
-    rc = scone_ensure_ell(h, BT);
+    rc = scone_ensure_ell(h, ws.w, BT);
     if (rc) return rc;
-    rc = scone_launch_match_ell(h, d_tok, B, T, h->d_ell, s);
+    rc = scone_launch_match_ell(h, d_tok, B, T, ws.w->d_ell, s);
     if (rc) return rc;
-    a.ell = h->d_ell;
+    a.ell = ws.w->d_ell;
   } else {
-    rc = scone_ensure_hits(h, BT);
+    rc = scone_ensure_hits(h, ws.w, BT);
     if (rc) return rc;
-    rc = scone_launch_match(h, d_tok, B, T, h->d_hits, s);
+    rc = scone_launch_match(h, d_tok, B, T, ws.w->d_hits, s);
     if (rc) return rc;
-    a.hits = h->d_hits;
+    a.hits = ws.w->d_hits;
   }
   a.reduce = SCONE_REDUCE_SUM, a.partial = d_partial, a.counts = d_counts, a.status = h->d_status;
   return launch_fmt(h, a, SRC_HITS, MODE_PARTIAL, SCONE_DT_F32, s);
@@ -329,7 +373,7 @@ extern "C" int scone_finalize(scone_handle *h, const float *d_sum, const int32_t
     return scone_fail(h, SCONE_EINVAL, "scone_finalize: null pointer");
   if (reduce != SCONE_REDUCE_MEAN && reduce != SCONE_REDUCE_SUM)
     return scone_fail(h, SCONE_EINVAL, "scone_finalize: bad reduce");
-  SCONE_HIP(h, hipSetDevice(h->device));
+  SCONE_ON_DEVICE(h);
   embed_args a = {};
   fill_table_view(h, a.tv);
   a.BT = BT, a.T = T, a.max_n = h->cfg.max_n;

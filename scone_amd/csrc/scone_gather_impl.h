@@ -136,7 +136,7 @@ __device__ __forceinline__ float load_scale(const table_view &tv, long long lr, 
     return __half2float(tv.scales[lr]);
   } else if constexpr (FMT == SCONE_FMT_I4) {
     // 32 elements per vector, 128 per group -> 4 vectors share a scale
-    return __half2float(tv.scales[lr * (long long)(tv.d / SCONE_I4_GROUP) + (v >> 2)]);
+    return __half2float(tv.scales[lr * (long long)(tv.d / SCONE_I4_GROUP) + scone_i4_scale_slot(v >> 2, tv.d)]);
   } else {
     return 1.0f;
   }

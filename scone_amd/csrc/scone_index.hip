@@ -453,7 +453,7 @@ extern "C" int scone_index_build_device(scone_handle *h, const uint32_t *d_keys,
   if (n == 0) return SCONE_OK;
   if (!d_keys || !d_lens) return scone_fail(h, SCONE_EINVAL, "scone_index_build: null keys/lens");
   if (id0 + n > 0xFFFFFFFEull) return scone_fail(h, SCONE_ERANGE, "scone_index_build: ids must be < 2^32-2");
-  SCONE_HIP(h, hipSetDevice(h->device));
+  SCONE_ON_DEVICE(h);
   unsigned long long blocks = (n + 255) / 256;
   if (!scone_grid_fits(blocks, 256)) return scone_fail(h, SCONE_EINVAL, "scone_index_build: chunk too large");
   hipLaunchKernelGGL(k_index_insert, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, h->slots,
@@ -468,7 +468,7 @@ extern "C" int scone_index_build(scone_handle *h, const uint32_t *h_keys, const 
   if (!h) return SCONE_EINVAL;
   if (n == 0) return SCONE_OK;
   if (!h_keys || !h_lens) return scone_fail(h, SCONE_EINVAL, "scone_index_build: null keys/lens");
-  SCONE_HIP(h, hipSetDevice(h->device));
+  SCONE_ON_DEVICE(h);
   const uint64_t chunk = 1ull << 22;  // keys per staging round
   const int max_n = h->cfg.max_n;
   uint32_t *d_keys = nullptr;
@@ -508,7 +508,7 @@ extern "C" int scone_index_build(scone_handle *h, const uint32_t *h_keys, const 
 
 extern "C" int scone_index_stats(scone_handle *h, uint64_t *n_keys, uint64_t *capacity, uint64_t *n_dups) {
   if (!h) return SCONE_EINVAL;
-  SCONE_HIP(h, hipSetDevice(h->device));
+  SCONE_ON_DEVICE(h);
   SCONE_HIP(h, hipDeviceSynchronize());
   unsigned long long c[2] = {0, 0};
   SCONE_HIP(h, hipMemcpy(c, h->d_counters, sizeof(c), hipMemcpyDeviceToHost));
@@ -524,7 +524,7 @@ extern "C" int scone_match(scone_handle *h, const int32_t *d_tok, int32_t B, int
   if (B < 0 || T < 0) return scone_fail(h, SCONE_EINVAL, "scone_match: negative B or T");
   if ((long long)B * T == 0) return SCONE_OK;
   if (!d_tok || !d_hits) return scone_fail(h, SCONE_EINVAL, "scone_match: null pointer");
-  SCONE_HIP(h, hipSetDevice(h->device));
+  SCONE_ON_DEVICE(h);
   return scone_launch_match(h, d_tok, B, T, d_hits, (hipStream_t)stream);
 }
 
@@ -533,7 +533,7 @@ extern "C" int scone_match_csr(scone_handle *h, const int32_t *d_tok, int32_t B,
   if (!h) return SCONE_EINVAL;
   if (B < 0 || T < 0 || ids_cap < 0) return scone_fail(h, SCONE_EINVAL, "scone_match_csr: negative size");
   if (!d_offsets || !h_total) return scone_fail(h, SCONE_EINVAL, "scone_match_csr: null pointer");
-  SCONE_HIP(h, hipSetDevice(h->device));
+  SCONE_ON_DEVICE(h);
   hipStream_t s = (hipStream_t)stream;
   long long BT = (long long)B * T;
   if (BT == 0) {
@@ -544,27 +544,30 @@ extern "C" int scone_match_csr(scone_handle *h, const int32_t *d_tok, int32_t B,
   }
   if (!d_tok) return scone_fail(h, SCONE_EINVAL, "scone_match_csr: null tokens");
   if (BT * SCONE_MAX_CAND > 0x7FFFFFFFll) return scone_fail(h, SCONE_EINVAL, "scone_match_csr: B*T too large for int32 offsets");
-  int rc = scone_ensure_hits(h, BT);
+  scone_ws_lock ws(scone_ws_acquire(h, s));  // this stream's workspace, held until the total has been read back
+  if (!ws.w) return scone_fail(h, SCONE_ENOMEM, "scone_match_csr: out of memory");
+  scone_ws *w = ws.w;
+  int rc = scone_ensure_hits(h, w, BT);
   if (rc) return rc;
-  rc = scone_launch_match(h, d_tok, B, T, h->d_hits, s);
+  rc = scone_launch_match(h, d_tok, B, T, w->d_hits, s);
   if (rc) return rc;
   long long nb = (BT + CSR_TILE - 1) / CSR_TILE;
-  if (nb > h->block_sums_cap) {
-    if (h->d_block_sums) SCONE_HIP(h, hipFree(h->d_block_sums));
-    h->d_block_sums = nullptr;
-    h->block_sums_cap = 0;
-    SCONE_HIP(h, hipMalloc(&h->d_block_sums, (size_t)nb * sizeof(int32_t)));
-    h->block_sums_cap = nb;
+  if (nb > w->block_sums_cap) {
+    if (w->d_block_sums) SCONE_HIP(h, hipFree(w->d_block_sums));
+    w->d_block_sums = nullptr;
+    w->block_sums_cap = 0;
+    SCONE_HIP(h, hipMalloc(&w->d_block_sums, (size_t)nb * sizeof(int32_t)));
+    w->block_sums_cap = nb;
   }
-  hipLaunchKernelGGL(k_csr_block_sums, dim3((unsigned)nb), dim3(CSR_BLOCK), 0, s, h->d_hits, BT, T, h->cfg.max_n,
-                     h->d_block_sums);
-  hipLaunchKernelGGL(k_csr_scan_sums, dim3(1), dim3(CSR_BLOCK), 0, s, h->d_block_sums, nb,
-                     (long long *)h->d_total);
-  hipLaunchKernelGGL(k_csr_fill, dim3((unsigned)nb), dim3(CSR_BLOCK), 0, s, h->d_hits, BT, T, h->cfg.max_n,
-                     h->d_block_sums, d_offsets, d_ids, d_ids ? (long long)ids_cap : 0ll);
+  if (!w->d_total) SCONE_HIP(h, hipMalloc(&w->d_total, sizeof(int64_t)));
+  hipLaunchKernelGGL(k_csr_block_sums, dim3((unsigned)nb), dim3(CSR_BLOCK), 0, s, w->d_hits, BT, T, h->cfg.max_n,
+                     w->d_block_sums);
+  hipLaunchKernelGGL(k_csr_scan_sums, dim3(1), dim3(CSR_BLOCK), 0, s, w->d_block_sums, nb, (long long *)w->d_total);
+  hipLaunchKernelGGL(k_csr_fill, dim3((unsigned)nb), dim3(CSR_BLOCK), 0, s, w->d_hits, BT, T, h->cfg.max_n,
+                     w->d_block_sums, d_offsets, d_ids, d_ids ? (long long)ids_cap : 0ll);
   SCONE_HIP(h, hipGetLastError());
   long long total = 0;
-  SCONE_HIP(h, hipMemcpyAsync(&total, h->d_total, sizeof(total), hipMemcpyDeviceToHost, s));
+  SCONE_HIP(h, hipMemcpyAsync(&total, w->d_total, sizeof(total), hipMemcpyDeviceToHost, s));
   SCONE_HIP(h, hipStreamSynchronize(s));
   *h_total = total;
   if (total > ids_cap) return scone_fail(h, SCONE_ERANGE, "scone_match_csr: ids_cap too small");

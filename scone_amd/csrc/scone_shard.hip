@@ -43,6 +43,9 @@ struct scone_shard_state {
   int32_t *uniq_list = nullptr;    // [cap_uniq] claimed row ids
   long long cap_uniq = 0;
   unsigned long long n_uniq = 0;   // records of the current plan
+  uint32_t *chunk_ends = nullptr;  // [64] value of the claim counter after each chunk of the plan
+  int32_t plan_B = 0, plan_T = 0, plan_chunks = 0;
+  long long rhash_cap_now = 0;     // capacity the receiver's map was cleared for (current exchange)
   unsigned long long *rhash = nullptr;  // receiver: open-addressing map row id -> record number
   long long cap_rhash = 0;
 };
@@ -253,7 +256,7 @@ void scone_shard_destroy(scone_handle *h) {
   scone_shard_state *st = h->shard;
   if (!st) return;
   void *ptrs[] = {st->ell_send, st->ell_slice, st->counters, st->send_src, st->slot_of_ref, st->scales,
-                  st->head_rows, st->head_scales, st->uniq_claim, st->uniq_list, st->rhash};
+                  st->head_rows, st->head_scales, st->uniq_claim, st->uniq_list, st->rhash, st->chunk_ends};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   delete st;
@@ -289,7 +292,7 @@ extern "C" int scone_shard_plan(scone_handle *h, const int32_t *d_tok, int32_t B
   if (h->cfg.dim <= 0 || !h->rows) return scone_fail(h, SCONE_ESTATE, "scone_shard_plan: handle has no table");
   if (B < 0 || T <= 0 || world < 1 || world > 64 || rank < 0 || rank >= world || !h_send_counts || !h_recv_counts || !d_tok)
     return scone_fail(h, SCONE_EINVAL, "scone_shard_plan: bad argument (world <= 64)");
-  SCONE_HIP(h, hipSetDevice(h->device));
+  SCONE_ON_DEVICE(h);
   hipStream_t s = (hipStream_t)stream;
   if (!h->shard) {
     h->shard = new (std::nothrow) scone_shard_state();
@@ -341,7 +344,7 @@ extern "C" int scone_shard_pack(scone_handle *h, int32_t B, int32_t T, int32_t w
                                 void *d_send_buf, scone_stream_t stream) {
   if (!h || !h->shard) return h ? scone_fail(h, SCONE_ESTATE, "scone_shard_pack: call scone_shard_plan first") : SCONE_EINVAL;
   if (world < 1 || world > 64 || !h_send_counts) return scone_fail(h, SCONE_EINVAL, "scone_shard_pack: bad argument");
-  SCONE_HIP(h, hipSetDevice(h->device));
+  SCONE_ON_DEVICE(h);
   hipStream_t s = (hipStream_t)stream;
   scone_shard_state *st = h->shard;
   const int W = SCONE_ELL_W(h->cfg.max_n), NC = h->cfg.max_n * (h->cfg.max_n + 1) / 2;
@@ -356,6 +359,9 @@ extern "C" int scone_shard_pack(scone_handle *h, int32_t B, int32_t T, int32_t w
   int rc = grow(h, &st->send_src, &cap, (long long)total, 2);
   if (rc) return rc;
   st->cap_send = cap;
+  // the pack cursors start at zero for EVERY pack (a second pack after one plan -- a retry, another send buffer --
+  // would otherwise continue behind the first one's records and write past `total`)
+  SCONE_HIP(h, hipMemsetAsync(st->counters + 128, 0, 64 * sizeof(uint32_t), s));
   const unsigned blocks = (unsigned)((ntok + 255) / 256 < SHARD_BLOCKS ? (ntok + 255) / 256 : SHARD_BLOCKS);
   hipLaunchKernelGGL(k_shard_claim, dim3(blocks), dim3(256), 0, s, st->ell_send, ntok, W, NC, slice_tokens, off,
                      st->counters + 128, st->send_src);
@@ -419,7 +425,7 @@ extern "C" int scone_shard_set_head(scone_handle *h, uint64_t n_head) {
   if (h->cfg.placement != SCONE_PLACE_HBM) return scone_fail(h, SCONE_EINVAL, "scone_shard_set_head: HBM tables only");
   if (n_head > h->cfg.n_rows) n_head = h->cfg.n_rows;
   if (n_head > 0x7FFFFFFFull) return scone_fail(h, SCONE_EINVAL, "scone_shard_set_head: head too large");
-  SCONE_HIP(h, hipSetDevice(h->device));
+  SCONE_ON_DEVICE(h);
   if (!h->shard) {
     h->shard = new (std::nothrow) scone_shard_state();
     if (!h->shard) return scone_fail(h, SCONE_ENOMEM, "scone_shard_set_head: out of memory");
@@ -448,7 +454,7 @@ extern "C" int scone_shard_head_store_f32(scone_handle *h, const float *d_rows_f
   if (nrows == 0) return SCONE_OK;
   if (!d_rows_f32) return scone_fail(h, SCONE_EINVAL, "scone_shard_head_store_f32: null rows");
   if (row0 + nrows > h->shard->n_head) return scone_fail(h, SCONE_ERANGE, "scone_shard_head_store_f32: rows outside [0, n_head)");
-  SCONE_HIP(h, hipSetDevice(h->device));
+  SCONE_ON_DEVICE(h);
   return scone_store_f32_into(h, head_store(h), h->shard->head_scales, 0, h->shard->n_head, d_rows_f32, nullptr, row0, nrows,
                               (hipStream_t)stream);
 }
@@ -528,16 +534,31 @@ __global__ __launch_bounds__(256) void k_gather_pack(const int32_t *__restrict__
   }
 }
 
+// records [first, first + n) of a send buffer become padding
+__global__ __launch_bounds__(256) void k_gather_mark_pad(uint8_t *__restrict__ buf, unsigned long long first, unsigned long long n,
+                                                         int rec_bytes) {
+  const unsigned long long p = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  uint32_t *hdr = reinterpret_cast<uint32_t *>(buf + (first + p) * (unsigned long long)rec_bytes + rec_bytes - 8);
+  hdr[0] = 0xFFFFFFFFu;
+  hdr[1] = 0xFFFFFFFFu;
+}
+
 // receiver: record p holds row id hdr[0] -> hash map id -> p (key id + 1, empty 0; smallest p wins on a duplicate), scales
+// `recv` points at record number `record0` of the gathered buffer; `scales` at its scale slot.  Padding records (a rank's
+// contribution is padded to the largest one of its all-gather; the sender marks them with row id 0xFFFFFFFF) are skipped.
 __global__ __launch_bounds__(256) void k_gather_index(const uint8_t *__restrict__ recv, unsigned long long n_recv, int rec_bytes,
                                                       int row_bytes, int scale_bytes, unsigned long long *__restrict__ rhash,
-                                                      unsigned long long hmask, uint8_t *__restrict__ scales) {
-  const unsigned long long p = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+                                                      unsigned long long hmask, uint8_t *__restrict__ scales,
+                                                      unsigned long long record0) {
+  unsigned long long p = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n_recv) return;
   const uint8_t *rec = recv + p * (unsigned long long)rec_bytes;
   const uint32_t id = reinterpret_cast<const uint32_t *>(rec + rec_bytes - 8)[0];
+  if (id == 0xFFFFFFFFu) return;
   for (int b = 0; b < scale_bytes / 2; ++b)
     reinterpret_cast<unsigned short *>(scales + p * scale_bytes)[b] = reinterpret_cast<const unsigned short *>(rec + row_bytes)[b];
+  p += record0;
   const unsigned long long key = (unsigned long long)id + 1ull, mine = (key << 32) | p;
   unsigned long long s = scone_hash_key(key, 0u) & hmask;
   for (unsigned long long probe = 0; probe <= hmask; ++probe) {
@@ -585,21 +606,31 @@ __global__ __launch_bounds__(256) void k_gather_remap(int32_t *__restrict__ ell,
 
 }  // namespace
 
-extern "C" int scone_shard_gather_plan(scone_handle *h, const int32_t *d_tok, int32_t B, int32_t T, uint64_t *h_n_records,
-                                       scone_stream_t stream) {
+// chunk c of a batch of B sequences cut into n_chunks: sequences [c * ceil(B / n_chunks), ...)
+static void chunk_seqs(int32_t B, int32_t n_chunks, int32_t c, int32_t *s0, int32_t *s1) {
+  const long long per = ((long long)B + n_chunks - 1) / n_chunks;
+  const long long a = c * per, b = a + per;
+  *s0 = (int32_t)(a < B ? a : B);
+  *s1 = (int32_t)(b < B ? b : B);
+}
+
+extern "C" int scone_shard_gather_plan_chunks(scone_handle *h, const int32_t *d_tok, int32_t B, int32_t T, int32_t n_chunks,
+                                              uint64_t *h_chunk_end, scone_stream_t stream) {
   if (!h) return SCONE_EINVAL;
   if (h->cfg.dim <= 0 || !h->rows) return scone_fail(h, SCONE_ESTATE, "scone_shard_gather_plan: handle has no table");
-  if (B < 0 || T <= 0 || !h_n_records || !d_tok) return scone_fail(h, SCONE_EINVAL, "scone_shard_gather_plan: bad argument");
+  if (B < 0 || T <= 0 || !h_chunk_end || !d_tok || n_chunks < 1 || n_chunks > 64)
+    return scone_fail(h, SCONE_EINVAL, "scone_shard_gather_plan: bad argument (1 <= n_chunks <= 64)");
   if (h->cfg.placement != SCONE_PLACE_HBM) return scone_fail(h, SCONE_EINVAL, "scone_shard_gather_plan: HBM tables only");
-  SCONE_HIP(h, hipSetDevice(h->device));
+  SCONE_ON_DEVICE(h);
   hipStream_t s = (hipStream_t)stream;
   if (!h->shard) {
     h->shard = new (std::nothrow) scone_shard_state();
     if (!h->shard) return scone_fail(h, SCONE_ENOMEM, "scone_shard_gather_plan: out of memory");
   }
   scone_shard_state *st = h->shard;
-  *h_n_records = 0;
+  for (int c = 0; c < n_chunks; ++c) h_chunk_end[c] = 0;
   st->n_uniq = 0;
+  st->plan_B = B, st->plan_T = T, st->plan_chunks = n_chunks;
   const int W = SCONE_ELL_W(h->cfg.max_n), NC = h->cfg.max_n * (h->cfg.max_n + 1) / 2;
   const long long ntok = (long long)B * T;
   if (ntok == 0) return SCONE_OK;
@@ -610,6 +641,7 @@ extern "C" int scone_shard_gather_plan(scone_handle *h, const int32_t *d_tok, in
   if (rc) return rc;
   st->cap_slice = cs;
   if (!st->counters) SCONE_HIP(h, hipMalloc(&st->counters, 3 * 64 * sizeof(uint32_t)));
+  if (!st->chunk_ends) SCONE_HIP(h, hipMalloc(&st->chunk_ends, 64 * sizeof(uint32_t)));
   if (!st->uniq_claim) {
     SCONE_HIP(h, hipMalloc(&st->uniq_claim, (size_t)(h->local_rows ? h->local_rows : 1) * sizeof(uint32_t)));
     SCONE_HIP(h, hipMemset(st->uniq_claim, 0, (size_t)(h->local_rows ? h->local_rows : 1) * sizeof(uint32_t)));
@@ -626,68 +658,120 @@ extern "C" int scone_shard_gather_plan(scone_handle *h, const int32_t *d_tok, in
   SCONE_HIP(h, hipMemsetAsync(st->counters, 0, 3 * 64 * sizeof(uint32_t), s));
   const long long n_head = (long long)st->n_head;
   const long long send_begin = (long long)h->cfg.row_begin > n_head ? (long long)h->cfg.row_begin : n_head;
-  // ONE match of the whole batch against ALL rows: the lists the lookup kernel will walk, and what the claim pass filters
+  // ONE match of the whole batch against ALL rows: the lists the lookup kernel will walk, and what the claim passes filter
   rc = scone_launch_match_ell_ex(h, d_tok, B, T, st->ell_slice, 0, (long long)h->cfg.n_rows, 0, s);
   if (rc) return rc;
-  const unsigned blocks = (unsigned)((ntok + 255) / 256 < SHARD_BLOCKS ? (ntok + 255) / 256 : SHARD_BLOCKS);
-  hipLaunchKernelGGL(k_gather_claim, dim3(blocks), dim3(256), 0, s, st->ell_slice, ntok, W, NC, (long long)h->cfg.row_begin,
-                     send_begin, (long long)h->cfg.row_end, st->uniq_claim, st->uniq_gen, st->counters, st->uniq_list,
-                     st->cap_uniq);
+  // one claim pass per chunk, in chunk order, all in ONE generation: a row already claimed by an earlier chunk is not
+  // sent again -- the receiver's row map is cumulative, and chunk c is reduced after the records of chunks 0..c arrived
+  for (int c = 0; c < n_chunks; ++c) {
+    int32_t s0, s1;
+    chunk_seqs(B, n_chunks, c, &s0, &s1);
+    const long long nt = (long long)(s1 - s0) * T;
+    if (nt > 0) {
+      const unsigned blocks = (unsigned)((nt + 255) / 256 < SHARD_BLOCKS ? (nt + 255) / 256 : SHARD_BLOCKS);
+      hipLaunchKernelGGL(k_gather_claim, dim3(blocks), dim3(256), 0, s, st->ell_slice + (long long)s0 * T * W, nt, W, NC,
+                         (long long)h->cfg.row_begin, send_begin, (long long)h->cfg.row_end, st->uniq_claim, st->uniq_gen,
+                         st->counters, st->uniq_list, st->cap_uniq);
+    }
+    SCONE_HIP(h, hipMemcpyAsync(st->chunk_ends + c, st->counters, sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+  }
   SCONE_HIP(h, hipGetLastError());
-  uint32_t cnt = 0;
-  SCONE_HIP(h, hipMemcpyAsync(&cnt, st->counters, sizeof(cnt), hipMemcpyDeviceToHost, s));
+  uint32_t ends[64];
+  SCONE_HIP(h, hipMemcpyAsync(ends, st->chunk_ends, (size_t)n_chunks * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
   SCONE_HIP(h, hipStreamSynchronize(s));
-  st->n_uniq = cnt;
-  *h_n_records = cnt;
+  for (int c = 0; c < n_chunks; ++c) h_chunk_end[c] = ends[c];
+  st->n_uniq = ends[n_chunks - 1];
+  return SCONE_OK;
+}
+
+extern "C" int scone_shard_gather_plan(scone_handle *h, const int32_t *d_tok, int32_t B, int32_t T, uint64_t *h_n_records,
+                                       scone_stream_t stream) {
+  if (!h_n_records) return h ? scone_fail(h, SCONE_EINVAL, "scone_shard_gather_plan: bad argument") : SCONE_EINVAL;
+  return scone_shard_gather_plan_chunks(h, d_tok, B, T, 1, h_n_records, stream);
+}
+
+extern "C" int scone_shard_gather_pack_range(scone_handle *h, uint64_t first, uint64_t count, uint64_t pad, void *d_send_buf,
+                                             scone_stream_t stream) {
+  if (!h || !h->shard) return h ? scone_fail(h, SCONE_ESTATE, "scone_shard_gather_pack: call scone_shard_gather_plan first") : SCONE_EINVAL;
+  scone_shard_state *st = h->shard;
+  if (first + count > st->n_uniq) return scone_fail(h, SCONE_ERANGE, "scone_shard_gather_pack: records outside the plan");
+  if (count + pad == 0) return SCONE_OK;
+  if (!d_send_buf) return scone_fail(h, SCONE_EINVAL, "scone_shard_gather_pack: null send buffer");
+  SCONE_ON_DEVICE(h);
+  if (count) {
+    unsigned pb = (unsigned)((count + 3) / 4);
+    if (pb > 4096) pb = 4096;
+    hipLaunchKernelGGL(k_gather_pack, dim3(pb), dim3(256), 0, (hipStream_t)stream, st->uniq_list + first, count,
+                       scone_store_of(h), (long long)h->cfg.row_begin, (const uint8_t *)h->scales, (int)h->scale_bytes_per_row,
+                       scone_shard_rec_bytes(h), (uint8_t *)d_send_buf);
+  }
+  if (pad)
+    hipLaunchKernelGGL(k_gather_mark_pad, dim3((unsigned)((pad + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (uint8_t *)d_send_buf, (unsigned long long)count, (unsigned long long)pad, scone_shard_rec_bytes(h));
+  SCONE_HIP(h, hipGetLastError());
   return SCONE_OK;
 }
 
 extern "C" int scone_shard_gather_pack(scone_handle *h, void *d_send_buf, scone_stream_t stream) {
   if (!h || !h->shard) return h ? scone_fail(h, SCONE_ESTATE, "scone_shard_gather_pack: call scone_shard_gather_plan first") : SCONE_EINVAL;
+  return scone_shard_gather_pack_range(h, 0, h->shard->n_uniq, 0, d_send_buf, stream);
+}
+
+// Receiver, step 1: records [record0, record0 + n) of the gathered buffer (d_records points at record record0; the
+// whole buffer will hold n_total) join the row map; record0 == 0 starts a new exchange (the map is cleared).
+int scone_shard_gather_add(scone_handle *h, const void *d_records, uint64_t n, uint64_t record0, uint64_t n_total,
+                           hipStream_t s) {
   scone_shard_state *st = h->shard;
-  if (st->n_uniq == 0) return SCONE_OK;
-  if (!d_send_buf) return scone_fail(h, SCONE_EINVAL, "scone_shard_gather_pack: null send buffer");
-  SCONE_HIP(h, hipSetDevice(h->device));
-  unsigned pb = (unsigned)((st->n_uniq + 3) / 4);
-  if (pb > 4096) pb = 4096;
-  hipLaunchKernelGGL(k_gather_pack, dim3(pb), dim3(256), 0, (hipStream_t)stream, st->uniq_list, st->n_uniq, scone_store_of(h),
-                     (long long)h->cfg.row_begin, (const uint8_t *)h->scales, (int)h->scale_bytes_per_row,
-                     scone_shard_rec_bytes(h), (uint8_t *)d_send_buf);
+  const size_t sb = h->scale_bytes_per_row;
+  const unsigned long long n_head = st->n_head;
+  if (n_total > 0xFFFFFFF0ull || record0 + n > n_total) return scone_fail(h, SCONE_EINVAL, "scone_shard_gather_embed: bad record range");
+  if (record0 == 0) {
+    if (sb) {
+      long long cap = st->cap_recv;
+      uint8_t *p = st->scales;
+      int rc = grow(h, &p, &cap, (long long)(n_head + n_total), sb);
+      st->scales = p, st->cap_recv = cap;
+      if (rc) return rc;
+      if (n_head) SCONE_HIP(h, hipMemcpyAsync(st->scales, st->head_scales, (size_t)n_head * sb, hipMemcpyDeviceToDevice, s));
+    }
+    long long hcap = 1024;
+    while (hcap < 2 * (long long)n_total) hcap <<= 1;
+    int rc = grow(h, &st->rhash, &st->cap_rhash, hcap, 1);
+    if (rc) return rc;
+    SCONE_HIP(h, hipMemsetAsync(st->rhash, 0, (size_t)hcap * sizeof(unsigned long long), s));
+    st->rhash_cap_now = hcap;
+  } else if (st->rhash_cap_now < 2 * (long long)n_total || (sb && st->cap_recv < (long long)(n_head + n_total))) {
+    return scone_fail(h, SCONE_ESTATE, "scone_shard_gather_embed: records added out of order (start with record 0)");
+  }
+  if (n)
+    hipLaunchKernelGGL(k_gather_index, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const uint8_t *)d_records,
+                       (unsigned long long)n, scone_shard_rec_bytes(h), (int)h->row_payload_bytes, (int)sb, st->rhash,
+                       (unsigned long long)st->rhash_cap_now - 1,
+                       st->scales ? st->scales + (size_t)(n_head + record0) * sb : nullptr, (unsigned long long)record0);
   SCONE_HIP(h, hipGetLastError());
   return SCONE_OK;
 }
 
-// index the gathered records by row id, unpack their scales behind the head's, remap the lists of the whole batch
-int scone_shard_gather_prepare_embed(scone_handle *h, int32_t B, int32_t T, const void *d_recv, uint64_t n_recv,
-                                     const int32_t **ell, const void **scales, hipStream_t s) {
+// Receiver, step 2: the lists of sequences [seq0, seq1) of the planned batch are remapped to record numbers.
+int scone_shard_gather_remap(scone_handle *h, int32_t T, int32_t seq0, int32_t seq1, const int32_t **ell, const void **scales,
+                             hipStream_t s) {
   scone_shard_state *st = h->shard;
   const int W = SCONE_ELL_W(h->cfg.max_n), NC = h->cfg.max_n * (h->cfg.max_n + 1) / 2;
-  const long long ntok = (long long)B * T;
-  const size_t sb = h->scale_bytes_per_row;
-  const unsigned long long n_head = st->n_head;
-  if (n_recv > 0xFFFFFFF0ull) return scone_fail(h, SCONE_EINVAL, "scone_shard_gather_embed: too many records");
-  if (sb) {
-    long long cap = st->cap_recv;
-    uint8_t *p = st->scales;
-    int rc = grow(h, &p, &cap, (long long)(n_head + n_recv), sb);
-    st->scales = p, st->cap_recv = cap;
-    if (rc) return rc;
-    if (n_head) SCONE_HIP(h, hipMemcpyAsync(st->scales, st->head_scales, (size_t)n_head * sb, hipMemcpyDeviceToDevice, s));
+  const long long nt = (long long)(seq1 - seq0) * T;
+  int32_t *e = st->ell_slice + (long long)seq0 * T * W;
+  if (nt > 0) {
+    const unsigned blocks = (unsigned)((nt + 255) / 256 < SHARD_BLOCKS ? (nt + 255) / 256 : SHARD_BLOCKS);
+    hipLaunchKernelGGL(k_gather_remap, dim3(blocks), dim3(256), 0, s, e, nt, W, NC, st->rhash,
+                       (unsigned long long)st->rhash_cap_now - 1, (long long)st->n_head, h->d_status);
   }
-  long long hcap = 1024;
-  while (hcap < 2 * (long long)n_recv) hcap <<= 1;
-  int rc = grow(h, &st->rhash, &st->cap_rhash, hcap, 1);
-  if (rc) return rc;
-  SCONE_HIP(h, hipMemsetAsync(st->rhash, 0, (size_t)hcap * sizeof(unsigned long long), s));
-  if (n_recv)
-    hipLaunchKernelGGL(k_gather_index, dim3((unsigned)((n_recv + 255) / 256)), dim3(256), 0, s, (const uint8_t *)d_recv,
-                       (unsigned long long)n_recv, scone_shard_rec_bytes(h), (int)h->row_payload_bytes, (int)sb, st->rhash,
-                       (unsigned long long)hcap - 1, st->scales ? st->scales + (size_t)n_head * sb : nullptr);
-  const unsigned blocks = (unsigned)((ntok + 255) / 256 < SHARD_BLOCKS ? (ntok + 255) / 256 : SHARD_BLOCKS);
-  hipLaunchKernelGGL(k_gather_remap, dim3(blocks), dim3(256), 0, s, st->ell_slice, ntok, W, NC, st->rhash,
-                     (unsigned long long)hcap - 1, (long long)n_head, h->d_status);
   SCONE_HIP(h, hipGetLastError());
-  *ell = st->ell_slice;
+  *ell = e;
   *scales = st->scales;
+  return SCONE_OK;
+}
+
+int scone_shard_plan_shape(const scone_handle *h, int32_t *B, int32_t *T) {
+  if (!h->shard) return SCONE_ESTATE;
+  *B = h->shard->plan_B, *T = h->shard->plan_T;
   return SCONE_OK;
 }

@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void k_store_f32(const float *__restrict__ src
         qb = (int)fminf(fmaxf(rintf(b / sf), -7.f), 7.f);
       }
       o[grp * (SCONE_I4_GROUP / 2) + lane] = (uint8_t)((qa + 8) | ((qb + 8) << 4));
-      if (lane == 0) scales[lr * ng + grp] = sh;
+      if (lane == 0) scales[lr * ng + scone_i4_scale_slot(grp, d)] = sh;
     }
   }
   }  // grid-stride loop over rows
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void k_fill_synth(unsigned long long row_begin
     uint32_t *o = reinterpret_cast<uint32_t *>(st.row(lr));
     for (int w = lane; w < nw; w += 64) o[w] = scone_hash32(base + (uint32_t)w);
     for (int grp = lane; grp < ng; grp += 64)
-      scales[lr * ng + grp] = synth_scale(seed, g * (unsigned long long)ng + grp, base_scale);
+      scales[lr * ng + scone_i4_scale_slot(grp, d)] = synth_scale(seed, g * (unsigned long long)ng + grp, base_scale);
     continue;
   }
   const int nw = d / 4;
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void k_gather_rows(scone_row_store st, const _
     const uint8_t *x = st.row(lr);
     const int ng = d / SCONE_I4_GROUP;
     for (int b = lane; b < d / 2; b += 64) {
-      const float sf = __half2float(scales[lr * ng + (2 * b) / SCONE_I4_GROUP]);
+      const float sf = __half2float(scales[lr * ng + scone_i4_scale_slot((2 * b) / SCONE_I4_GROUP, d)]);
       const uint8_t v = x[b];
       o[2 * b] = (float)((int)(v & 0xF) - 8) * sf;
       o[2 * b + 1] = (float)((int)(v >> 4) - 8) * sf;
@@ -196,6 +196,38 @@ void table_modified(scone_handle *h) {
   if (h->stage) scone_stage_destroy(h);
 }
 
+// logical <-> physical order of INT4 group scales (scone_i4_scale_slot), in place, one thread per row
+__global__ __launch_bounds__(256) void k_i4_scales_reorder(__half *__restrict__ s, unsigned long long n_rows, int ng, int d,
+                                                           int to_physical) {
+  const unsigned long long r = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_rows || ng > 16) return;
+  __half v[16];
+  for (int g = 0; g < ng; ++g) v[g] = s[r * ng + g];
+  for (int g = 0; g < ng; ++g) {
+    if (to_physical)
+      s[r * ng + scone_i4_scale_slot(g, d)] = v[g];
+    else
+      s[r * ng + g] = v[scone_i4_scale_slot(g, d)];
+  }
+}
+
+bool i4_scales_permuted(const scone_handle *h) {
+  return h->cfg.table_fmt == SCONE_FMT_I4 && scone_i4_scale_slot(1, h->cfg.dim) != 1;
+}
+
+void i4_scales_reorder_host(uint16_t *s, uint64_t n_rows, int ng, int d, bool to_physical) {
+  uint16_t v[16];
+  for (uint64_t r = 0; r < n_rows; ++r) {
+    for (int g = 0; g < ng; ++g) v[g] = s[r * ng + g];
+    for (int g = 0; g < ng; ++g) {
+      if (to_physical)
+        s[r * ng + scone_i4_scale_slot(g, d)] = v[g];
+      else
+        s[r * ng + g] = v[scone_i4_scale_slot(g, d)];
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int scone_table_upload(scone_handle *h, const void *rows, const void *scales, uint64_t row0, uint64_t nrows,
@@ -207,7 +239,7 @@ extern "C" int scone_table_upload(scone_handle *h, const void *rows, const void 
   if (h->scale_bytes_per_row && !scales) return scone_fail(h, SCONE_EINVAL, "scone_table_upload: format needs scales");
   if (row0 < h->cfg.row_begin || row0 + nrows > h->cfg.row_end)
     return scone_fail(h, SCONE_ERANGE, "scone_table_upload: rows outside [row_begin,row_end)");
-  SCONE_HIP(h, hipSetDevice(h->device));
+  SCONE_ON_DEVICE(h);
   table_modified(h);
   hipStream_t s = (hipStream_t)stream;
   const uint64_t lr = row0 - h->cfg.row_begin;
@@ -220,10 +252,16 @@ extern "C" int scone_table_upload(scone_handle *h, const void *rows, const void 
     SCONE_HIP(h, hipMemcpyAsync(reinterpret_cast<uint8_t *>(h->rows_host) + (lr + n_hot - h->hot_local) * rb,
                                 reinterpret_cast<const uint8_t *>(rows) + n_hot * rb, (nrows - n_hot) * rb,
                                 src_is_device ? hipMemcpyDeviceToHost : hipMemcpyHostToHost, s));
-  if (h->scale_bytes_per_row)
-    SCONE_HIP(h, hipMemcpyAsync(reinterpret_cast<uint8_t *>(h->scales) + lr * h->scale_bytes_per_row, scales,
-                                nrows * h->scale_bytes_per_row,
+  if (h->scale_bytes_per_row) {
+    uint8_t *dst = reinterpret_cast<uint8_t *>(h->scales) + lr * h->scale_bytes_per_row;
+    SCONE_HIP(h, hipMemcpyAsync(dst, scales, nrows * h->scale_bytes_per_row,
                                 src_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
+    if (i4_scales_permuted(h)) {  // the ABI speaks the logical group order; the table keeps scone_i4_scale_slot's
+      hipLaunchKernelGGL(k_i4_scales_reorder, dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, s, (__half *)dst,
+                         (unsigned long long)nrows, h->cfg.dim / SCONE_I4_GROUP, h->cfg.dim, 1);
+      SCONE_HIP(h, hipGetLastError());
+    }
+  }
   if (!src_is_device) SCONE_HIP(h, hipStreamSynchronize(s));  // the host buffer may be pageable / reused
   return SCONE_OK;
 }
@@ -237,7 +275,7 @@ extern "C" int scone_table_download(scone_handle *h, void *rows, void *scales, u
   if (h->scale_bytes_per_row && !scales) return scone_fail(h, SCONE_EINVAL, "scone_table_download: format has scales");
   if (row0 < h->cfg.row_begin || row0 + nrows > h->cfg.row_end)
     return scone_fail(h, SCONE_ERANGE, "scone_table_download: rows outside [row_begin,row_end)");
-  SCONE_HIP(h, hipSetDevice(h->device));
+  SCONE_ON_DEVICE(h);
   hipStream_t s = (hipStream_t)stream;
   const uint64_t lr = row0 - h->cfg.row_begin;
   const size_t rb = h->row_payload_bytes;
@@ -249,11 +287,21 @@ extern "C" int scone_table_download(scone_handle *h, void *rows, void *scales, u
     SCONE_HIP(h, hipMemcpyAsync(reinterpret_cast<uint8_t *>(rows) + n_hot * rb,
                                 reinterpret_cast<const uint8_t *>(h->rows_host) + (lr + n_hot - h->hot_local) * rb,
                                 (nrows - n_hot) * rb, dst_is_device ? hipMemcpyHostToDevice : hipMemcpyHostToHost, s));
-  if (h->scale_bytes_per_row)
+  if (h->scale_bytes_per_row) {
     SCONE_HIP(h, hipMemcpyAsync(scales, reinterpret_cast<const uint8_t *>(h->scales) + lr * h->scale_bytes_per_row,
                                 nrows * h->scale_bytes_per_row,
                                 dst_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s));
-  if (!dst_is_device) SCONE_HIP(h, hipStreamSynchronize(s));
+    if (i4_scales_permuted(h) && dst_is_device) {  // back to the logical group order
+      hipLaunchKernelGGL(k_i4_scales_reorder, dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, s, (__half *)scales,
+                         (unsigned long long)nrows, h->cfg.dim / SCONE_I4_GROUP, h->cfg.dim, 0);
+      SCONE_HIP(h, hipGetLastError());
+    }
+  }
+  if (!dst_is_device) {
+    SCONE_HIP(h, hipStreamSynchronize(s));
+    if (i4_scales_permuted(h))
+      i4_scales_reorder_host(reinterpret_cast<uint16_t *>(scales), nrows, h->cfg.dim / SCONE_I4_GROUP, h->cfg.dim, false);
+  }
   return SCONE_OK;
 }
 
@@ -287,7 +335,7 @@ static int store_f32_common(scone_handle *h, const float *d_src, const int64_t *
                             hipStream_t s) {
   if (nrows == 0) return SCONE_OK;
   if (!d_src) return scone_fail(h, SCONE_EINVAL, "scone_table_store_f32: null rows");
-  SCONE_HIP(h, hipSetDevice(h->device));
+  SCONE_ON_DEVICE(h);
   table_modified(h);
   return scone_store_f32_into(h, scone_store_of(h), h->scales, h->cfg.row_begin, h->cfg.row_end, d_src, d_ids, row0, nrows, s);
 }
@@ -312,7 +360,7 @@ extern "C" int scone_table_store_f32_ids(scone_handle *h, const float *d_rows_f3
 extern "C" int scone_table_fill_synthetic(scone_handle *h, uint32_t seed, float base_scale, scone_stream_t stream) {
   int rc = check_table(h, "scone_table_fill_synthetic: handle has no table (dim == 0)");
   if (rc) return rc;
-  SCONE_HIP(h, hipSetDevice(h->device));
+  SCONE_ON_DEVICE(h);
   table_modified(h);
   rc = scone_fill_synth_into(h, scone_store_of(h), h->scales, h->cfg.row_begin, h->local_rows, seed, base_scale,
                              (hipStream_t)stream);
@@ -326,7 +374,7 @@ extern "C" int scone_table_gather_rows(scone_handle *h, const int64_t *d_ids, ui
   if (rc) return rc;
   if (n == 0) return SCONE_OK;
   if (!d_ids || !d_out) return scone_fail(h, SCONE_EINVAL, "scone_table_gather_rows: null pointer");
-  SCONE_HIP(h, hipSetDevice(h->device));
+  SCONE_ON_DEVICE(h);
   const unsigned blocks = scone_capped_blocks((n + 3) / 4);
   int bad = dispatch_fmt(h->cfg.table_fmt, [&](auto F) {
     hipLaunchKernelGGL((k_gather_rows<decltype(F)::value>), dim3(blocks), dim3(256), 0, (hipStream_t)stream,

@@ -72,6 +72,23 @@ def _all_gather(out: torch.Tensor, inp: torch.Tensor, group) -> None:
         dist.all_gather_into_tensor(out, inp, group=group)
 
 
+class _Done:
+    """Stand-in for a completed collective (host-staged groups run synchronously)."""
+
+    def wait(self) -> None:
+        pass
+
+
+def _all_gather_async(out: torch.Tensor, inp: torch.Tensor, group):
+    """``all_gather_into_tensor`` that returns a handle with ``wait()``: over RCCL the collective runs on the
+    communicator's stream behind everything already queued on the current stream, and the current stream only waits
+    for it at ``wait()`` -- kernels enqueued in between overlap the transfer."""
+    if _host_staged(group) and inp.is_cuda:
+        _all_gather(out, inp, group)
+        return _Done()
+    return dist.all_gather_into_tensor(out, inp, group=group, async_op=True)
+
+
 def _all_to_all(out: torch.Tensor, inp: torch.Tensor, out_splits, in_splits, group) -> None:
     if _host_staged(group) and inp.is_cuda:
         o = torch.empty(out.shape, dtype=out.dtype)
@@ -101,8 +118,10 @@ class ShardedEmbeddingCache:
 
     def __init__(self, n_gram_extractor: NGramExtractor, embedding_dim: int, *, table_format: str = "int8",
                  rank: Optional[int] = None, world: Optional[int] = None, group=None, device=None,
-                 n_rows: Optional[int] = None, placement: str = "hbm", table=None, replicated_rows: int = 0) -> None:
+                 n_rows: Optional[int] = None, placement: str = "hbm", table=None, replicated_rows: int = 0,
+                 gather_chunks: int = 4) -> None:
         self.group = group
+        self.gather_chunks = int(gather_chunks)    # "gather_rows": the batch is exchanged and reduced in this many chunks
         self.rank = dist.get_rank(group) if rank is None else int(rank)
         self.world = dist.get_world_size(group) if world is None else int(world)
         self.n_gram_extractor = n_gram_extractor
@@ -118,6 +137,8 @@ class ShardedEmbeddingCache:
                 table.shard_set_head(replicated_rows)
         self.table = table
         self.replicated_rows = min(int(replicated_rows), self.n_rows)
+        self._prof = None
+        self._keep = None
 
     @classmethod
     def from_synthetic(cls, n_gram_extractor: NGramExtractor, embedding_dim: int, *, table_format: str = "int8",
@@ -142,7 +163,7 @@ class ShardedEmbeddingCache:
     def embed_tokens(self, input_ids: torch.Tensor, *, reduce: str = "mean", wte: Optional[torch.Tensor] = None,
                      wpe: Optional[torch.Tensor] = None, position_ids: Optional[torch.Tensor] = None,
                      out_dtype: Optional[torch.dtype] = None, gather_output: bool = True,
-                     exchange: str = "auto") -> torch.Tensor:
+                     exchange: str = "auto", profile: bool = False):
         """Same result as ``EmbeddingCache.embed_tokens`` on the unsharded table -- bit-identical with the row
         exchanges, up to the fp32 summation order across shards with ``"partial_sums"``.  Every rank passes the SAME
         ``input_ids [B, T]``.
@@ -150,7 +171,29 @@ class ShardedEmbeddingCache:
         ``gather_output=True``: every rank gets the whole ``[B, T, d]``; ``False``: only this rank's slice
         ``[ceil(B/W)*T, d]`` (zero-padded at the tail; for consumers that are themselves data-parallel over the same
         slices).  ``exchange``: ``"auto"`` (``"gather_rows"`` for the whole output, ``"rows"`` for slices), ``"rows"``,
-        ``"gather_rows"`` or ``"partial_sums"`` -- see the module docstring."""
+        ``"gather_rows"`` or ``"partial_sums"`` -- see the module docstring.
+
+        ``profile=True`` (row exchanges only): returns ``(out, phases)`` -- the device is synchronised between the phases
+        of the step and ``phases`` holds their milliseconds (``plan_ms, pack_ms, collective_ms, embed_ms, gather_out_ms``)
+        and ``bytes_received`` (payload this rank received over the group); an instrumented step, not a fast one."""
+        self._prof = {} if profile else None
+        out = self._embed_tokens(input_ids, reduce, wte, wpe, position_ids, out_dtype, gather_output, exchange)
+        if profile:
+            prof, self._prof = self._prof, None
+            return out, prof
+        return out
+
+    def _tick(self, name: str, t0: float) -> float:
+        """profile mode: close phase ``name`` (synchronise, add the elapsed milliseconds), return the new start time."""
+        import time
+        if self._prof is None:
+            return t0
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        self._prof[name] = self._prof.get(name, 0.0) + (t1 - t0) * 1e3
+        return t1
+
+    def _embed_tokens(self, input_ids, reduce, wte, wpe, position_ids, out_dtype, gather_output, exchange):
         tok = torch.as_tensor(input_ids)
         if tok.dim() == 1:
             tok = tok.unsqueeze(0)
@@ -208,7 +251,85 @@ class ShardedEmbeddingCache:
         return full[:ntok].reshape(B, T, d)
 
     def _embed_gather_rows(self, tok, reduce, wte, wpe, position_ids, out_dtype):
-        """All-gather of the quantised rows the batch references; every rank then embeds the whole batch."""
+        """All-gather of the quantised rows the batch references; every rank then embeds the whole batch.
+
+        Pipelined over ``gather_chunks`` runs of sequences: ONE plan (one match of the batch; one claim pass per chunk, a
+        row claimed by an earlier chunk is not sent again), ONE exchange of the per-chunk record counts, then the packs and
+        the C all-gathers are queued back to back and chunk c is reduced as soon as ITS records are in -- the transfers of
+        chunks c+1.. overlap the reduction of chunk c, which is what every rank spends most of the step on (it reduces the
+        whole batch).  The receive buffer is one allocation ``[sum_c W * max_c, record]`` (a contribution is padded to
+        the largest of its chunk; padding records carry row id 0xFFFFFFFF and are skipped), so the lookup kernel reads
+        all records received so far as one row store."""
+        import time
+        t0 = time.perf_counter() if self._prof is not None else 0.0
+        B, T = tok.shape
+        W, t = self.world, self.table
+        d = self.embedding_dim
+        if not hasattr(t, "shard_gather_plan_chunks"):          # stand-in handles (CPU tests of the exchange logic)
+            return self._embed_gather_rows_unchunked(tok, reduce, wte, wpe, position_ids, out_dtype)
+        tok = t._tok(tok)
+        if position_ids is not None:
+            position_ids = position_ids.to(device=tok.device, dtype=torch.int32).expand(B, T).contiguous()
+        C = max(1, min(self.gather_chunks, B, 64))
+        per = (B + C - 1) // C
+        ends = t.shard_gather_plan_chunks(tok, C)                       # synchronises: this rank's record counts
+        mine = [ends[0]] + [ends[c] - ends[c - 1] for c in range(1, C)]
+        t0 = self._tick("plan_ms", t0)
+        if W > 1:
+            cnt = torch.tensor(mine, dtype=torch.int64, device=tok.device)
+            allc = torch.empty((W, C), dtype=torch.int64, device=tok.device)
+            _all_gather(allc.view(-1), cnt, self.group)
+            maxc = allc.max(dim=0).values.tolist()                      # host: the all-gather sizes
+        else:
+            maxc = list(mine)
+        base = [0]
+        for c in range(C):
+            base.append(base[-1] + W * int(maxc[c]))
+        total = base[-1]
+        rec = t.shard_record_bytes()
+        full = torch.empty((max(total, 1), rec), dtype=torch.uint8, device=tok.device)
+        t0 = self._tick("collective_ms", t0)
+        works = []
+        first = 0
+        for c in range(C):
+            m = int(maxc[c])
+            region = full[base[c]:base[c + 1]]
+            if m == 0:
+                works.append(None)
+            elif W > 1:
+                send = torch.empty((m, rec), dtype=torch.uint8, device=tok.device)
+                t.shard_gather_pack_range(first, mine[c], send)          # my records of chunk c + padding to m
+                t0 = self._tick("pack_ms", t0)
+                work = _all_gather_async(region.view(-1), send.view(-1), self.group)
+                if self._prof is not None:                               # instrumented step: no overlap, phases add up
+                    work.wait()
+                    t0 = self._tick("collective_ms", t0)
+                works.append((work, send))
+            else:
+                t.shard_gather_pack_range(first, mine[c], region)
+                t0 = self._tick("pack_ms", t0)
+                works.append(None)
+            first += mine[c]
+        if self._prof is not None:
+            self._prof["bytes_received"] = float(total * rec * (W - 1) // max(W, 1))
+        out = torch.empty((B * T, d), dtype=out_dtype, device=tok.device)
+        records = full[:total]
+        for c in range(C):
+            if works[c] is not None:
+                works[c][0].wait()                                       # the current stream waits for chunk c's records
+                t0 = self._tick("collective_ms", t0)
+            if c == 0 or base[c + 1] > base[c]:                          # chunk 0 always: it starts the exchange (clears the map)
+                t.shard_gather_add_records(records, base[c], base[c + 1] - base[c])
+            s0, s1 = min(c * per, B), min(c * per + per, B)
+            if s1 > s0:
+                t.shard_gather_embed_range(tok, s0, s1, records, out, wte=wte, wpe=wpe, position_ids=position_ids,
+                                           reduce=reduce)
+            t0 = self._tick("embed_ms", t0)
+        self._keep = (full, works)                                       # read in place until the stream has passed
+        return out
+
+    def _embed_gather_rows_unchunked(self, tok, reduce, wte, wpe, position_ids, out_dtype):
+        """One plan, one all-gather, one reduction (the form the chunked path degenerates to with one chunk)."""
         B, T = tok.shape
         W = self.world
         # one record per DISTINCT row I own (outside the replicated head) that the batch references
@@ -236,26 +357,37 @@ class ShardedEmbeddingCache:
     def _embed_row_exchange(self, tok, reduce, wte, wpe, position_ids, out_dtype, gather_output):
         B, T = tok.shape
         d, W, r = self.embedding_dim, self.world, self.rank
+        import time
+        t0 = time.perf_counter() if self._prof is not None else 0.0
         bper = (B + W - 1) // W                                              # sequences per slice
         send_counts, recv_counts = self.table.shard_plan(tok, W, r)
+        t0 = self._tick("plan_ms", t0)
         send = self.table.shard_pack(B, T, W, send_counts)                   # uint8 [n_send, record_bytes]
+        t0 = self._tick("pack_ms", t0)
         rec = send.shape[1]
         if W > 1:
             recv = torch.empty((int(sum(recv_counts)), rec), dtype=torch.uint8, device=send.device)
             _all_to_all(recv, send, [int(c) for c in recv_counts], [int(c) for c in send_counts], self.group)
         else:
             recv = send
+        t0 = self._tick("collective_ms", t0)
+        if self._prof is not None:
+            self._prof["bytes_received"] = float((int(sum(recv_counts)) - int(recv_counts[r])) * rec)
         b0, b1 = min(r * bper, B), min(r * bper + bper, B)
         out_slice = torch.zeros((bper * T, d), dtype=out_dtype, device=send.device) if (b1 - b0) < bper else \
             torch.empty((bper * T, d), dtype=out_dtype, device=send.device)
         if b1 > b0:
             self.table.shard_embed(tok, W, r, recv, wte=wte, wpe=wpe, position_ids=position_ids, reduce=reduce,
                                    out_dtype=out_dtype, out=out_slice[:(b1 - b0) * T])
+        t0 = self._tick("embed_ms", t0)
         if not gather_output:
             return out_slice
         if W > 1:
             full = torch.empty((bper * T * W, d), dtype=out_dtype, device=send.device)
             _all_gather(full, out_slice, self.group)
+            if self._prof is not None:
+                self._prof["bytes_received"] += float(full.numel() * full.element_size() * (W - 1) // W)
         else:
             full = out_slice
+        self._tick("gather_out_ms", t0)
         return full[:B * T].reshape(B, T, d)

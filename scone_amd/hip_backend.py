@@ -322,6 +322,16 @@ class SconeTable:
         self._check(L.lib().scone_profile_read(self._h, C.byref(n), C.byref(ms), int(reset)), "scone_profile_read")
         return n.value, ms.value
 
+    def profile_samples(self) -> np.ndarray:
+        """Milliseconds of every timed launch since the last reset (launch order)."""
+        n = C.c_uint64(0)
+        self._check(L.lib().scone_profile_samples(self._h, None, 0, C.byref(n)), "scone_profile_samples")
+        out = np.zeros(n.value, dtype=np.float32)
+        if n.value:
+            self._check(L.lib().scone_profile_samples(self._h, out.ctypes.data_as(C.POINTER(C.c_float)), n.value,
+                                                      C.byref(n)), "scone_profile_samples")
+        return out[:n.value]
+
     def embed_partial(self, tok: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         tok = self._tok(tok)
         B, T = tok.shape
@@ -419,6 +429,50 @@ class SconeTable:
             rc = L.lib().scone_shard_gather_pack(self._h, _ptr(buf), _stream())
         self._check(rc, "scone_shard_gather_pack")
         return buf
+
+    def shard_gather_plan_chunks(self, tok: torch.Tensor, n_chunks: int) -> list:
+        """Chunked plan: ``ends[c]`` = records this shard contributes to chunks ``0..c`` of the batch (chunk c = sequences
+        ``[c * ceil(B / n_chunks), ...)``); a row claimed by an earlier chunk is not claimed again (synchronises)."""
+        tok = self._tok(tok)
+        B, T = tok.shape
+        ends = (C.c_uint64 * 64)()
+        with torch.cuda.device(self.device):
+            rc = L.lib().scone_shard_gather_plan_chunks(self._h, _ptr(tok), B, T, int(n_chunks), ends, _stream())
+        self._check(rc, "scone_shard_gather_plan_chunks")
+        self._shard_keepalive = (tok,)
+        return [int(e) for e in ends[:n_chunks]]
+
+    def shard_gather_pack_range(self, first: int, count: int, out: torch.Tensor) -> None:
+        """Records ``[first, first + count)`` of the plan into ``out[:count]``; the rest of ``out`` becomes padding."""
+        assert out.is_cuda and out.is_contiguous() and out.dtype == torch.uint8 and out.shape[1] == self.shard_record_bytes()
+        with torch.cuda.device(self.device):
+            rc = L.lib().scone_shard_gather_pack_range(self._h, int(first), int(count), int(out.shape[0] - count), _ptr(out),
+                                                       _stream())
+        self._check(rc, "scone_shard_gather_pack_range")
+
+    def shard_gather_add_records(self, records: torch.Tensor, record0: int, n_records: int) -> None:
+        """Receiver: records ``[record0, record0 + n_records)`` of the gathered buffer ``records [n_total, record_bytes]``
+        join the row map (``record0 == 0`` starts a new exchange)."""
+        assert records.is_cuda and records.is_contiguous() and records.dtype == torch.uint8
+        with torch.cuda.device(self.device):
+            rc = L.lib().scone_shard_gather_add_records(self._h, _ptr(records), int(record0), int(n_records),
+                                                        records.shape[0], _stream())
+        self._check(rc, "scone_shard_gather_add_records")
+
+    def shard_gather_embed_range(self, tok: torch.Tensor, seq_begin: int, seq_end: int, records: torch.Tensor,
+                                 out: torch.Tensor, wte: Optional[torch.Tensor] = None, wpe: Optional[torch.Tensor] = None,
+                                 position_ids: Optional[torch.Tensor] = None, reduce: str = "mean") -> None:
+        """Sequences ``[seq_begin, seq_end)`` of the planned batch into their place in ``out [B*T, d]``."""
+        tok = self._tok(tok)
+        B, T = tok.shape
+        assert out.is_cuda and out.is_contiguous() and out.numel() == B * T * self.dim
+        with torch.cuda.device(self.device):
+            rc = L.lib().scone_shard_gather_embed_range(self._h, _ptr(tok), B, T, int(seq_begin), int(seq_end), _ptr(records),
+                                                        records.shape[0], _ptr(wte), 0 if wte is None else wte.shape[0],
+                                                        _ptr(wpe), 0 if wpe is None else wpe.shape[0], _ptr(position_ids),
+                                                        _REDUCE[reduce], _ptr(out), _DT[out.dtype], _stream())
+        self._shard_keepalive = (records, tok, position_ids, wte, wpe, out)
+        self._check(rc, "scone_shard_gather_embed_range")
 
     def shard_gather_embed(self, tok: torch.Tensor, records: torch.Tensor, wte: Optional[torch.Tensor] = None,
                            wpe: Optional[torch.Tensor] = None, position_ids: Optional[torch.Tensor] = None,

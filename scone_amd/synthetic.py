@@ -46,40 +46,109 @@ def make_keys(n_rows: int, vocab: int = GPT2_VOCAB, max_n: int = 3, seed: int = 
     return keys, lens
 
 
-def make_keys_structured(n_rows: int, vocab: int = GPT2_VOCAB, max_n: int = 3) -> Tuple[np.ndarray, np.ndarray]:
-    """Distinct-by-construction vocabulary for very large tables (1e8 .. 1e9 rows), no de-duplication
-    pass: ids 0..vocab-1 are the unigrams, then half bigrams and half trigrams whose tokens are the
-    mixed-radix digits of a running counter (multiplied by odd constants mod vocab, so neighbouring
-    ids do not share tokens)."""
+def structured_keys_for_ids(ids: np.ndarray, n_rows: int, vocab: int = GPT2_VOCAB, max_n: int = 3) -> Tuple[np.ndarray, np.ndarray]:
+    """Rows ``ids`` of :func:`make_keys_structured` in closed form (any subset of a 1e9-row vocabulary without
+    materialising it): ids 0..vocab-1 are the unigrams, then half bigrams and half trigrams whose tokens are the
+    mixed-radix digits of a running counter (multiplied by odd constants mod vocab, so neighbouring ids do not share
+    tokens)."""
     assert max_n >= 3 and n_rows >= vocab
-    keys = np.zeros((n_rows, max_n), dtype=np.uint32)
-    lens = np.ones(n_rows, dtype=np.uint8)
-    keys[:vocab, 0] = np.arange(vocab, dtype=np.uint32)
+    ids = np.asarray(ids, dtype=np.int64)
+    keys = np.zeros((ids.shape[0], max_n), dtype=np.uint32)
+    lens = np.ones(ids.shape[0], dtype=np.uint8)
+    V = np.uint64(vocab)
     rest = n_rows - vocab
     nb = rest // 2
-    j = np.arange(nb, dtype=np.uint64)
-    V = np.uint64(vocab)
-    keys[vocab:vocab + nb, 0] = ((j % V) * np.uint64(40503) + np.uint64(17)) % V
-    keys[vocab:vocab + nb, 1] = (((j // V) % V) * np.uint64(30011) + np.uint64(5)) % V
-    lens[vocab:vocab + nb] = 2
-    j = np.arange(rest - nb, dtype=np.uint64)
-    keys[vocab + nb:, 0] = ((j % V) * np.uint64(40503) + np.uint64(29)) % V
-    keys[vocab + nb:, 1] = (((j // V) % V) * np.uint64(30011) + np.uint64(3)) % V
-    keys[vocab + nb:, 2] = (((j // (V * V)) % V) * np.uint64(20011) + np.uint64(11)) % V
-    lens[vocab + nb:] = 3
+    uni = ids < vocab
+    bi = (~uni) & (ids < vocab + nb)
+    tri = ids >= vocab + nb
+    keys[uni, 0] = ids[uni].astype(np.uint32)
+    j = (ids[bi] - vocab).astype(np.uint64)
+    keys[bi, 0] = ((j % V) * np.uint64(40503) + np.uint64(17)) % V
+    keys[bi, 1] = (((j // V) % V) * np.uint64(30011) + np.uint64(5)) % V
+    lens[bi] = 2
+    j = (ids[tri] - vocab - nb).astype(np.uint64)
+    keys[tri, 0] = ((j % V) * np.uint64(40503) + np.uint64(29)) % V
+    keys[tri, 1] = (((j // V) % V) * np.uint64(30011) + np.uint64(3)) % V
+    keys[tri, 2] = (((j // (V * V)) % V) * np.uint64(20011) + np.uint64(11)) % V
+    lens[tri] = 3
     return keys, lens
 
 
-def stream_uniform_ids(keys: np.ndarray, lens: np.ndarray, B: int, T: int, seed: int) -> np.ndarray:
+def make_keys_structured(n_rows: int, vocab: int = GPT2_VOCAB, max_n: int = 3) -> Tuple[np.ndarray, np.ndarray]:
+    """Distinct-by-construction vocabulary for very large tables (1e8 .. 1e9 rows), no de-duplication pass."""
+    out_k = np.zeros((n_rows, max_n), dtype=np.uint32)
+    out_l = np.ones(n_rows, dtype=np.uint8)
+    step = 1 << 24
+    for a in range(0, n_rows, step):
+        b = min(a + step, n_rows)
+        out_k[a:b], out_l[a:b] = structured_keys_for_ids(np.arange(a, b, dtype=np.int64), n_rows, vocab, max_n)
+    return out_k, out_l
+
+
+class StructuredVocab:
+    """The structured vocabulary as an object a (sharded) cache can index WITHOUT host key arrays: the index of a
+    1e9-key table is built from keys generated on the GPU in chunks (``torch`` arithmetic + ``index_build_device``),
+    and the keys of any ids are available in closed form for laying out token streams.  Duck-types the part of
+    ``NGramExtractor`` that ``ShardedEmbeddingCache`` / ``EmbeddingCache.from_synthetic`` use (``max_n``, ``len()``,
+    ``build_index``)."""
+
+    def __init__(self, n_rows: int, vocab: int = GPT2_VOCAB, max_n: int = 3) -> None:
+        assert max_n == 3 and n_rows >= vocab
+        self.n_rows, self.vocab, self.max_n = int(n_rows), int(vocab), int(max_n)
+
+    def __len__(self) -> int:
+        return self.n_rows
+
+    def keys_for(self, ids: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+        return structured_keys_for_ids(ids, self.n_rows, self.vocab, self.max_n)
+
+    def build_index(self, table, chunk: int = 1 << 25) -> None:
+        import torch
+        dev = table.device
+        V, n, nb = self.vocab, self.n_rows, (self.n_rows - self.vocab) // 2
+        for a in range(0, n, chunk):
+            b = min(a + chunk, n)
+            ids = torch.arange(a, b, dtype=torch.int64, device=dev)
+            keys = torch.zeros((b - a, 3), dtype=torch.int64, device=dev)
+            lens = torch.ones(b - a, dtype=torch.uint8, device=dev)
+            uni = ids < V
+            keys[:, 0] = torch.where(uni, ids, keys[:, 0])
+            bi = (~uni) & (ids < V + nb)
+            j = ids - V
+            k0 = ((j % V) * 40503 + 17) % V
+            k1 = (((j // V) % V) * 30011 + 5) % V
+            keys[:, 0] = torch.where(bi, k0, keys[:, 0])
+            keys[:, 1] = torch.where(bi, k1, keys[:, 1])
+            lens = torch.where(bi, torch.full_like(lens, 2), lens)
+            tri = ids >= V + nb
+            j = ids - V - nb
+            k0 = ((j % V) * 40503 + 29) % V
+            k1 = (((j // V) % V) * 30011 + 3) % V
+            k2 = (((j // (V * V)) % V) * 20011 + 11) % V
+            keys[:, 0] = torch.where(tri, k0, keys[:, 0])
+            keys[:, 1] = torch.where(tri, k1, keys[:, 1])
+            keys[:, 2] = torch.where(tri, k2, keys[:, 2])
+            lens = torch.where(tri, torch.full_like(lens, 3), lens)
+            table.index_build_device(keys.to(torch.int32).contiguous(), lens.contiguous(), id0=a)
+            torch.cuda.synchronize(dev)        # the chunk's temporaries are freed before the next one is built
+            del ids, keys, lens, uni, bi, tri, j, k0, k1, k2
+
+
+def stream_uniform_ids(keys, lens, B: int, T: int, seed: int) -> np.ndarray:
     """S_uniform: f-grams with ids uniform in [0, N) laid end to end -- row reads that defeat
-    L2 / Infinity-Cache reuse (the roofline run)."""
+    L2 / Infinity-Cache reuse (the roofline run).  ``keys`` is the dense key array, or a :class:`StructuredVocab`
+    (``lens`` ignored) whose keys are computed for the drawn ids only."""
     rng = np.random.default_rng(seed)
     need = B * T
+    n_rows = len(keys) if isinstance(keys, StructuredVocab) else keys.shape[0]
     out = np.empty(0, dtype=np.int64)
     while out.size < need:
-        ids = rng.integers(0, keys.shape[0], size=max(1024, int((need - out.size) / 1.8) + 1024))
-        k = keys[ids]
-        mask = np.arange(keys.shape[1])[None, :] < lens[ids][:, None]
+        ids = rng.integers(0, n_rows, size=max(1024, int((need - out.size) / 1.8) + 1024))
+        if isinstance(keys, StructuredVocab):
+            k, l = keys.keys_for(ids)
+        else:
+            k, l = keys[ids], lens[ids]
+        mask = np.arange(k.shape[1])[None, :] < l[:, None]
         out = np.concatenate([out, k[mask].astype(np.int64)])
     return out[:need].reshape(B, T)
 

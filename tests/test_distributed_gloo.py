@@ -155,6 +155,71 @@ class OracleShard:
             x = x + wpe.float()[pos]
         return x.to(out_dtype)
 
+    # ---- chunked all-gather form (scone_shard_gather_plan_chunks / _pack_range / _add_records / _embed_range)
+    def _tok(self, tok):
+        return tok
+
+    def shard_record_bytes(self):
+        return self.dim * 4 + 8
+
+    def shard_gather_plan_chunks(self, tok, n_chunks):
+        B, T = tok.shape
+        per = (B + n_chunks - 1) // n_chunks
+        claimed, order, ends = set(), [], []
+        for c in range(n_chunks):
+            s0, s1 = min(c * per, B), min(c * per + per, B)
+            if s1 > s0:
+                off, ids, tix, jix = self._refs(tok[s0:s1])
+                for i in np.unique(ids[(ids >= max(self.row_begin, self.n_head)) & (ids < self.row_end)])[::-1].tolist():
+                    if i not in claimed:                              # claimed by an earlier chunk: not sent again
+                        claimed.add(i)
+                        order.append(i)
+            ends.append(len(order))
+        self._uniq, self._planned = np.asarray(order, dtype=np.int64), tuple(tok.shape)
+        return ends
+
+    def shard_gather_pack_range(self, first, count, out):
+        assert first + count <= len(self._uniq) and out.shape[1] == self.dim * 4 + 8
+        o = out.numpy()
+        for k, i in enumerate(self._uniq[first:first + count]):
+            o[k, :self.dim * 4] = self.table[i].view(np.uint8)
+            o[k, self.dim * 4:] = np.array([i, -1], dtype=np.int32).view(np.uint8)
+        o[count:] = 0xAB                                              # stale bytes ...
+        o[count:, self.dim * 4:] = 0xFF                               # ... marked as padding (row id 0xFFFFFFFF)
+
+    def shard_gather_add_records(self, records, record0, n_records):
+        if record0 == 0:
+            self._by_id, self._added = {}, 0
+        assert record0 == self._added, "records must be added in order"
+        r = records.numpy()
+        for p in range(record0, record0 + n_records):
+            i = int(r[p, self.dim * 4:].view(np.int32)[0])
+            if i == -1:
+                continue                                              # padding
+            assert i not in self._by_id, "a row arrived twice"
+            self._by_id[i] = p
+        self._added = record0 + n_records
+
+    def shard_gather_embed_range(self, tok, seq_begin, seq_end, records, out, wte=None, wpe=None, position_ids=None,
+                                 reduce="mean"):
+        assert tuple(tok.shape) == self._planned
+        B, T = tok.shape
+        sl = tok[seq_begin:seq_end]
+        off, ids, tix, jix = self._refs(sl)
+        r = records.numpy()
+        rows = np.zeros((len(ids), self.dim), dtype=np.float32)
+        for k, i in enumerate(ids.tolist()):                          # KeyError = a needed row has not arrived yet
+            rows[k] = self.table[i] if i < self.n_head else r[self._by_id[i], :self.dim * 4].view(np.float32)
+        assert np.array_equal(rows, self.table[ids])
+        x = torch.from_numpy(self.R.embed_numpy(rows, off, np.arange(len(ids)), reduce))
+        flat = sl.reshape(-1).long()
+        if wte is not None:
+            x = wte.float()[flat] + x
+        if wpe is not None:
+            pos = (torch.arange(flat.numel()) % T) if position_ids is None else position_ids[seq_begin:seq_end].reshape(-1).long()
+            x = x + wpe.float()[pos]
+        out.view(B * T, self.dim)[seq_begin * T:seq_end * T] = x.to(out.dtype)
+
     def finalize(self, sums, counts, tok, a, b, wte=None, wpe=None, position_ids=None, reduce="mean",
                  out_dtype=torch.float32, out=None):
         x = sums.clone()
@@ -175,7 +240,7 @@ class OracleShard:
         return x
 
 
-def _worker(rank, world, port, ntok_shape, out_dtype_name, exchange, q):
+def _worker(rank, world, port, ntok_shape, out_dtype_name, exchange, q, chunks=4, head=0):
     try:
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -195,8 +260,13 @@ def _worker(rank, world, port, ntok_shape, out_dtype_name, exchange, q):
         out_dtype = getattr(torch, out_dtype_name)
         ex = NGramExtractor.from_arrays(keys, lens, max_n=max_n)
         a, b = shard_range(n, rank, world)
-        cache = ShardedEmbeddingCache(ex, d, rank=rank, world=world, n_rows=n,
-                                      table=OracleShard(keys, lens, max_n, table, a, b))
+        shard = OracleShard(keys, lens, max_n, table, a, b)
+        if chunks == 0:                                               # the one-shot form (plan / pack / embed)
+            del OracleShard.shard_gather_plan_chunks                 # (this worker process only)
+        if head:
+            shard.shard_set_head(head)
+        cache = ShardedEmbeddingCache(ex, d, rank=rank, world=world, n_rows=n, table=shard, replicated_rows=head,
+                                      gather_chunks=max(chunks, 1))
         assert (cache.row_begin, cache.row_end) == (a, b)
         out = cache.embed_tokens(tok, wte=wte.to(out_dtype), wpe=wpe.to(out_dtype), out_dtype=out_dtype,
                                  exchange=exchange)
@@ -239,6 +309,27 @@ def test_sharded_exchange_world2_gloo(shape, dtype, exchange):
         assert out_shape == (shape[0], shape[1], 32)
         assert err < (1e-6 if dtype == "float32" else 2e-3), (rank, err)
         assert ok_slice
+
+
+@pytest.mark.parametrize("chunks,head", [(0, 0), (1, 0), (2, 40), (3, 0), (8, 25)])
+def test_gather_rows_chunked_pipeline_world2_gloo(chunks, head):
+    """The pipelined all-gather form: one plan with a claim pass per chunk (a row sent by an earlier chunk is not sent
+    again), per-chunk all-gathers padded to the largest contribution (padding records skipped), records added and
+    sequences reduced chunk by chunk -- same output as the unsharded table for any chunk count (0 = the one-shot form),
+    with and without a replicated head."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    shape = (5, 13)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, shape, "float32", "gather_rows", q, chunks, head)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, err, out_shape, ok_slice in results:
+        assert isinstance(err, float), f"rank {rank} failed: {err}"
+        assert out_shape == (shape[0], shape[1], 32) and err < 1e-6 and ok_slice
 
 
 def test_load_rows_stores_owned_range_and_replicated_head():

@@ -1282,3 +1282,56 @@ def test_one_handle_from_two_host_threads():
     for t in threads:
         t.join()
     assert not errors, errors[:3]
+
+
+@pytest.mark.parametrize("shared_stream", [False, True])
+def test_one_handle_large_batches_from_host_threads(shared_stream):
+    """SURVEY 8b "lookups are thread-safe and stream-ordered" for batches ABOVE the one-launch limit: 64k-token batches
+    use a workspace (per-token id records) that belongs to the stream of the call and is locked while the match that
+    writes it and the lookup that reads it are enqueued.  Three host threads -- each on its own stream, or all on ONE
+    stream -- run scone_embed (two batch shapes) and scone_match_csr on one handle; every result equals the
+    single-threaded answer."""
+    import threading
+    rng = np.random.default_rng(32)
+    vocab, n, d = 61, 4000, 768
+    lens = rng.integers(1, 4, size=n).astype(np.uint8)
+    keys = rng.integers(0, vocab, size=(n, 3)).astype(np.uint32)
+    keys[np.arange(3)[None, :] >= lens[:, None]] = 0
+    cache = _cache(keys, lens, 3, rng.standard_normal((n, d)).astype(np.float32), "int8")
+    wte = torch.from_numpy(rng.standard_normal((vocab, d)).astype(np.float32)).half().cuda()
+    wpe = torch.from_numpy(rng.standard_normal((512, d)).astype(np.float32)).half().cuda()
+    toks = [torch.from_numpy(rng.integers(0, vocab, size=s)).to("cuda", torch.int32) for s in ((128, 512), (160, 448), (96, 512))]
+    assert all(t.numel() > 32768 for t in toks)
+    want = [cache.embed_tokens(t, wte=wte, wpe=wpe).clone() for t in toks]
+    want_csr = [tuple(x.clone() for x in cache.table.match_csr(t)) for t in toks]
+    torch.cuda.synchronize()
+    errors = []
+    one = torch.cuda.Stream()
+
+    def worker(seed):
+        try:
+            r = np.random.default_rng(seed)
+            stream = one if shared_stream else torch.cuda.Stream()
+            with torch.cuda.stream(stream):
+                for it in range(60):
+                    k = int(r.integers(len(toks)))
+                    if it % 7 == 3:
+                        off, ids = cache.table.match_csr(toks[k])            # synchronises its stream
+                        if not (torch.equal(off, want_csr[k][0]) and torch.equal(ids, want_csr[k][1])):
+                            errors.append((seed, it, k, "csr"))
+                        continue
+                    out = cache.embed_tokens(toks[k], wte=wte, wpe=wpe)
+                    if it % 5 == 0:
+                        stream.synchronize()
+                        if not torch.equal(out, want[k]):
+                            errors.append((seed, it, k))
+            stream.synchronize()
+        except Exception as e:          # surface in the main thread
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=worker, args=(s,)) for s in (1, 2, 3)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:3]

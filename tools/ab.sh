@@ -12,7 +12,7 @@ cd $R
 for round in 1 2 3; do
   for v in A B; do
     lib=$A; [ $v = B ] && lib=$B
-    SCONE_HIP_LIB=$R/$lib timeout 300 python bench.py --steps 50 --warmup 5 --no-cpu-baseline "$@" > $O/bench_$v$round.json 2>> $O/bench.err || exit 1
+    SCONE_HIP_LIB=$R/$lib timeout 300 python bench.py --steps 50 --warmup 5 --quick "$@" > $O/bench_$v$round.json 2>> $O/bench.err || exit 1
     python - "$O/bench_$v$round.json" $v$round <<'EOF'
 import json, sys
 r = json.load(open(sys.argv[1]))
@@ -24,7 +24,7 @@ cd /tmp && export TMPDIR=/tmp
 for v in A B; do
   lib=$A; [ $v = B ] && lib=$B
   export SCONE_HIP_LIB=$R/$lib
-  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_$v -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline "$@" > $O/trace_$v.log 2>&1 || exit 1
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_$v -- python3 $R/bench.py --steps 20 --warmup 3 --quick "$@" > $O/trace_$v.log 2>&1 || exit 1
   f=$(ls $O/trace_$v/*/*kernel_stats.csv | head -1)
   cp $f $O/kernel_stats_$v.csv
   echo "== $v ($lib)"; python3 - $f <<'EOF'

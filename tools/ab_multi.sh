@@ -13,7 +13,7 @@ cd $R
 for round in $(seq 1 $ROUNDS); do
   for lib in "${LIBS[@]}"; do
     n=$(basename $lib .so)
-    SCONE_HIP_LIB=$R/$lib timeout 300 python bench.py --steps 50 --warmup 5 --no-cpu-baseline "$@" > $O/${n}_$round.json 2>> $O/err.log || { echo "$n failed"; tail -3 $O/err.log; exit 1; }
+    SCONE_HIP_LIB=$R/$lib timeout 300 python bench.py --steps 50 --warmup 5 --quick "$@" > $O/${n}_$round.json 2>> $O/err.log || { echo "$n failed"; tail -3 $O/err.log; exit 1; }
     python3 - $O/${n}_$round.json $n $round <<'PY'
 import json, sys
 r = json.load(open(sys.argv[1]))

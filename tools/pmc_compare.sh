@@ -14,7 +14,7 @@ for spec in "$@"; do
            "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_INSTS_SALU GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM_RD" \
            "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum" "TA_BUSY_avr TA_TA_BUSY_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum"; do
     i=$((i+1))
-    timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/${name}_$i -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline $args > $O/${name}_$i.log 2>&1 || echo "pass $i of $name failed: $(tail -1 $O/${name}_$i.log)"
+    timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/${name}_$i -- python3 $R/bench.py --steps 5 --warmup 2 --quick $args > $O/${name}_$i.log 2>&1 || echo "pass $i of $name failed: $(tail -1 $O/${name}_$i.log)"
   done
 done
 python3 - $O <<'PY'

@@ -9,7 +9,7 @@ cd $R
 run() {
   name=$1; shift
   echo "== $name: bench.py $*" | tee -a $O/configs.log
-  timeout -k 10 900 python bench.py --no-cpu-baseline "$@" > $O/$name.json 2>> $O/configs.log || { echo "$name FAILED"; tail -5 $O/configs.log; return 1; }
+  timeout -k 10 900 python bench.py --quick "$@" > $O/$name.json 2>> $O/configs.log || { echo "$name FAILED"; tail -5 $O/configs.log; return 1; }
   python3 - $O/$name.json $name >> $O/configs.jsonl <<'PY'
 import json, sys
 r = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])

@@ -14,7 +14,7 @@ cd /tmp && export TMPDIR=/tmp
 for lib in "${LIBS[@]}"; do
   n=$(basename $lib .so)
   export SCONE_HIP_LIB=$R/$lib
-  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_$n -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline "$@" > $O/trace_$n.log 2>&1 || { echo "$n failed"; tail -5 $O/trace_$n.log; exit 1; }
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_$n -- python3 $R/bench.py --steps 20 --warmup 3 --quick "$@" > $O/trace_$n.log 2>&1 || { echo "$n failed"; tail -5 $O/trace_$n.log; exit 1; }
   f=$(ls $O/trace_$n/*/*kernel_stats.csv | head -1)
   cp $f $O/kernel_stats_$n.csv
   python3 - $f $n "$PAT" <<'PY'

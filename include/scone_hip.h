@@ -108,7 +108,8 @@ void scone_destroy(scone_handle *h);
 const char *scone_last_error(const scone_handle *h);
 /* Sticky device-side status bits raised by kernels (bit 0: token outside the
  * base-embedding vocabulary, bit 1: f-gram id outside the table, bit 2: index
- * full); synchronises the stream, returns the bits in *bits and clears them. */
+ * full, bit 3: the staging buffer of a staged pinned-host lookup overflowed -- sized so that it cannot; the affected
+ * tokens read a wrong row); synchronises the stream, returns the bits in *bits and clears them. */
 int scone_status(scone_handle *h, uint32_t *bits, scone_stream_t stream);
 
 /* ---- index: f-gram -> id (replaces NGramExtractor.f_grams / f_gram_to_id,
@@ -123,6 +124,14 @@ int scone_index_build_device(scone_handle *h, const uint32_t *d_keys, const uint
                              uint64_t n, uint64_t id0, scone_stream_t stream);
 /* Synchronises.  n_keys = distinct keys stored, n_dups = duplicate insertions seen. */
 int scone_index_stats(scone_handle *h, uint64_t *n_keys, uint64_t *capacity, uint64_t *n_dups);
+
+/* The built index as three host blobs -- hash slots, direct unigram table, presence bitmap -- so that a table file can
+ * carry it (scone_amd's native file: EmbeddingCache.save_native(with_index=True)) and a shard of a 1e9-key table loads
+ * without rebuilding it from the keys.  Import needs a handle created with the same max_n and index_capacity (compare
+ * scone_index_blob_sizes) and replaces the index; both synchronise the device. */
+int scone_index_blob_sizes(scone_handle *h, uint64_t *slot_bytes, uint64_t *uni_bytes, uint64_t *bloom_bytes);
+int scone_index_export(scone_handle *h, void *h_slots, void *h_uni, void *h_bloom, uint64_t *n_keys);
+int scone_index_import(scone_handle *h, const void *h_slots, const void *h_uni, const void *h_bloom, uint64_t n_keys);
 
 /* ---- vocabulary construction on the GPU (NGramExtractor.fit, n_gram_extractor.py:72-104) -----
  * d_tokens[n_tokens] int32: the corpus, texts back to back; d_text_offsets[n_texts+1] int64.

@@ -24,7 +24,7 @@ DT_F32, DT_F16, DT_BF16 = 0, 1, 2
 
 OK, ESTATE, EHIP, ENOMEM, ENODEV, EINVAL, ERANGE = 0, -1, -5, -12, -19, -22, -34
 
-ST_BAD_TOKEN, ST_BAD_ID, ST_INDEX_FULL = 1, 2, 4
+ST_BAD_TOKEN, ST_BAD_ID, ST_INDEX_FULL, ST_STAGE_OVERFLOW = 1, 2, 4, 8
 
 
 class SconeCfg(C.Structure):
@@ -59,6 +59,9 @@ SIGNATURES = {
     "scone_index_build": (C.c_int, [_P, _P, _P, _U64, _U64]),
     "scone_index_build_device": (C.c_int, [_P, _P, _P, _U64, _U64, _P]),
     "scone_index_stats": (C.c_int, [_P, C.POINTER(_U64), C.POINTER(_U64), C.POINTER(_U64)]),
+    "scone_index_blob_sizes": (C.c_int, [_P, C.POINTER(_U64), C.POINTER(_U64), C.POINTER(_U64)]),
+    "scone_index_export": (C.c_int, [_P, _P, _P, _P, C.POINTER(_U64)]),
+    "scone_index_import": (C.c_int, [_P, _P, _P, _P, _U64]),
     "scone_fit": (C.c_int, [_I32, _P, _I64, _P, _I64, _I32, _U32, _U64, _P, _P, _P, _U64, C.POINTER(_U64),
                             C.POINTER(_U64), _P]),
     "scone_table_upload": (C.c_int, [_P, _P, _P, _U64, _U64, C.c_int, _P]),

@@ -23,6 +23,7 @@
 #define SCONE_ST_BAD_TOKEN 1u
 #define SCONE_ST_BAD_ID 2u
 #define SCONE_ST_INDEX_FULL 4u
+#define SCONE_ST_STAGE_OVERFLOW 8u
 
 // ---------------------------------------------------------------- hash index
 // 16-byte slot.  lo/ext hold the exact packed key (no fingerprints, so a probe

@@ -131,34 +131,31 @@ template <int FMT, int D> struct wave_geom {
 #ifndef SCONE_WAVE_BLOCKS
 #define SCONE_WAVE_BLOCKS 4096  // ~256 CUs x 8 resident workgroups x 2 rounds
 #endif
-// per-format switches (A/B builds override them with -D): rows live at once, and which formats have a HIGH-OCCUPANCY
+// per-format switches (A/B builds override them with -D): which formats have a HIGH-OCCUPANCY
 // variant of k_embed_wave (the wave's position row in LDS instead of 8 VGPRs -> one or two more waves per SIMD) that
 // launch_wave selects for tables of SCONE_HIOCC_MIN_BYTES and more.  Measured (tools/ab_multi.sh, one box, INT4 d = 1024,
 // 5 vs 7 waves / SIMD, gather kernel): 100M rows 0.906 -> 0.861 ms, 10M rows 0.890 -> 0.852 ms, 1M rows (512 MB: most row
 // reads are L2 / Infinity-Cache hits, more waves only evict each other's lines) 0.892 -> 0.917 ms.
-#ifndef SCONE_KLIVE_I4
-#define SCONE_KLIVE_I4 SCONE_MAX_CAND  // no batching: K > 4 is rare, but the batched bodies cost registers on every path
-#endif
 #ifndef SCONE_HIOCC_MASK
 #define SCONE_HIOCC_MASK (1 << SCONE_FMT_I4)
+#endif
+#ifndef SCONE_HIOCC_SLACK_CUT
+#define SCONE_HIOCC_SLACK_CUT 0
 #endif
 #ifndef SCONE_HIOCC_MIN_BYTES
 #define SCONE_HIOCC_MIN_BYTES (2ll << 30)
 #endif
-template <int FMT, int D> struct wave_klive {
-  static constexpr int value = FMT == SCONE_FMT_I4 ? SCONE_KLIVE_I4 : SCONE_MAX_CAND;
-};
 template <int FMT> struct wave_hiocc {
   static constexpr bool available = ((SCONE_HIOCC_MASK >> FMT) & 1) != 0;
 };
 template <int FMT, typename OutT, int D, int MAXN, bool FIXED_POS, bool HIOCC = false> struct wave_occupancy {
   static constexpr int NC = MAXN * (MAXN + 1) / 2;
-  static constexpr int KL = NC < wave_klive<FMT, D>::value ? NC : wave_klive<FMT, D>::value;  // rows in flight
+  static constexpr int KL = NC;  // rows in flight
   static constexpr int NWO = wave_geom<FMT, D>::EPL * (int)sizeof(OutT) / 4;
   // INT4 also holds one group-scale word per (row, segment) in flight
   static constexpr int EST = KL * (wave_geom<FMT, D>::NBR / 4) + (FMT == SCONE_FMT_I4 ? KL * (D == 1024 ? 1 : wave_geom<FMT, D>::NSEG) : 0) +
                              (FIXED_POS && !HIOCC ? 4 : 3) * NWO +
-                             wave_geom<FMT, D>::EPL + SCONE_WAVE_SLACK +
+                             wave_geom<FMT, D>::EPL + SCONE_WAVE_SLACK - (HIOCC ? SCONE_HIOCC_SLACK_CUT : 0) +
                              (FMT == SCONE_FMT_I4 && !HIOCC ? 8 : 0) +  // INT4 at 6 waves spills 44 B/lane on the K >= 4 paths
                              (MAXN >= 4 ? (FMT == SCONE_FMT_I4 ? 24 : 8) : 0) +  // the 10-way switch keeps more addresses live
                              (std::is_same<OutT, __hip_bfloat16>::value ? 4 : 0);  // round-to-nearest-even by hand
@@ -209,33 +206,38 @@ __device__ __forceinline__ void st_out_row(uint8_t *__restrict__ row, uint32_t l
 // One token with exactly K owned rows: straight-line code, every load unconditional and
 // issued before the first use (the K-way switch in the kernel keeps K a compile-time constant,
 // so the row registers are plain scalars and the waits are exact vmcnt counts).
-//
-// The rows of a token are requested in batches of at most KLIVE (wave_klive<>): what sets the kernel's occupancy
-// is the register file, and the registers a token needs grow with the rows it holds at once.  On the small-row
-// formats occupancy is what buys bandwidth (an INT4 d = 1024 row is 512 B: a wave has ~1.2 KB of rows + 2 KB of
-// wte in flight, and MI355X_MICROARCH.md "Indexed rows" wants ~72 KB per CU to hide an HBM miss), tokens with more
-// than KLIVE rows are rare (K > 4: a few per cent of the Zipf-keyed stream, none of the structured one), and they
-// only pay a second round of loads.  A/B on one box, INT4 100M x 1024, gather kernel: 5 waves / SIMD 0.872-0.888 ms,
-// 6 waves (position row moved to LDS) 0.803-0.812 ms, 7 and 8 waves WITH spills 0.82 / 0.88 ms.
-template <int FMT, typename OutT, int D, int KLIVE> struct token_regs {
+template <int FMT, typename OutT, int D, int K, bool FIXED_POS, bool PARTIAL, bool WPE_LDS = false>
+__device__ __forceinline__ void embed_token(const scone_row_store &rows, const void *__restrict__ scales_v,
+                                            const int32_t *__restrict__ rec, long long row_begin, int kfull, int reduce,
+                                            const uint8_t *__restrict__ wte_row, const uint8_t *__restrict__ wpe_row,
+                                            const uint32_t (&wpe_words)[wave_geom<FMT, D>::EPL * (int)sizeof(OutT) / 4],
+                                            uint8_t *__restrict__ out_row, uint32_t lane,
+                                            const uint32_t *__restrict__ wpe_lds = nullptr) {
   using G = wave_geom<FMT, D>;
-  static constexpr int NWR = G::NBR / 4, NSEG = G::NSEG, NWO = G::EPL * (int)sizeof(OutT) / 4;
-  uint32_t bw[NWO];           // wte row words of this lane
-  uint32_t bp[NWO];           // wpe row words (only loaded when the wave's position is not fixed)
-  uint32_t raw[KLIVE][NWR];   // table row words of the batch in flight
-  uint32_t scw[KLIVE][NSEG];  // I8: the scale pair word of the row; I4: the lane's group scale per segment
-};
+  constexpr int EPL = G::EPL, NWR = G::NBR / 4, NSEG = G::NSEG;
+  constexpr int NWO = EPL * (int)sizeof(OutT) / 4;
+  constexpr int OPW = pack_io<OutT>::PER_WORD;
+  constexpr int KK = K > 0 ? K : 1;
 
-// request rows [K0, K1) of the token's list into R.raw[0 .. K1 - K0)
-template <int FMT, typename OutT, int D, int K0, int K1, int KLIVE>
-__device__ __forceinline__ void rows_issue(token_regs<FMT, OutT, D, KLIVE> &R, const scone_row_store &rows,
-                                           const void *__restrict__ scales_v, const int32_t *__restrict__ rec,
-                                           long long row_begin, uint32_t lane) {
-  using G = wave_geom<FMT, D>;
-  constexpr int NSEG = G::NSEG;
-  static_assert(K1 - K0 <= KLIVE, "batch larger than the row registers");
+  uint32_t bw[NWO], bp[NWO];
+  if constexpr (PARTIAL) {
 #pragma unroll
-  for (int k = K0; k < K1; ++k) {
+    for (int w = 0; w < NWO; ++w) bw[w] = bp[w] = 0u;
+  } else {
+    ld_out_row<FMT, OutT, D>(wte_row, lane, bw);
+  }
+  if constexpr (PARTIAL) {
+  } else if constexpr (FIXED_POS) {
+    // this wave's position row, loaded once: in registers, or (high-occupancy variant) read back from LDS at the end
+#pragma unroll
+    for (int w = 0; w < NWO; ++w) bp[w] = WPE_LDS ? 0u : wpe_words[w];
+  } else {
+    ld_out_row<FMT, OutT, D>(wpe_row, lane, bp);
+  }
+  uint32_t raw[KK][NWR];
+  uint32_t scw[KK][NSEG];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
     const long long lr = (long long)rec[k] - row_begin;
     const uint8_t *rp = rows.row((unsigned long long)lr);  // HBM or mapped host DRAM (wave-uniform select)
 #pragma unroll
@@ -244,50 +246,47 @@ __device__ __forceinline__ void rows_issue(token_regs<FMT, OutT, D, KLIVE> &R, c
                                                               lane * (uint32_t)(G::seg_elems(s) * G::BPE4 / 4));
 #pragma unroll
       for (int i = 0; i < G::seg_row_words(s); ++i)  // wave-uniform choice between a plain and a streaming load
-        R.raw[k - K0][G::seg_row_word0(s) + i] = lr >= SCONE_NT_FROM_ROW ? __builtin_nontemporal_load(p + i) : p[i];
+        raw[k][G::seg_row_word0(s) + i] = lr >= SCONE_NT_FROM_ROW ? __builtin_nontemporal_load(p + i) : p[i];
       if constexpr (FMT == SCONE_FMT_I8) {
-        R.scw[k - K0][s] = s == 0 ? reinterpret_cast<const uint32_t *>(scales_v)[lr >> 1] : 0u;  // two half scales per word (scalar load)
+        scw[k][s] = s == 0 ? reinterpret_cast<const uint32_t *>(scales_v)[lr >> 1] : 0u;  // two half scales per word (scalar load)
       } else if constexpr (FMT == SCONE_FMT_I4) {
         if constexpr (D == 1024) {
           // scone_i4_scale_slot: the lane's two group scales (segment 0: group lane / 16, segment 1: group 4 + lane / 16)
-          // are the two halves of ONE dword
-          if (s == 0) R.scw[k - K0][0] = reinterpret_cast<const uint32_t *>(scales_v)[lr * (D / SCONE_I4_GROUP / 2) + (lane >> 4)];
+          // are the two halves of ONE dword -- one load and one register per row instead of two
+          scw[k][s] = s == 0 ? reinterpret_cast<const uint32_t *>(scales_v)[lr * (D / SCONE_I4_GROUP / 2) + (lane >> 4)] : 0u;
         } else {
-          R.scw[k - K0][s] = reinterpret_cast<const unsigned short *>(scales_v)[lr * (D / SCONE_I4_GROUP) +
-                                                                                scone_i4_scale_slot((G::seg_first(s) + lane * G::seg_elems(s)) / SCONE_I4_GROUP, D)];
+          scw[k][s] = reinterpret_cast<const unsigned short *>(scales_v)[lr * (D / SCONE_I4_GROUP) +
+                                                                         scone_i4_scale_slot((G::seg_first(s) + lane * G::seg_elems(s)) / SCONE_I4_GROUP, D)];
         }
       } else {
-        R.scw[k - K0][s] = 0;
+        scw[k][s] = 0;
       }
     }
   }
-}
 
-// acc += dequant(rows [K0, K1)), sequentially in list order (exact products: see accumulate<> in scone_gather_impl.h)
-template <int FMT, typename OutT, int D, int K0, int K1, int KLIVE>
-__device__ __forceinline__ void rows_accumulate(const token_regs<FMT, OutT, D, KLIVE> &R, const int32_t *__restrict__ rec,
-                                                long long row_begin, float (&acc)[wave_geom<FMT, D>::EPL]) {
-  using G = wave_geom<FMT, D>;
-  constexpr int NSEG = G::NSEG;
+  float acc[EPL];
 #pragma unroll
-  for (int k = K0; k < K1; ++k) {
+  for (int e = 0; e < EPL; ++e) acc[e] = 0.f;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
     float sc0 = 1.0f;
     if constexpr (FMT == SCONE_FMT_I8) {
       const long long lr = (long long)rec[k] - row_begin;
-      sc0 = __half2float(__ushort_as_half((unsigned short)((lr & 1) ? (R.scw[k - K0][0] >> 16) : (R.scw[k - K0][0] & 0xFFFFu))));
+      sc0 = __half2float(__ushort_as_half((unsigned short)((lr & 1) ? (scw[k][0] >> 16) : (scw[k][0] & 0xFFFFu))));
     }
 #pragma unroll
     for (int s = 0; s < NSEG; ++s) {
       float sc = sc0;
       if constexpr (FMT == SCONE_FMT_I4) {
         if constexpr (D == 1024)
-          sc = __half2float(__ushort_as_half((unsigned short)(s == 0 ? (R.scw[k - K0][0] & 0xFFFFu) : (R.scw[k - K0][0] >> 16))));
+          sc = __half2float(__ushort_as_half((unsigned short)(s == 0 ? (scw[k][0] & 0xFFFFu) : (scw[k][0] >> 16))));
         else
-          sc = __half2float(__ushort_as_half((unsigned short)R.scw[k - K0][s]));
+          sc = __half2float(__ushort_as_half((unsigned short)scw[k][s]));
       }
+      // acc[seg_acc(s) ..] += dequant(raw[k][seg words]); exact products, list order (see accumulate<>)
 #pragma unroll
       for (int i = 0; i < G::seg_row_words(s); ++i) {
-        const uint32_t w = R.raw[k - K0][G::seg_row_word0(s) + i];
+        const uint32_t w = raw[k][G::seg_row_word0(s) + i];
         if constexpr (FMT == SCONE_FMT_F32) {
           acc[G::seg_acc(s) + i] += __uint_as_float(w);
         } else if constexpr (FMT == SCONE_FMT_F16) {
@@ -305,19 +304,6 @@ __device__ __forceinline__ void rows_accumulate(const token_regs<FMT, OutT, D, K
       }
     }
   }
-}
-
-// mean, (wte + mean) + wpe, one rounding to OutT, streamed out -- or the raw fp32 sums of a shard (PARTIAL)
-template <int FMT, typename OutT, int D, bool FIXED_POS, bool PARTIAL, int KLIVE>
-__device__ __forceinline__ void token_combine_store(const token_regs<FMT, OutT, D, KLIVE> &R, float (&acc)[wave_geom<FMT, D>::EPL],
-                                                    int kfull, int reduce,
-                                                    const uint32_t (&wpe_words)[wave_geom<FMT, D>::EPL * (int)sizeof(OutT) / 4],
-                                                    const uint32_t *__restrict__ wpe_lds, uint8_t *__restrict__ out_row,
-                                                    uint32_t lane) {
-  using G = wave_geom<FMT, D>;
-  constexpr int EPL = G::EPL;
-  constexpr int NWO = EPL * (int)sizeof(OutT) / 4;
-  constexpr int OPW = pack_io<OutT>::PER_WORD;
   if constexpr (PARTIAL) {
     // row-sharded tables: the fp32 sum over the rows THIS handle owns goes out as is (the other
     // shards' sums are added by the reduce-scatter; scone_finalize divides and combines)
@@ -343,67 +329,16 @@ __device__ __forceinline__ void token_combine_store(const token_regs<FMT, OutT, 
 #pragma unroll
   for (int w = 0; w < NWO; ++w) {
     float b[OPW], c[OPW], v[OPW];
-    pack_io<OutT>::unpack(R.bw[w], b);
-    if constexpr (FIXED_POS)
-      pack_io<OutT>::unpack(wpe_lds ? wpe_lds[w * 64 + lane] : wpe_words[w], c);  // this wave's position row, loaded once
+    pack_io<OutT>::unpack(bw[w], b);
+    if constexpr (WPE_LDS)
+      pack_io<OutT>::unpack(wpe_lds[w * 64 + lane], c);
     else
-      pack_io<OutT>::unpack(R.bp[w], c);
+      pack_io<OutT>::unpack(bp[w], c);
 #pragma unroll
     for (int k = 0; k < OPW; ++k) v[k] = (b[k] + acc[w * OPW + k]) + c[k];  // language_model.py:242-243, :253-254
     ow[w] = pack_io<OutT>::pack(v);
   }
   st_out_row<FMT, OutT, D>(out_row, lane, ow);
-}
-
-// the batches after the first one: rows [K0, K) in steps of KLIVE
-template <int FMT, typename OutT, int D, int K0, int K, int KLIVE>
-__device__ __forceinline__ void rows_more(token_regs<FMT, OutT, D, KLIVE> &R, const scone_row_store &rows,
-                                          const void *__restrict__ scales_v, const int32_t *__restrict__ rec,
-                                          long long row_begin, float (&acc)[wave_geom<FMT, D>::EPL], uint32_t lane) {
-  if constexpr (K0 < K) {
-    constexpr int K1 = K < K0 + KLIVE ? K : K0 + KLIVE;
-    rows_issue<FMT, OutT, D, K0, K1, KLIVE>(R, rows, scales_v, rec, row_begin, lane);
-    rows_accumulate<FMT, OutT, D, K0, K1, KLIVE>(R, rec, row_begin, acc);
-    rows_more<FMT, OutT, D, K1, K, KLIVE>(R, rows, scales_v, rec, row_begin, acc, lane);
-  }
-}
-
-// everything after the first batch of loads is out: the accumulators are born here, so nothing of the reduce is live
-// while the wave waits for its rows
-template <int FMT, typename OutT, int D, int K, int KA, bool FIXED_POS, bool PARTIAL, int KLIVE>
-__device__ __forceinline__ void token_finish(token_regs<FMT, OutT, D, KLIVE> &R, const scone_row_store &rows,
-                                             const void *__restrict__ scales_v, const int32_t *__restrict__ rec,
-                                             long long row_begin, int kfull, int reduce,
-                                             const uint32_t (&wpe_words)[wave_geom<FMT, D>::EPL * (int)sizeof(OutT) / 4],
-                                             const uint32_t *__restrict__ wpe_lds, uint8_t *__restrict__ out_row, uint32_t lane) {
-  float acc[wave_geom<FMT, D>::EPL];
-#pragma unroll
-  for (int e = 0; e < wave_geom<FMT, D>::EPL; ++e) acc[e] = 0.f;
-  rows_accumulate<FMT, OutT, D, 0, KA, KLIVE>(R, rec, row_begin, acc);
-  if constexpr (K > KA) rows_more<FMT, OutT, D, KA, K, KLIVE>(R, rows, scales_v, rec, row_begin, acc, lane);
-  token_combine_store<FMT, OutT, D, FIXED_POS, PARTIAL, KLIVE>(R, acc, kfull, reduce, wpe_words, wpe_lds, out_row, lane);
-}
-
-template <int FMT, typename OutT, int D, int K, bool FIXED_POS, bool PARTIAL>
-__device__ __forceinline__ void embed_token(const scone_row_store &rows, const void *__restrict__ scales_v,
-                                            const int32_t *__restrict__ rec, long long row_begin, int kfull, int reduce,
-                                            const uint8_t *__restrict__ wte_row, const uint8_t *__restrict__ wpe_row,
-                                            const uint32_t (&wpe_words)[wave_geom<FMT, D>::EPL * (int)sizeof(OutT) / 4],
-                                            uint8_t *__restrict__ out_row, uint32_t lane,
-                                            const uint32_t *__restrict__ wpe_lds = nullptr) {
-  using G = wave_geom<FMT, D>;
-  constexpr int NWO = G::EPL * (int)sizeof(OutT) / 4;
-  constexpr int KL0 = wave_klive<FMT, D>::value;
-  constexpr int KL = K < KL0 ? (K > 0 ? K : 1) : KL0;  // registers for min(K, KLIVE) rows
-  token_regs<FMT, OutT, D, KL> R;
-  if constexpr (!PARTIAL) {
-    ld_out_row<FMT, OutT, D>(wte_row, lane, R.bw);
-    if constexpr (!FIXED_POS) ld_out_row<FMT, OutT, D>(wpe_row, lane, R.bp);
-  }
-  constexpr int KA = K < KL ? K : KL;
-  rows_issue<FMT, OutT, D, 0, KA, KL>(R, rows, scales_v, rec, row_begin, lane);
-  token_finish<FMT, OutT, D, K, KA, FIXED_POS, PARTIAL, KL>(R, rows, scales_v, rec, row_begin, kfull, reduce, wpe_words, wpe_lds,
-                                                            out_row, lane);
 }
 
 // Work assignment: a workgroup's 4 waves own 4 CONSECUTIVE positions i0..i0+3 and walk the same
@@ -478,13 +413,6 @@ __global__ __launch_bounds__(256, (wave_occupancy<FMT, OutT, D, MAXN, FIXED_POS,
   int32_t tokv = wte ? tok[p] : 0;
   int32_t posv = (!FIXED_POS && wpe) ? pos[p] : 0;
 
-  // the wte row a token reads: absent / out-of-range base rows read a row of zeros (the adds stay unconditional);
-  // paper mode: a matched f-gram REPLACES the token embedding (Algorithm 2), so wte is skipped
-  auto wte_row_of = [&](int32_t tv, int kf) {
-    const bool ok = wte && tv >= 0 && (long long)tv < q.vocab;
-    const bool use = ok && !(q.mode == SCONE_MODE_LONGEST_SUFFIX && kf > 0);
-    return use ? reinterpret_cast<const uint8_t *>(wte + (long long)tv * D) : zero_row;
-  };
   while (true) {
     const bool tok_ok = wte && tokv >= 0 && (long long)tokv < q.vocab;
     bool pos_ok = true;
@@ -493,7 +421,10 @@ __global__ __launch_bounds__(256, (wave_occupancy<FMT, OutT, D, MAXN, FIXED_POS,
       if (lane == 0) atomicOr(status, SCONE_ST_BAD_TOKEN);
     }
     const int kown = rec[W - 2] & 0xFF, kfull = rec[W - 2] >> 8;
-    const uint8_t *wte_row = wte_row_of(tokv, kfull);
+    // absent / out-of-range base rows read a row of zeros: the adds stay unconditional
+    // paper mode: a matched f-gram REPLACES the token embedding (Algorithm 2), so wte is skipped
+    const bool use_wte = tok_ok && !(q.mode == SCONE_MODE_LONGEST_SUFFIX && kfull > 0);
+    const uint8_t *wte_row = use_wte ? reinterpret_cast<const uint8_t *>(wte + (long long)tokv * D) : zero_row;
     const uint8_t *wpe_row = zero_row;
     if constexpr (!FIXED_POS) {
       if (pos_ok) wpe_row = reinterpret_cast<const uint8_t *>(wpe + (long long)posv * D);
@@ -517,8 +448,8 @@ __global__ __launch_bounds__(256, (wave_occupancy<FMT, OutT, D, MAXN, FIXED_POS,
 #define SCONE_CASE(K)                                                                                          \
   case K:                                                                                                      \
     if constexpr (K <= NC)                                                                                     \
-      embed_token<FMT, OutT, D, K, FIXED_POS, PARTIAL>(rows, scales_v, rec, q.row_begin, kfull, q.reduce, wte_row, \
-                                                       wpe_row, wpe_words, out_row, lane, wpe_lds);            \
+      embed_token<FMT, OutT, D, K, FIXED_POS, PARTIAL, WPE_LDS>(rows, scales_v, rec, q.row_begin, kfull, q.reduce,   \
+                                                                wte_row, wpe_row, wpe_words, out_row, lane, wpe_lds); \
     break;
     switch (kown) {
       SCONE_CASE(0) SCONE_CASE(1) SCONE_CASE(2) SCONE_CASE(3) SCONE_CASE(4) SCONE_CASE(5) SCONE_CASE(6)

@@ -518,6 +518,43 @@ extern "C" int scone_index_stats(scone_handle *h, uint64_t *n_keys, uint64_t *ca
   return SCONE_OK;
 }
 
+// The built index as three host blobs (hash slots, direct unigram table, presence bitmap): a table file that carries
+// them restores a 1e9-key index with three copies instead of a ~16 s rebuild from the keys.
+extern "C" int scone_index_blob_sizes(scone_handle *h, uint64_t *slot_bytes, uint64_t *uni_bytes, uint64_t *bloom_bytes) {
+  if (!h || !slot_bytes || !uni_bytes || !bloom_bytes) return SCONE_EINVAL;
+  *slot_bytes = h->cap * sizeof(scone_slot);
+  *uni_bytes = (uint64_t)SCONE_UNI_CAP * sizeof(int32_t);
+  *bloom_bytes = (h->bloom_mask + 1) / 8;
+  return SCONE_OK;
+}
+
+extern "C" int scone_index_export(scone_handle *h, void *h_slots, void *h_uni, void *h_bloom, uint64_t *n_keys) {
+  if (!h || !h_slots || !h_uni || !h_bloom) return h ? scone_fail(h, SCONE_EINVAL, "scone_index_export: null pointer") : SCONE_EINVAL;
+  SCONE_ON_DEVICE(h);
+  SCONE_HIP(h, hipDeviceSynchronize());
+  SCONE_HIP(h, hipMemcpy(h_slots, h->slots, h->cap * sizeof(scone_slot), hipMemcpyDeviceToHost));
+  SCONE_HIP(h, hipMemcpy(h_uni, h->d_uni, (size_t)SCONE_UNI_CAP * sizeof(int32_t), hipMemcpyDeviceToHost));
+  SCONE_HIP(h, hipMemcpy(h_bloom, h->d_bloom, (h->bloom_mask + 1) / 8, hipMemcpyDeviceToHost));
+  unsigned long long c[2] = {0, 0};
+  SCONE_HIP(h, hipMemcpy(c, h->d_counters, sizeof(c), hipMemcpyDeviceToHost));
+  if (n_keys) *n_keys = c[0];
+  return SCONE_OK;
+}
+
+// The handle must have been created with the same max_n and index_capacity as the exporting one (the blob sizes are
+// checked by the caller through scone_index_blob_sizes); replaces whatever the index held.
+extern "C" int scone_index_import(scone_handle *h, const void *h_slots, const void *h_uni, const void *h_bloom, uint64_t n_keys) {
+  if (!h || !h_slots || !h_uni || !h_bloom) return h ? scone_fail(h, SCONE_EINVAL, "scone_index_import: null pointer") : SCONE_EINVAL;
+  SCONE_ON_DEVICE(h);
+  SCONE_HIP(h, hipDeviceSynchronize());
+  SCONE_HIP(h, hipMemcpy(h->slots, h_slots, h->cap * sizeof(scone_slot), hipMemcpyHostToDevice));
+  SCONE_HIP(h, hipMemcpy(h->d_uni, h_uni, (size_t)SCONE_UNI_CAP * sizeof(int32_t), hipMemcpyHostToDevice));
+  SCONE_HIP(h, hipMemcpy(h->d_bloom, h_bloom, (h->bloom_mask + 1) / 8, hipMemcpyHostToDevice));
+  unsigned long long c[2] = {n_keys, 0};
+  SCONE_HIP(h, hipMemcpy(h->d_counters, c, sizeof(c), hipMemcpyHostToDevice));
+  return SCONE_OK;
+}
+
 extern "C" int scone_match(scone_handle *h, const int32_t *d_tok, int32_t B, int32_t T, int32_t *d_hits,
                            scone_stream_t stream) {
   if (!h) return SCONE_EINVAL;

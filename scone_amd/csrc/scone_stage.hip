@@ -17,6 +17,7 @@
 // buffers it idled for that chain once per chunk: ~40 GB/s instead of ~50 GB/s over Gen5 x16).
 #include "scone_common.h"
 
+#include <cstdlib>
 #include <new>
 
 namespace {
@@ -26,7 +27,7 @@ namespace {
 __global__ __launch_bounds__(256) void k_stage_claim(const int32_t *__restrict__ ell, long long ntok, int W, int NC,
                                                      long long n_hot, uint32_t *__restrict__ slot_of, uint32_t gen,
                                                      uint32_t *__restrict__ count, int32_t *__restrict__ list,
-                                                     uint32_t cap) {
+                                                     uint32_t cap, uint32_t *__restrict__ status) {
   const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long t = gid / NC;
   const int j = (int)(gid - t * NC);
@@ -43,6 +44,12 @@ __global__ __launch_bounds__(256) void k_stage_claim(const int32_t *__restrict__
     if (s < cap) {
       list[s] = (int32_t)id;
       *e = (gen << 24) | s;  // read only by the next kernel
+    } else {
+      // more distinct cold rows than staging slots.  scone_stage_prepare sizes the buffer for the worst case of a
+      // chunk, so this is unreachable from scone_embed; should it ever happen the reference must not stay PENDING
+      // (the remap would send the lookup 16M rows past the buffer): it reads slot 0 and the call is flagged
+      *e = (gen << 24) | 0u;
+      atomicOr(status, SCONE_ST_STAGE_OVERFLOW);
     }
   }
 }
@@ -135,6 +142,10 @@ int scone_stage_prepare(scone_handle *h, long long chunk_tokens) {
   if (chunk_tokens * NC > 0xFFFFFEll && n_cold > 0xFFFFFEll) chunk_tokens = 0xFFFFFEll / NC;
   long long cap = chunk_tokens * NC;
   if (cap > n_cold) cap = n_cold;
+  if (const char *ev = getenv("SCONE_STAGE_CAP_ROWS")) {  // test hook: an undersized buffer exercises the overflow path
+    const long long forced = atoll(ev);
+    if (forced > 0 && forced < cap) cap = forced;
+  }
   st->chunk_tokens = chunk_tokens;
   st->requested_tokens = requested;
   st->cap = (uint32_t)cap;
@@ -181,7 +192,7 @@ int scone_stage_chunk(scone_handle *h, int buf, const int32_t *d_tok, int32_t Bc
     return scone_fail(h, SCONE_EINVAL, "scone_embed(staged): chunk too large for one launch (lower stage_tokens)");
   const unsigned blocks = (unsigned)((work + 255) / 256);
   hipLaunchKernelGGL(k_stage_claim, dim3(blocks), dim3(256), 0, s, st->ell[buf], ntok, W, NC, (long long)h->hot_local,
-                     st->slot_of, st->gen, st->count[buf], st->list[buf], st->cap);
+                     st->slot_of, st->gen, st->count[buf], st->list[buf], st->cap, h->d_status);
   hipLaunchKernelGGL(k_stage_remap, dim3(blocks), dim3(256), 0, s, st->ell[buf], ntok, W, NC, (long long)h->hot_local,
                      st->slot_of);
   SCONE_HIP(h, hipGetLastError());

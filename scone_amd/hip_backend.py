@@ -169,6 +169,29 @@ class SconeTable:
         self._check(L.lib().scone_index_stats(self._h, C.byref(a), C.byref(b), C.byref(c)), "scone_index_stats")
         return a.value, b.value, c.value
 
+    def index_export(self):
+        """The built index as host arrays ``(slots uint8, uni int32, bloom uint8, n_keys, capacity)``."""
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        self._check(L.lib().scone_index_blob_sizes(self._h, C.byref(a), C.byref(b), C.byref(c)), "scone_index_blob_sizes")
+        slots = np.empty(a.value, dtype=np.uint8)
+        uni = np.empty(b.value // 4, dtype=np.int32)
+        bloom = np.empty(c.value, dtype=np.uint8)
+        n = C.c_uint64(0)
+        rc = L.lib().scone_index_export(self._h, slots.ctypes.data_as(C.c_void_p), uni.ctypes.data_as(C.c_void_p),
+                                        bloom.ctypes.data_as(C.c_void_p), C.byref(n))
+        self._check(rc, "scone_index_export")
+        return slots, uni, bloom, n.value, a.value // 16
+
+    def index_import(self, slots: np.ndarray, uni: np.ndarray, bloom: np.ndarray, n_keys: int) -> None:
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        self._check(L.lib().scone_index_blob_sizes(self._h, C.byref(a), C.byref(b), C.byref(c)), "scone_index_blob_sizes")
+        slots, uni, bloom = (np.ascontiguousarray(x) for x in (slots, uni, bloom))
+        if (slots.nbytes, uni.nbytes, bloom.nbytes) != (a.value, b.value, c.value):
+            raise ValueError("index blobs do not fit this handle (create it with the same max_n and index_capacity)")
+        rc = L.lib().scone_index_import(self._h, slots.ctypes.data_as(C.c_void_p), uni.ctypes.data_as(C.c_void_p),
+                                        bloom.ctypes.data_as(C.c_void_p), int(n_keys))
+        self._check(rc, "scone_index_import")
+
     # -- table ------------------------------------------------------------------
     def upload(self, rows, scales=None, row0: int = 0) -> None:
         """Raw rows already in the table format (numpy host arrays or device tensors)."""

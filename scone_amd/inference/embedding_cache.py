@@ -290,33 +290,42 @@ class EmbeddingCache:
     # ------------------------------------------------------------------ native shard format
     NATIVE_MAGIC = "scone_amd.table.v1"
 
-    def save_native(self, path: str, chunk_rows: int = 1 << 18) -> None:
+    def save_native(self, path: str, chunk_rows: int = 1 << 18, with_index: bool = False) -> None:
         """Write the device table as it is stored (quantised rows + scales) together with the
         f-gram keys, so :meth:`load_native` restores it without re-quantising.  One ``.npz``
         (uncompressed): ``meta`` (json), ``keys [N, max_n] uint32``, ``lens [N] uint8``,
-        ``rows [N, payload_bytes] uint8``, ``scales [N, scales_per_row] float16``."""
+        ``rows [row_end - row_begin, payload_bytes] uint8``, ``scales [row_end - row_begin, scales_per_row] float16``
+        -- the rows THIS handle owns only (a shard of a 1e9-row table writes its 125M rows, not a 528 GB array) --
+        and, with ``with_index=True``, the built device index (``index_slots / index_uni / index_bloom``) so that a load
+        copies it back instead of re-inserting every key (1e9 keys: ~16 s)."""
         import json
         table = self.to_device()
-        n = table.n_rows
-        rows = np.empty((n, table.payload_bytes()), dtype=np.uint8)
+        n, a, b = table.n_rows, table.row_begin, table.row_end
+        rows = np.empty((b - a, table.payload_bytes()), dtype=np.uint8)
         spr = table.scales_per_row()
-        scales = np.empty((n, spr), dtype=np.float16)
-        for a in range(table.row_begin, table.row_end, chunk_rows):
-            m = min(chunk_rows, table.row_end - a)
-            r, sc = table.download(a, m)
-            rows[a:a + m] = r
+        scales = np.empty((b - a, spr), dtype=np.float16)
+        for r0 in range(a, b, chunk_rows):
+            m = min(chunk_rows, b - r0)
+            r, sc = table.download(r0, m)
+            rows[r0 - a:r0 - a + m] = r
             if spr:
-                scales[a:a + m] = sc
+                scales[r0 - a:r0 - a + m] = sc
         keys, lens = self.n_gram_extractor.key_arrays()
         meta = {"magic": self.NATIVE_MAGIC, "table_format": self.table_format, "embedding_dim": self.embedding_dim,
-                "max_n": self.n_gram_extractor.max_n, "n_rows": n, "row_begin": table.row_begin, "row_end": table.row_end}
+                "max_n": self.n_gram_extractor.max_n, "n_rows": n, "row_begin": a, "row_end": b, "rows_are_local": True}
+        extra = {}
+        if with_index:
+            slots, uni, bloom, n_keys, cap = table.index_export()
+            meta.update(index_keys=int(n_keys), index_capacity=int(cap))
+            extra = {"index_slots": slots, "index_uni": uni, "index_bloom": bloom}
         np.savez(path, meta=np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8), keys=keys, lens=lens, rows=rows,
-                 scales=scales)
+                 scales=scales, **extra)
 
     @classmethod
     def load_native(cls, path: str, *, placement: str = "hbm", device=None, hot_rows: int = 0) -> "EmbeddingCache":
-        """Restore a cache written by :meth:`save_native` (extractor included)."""
+        """Restore a cache written by :meth:`save_native` (extractor included; the index from the file when it is there)."""
         import json
+        from scone_amd.hip_backend import SconeTable
         z = np.load(path if str(path).endswith(".npz") else str(path) + ".npz")
         meta = json.loads(bytes(z["meta"]).decode())
         if meta.get("magic") != cls.NATIVE_MAGIC:
@@ -324,13 +333,25 @@ class EmbeddingCache:
         ex = NGramExtractor.from_arrays(z["keys"], z["lens"], max_n=meta["max_n"])
         cache = cls(ex, meta["embedding_dim"], table_format=meta["table_format"], placement=placement, device=device,
                     keep_host_copy=False, hot_rows=hot_rows)
-        table = cache._make_table(meta["n_rows"])
         a, b = meta["row_begin"], meta["row_end"]
+        if "index_slots" in z.files:
+            table = SconeTable(ex.max_n, meta["n_rows"], dim=cache.embedding_dim, table_format=cache.table_format,
+                               placement=placement, device=device, hot_rows=hot_rows, lookup_mode=cache.lookup_mode,
+                               index_capacity=meta["index_capacity"], row_begin=a, row_end=b)
+            table.index_import(z["index_slots"], z["index_uni"], z["index_bloom"], meta["index_keys"])
+        elif (a, b) == (0, meta["n_rows"]):
+            table = cache._make_table(meta["n_rows"])
+        else:
+            table = SconeTable(ex.max_n, meta["n_rows"], dim=cache.embedding_dim, table_format=cache.table_format,
+                               placement=placement, device=device, hot_rows=hot_rows, lookup_mode=cache.lookup_mode,
+                               row_begin=a, row_end=b)
+            ex.build_index(table)
         rows, scales = z["rows"], z["scales"]
+        off = a if meta.get("rows_are_local") else 0          # files of the first layout hold all n_rows rows
         chunk = 1 << 18
         for r0 in range(a, b, chunk):
             m = min(chunk, b - r0)
-            table.upload(rows[r0:r0 + m], scales[r0:r0 + m] if scales.shape[1] else None, row0=r0)
+            table.upload(rows[r0 - off:r0 - off + m], scales[r0 - off:r0 - off + m] if scales.shape[1] else None, row0=r0)
         cache._table, cache._dirty = table, False
         cache._present = np.ones(meta["n_rows"], dtype=bool)
         return cache

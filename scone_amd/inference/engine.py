@@ -58,6 +58,60 @@ class SconeInferenceEngine:
         self.causal = getattr(embedding_cache, "lookup_mode", "cover") == "longest_suffix"
         self.max_n = embedding_cache.n_gram_extractor.max_n
 
+    @classmethod
+    def from_pretrained(cls, model_path: str, tokenizer_path: Optional[str] = None,
+                        f_gram_tokenizer_path: Optional[str] = None, embedding_cache_path: Optional[str] = None,
+                        device: Optional[torch.device] = None, quantization: Optional[str] = None,
+                        use_memory_map: bool = True, *, tokenizer=None, table_format: str = "fp32",
+                        lookup_mode: str = "cover") -> "SconeInferenceEngine":
+        """``SconeInferenceEngine.from_pretrained`` of the reference (engine.py:129-190): same arguments, same default
+        paths (``tokenizer_path`` / ``f_gram_tokenizer_path`` = ``model_path``, the cache at
+        ``{model_path}/embedding_cache.npy``), same loading order -- model, tokenizer, f-gram tokenizer
+        (``n_gram_extractor.npy``), embedding cache (``EmbeddingCache.load(path, extractor, use_memory_map=...)``, the
+        kwarg the reference passes at :180 and its own ``load`` rejects).  Additive: ``tokenizer=`` supplies the base
+        tokenizer object when ``AutoTokenizer`` cannot reach its files; ``table_format`` / ``lookup_mode`` choose the
+        device table's row format and the lookup.
+
+        The cache file holds rows of the f-gram model's size; the checkpoint's bias-free ``f_gram_projection`` is folded
+        into them here (``fold_projection``: ``proj(mean(rows)) == mean(proj(rows))``), so that the fused lookup adds
+        hidden-size rows straight to ``wte`` -- the result ``SconeLanguageModel.forward`` computes with its GEMM."""
+        import numpy as np
+        from scone_amd.inference.embedding_cache import EmbeddingCache
+        from scone_amd.models.language_model import SconeLanguageModel, fold_projection
+        from scone_amd.tokenization.f_gram_tokenizer import FGramTokenizer
+        if tokenizer_path is None:
+            tokenizer_path = model_path
+        if f_gram_tokenizer_path is None:
+            f_gram_tokenizer_path = model_path
+        if embedding_cache_path is None:
+            embedding_cache_path = f"{model_path}/embedding_cache.npy"
+        model = SconeLanguageModel.from_pretrained(model_path)
+        if tokenizer is None:
+            from transformers import AutoTokenizer
+            tokenizer = AutoTokenizer.from_pretrained(tokenizer_path)
+        f_gram_tokenizer = FGramTokenizer.from_pretrained(f_gram_tokenizer_path, base_tokenizer=tokenizer)
+        ex = f_gram_tokenizer.n_gram_extractor
+        loaded = EmbeddingCache.load(embedding_cache_path, ex, use_memory_map=use_memory_map)
+        hidden = model.base_model.transformer.wte.weight.shape[1]
+        # rows of the file, in id order, projected to hidden size and stored in the device table's format
+        if loaded.use_memory_map:
+            ids = np.arange(loaded.memory_mapped_embeddings.shape[0], dtype=np.int64)
+            rows = torch.from_numpy(np.ascontiguousarray(loaded.memory_mapped_embeddings))
+        else:
+            ids = np.asarray(sorted(loaded.embeddings.keys()), dtype=np.int64)
+            rows = torch.from_numpy(np.stack([np.asarray(loaded.embeddings[int(i)], dtype=np.float32).reshape(-1) for i in ids])
+                                    if len(ids) else np.zeros((0, loaded.embedding_dim), dtype=np.float32))
+        if model.f_gram_projection is not None and rows.shape[1] == model.f_gram_projection.weight.shape[1]:
+            rows = fold_projection(rows, model.f_gram_projection.weight.detach().cpu())
+        if rows.shape[1] != hidden:
+            raise ValueError(f"embedding cache rows have {rows.shape[1]} dims; the model needs {hidden} "
+                             "(or rows of the f_gram_projection's input size)")
+        cache = EmbeddingCache(ex, hidden, table_format=table_format, lookup_mode=lookup_mode)
+        cache.cache_embeddings(ids.tolist(), rows, verbose=False)
+        model.embed.embedding_cache = cache
+        return cls(model=model, tokenizer=tokenizer, f_gram_tokenizer=f_gram_tokenizer, embedding_cache=cache, device=device,
+                   quantization=quantization)
+
     # ------------------------------------------------------------------ lookup
     def _weights(self):
         wte = self.base.transformer.wte.weight.detach().contiguous()

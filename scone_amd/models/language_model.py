@@ -81,6 +81,49 @@ class SconeLanguageModel(nn.Module):
         self.embed = SconeEmbedding(base_model.transformer.wte, base_model.transformer.wpe, f_gram_projection,
                                     embedding_cache)
 
+    @classmethod
+    def from_pretrained(cls, model_path: str, embedding_cache=None, **kwargs) -> "SconeLanguageModel":
+        """Load a checkpoint directory written by the reference's ``SconeLanguageModel.save_pretrained`` (a HF
+        ``PreTrainedModel``: ``config.json`` with ``SconeConfig``'s fields, language_model.py:12-98, and the weights as
+        ``model.safetensors`` or ``pytorch_model.bin`` with the module names of language_model.py:125-176 --
+        ``base_model.*`` = ``GPT2LMHeadModel``, ``f_gram_projection.weight``, ``f_gram_model.*``).
+
+        The transformer is rebuilt from the config exactly as ``__init__`` builds it (:125-139: GPT-2 with the config's
+        sizes; no hub access needed), ``base_model.*`` and ``f_gram_projection.weight`` are loaded; the BERT-style
+        ``f_gram_model`` (:141-170) produces the table offline and is not needed to serve a precomputed cache, so its
+        weights are skipped."""
+        import json
+        import os
+        from transformers import GPT2Config, GPT2LMHeadModel
+        cfg = json.load(open(os.path.join(model_path, "config.json")))
+        hidden = int(cfg.get("hidden_size", 768))
+        drop = float(cfg.get("hidden_dropout_prob", 0.1))
+        base = GPT2LMHeadModel(GPT2Config(
+            vocab_size=int(cfg.get("vocab_size", 30522)), n_positions=int(cfg.get("max_position_embeddings", 512)),
+            n_embd=hidden, n_layer=int(cfg.get("num_hidden_layers", 12)), n_head=int(cfg.get("num_attention_heads", 12)),
+            resid_pdrop=drop, embd_pdrop=drop, attn_pdrop=float(cfg.get("attention_probs_dropout_prob", 0.1)),
+            layer_norm_epsilon=float(cfg.get("layer_norm_eps", 1e-12))))
+        st = os.path.join(model_path, "model.safetensors")
+        if os.path.exists(st):
+            from safetensors.torch import load_file
+            state = load_file(st)
+        else:
+            state = torch.load(os.path.join(model_path, "pytorch_model.bin"), map_location="cpu", weights_only=True)
+        base_state = {k[len("base_model."):]: v for k, v in state.items() if k.startswith("base_model.")}
+        if "lm_head.weight" not in base_state and "transformer.wte.weight" in base_state:
+            base_state["lm_head.weight"] = base_state["transformer.wte.weight"]      # tied weights are saved once
+        missing, unexpected = base.load_state_dict(base_state, strict=False)
+        missing = [k for k in missing if not k.endswith((".attn.bias", ".attn.masked_bias"))]   # buffers, not weights
+        if missing or unexpected:
+            raise ValueError(f"checkpoint does not match the config: missing {missing[:4]}, unexpected {list(unexpected)[:4]}")
+        use_fg = bool(cfg.get("use_f_gram_embeddings", True))
+        proj = None
+        if use_fg and "f_gram_projection.weight" in state:
+            w = state["f_gram_projection.weight"]
+            proj = nn.Linear(w.shape[1], w.shape[0], bias=False)
+            proj.weight.data.copy_(w)
+        return cls(base.eval(), proj, embedding_cache, use_f_gram_embeddings=use_fg)
+
     def forward(self, input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor] = None,
                 token_type_ids: Optional[torch.Tensor] = None, position_ids: Optional[torch.Tensor] = None,
                 f_gram_ids: Optional[torch.Tensor] = None, f_gram_attention_mask: Optional[torch.Tensor] = None,

@@ -109,7 +109,8 @@ def test_bench_two_ranks_launched_like_the_driver(mode):
     env = dict(os.environ, SCONE_DIST_BACKEND="gloo", SCONE_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
-           "--gpus", "2", "--steps", "5", "--warmup", "2", "--rows", "200000", "--batch", "256", "--table-mode", mode.split("-")[0]]
+           "--gpus", "2", "--steps", "5", "--warmup", "2", "--rows", "200000", "--batch", "256", "--table-mode", mode.split("-")[0],
+           "--sharded-rows-per-rank", "300000", "--sharded-steps", "2"]
     if mode == "sharded-slices":
         cmd.append("--no-gather-output")
     p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
@@ -123,3 +124,102 @@ def test_bench_two_ranks_launched_like_the_driver(mode):
     assert abs(r["value"] - ranks_counted * 256 * 512 * 5 / (r["ms_per_step"] * 5e-3)) / r["value"] < 1e-6
     if mode == "replicated":
         assert r["roofline"]["timed_launches"] == 5
+        km = r["roofline"]["kernel_ms"]
+        assert km["n"] == 5 and km["min"] <= km["median"] <= km["max"]
+        _check_sharded_record(r["sharded"], 2)
+    else:
+        assert "sharded" not in r
+
+
+def _check_sharded_record(rec, world):
+    """The C5-shaped sub-record of an N > 1 line: both whole-output exchanges ran on `world` ranks, their phase split and
+    wire bytes are there, and they produced the same output."""
+    assert "error" not in rec, rec
+    assert rec["world_size"] == world and rec["device_count"] >= 1 and "n1_baseline" in rec
+    for name in ("rows+all_gather", "gather_rows"):
+        e = rec["exchanges"][name]
+        assert "error" not in e, e
+        assert e["ms_per_step"] > 0 and e["tokens_per_s"] > 0 and e["wire_bytes_received_rank0"] > 0
+        for ph in ("plan_ms", "pack_ms", "collective_ms", "embed_ms"):
+            assert e["phase_ms_slowest_rank"][ph] >= 0.0, (name, ph)
+    assert "gather_out_ms" in rec["exchanges"]["rows+all_gather"]["phase_ms_slowest_rank"]
+    assert rec["exchanges_agree"] is True
+
+
+def test_bench_starts_its_own_ranks_when_no_launcher_did():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset: bench.py spawns the two ranks itself (before it touches a GPU) and
+    forwards ONE line that says n_gpus = 2; `--gpus 64` on this box exits non-zero instead of printing a 1-GPU line."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(SCONE_DIST_BACKEND="gloo", SCONE_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--rows", "200000",
+           "--batch", "128", "--sharded-rows-per-rank", "200000", "--sharded-steps", "1"]
+    p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and "started 2 ranks itself" in r["launcher"]
+    _check_sharded_record(r["sharded"], 2)
+    env.pop("SCONE_ONE_DEVICE")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64", "--steps", "1"], env=env, cwd=ROOT,
+                       capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0 and not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+
+
+def _nccl_worker(rank, world, port, q):
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        import torch.distributed as dist
+        torch.cuda.set_device(rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+        from scone_amd import EmbeddingCache, NGramExtractor
+        from scone_amd.distributed import ShardedEmbeddingCache
+        res = []
+        for fmt, d, max_n, head, chunks in (("int8", 768, 3, 0, 1), ("int4", 1024, 3, 100, 3), ("fp16", 768, 4, 37, 4)):
+            keys, lens, table, tok, wte, wpe = _problem(fmt, d, max_n)
+            ex = NGramExtractor.from_arrays(keys, lens, max_n=max_n)
+            sh = ShardedEmbeddingCache(ex, d, table_format=fmt, rank=rank, world=world, replicated_rows=head,
+                                       gather_chunks=chunks)
+            sh.load_rows(torch.from_numpy(table), 0)
+            wte_d, wpe_d = torch.from_numpy(wte).half().cuda(), torch.from_numpy(wpe).half().cuda()
+            full = EmbeddingCache(ex, d, table_format=fmt)
+            full.cache_embeddings(list(range(len(lens))), torch.from_numpy(table), verbose=False)
+            ref = full.embed_tokens(torch.from_numpy(tok), wte=wte_d, wpe=wpe_d)
+            for exchange in ("rows", "gather_rows", "partial_sums"):
+                got = sh.embed_tokens(torch.from_numpy(tok), wte=wte_d, wpe=wpe_d, exchange=exchange)
+                err = float((got.float() - ref.float()).abs().max() / ref.float().abs().max())
+                res.append((fmt, exchange, bool(torch.equal(got, ref)), err))
+        q.put((rank, res, None))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:
+        import traceback
+        q.put((rank, None, repr(e) + traceback.format_exc()))
+
+
+def test_sharded_exchanges_under_rccl_one_rank_per_gpu():
+    """The first box with two or more GPUs runs this: backend "nccl" (= RCCL), one rank per device, all three exchanges
+    -- all_to_all_single with uneven uint8 splits, the chunked all_gather_into_tensor of records, reduce_scatter_tensor
+    of fp32 sums, and the all-gather of the finished vectors -- on device buffers over xGMI, checked against the
+    unsharded table on the same GPUs (row exchanges bit-identical).  Skipped on one-GPU boxes."""
+    world = min(torch.cuda.device_count(), 6)           # the pool allows at most 6 processes on the GPUs at once
+    if world < 2:
+        pytest.skip("needs two or more GPUs (RCCL refuses two ranks on one device)")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_nccl_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, res, err in results:
+        assert res is not None, f"rank {rank} failed: {err}"
+        for fmt, exchange, same, e in res:
+            if exchange == "partial_sums":
+                assert e < 1e-3, (rank, fmt, exchange, e)
+            else:
+                assert same, (rank, fmt, exchange, e)

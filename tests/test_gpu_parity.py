@@ -689,6 +689,226 @@ def test_engine_generation_consumes_fgram_embeddings(mode):
     assert stats["tokens_per_second"] > 0
 
 
+def test_staging_buffer_overflow_is_flagged_and_never_reads_out_of_bounds(monkeypatch):
+    """k_stage_claim's `slot >= capacity` path.  The staging buffer is sized for the worst case of a chunk, so the path is
+    unreachable from scone_embed; the test hook SCONE_STAGE_CAP_ROWS shrinks the buffer to 8 rows while a chunk references
+    hundreds of distinct cold rows.  Every reference that found no slot must have been redirected INSIDE the buffer (a
+    PENDING tag left in the slot map would send the lookup 16M rows past it) and the call must be flagged: status bit 3;
+    tokens whose rows all got slots are still exact."""
+    from scone_amd import EmbeddingCache
+    from scone_amd import _lib as L
+    rng = np.random.default_rng(91)
+    vocab, n, d, max_n = 41, 2500, 768, 3
+    lens = rng.integers(1, 4, size=n).astype(np.uint8)
+    keys = rng.integers(0, vocab, size=(n, 3)).astype(np.uint32)
+    keys[np.arange(3)[None, :] >= lens[:, None]] = 0
+    ex = _extractor(keys, lens, max_n)
+    keys, lens = ex.key_arrays()
+    n = len(lens)
+    table = rng.standard_normal((n, d)).astype(np.float32)
+    tok = torch.from_numpy(rng.integers(0, vocab, size=(6, 64)))
+    ref = EmbeddingCache(ex, d, table_format="int8")
+    ref.cache_embeddings(list(range(n)), torch.from_numpy(table), verbose=False)
+    want = ref.embed_tokens(tok, out_dtype=torch.float32)
+    monkeypatch.setenv("SCONE_STAGE_CAP_ROWS", "8")
+    tiny = EmbeddingCache(ex, d, table_format="int8", placement="pinned_host", hot_rows=16, stage_tokens=128)
+    tiny.cache_embeddings(list(range(n)), torch.from_numpy(table), verbose=False)
+    got = tiny.embed_tokens(tok, out_dtype=torch.float32)
+    torch.cuda.synchronize()
+    assert tiny.table.status() & L.ST_STAGE_OVERFLOW
+    assert bool(torch.isfinite(got).all())
+    # second call: the flag is sticky per call, not stuck
+    monkeypatch.delenv("SCONE_STAGE_CAP_ROWS")
+    ok = EmbeddingCache(ex, d, table_format="int8", placement="pinned_host", hot_rows=16, stage_tokens=128)
+    ok.cache_embeddings(list(range(n)), torch.from_numpy(table), verbose=False)
+    assert torch.equal(ok.embed_tokens(tok, out_dtype=torch.float32), want) and not ok.table.status() & L.ST_STAGE_OVERFLOW
+
+
+def _oracle_inputs_embeds(mode, keys, lens, max_n, table, ids, wte, wpe):
+    """``inputs_embeds [B, T, H]`` fp32 as the reference computes them, from the oracle alone (no scone_amd lookup):
+    cover: match (n_gram_extractor.py:106-126) -> mean of the rows (engine.py:247-259) -> wte + fg + wpe
+    (language_model.py:239-254); longest_suffix: the paper's Algorithm 2."""
+    tok = ids.cpu().numpy()
+    B, T = tok.shape
+    if mode == "cover":
+        ro, ri = R.hits_to_csr(R.match_hits(keys, lens, tok, max_n))
+        fg = torch.from_numpy(R.embed_numpy(table, ro, ri, "mean").reshape(B, T, -1))
+        return R.combine(ids.cpu(), fg, wte, wpe)
+    return torch.from_numpy(R.paper_embed(R._key_dict(keys, lens), max_n, tok, table, wte.numpy(), wpe.numpy()))
+
+
+@pytest.mark.parametrize("mode", ["cover", "longest_suffix"])
+def test_engine_greedy_decoding_equals_hf_gpt2_driven_by_the_oracle(mode):
+    """SURVEY 8f rank 3, anchored to the oracle: every greedy token SconeInferenceEngine.generate_ids emits (KV-cache
+    decoding, roll-back in cover mode) equals the token of an HF GPT-2 that is handed, at every step and for the whole
+    prefix, ``inputs_embeds`` built by the ORACLE (R.combine(R.embed_numpy(...)) / R.paper_embed) -- the engine's lookup is
+    not on that side of the comparison.  Step-0 logits agree within 1e-3."""
+    from transformers import GPT2Config, GPT2LMHeadModel
+    from scone_amd import EmbeddingCache, SconeLanguageModel
+    from scone_amd.inference import SconeInferenceEngine
+    torch.manual_seed(1)
+    rng = np.random.default_rng(4)
+    vocab, H, n, max_n = 61, 768, 500, 3
+    lens = rng.integers(1, 4, size=n).astype(np.uint8)
+    keys = rng.integers(0, vocab, size=(n, 3)).astype(np.uint32)
+    keys[np.arange(3)[None, :] >= lens[:, None]] = 0
+    ex = _extractor(keys, lens, max_n)
+    keys, lens = ex.key_arrays()                                     # de-duplicated: smallest id wins
+    table = (rng.standard_normal((len(lens), H)) * 0.5).astype(np.float32)
+    cache = EmbeddingCache(ex, H, table_format="fp32", lookup_mode=mode)
+    cache.cache_embeddings(list(range(len(lens))), torch.from_numpy(table), verbose=False)
+    base = GPT2LMHeadModel(GPT2Config(vocab_size=vocab, n_positions=64, n_embd=H, n_layer=2, n_head=4)).eval()
+    model = SconeLanguageModel(base, None, cache).cuda().eval()
+    engine = SconeInferenceEngine(model, embedding_cache=cache)
+    wte, wpe = base.transformer.wte.weight.detach().float().cpu(), base.transformer.wpe.weight.detach().float().cpu()
+    prompt = torch.from_numpy(rng.integers(0, vocab, size=(2, 7)))
+    L = 20
+    got = engine.generate_ids(prompt, max_length=L, do_sample=False).cpu()
+    ids = prompt.clone()
+    with torch.no_grad():
+        first = True
+        while ids.shape[1] < L:
+            x = _oracle_inputs_embeds(mode, keys, lens, max_n, table, ids, wte, wpe).cuda()
+            h = base.transformer(inputs_embeds=x, return_dict=True).last_hidden_state[:, -1, :]
+            logits = base.lm_head(h).float()
+            if first:                                               # the engine's own first step, same prefix
+                mine = base.lm_head(base.transformer(inputs_embeds=engine.embed(ids.cuda()), return_dict=True)
+                                    .last_hidden_state[:, -1, :]).float()
+                assert float((mine - logits).abs().max()) <= 1e-3 * float(logits.abs().max())
+                first = False
+            ids = torch.cat([ids, logits.argmax(-1, keepdim=True).cpu()], dim=1)
+    assert torch.equal(got, ids)
+
+
+def test_engine_from_pretrained_reads_a_reference_checkpoint_layout(tmp_path):
+    """SconeInferenceEngine.from_pretrained (engine.py:129-190): config.json + weights under the reference's module names
+    (base_model.* = GPT2LMHeadModel, f_gram_projection.weight, f_gram_model.* ignored), n_gram_extractor.npy, the
+    reference-format embedding_cache.npy with rows of the f-gram model's size.  The projection is folded into the table;
+    the engine's inputs_embeds equal wte + proj(mean(rows)) + wpe computed from the oracle."""
+    import json
+    import sys
+    from safetensors.torch import save_file
+    from transformers import GPT2Config, GPT2LMHeadModel
+    from scone_amd import EmbeddingCache
+    from scone_amd.inference import SconeInferenceEngine
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from stub_tokenizer import StubTokenizer
+    torch.manual_seed(2)
+    rng = np.random.default_rng(6)
+    vocab, H, df, n, max_n = 61, 768, 384, 300, 3
+    lens = rng.integers(1, 4, size=n).astype(np.uint8)
+    keys = rng.integers(2, vocab, size=(n, 3)).astype(np.uint32)
+    keys[np.arange(3)[None, :] >= lens[:, None]] = 0
+    ex = _extractor(keys, lens, max_n)
+    keys, lens = ex.key_arrays()
+    d = str(tmp_path / "ckpt")
+    os.makedirs(d)
+    json.dump({"model_type": "scone", "vocab_size": vocab, "hidden_size": H, "num_hidden_layers": 2, "num_attention_heads": 4,
+               "max_position_embeddings": 64, "hidden_dropout_prob": 0.1, "attention_probs_dropout_prob": 0.1,
+               "layer_norm_eps": 1e-5, "use_f_gram_embeddings": True}, open(os.path.join(d, "config.json"), "w"))
+    base = GPT2LMHeadModel(GPT2Config(vocab_size=vocab, n_positions=64, n_embd=H, n_layer=2, n_head=4, layer_norm_epsilon=1e-5)).eval()
+    W = (torch.randn(H, df) * 0.05)
+    state = {"base_model." + k: v.clone().contiguous() for k, v in base.state_dict().items() if k != "lm_head.weight"}   # tied: saved once
+    state["f_gram_projection.weight"] = W
+    state["f_gram_model.embeddings.word_embeddings.weight"] = torch.zeros(4, 4)     # the f-gram BERT: not needed to serve a cache
+    save_file(state, os.path.join(d, "model.safetensors"))
+    ex.save(os.path.join(d, "n_gram_extractor"))
+    table = (rng.standard_normal((len(lens), df)) * 0.5).astype(np.float32)
+    host = EmbeddingCache(ex, df)
+    host.cache_embeddings(list(range(len(lens))), torch.from_numpy(table), verbose=False)
+    host.save(os.path.join(d, "embedding_cache"))
+    engine = SconeInferenceEngine.from_pretrained(d, tokenizer=StubTokenizer(vocab), use_memory_map=False)
+    assert engine.embedding_cache.embedding_dim == H and engine.max_n == max_n
+    ids = torch.from_numpy(rng.integers(2, vocab, size=(2, 11)))
+    ro, ri = R.hits_to_csr(R.match_hits(keys, lens, ids.numpy(), max_n))
+    fg = torch.from_numpy(R.embed_numpy(table, ro, ri, "mean").reshape(2, 11, df))
+    wte, wpe = base.transformer.wte.weight.detach().float(), base.transformer.wpe.weight.detach().float()
+    ref = R.combine(ids, torch.nn.functional.linear(fg, W), wte, wpe)               # language_model.py:235-254 as written
+    got = engine.embed(ids.cuda()).float().cpu()
+    assert float((got - ref).abs().max()) <= 1e-5 * float(ref.abs().max()) + 1e-6   # proj(mean) vs mean(proj): fp32 rounding
+    out = engine.generate("alpha beta gamma delta", max_length=9, do_sample=False)
+    assert len(out) == 1 and isinstance(out[0], list if engine.tokenizer is None else (str, list))
+
+
+def test_reference_written_files_give_reference_lookups_on_the_gpu(golden_dir):
+    """the extractor and cache files the REFERENCE wrote (tests/golden/tiny_extractor.npy, tiny_cache.npy,
+    n_gram_extractor.py:128-165, embedding_cache.py:183-243) loaded through this package's load() and looked up on the
+    GPU give the reference's own outputs for that table (lookup.npz case c4, captured from the reference)."""
+    from scone_amd import EmbeddingCache, NGramExtractor
+    z = np.load(os.path.join(golden_dir, "lookup.npz"))
+    ex = NGramExtractor.load(os.path.join(golden_dir, "tiny_extractor.npy"))
+    cache = EmbeddingCache.load(os.path.join(golden_dir, "tiny_cache.npy"), ex, use_memory_map=False)
+    c = "c4"
+    tok = torch.from_numpy(z[f"{c}_tok"])[None, :]
+    off, ids = cache.match(tok)
+    assert np.array_equal(off.cpu().numpy(), z[f"{c}_off"]) and np.array_equal(ids.cpu().numpy(), z[f"{c}_ids"])
+    assert np.array_equal(cache.get_embeddings(z[f"{c}_gather_ids"].tolist()).numpy(), z[f"{c}_gather_out"])
+    te = cache.get_token_embeddings(z[f"{c}_tok"].tolist())
+    assert sorted(te.keys()) == z[f"{c}_te_positions"].tolist()
+    p = 0
+    for pos, rows in zip(z[f"{c}_te_positions"], z[f"{c}_te_rows"]):
+        assert np.array_equal(te[int(pos)].numpy(), z[f"{c}_te_stacks"][p:p + rows])
+        p += rows
+    assert np.array_equal(cache.embed_tokens(tok, out_dtype=torch.float32).cpu().numpy(), z[f"{c}_agg_f32"])
+    assert np.array_equal(cache.embed_tokens(tok, out_dtype=torch.float16).cpu().numpy().view(np.uint16),
+                          z[f"{c}_agg_f16"].view(np.uint16))
+    tfg = ex.get_token_f_grams(z[f"{c}_tok"].tolist())               # the tuples, matched on the GPU
+    f2id = ex.f_gram_to_id
+    flat = [f2id[g] for pos in range(tok.shape[1]) for g in tfg[pos]]
+    assert flat == z[f"{c}_ids"].tolist()
+
+
+@pytest.mark.parametrize("fmt", ["int8", "int4", "fp16"])
+@pytest.mark.parametrize("with_index", [False, True])
+def test_native_table_file_round_trip_against_the_oracle(tmp_path, fmt, with_index):
+    """save_native -> load_native, checked against the ORACLE on the dequantised table (not against the handle that
+    wrote the file): whole table and a shard (rows [row_begin, row_end) only in the file), with and without the persisted
+    index (slots + unigram table + presence bitmap copied back instead of rebuilt)."""
+    from scone_amd import EmbeddingCache
+    from scone_amd.hip_backend import SconeTable
+    rng = np.random.default_rng(78)
+    vocab, n, d, max_n = 29, 900, 1024, 3
+    lens = rng.integers(1, 4, size=n).astype(np.uint8)
+    keys = rng.integers(0, vocab, size=(n, 3)).astype(np.uint32)
+    keys[np.arange(3)[None, :] >= lens[:, None]] = 0
+    ex = _extractor(keys, lens, max_n)
+    keys, lens = ex.key_arrays()
+    n = len(lens)
+    table = rng.standard_normal((n, d)).astype(np.float32)
+    deq = {"int8": lambda t: R.dequantize_i8(*R.quantize_i8(t)), "int4": lambda t: R.dequantize_i4(*R.quantize_i4(t)),
+           "fp16": lambda t: t.astype(np.float16).astype(np.float32)}[fmt](table)
+    tok = rng.integers(0, vocab, size=(3, 40))
+    ro, ri = R.hits_to_csr(R.match_hits(keys, lens, tok, max_n))
+    want = R.embed_numpy(deq, ro, ri, "mean").reshape(3, 40, d)
+    cache = EmbeddingCache(ex, d, table_format=fmt)
+    cache.cache_embeddings(list(range(n)), torch.from_numpy(table), verbose=False)
+    p = str(tmp_path / "table")
+    cache.save_native(p, with_index=with_index)
+    again = EmbeddingCache.load_native(p)
+    assert np.array_equal(again.embed_tokens(torch.from_numpy(tok), out_dtype=torch.float32).cpu().numpy(), want)
+    assert again.table.index_stats()[0] == n
+    # a shard: only its own rows are in the file
+    a, b = n // 3, 2 * n // 3
+    shard = EmbeddingCache(ex, d, table_format=fmt)
+    shard._table = SconeTable(max_n, n, dim=d, table_format=fmt, row_begin=a, row_end=b)
+    ex.build_index(shard._table)
+    shard._table.store_f32(torch.from_numpy(table[a:b]), row0=a)
+    shard._dirty, shard.keep_host_copy = False, False
+    ps = str(tmp_path / "shard")
+    shard.save_native(ps, with_index=with_index)
+    zf = np.load(ps + ".npz")
+    assert zf["rows"].shape[0] == b - a and zf["scales"].shape[0] == b - a
+    sh2 = EmbeddingCache.load_native(ps)
+    assert (sh2.table.row_begin, sh2.table.row_end) == (a, b)
+    partial, counts = sh2.table.embed_partial(torch.from_numpy(tok))
+    own = (ri >= a) & (ri < b)
+    seg = np.repeat(np.arange(len(ro) - 1), np.diff(ro))
+    off_own = np.zeros(len(ro), dtype=np.int64)
+    np.cumsum(np.bincount(seg[own], minlength=len(ro) - 1), out=off_own[1:])
+    assert np.array_equal(partial.cpu().numpy(), R.embed_numpy(deq, off_own, ri[own], "sum"))
+    assert np.array_equal(counts.cpu().numpy(), np.diff(ro))
+
+
 @pytest.mark.parametrize("fmt,d", [("int8", 768), ("int4", 1024), ("fp16", 1280)])
 def test_staged_prefetch_matches_hbm(fmt, d):
     """SCONE_PLACE_PINNED_HOST with stage_tokens > 0 (side-stream match + de-duplicated host->HBM staging,

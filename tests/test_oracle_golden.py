@@ -173,6 +173,71 @@ def test_c_oracle_bit_exact_vs_golden(golden_dir):
         assert np.array_equal(out, z[f"{c}_agg_f32"]), c
 
 
+def test_c_oracle_under_asan_ubsan_vs_golden(golden_dir, tmp_path):
+    """SURVEY section 5 "race detection / sanitizers" (CPU only): oracle/oracle.c built with
+    -fsanitize=address,undefined (oracle/Makefile target `asan`) runs every golden match / lookup case plus the edge
+    shapes (T = 0, T < max_n, all-miss, ids beyond 32 bits) through index build, match and the OpenMP batch mean; the
+    sanitizers abort on any finding, leaks included, and the outputs still equal the reference's."""
+    import struct
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run(["make", "-C", os.path.join(root, "oracle"), "asan"], check=True, capture_output=True)
+    cases, expect = [], []
+    zm, zl = _load(golden_dir, "match.npz"), _load(golden_dir, "lookup.npz")
+    rng = np.random.default_rng(0)
+    for c in zm["cases"]:
+        keys, lens, max_n = zm[f"{c}_keys"], zm[f"{c}_lens"], int(zm[f"{c}_max_n"])
+        for si in range(int(zm["n_streams"])):
+            tok = zm[f"{c}_s{si}_tok"].astype(np.int64).reshape(1, -1)
+            table = rng.standard_normal((len(lens), 4)).astype(np.float32)
+            cases.append((keys, lens, max_n, table, tok))
+            expect.append((zm[f"{c}_s{si}_off"], zm[f"{c}_s{si}_ids"], None))
+    for c in zl["cases"]:
+        tok = zl[f"{c}_tok"].astype(np.int64).reshape(1, -1)
+        cases.append((zl[f"{c}_keys"], zl[f"{c}_lens"], int(zl[f"{c}_max_n"]), zl[f"{c}_table"], tok))
+        expect.append((zl[f"{c}_off"], zl[f"{c}_ids"], zl[f"{c}_agg_f32"]))
+    k = np.array([[5, 0, 0], [5, 6, 0], [5, 6, 7]], dtype=np.uint32)
+    l = np.array([1, 2, 3], dtype=np.uint8)
+    t4 = np.eye(3, 4, dtype=np.float32)
+    for tok in (np.zeros((2, 0), np.int64), np.array([[5, 6]]), np.array([[9, 9, 9, 9]]), np.array([[5, 2**33, -1, 5]])):
+        cases.append((k, l, 3, t4, tok.astype(np.int64)))
+        expect.append(None)
+    src, dst = str(tmp_path / "cases.bin"), str(tmp_path / "out.bin")
+    with open(src, "wb") as f:
+        f.write(struct.pack("<q", len(cases)))
+        for keys, lens, max_n, table, tok in cases:
+            f.write(struct.pack("<5q", len(lens), max_n, table.shape[1], tok.shape[0], tok.shape[1]))
+            f.write(np.ascontiguousarray(keys, dtype=np.uint32).tobytes())
+            f.write(np.ascontiguousarray(lens, dtype=np.uint8).tobytes())
+            f.write(np.ascontiguousarray(table, dtype=np.float32).tobytes())
+            f.write(np.ascontiguousarray(tok, dtype=np.int64).tobytes())
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0:exitcode=23", UBSAN_OPTIONS="halt_on_error=1:exitcode=24")
+    p = subprocess.run([os.path.join(root, "oracle", "_build", "oracle_asan"), src, dst], env=env, capture_output=True, text=True,
+                       timeout=300)
+    assert p.returncode == 0, p.stderr[-3000:]
+    buf = open(dst, "rb").read()
+    pos = 0
+    for (keys, lens, max_n, table, tok), exp in zip(cases, expect):
+        B, T, d = tok.shape[0], tok.shape[1], table.shape[1]
+        total = struct.unpack_from("<q", buf, pos)[0]
+        pos += 8
+        off = np.frombuffer(buf, dtype=np.int64, count=B * (T + 1), offset=pos)
+        pos += 8 * B * (T + 1)
+        ids = np.frombuffer(buf, dtype=np.int64, count=total, offset=pos)
+        pos += 8 * total
+        mean = np.frombuffer(buf, dtype=np.float32, count=B * T * d, offset=pos).reshape(B, T, d)
+        pos += 4 * B * T * d
+        if exp is None:
+            ro, ri = R.hits_to_csr(R.match_hits(keys, lens, np.where((tok < 0) | (tok >= 2**32 - 1), 2**31 - 1, tok), max_n)) \
+                if T else (np.zeros(1, np.int64), np.zeros(0, np.int64))
+            assert total == len(ri)
+            continue
+        assert np.array_equal(off, exp[0]) and np.array_equal(ids, exp[1])
+        if exp[2] is not None:
+            assert np.array_equal(mean, exp[2])
+    assert pos == len(buf)
+
+
 def test_callers_fixture_is_reproduced_by_the_oracle(golden_dir):
     """callers.npz (FGramTokenizer.tokenize / batch_tokenize and SconeDataset's id vector, captured from the
     reference with tests/stub_tokenizer.py): the stub still produces the recorded token ids and the oracle's

@@ -616,7 +616,8 @@ def main():
         step_kernel_ms = kern_ms / args.steps if n_launch else dt / args.steps * 1e3
         achieved = bytes_per_launch / (step_kernel_ms * 1e-3) / 1e9
         sig = (f"{args.format}-d{d}-N{N}-B{B}-T{T}-{args.stream}-{args.placement}" + ("-sharded" if sharded else "") + (f"-shard{args.shard_of}" if emu else "")
-               + (f"-hot{args.hot_rows}-stage{args.stage_tokens}" if args.placement != "hbm" else ""))
+               + (f"-hot{args.hot_rows}-stage{args.stage_tokens}" if args.placement != "hbm" else "")
+               + ("-structured" if args.keygen == "structured" else ""))
         tr, stale = read_traffic(sig)
         traffic = None if (tr is None or stale) else tr.get("hbm_bytes_per_launch")
         in_hbm = args.placement == "hbm"

@@ -131,19 +131,23 @@ template <int FMT, int D> struct wave_geom {
 #ifndef SCONE_WAVE_BLOCKS
 #define SCONE_WAVE_BLOCKS 4096  // ~256 CUs x 8 resident workgroups x 2 rounds
 #endif
-// per-format switches (A/B builds override them with -D): which formats have a HIGH-OCCUPANCY
-// variant of k_embed_wave (the wave's position row in LDS instead of 8 VGPRs -> one or two more waves per SIMD) that
-// launch_wave selects for tables of SCONE_HIOCC_MIN_BYTES and more.  Measured (tools/ab_multi.sh, one box, INT4 d = 1024,
-// 5 vs 7 waves / SIMD, gather kernel): 100M rows 0.906 -> 0.861 ms, 10M rows 0.890 -> 0.852 ms, 1M rows (512 MB: most row
-// reads are L2 / Infinity-Cache hits, more waves only evict each other's lines) 0.892 -> 0.917 ms.
+// The HIGH-OCCUPANCY variant of k_embed_wave: the wave's position row lives in LDS instead of 6-10 VGPRs, which buys one
+// to three more waves per SIMD (INT8 d = 768: 7 -> 8, fp16 d = 768: 6 -> 7, INT4 d = 1024: 5 -> 8).  More waves = more
+// row requests in flight per CU, which is what a latency-bound gather converts into bandwidth.  launch_wave takes it
+// whenever the position ids are the default arange(T) (with caller-supplied positions the row is per token: nothing to
+// keep).  Measured against the round-1 kernel, alternating runs on one box (tools/ab_r1.sh, gather kernel, 1M tokens):
+//   INT4 100M x 1024 0.794 -> 0.742 ms   INT4 1M x 1024 0.814 -> 0.771 ms   fp16 1M x 768 0.792 -> 0.735 ms
+//   INT8 1M x 768 Zipf stream 0.572 -> 0.542 ms   INT8 1M x 768 S_uniform 0.726 -> 0.705 ms   INT8 10M x 1024 0.906 -> 0.908 ms
+// Switches for A/B builds: SCONE_HIOCC_MASK (bit FMT), SCONE_HIOCC_SLACK_CUT (registers taken off the occupancy
+// estimate of the variant), SCONE_HIOCC_MIN_BYTES (row-store size from which it is used; also an environment variable).
 #ifndef SCONE_HIOCC_MASK
-#define SCONE_HIOCC_MASK (1 << SCONE_FMT_I4)
+#define SCONE_HIOCC_MASK 15
 #endif
 #ifndef SCONE_HIOCC_SLACK_CUT
-#define SCONE_HIOCC_SLACK_CUT 0
+#define SCONE_HIOCC_SLACK_CUT 8
 #endif
 #ifndef SCONE_HIOCC_MIN_BYTES
-#define SCONE_HIOCC_MIN_BYTES (2ll << 30)
+#define SCONE_HIOCC_MIN_BYTES 0
 #endif
 template <int FMT> struct wave_hiocc {
   static constexpr bool available = ((SCONE_HIOCC_MASK >> FMT) & 1) != 0;
@@ -155,7 +159,8 @@ template <int FMT, typename OutT, int D, int MAXN, bool FIXED_POS, bool HIOCC = 
   // INT4 also holds one group-scale word per (row, segment) in flight
   static constexpr int EST = KL * (wave_geom<FMT, D>::NBR / 4) + (FMT == SCONE_FMT_I4 ? KL * (D == 1024 ? 1 : wave_geom<FMT, D>::NSEG) : 0) +
                              (FIXED_POS && !HIOCC ? 4 : 3) * NWO +
-                             wave_geom<FMT, D>::EPL + SCONE_WAVE_SLACK - (HIOCC ? SCONE_HIOCC_SLACK_CUT : 0) +
+                             wave_geom<FMT, D>::EPL + SCONE_WAVE_SLACK - (HIOCC && MAXN <= 3 && sizeof(OutT) == 2 ? SCONE_HIOCC_SLACK_CUT : 0) +
+                             (HIOCC && sizeof(OutT) == 4 ? 8 : 0) +  // fp32 output: the LDS read-back of the position row is twice as wide
                              (FMT == SCONE_FMT_I4 && !HIOCC ? 8 : 0) +  // INT4 at 6 waves spills 44 B/lane on the K >= 4 paths
                              (MAXN >= 4 ? (FMT == SCONE_FMT_I4 ? 24 : 8) : 0) +  // the 10-way switch keeps more addresses live
                              (std::is_same<OutT, __hip_bfloat16>::value ? 4 : 0);  // round-to-nearest-even by hand

@@ -48,8 +48,11 @@ def main(tag):
     kern = "k_embed_wave" if "k_embed_wave" in out else "k_embed"
     if kern in out and "FETCH_SIZE" in out[kern] and "WRITE_SIZE" in out[kern]:
         fetch_kb, write_kb = out[kern]["FETCH_SIZE"], out[kern]["WRITE_SIZE"]
+        sys.path.insert(0, ROOT)
+        from bench import kernel_source_sha
         entry = {
             "workload_sig": bench.get("workload_sig"),
+            "kernel_source_sha": kernel_source_sha(),      # bench.py quotes the entry only for the code it was measured on
             "hbm_bytes_per_launch": int((2 * fetch_kb + write_kb) * 1024),
             "fetch_size_kb_raw": fetch_kb, "write_size_kb": write_kb,
             "source": f"profiles/{tag}/pmc_summary.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), "

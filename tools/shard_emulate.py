@@ -45,6 +45,7 @@ def main():
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--check", action="store_true")
     ap.add_argument("--head", type=int, default=0, help="replicated head: global rows [0, head) kept on every shard")
+    ap.add_argument("--chunks", type=int, default=1, help="gather_rows: chunks of the pipelined exchange (1 = one shot)")
     ap.add_argument("--mode", default="rows", choices=["rows", "gather_rows"],
                     help="rows: all-to-all of records, every rank reduces its slice; gather_rows: all-gather of records, "
                          "every rank reduces the whole batch")
@@ -71,6 +72,9 @@ def main():
            "replicated_head_rows": a.head, "ranks": []}
     out = torch.empty(B * T, d, dtype=torch.float16, device="cuda")
     best = None
+    if a.mode == "gather_rows" and a.chunks > 1:
+        gather_rows_chunked(a, shards, tok, wte, wpe, out, res, keys, lens)
+        return
     if a.mode == "gather_rows":
         gather_rows_mode(a, shards, tok, wte, wpe, out, res, keys, lens)
         return
@@ -167,6 +171,68 @@ def gather_rows_mode(a, shards, tok, wte, wpe, out, res, keys, lens):
         full.index_build(keys, lens)
         full.fill_synthetic(7, 0.02 / 127)
         want = full.embed(tok, wte=wte, wpe=wpe).reshape(B * T, d)
+        res["bit_identical_to_unsharded"] = bool(torch.equal(out, want))
+    print(json.dumps(res))
+
+
+def gather_rows_chunked(a, shards, tok, wte, wpe, out, res, keys, lens):
+    """The pipelined all-gather form (ShardedEmbeddingCache._embed_gather_rows) with the C all-gathers done by hand: per rank,
+    plan (one match + C claim passes), the C packs, and per chunk add_records + embed_range.  What a rank cannot hide behind
+    its transfers: plan + first pack + 1/C of the collective + every chunk's reduction."""
+    N, W, d, B, T, C = a.rows, a.world, a.dim, a.batch, a.seq, a.chunks
+    rec = res["record_bytes"]
+    per = (B + C - 1) // C
+    best = None
+    for rep in range(a.reps):
+        ends, t_plan = [], []
+        for s in shards:
+            e, ms = timed(lambda: s.shard_gather_plan_chunks(tok, C))
+            ends.append(e)
+            t_plan.append(ms)
+        mine = [[e[0]] + [e[c] - e[c - 1] for c in range(1, C)] for e in ends]
+        maxc = [max(mine[r][c] for r in range(W)) for c in range(C)]
+        base = [0]
+        for c in range(C):
+            base.append(base[-1] + W * maxc[c])
+        full = torch.empty((max(base[-1], 1), rec), dtype=torch.uint8, device="cuda")
+        t_pack = [0.0] * W
+        for r, s in enumerate(shards):
+            first = 0
+            for c in range(C):
+                if maxc[c]:
+                    region = full[base[c] + r * maxc[c]:base[c] + (r + 1) * maxc[c]]      # = what the all-gather would deliver
+                    _, ms = timed(lambda: s.shard_gather_pack_range(first, mine[r][c], region))
+                    t_pack[r] += ms
+                first += mine[r][c]
+        records = full[:base[-1]]
+        t_embed = [0.0] * W
+        for q, s in enumerate(shards):
+            for c in range(C):
+                s0, s1 = min(c * per, B), min(c * per + per, B)
+
+                def step():
+                    if c == 0 or base[c + 1] > base[c]:
+                        s.shard_gather_add_records(records, base[c], base[c + 1] - base[c])
+                    if s1 > s0:
+                        s.shard_gather_embed_range(tok, s0, s1, records, out, wte=wte, wpe=wpe)
+                _, ms = timed(step)
+                t_embed[q] += ms
+        cur = [t_plan, t_pack, t_embed]
+        best = cur if best is None else [[min(x, y) for x, y in zip(b, c_)] for b, c_ in zip(best, cur)]
+        counts = [e[-1] for e in ends]
+        chunk_bytes = [W * m * rec for m in maxc]
+    for r in range(W):
+        res["ranks"].append({"rank": r, "plan_ms": best[0][r], "pack_ms_all_chunks": best[1][r], "embed_ms_all_chunks": best[2][r],
+                             "records_contributed": counts[r]})
+    loc = [x["plan_ms"] + x["pack_ms_all_chunks"] + x["embed_ms_all_chunks"] for x in res["ranks"]]
+    res["mode"], res["chunks"] = "gather_rows", C
+    res["local_ms_max"], res["local_ms_mean"] = max(loc), sum(loc) / len(loc)
+    res["all_gather_padded_bytes_per_chunk"] = chunk_bytes
+    if a.check:
+        full_t = SconeTable(3, N, d, a.format)
+        full_t.index_build(keys, lens)
+        full_t.fill_synthetic(7, 0.02 / 127)
+        want = full_t.embed(tok, wte=wte, wpe=wpe).reshape(B * T, d)
         res["bit_identical_to_unsharded"] = bool(torch.equal(out, want))
     print(json.dumps(res))
 

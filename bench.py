@@ -424,7 +424,10 @@ def sharded_record(args, dist, rank, world, backend, sync):
     that leave the whole [B, T, d] output on every rank:
       rows+all_gather   all-to-all of the quantised rows each slice needs, rank r reduces slice r, all-gather of the
                         finished fp16 vectors (the north-star's wording)
-      gather_rows       all-gather of the DISTINCT quantised rows the batch references, every rank reduces the whole batch
+      gather_rows       all-gather of the DISTINCT quantised rows the batch references, every rank reduces the whole batch;
+                        pipelined over `gather_chunks` chunks of sequences (gather_rows_one_shot: the same in one piece)
+    and, for contrast, rows_slices_only: the all-to-all alone, every rank keeps its own slice (a consumer that is
+    data-parallel over the same slices needs no more).
     Un-synchronised steps give ms/step; one instrumented step per exchange (device synchronised between phases) gives the
     phase split."""
     import torch
@@ -462,9 +465,13 @@ def sharded_record(args, dist, rank, world, backend, sync):
            "rccl_version": ".".join(str(x) for x in torch.cuda.nccl.version()) if backend == "nccl" else None,
            "build_s": t_build, "note": note, "exchanges": {}}
     checks = {}
+    chunks = cache.gather_chunks
     for name, kw in (("rows+all_gather", {"exchange": "rows", "gather_output": True}),
-                     ("gather_rows", {"exchange": "gather_rows", "gather_output": True})):
+                     ("gather_rows", {"exchange": "gather_rows", "gather_output": True}),
+                     ("gather_rows_one_shot", {"exchange": "gather_rows", "gather_output": True}),
+                     ("rows_slices_only", {"exchange": "rows", "gather_output": False})):
         try:
+            cache.gather_chunks = 1 if name == "gather_rows_one_shot" else chunks
             out = cache.embed_tokens(tok, wte=wte, wpe=wpe, **kw)                  # warm-up (allocations, RCCL channels)
             out = cache.embed_tokens(tok, wte=wte, wpe=wpe, **kw)
             sync()
@@ -480,7 +487,8 @@ def sharded_record(args, dist, rank, world, backend, sync):
             ph = torch.tensor([phases[k] for k in sorted(phases)], dtype=torch.float64,
                               device="cuda" if backend == "nccl" else "cpu")
             dist.all_reduce(ph, op=dist.ReduceOp.MAX)                                 # slowest rank per phase
-            checks[name] = float(out.float().abs().sum().item())
+            if kw["gather_output"]:
+                checks[name] = float(out.float().abs().sum().item())
             rec["exchanges"][name] = {
                 "ms_per_step": dt / args.sharded_steps * 1e3, "tokens_per_s": ntok * args.sharded_steps / dt,
                 "steps": args.sharded_steps,
@@ -489,9 +497,9 @@ def sharded_record(args, dist, rank, world, backend, sync):
             }
         except Exception as e:                                                        # the record never takes the line down
             rec["exchanges"][name] = {"error": repr(e)}
-    if len(checks) == 2:
-        a, b = checks["rows+all_gather"], checks["gather_rows"]
-        rec["exchanges_agree"] = bool(a == b)          # both are bit-identical to the unsharded table, hence to each other
+    if len(checks) == 3:                                # all bit-identical to the unsharded table, hence to each other
+        rec["exchanges_agree"] = bool(len(set(checks.values())) == 1)
+    rec["gather_chunks"] = chunks
     rec["n1_baseline"] = ("the N = 1 line's `sharded.n1_pinned_host` (one GPU cannot hold this table: rows in pinned host DRAM, "
                           "PCIe-bound, ~0.24 G tokens/s on MI355X); '>= 4x at 8 GPUs' is tokens_per_s here / that value")
     del cache, tok, wte, wpe

@@ -136,7 +136,7 @@ def _check_sharded_record(rec, world):
     wire bytes are there, and they produced the same output."""
     assert "error" not in rec, rec
     assert rec["world_size"] == world and rec["device_count"] >= 1 and "n1_baseline" in rec
-    for name in ("rows+all_gather", "gather_rows"):
+    for name in ("rows+all_gather", "gather_rows", "gather_rows_one_shot", "rows_slices_only"):
         e = rec["exchanges"][name]
         assert "error" not in e, e
         assert e["ms_per_step"] > 0 and e["tokens_per_s"] > 0 and e["wire_bytes_received_rank0"] > 0

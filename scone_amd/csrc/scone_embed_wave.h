@@ -23,8 +23,6 @@
 // the reference's list order, correctly rounded sum / K, (wte + mean) + wpe, one rounding to OutT.
 #pragma once
 
-#include <cstdlib>
-
 #include "scone_gather_impl.h"
 #include "scone_probe.h"
 
@@ -139,15 +137,12 @@ template <int FMT, int D> struct wave_geom {
 //   INT4 100M x 1024 0.794 -> 0.742 ms   INT4 1M x 1024 0.814 -> 0.771 ms   fp16 1M x 768 0.792 -> 0.735 ms
 //   INT8 1M x 768 Zipf stream 0.572 -> 0.542 ms   INT8 1M x 768 S_uniform 0.726 -> 0.705 ms   INT8 10M x 1024 0.906 -> 0.908 ms
 // Switches for A/B builds: SCONE_HIOCC_MASK (bit FMT), SCONE_HIOCC_SLACK_CUT (registers taken off the occupancy
-// estimate of the variant), SCONE_HIOCC_MIN_BYTES (row-store size from which it is used; also an environment variable).
+// estimate of the variant).
 #ifndef SCONE_HIOCC_MASK
 #define SCONE_HIOCC_MASK 15
 #endif
 #ifndef SCONE_HIOCC_SLACK_CUT
 #define SCONE_HIOCC_SLACK_CUT 8
-#endif
-#ifndef SCONE_HIOCC_MIN_BYTES
-#define SCONE_HIOCC_MIN_BYTES 0
 #endif
 template <int FMT> struct wave_hiocc {
   static constexpr bool available = ((SCONE_HIOCC_MASK >> FMT) & 1) != 0;
@@ -597,8 +592,13 @@ int try_launch_fused(scone_handle *h, const embed_args &a, hipStream_t s) {
   return -1;
 }
 
-template <int FMT, typename OutT, int D, int MAXN, bool HIOCC>
-int launch_wave_occ(scone_handle *h, const embed_args &a, hipStream_t s) {
+// Which instantiation a launch takes: shard partial sums -> <FIXED_POS, PARTIAL>; caller-supplied position ids -> the
+// position row is per token, nothing to keep; default positions -> the high-occupancy variant (position row in LDS)
+// where the format has one (wave_hiocc<>: all of them by default).
+template <int FMT, typename OutT, int D, int MAXN>
+int launch_wave(scone_handle *h, const embed_args &a, hipStream_t s) {
+  constexpr bool HI = wave_hiocc<FMT>::available;
+  const bool hi = HI && !a.partial && !a.pos;
   wave_params q;
   q.BT = a.BT, q.T = a.T, q.max_n = a.max_n;
   q.row_begin = a.tv.row_begin, q.row_end = a.tv.row_end;
@@ -611,7 +611,8 @@ int launch_wave_occ(scone_handle *h, const embed_args &a, hipStream_t s) {
 #ifdef SCONE_WAVE_BLOCKS_FIXED
   const long long target = SCONE_WAVE_BLOCKS_FIXED;
 #else
-  const long long target = 3ll * h->n_cus * wave_occupancy<FMT, OutT, D, MAXN, true, HIOCC>::WAVES;
+  const long long target = 3ll * h->n_cus * (hi ? wave_occupancy<FMT, OutT, D, MAXN, true, true>::WAVES
+                                                : wave_occupancy<FMT, OutT, D, MAXN, true, false>::WAVES);
 #endif
   long long chunks = (target + q.pos_groups / 2) / q.pos_groups;
   if (chunks < 1) chunks = 1;
@@ -622,7 +623,7 @@ int launch_wave_occ(scone_handle *h, const embed_args &a, hipStream_t s) {
   if (!scone_grid_fits((unsigned long long)blocks + 8, 256)) return scone_fail(h, SCONE_EINVAL, "scone_embed: too many tokens for one launch");
   q.n_blocks = (unsigned)blocks;
   blocks = (blocks + 7) / 8 * 8;
-  if constexpr (std::is_same<OutT, float>::value && !HIOCC) {
+  if constexpr (std::is_same<OutT, float>::value) {
     if (a.partial) {  // shard mode: fp32 partial sums + full hit counts
       hipLaunchKernelGGL((k_embed_wave<FMT, float, D, MAXN, true, true>), dim3((unsigned)blocks), dim3(256), 0, s,
                          a.tv.st, (const void *)a.tv.scales, a.ell, a.tok, (const int32_t *)nullptr,
@@ -637,27 +638,11 @@ int launch_wave_occ(scone_handle *h, const embed_args &a, hipStream_t s) {
                        (const void *)a.tv.scales, a.ell, a.tok, a.pos, (const OutT *)a.wte, (const OutT *)a.wpe,
                        (const uint8_t *)a.zero_row, (OutT *)a.out, (int32_t *)nullptr, a.status, q);
   else
-    hipLaunchKernelGGL((k_embed_wave<FMT, OutT, D, MAXN, true, false, HIOCC>), dim3((unsigned)blocks), dim3(256), 0, s, a.tv.st,
+    hipLaunchKernelGGL((k_embed_wave<FMT, OutT, D, MAXN, true, false, HI>), dim3((unsigned)blocks), dim3(256), 0, s, a.tv.st,
                        (const void *)a.tv.scales, a.ell, a.tok, a.pos, (const OutT *)a.wte, (const OutT *)a.wpe,
                        (const uint8_t *)a.zero_row, (OutT *)a.out, (int32_t *)nullptr, a.status, q);
   SCONE_HIP(h, hipGetLastError());
   return SCONE_OK;
-}
-
-// The high-occupancy variant (wave_hiocc<>) pays when row reads miss the caches, i.e. for tables much larger than the
-// 256 MB Infinity Cache: chosen per launch by the size of the row store the lookup reads (default positions only --
-// with caller-supplied position ids the position row is per token and there is nothing to move to LDS).
-template <int FMT, typename OutT, int D, int MAXN>
-int launch_wave(scone_handle *h, const embed_args &a, hipStream_t s) {
-  if constexpr (wave_hiocc<FMT>::available) {
-    const long long store_bytes = (a.tv.row_end - a.tv.row_begin) * (long long)a.tv.st.row_bytes;
-    static const long long min_bytes = [] {
-      const char *ev = getenv("SCONE_HIOCC_MIN_BYTES");  // tests run both variants; A/B runs
-      return ev && *ev ? atoll(ev) : (long long)SCONE_HIOCC_MIN_BYTES;
-    }();
-    if (!a.partial && !a.pos && store_bytes >= min_bytes) return launch_wave_occ<FMT, OutT, D, MAXN, true>(h, a, s);
-  }
-  return launch_wave_occ<FMT, OutT, D, MAXN, false>(h, a, s);
 }
 
 // ---------------------------------------------------------------------------------------------

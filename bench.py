@@ -417,6 +417,14 @@ def pinned_baseline(args, sync):
     return res
 
 
+def _rccl_version():
+    try:
+        import torch
+        return ".".join(str(x) for x in torch.cuda.nccl.version())
+    except Exception as e:
+        return f"unknown ({e!r})"
+
+
 def sharded_record(args, dist, rank, world, backend, sync):
     """N > 1: the row-sharded path on the C5-shaped workload -- INT4 d = 1024, `rows_per_rank` x N rows (1e9 at N = 8),
     replicated index built from keys generated on the GPU, every rank its own contiguous row range generated on its GPU,
@@ -462,7 +470,7 @@ def sharded_record(args, dist, rank, world, backend, sync):
                        f"replicated {cap}-slot index, replicated head {S.GPT2_VOCAB} rows, structured vocabulary, S_uniform, "
                        f"{B}x{T} tokens/step (the same batch on every rank), whole [B,T,d] fp16 output on every rank",
            "world_size": dist.get_world_size(), "device_count": torch.cuda.device_count(), "backend": backend,
-           "rccl_version": ".".join(str(x) for x in torch.cuda.nccl.version()) if backend == "nccl" else None,
+           "rccl_version": _rccl_version() if backend == "nccl" else None,
            "build_s": t_build, "note": note, "exchanges": {}}
     checks = {}
     chunks = cache.gather_chunks

@@ -283,19 +283,25 @@ int scone_shard_gather_embed(scone_handle *h, const int32_t *d_tok, int32_t B, i
                              const int32_t *d_pos, int32_t reduce, void *d_out, int32_t out_dtype, scone_stream_t stream);
 /* The same exchange cut into n_chunks (<= 64) runs of sequences (chunk c = sequences [c * ceil(B / n_chunks), ...)) so that
  * the all-gather of chunk c + 1 overlaps the reduction of chunk c:
- *   scone_shard_gather_plan_chunks   one match of the batch, one claim pass per chunk in chunk order; a row claimed by an
- *                                    earlier chunk is not claimed again.  h_chunk_end[c] = records claimed by chunks 0..c
- *                                    (this shard's records of chunk c are [h_chunk_end[c-1], h_chunk_end[c])); synchronises
+ *   scone_shard_gather_plan_chunks   one match of the batch, one claim pass per chunk in chunk order.
+ *                                    dedup_across_chunks = 1 (all-gather form): a row claimed by an earlier chunk is not
+ *                                    claimed again.  dedup_across_chunks = 0 with n_chunks = world (slice exchange: chunk q =
+ *                                    the sequences rank q finalises): every chunk lists each DISTINCT row of mine it
+ *                                    references -- what I send to rank q, one record per row however many of its tokens
+ *                                    reference it; the records go out with ONE all_to_all_single and the receiver uses
+ *                                    _add_records + _embed_range for its own slice.  h_chunk_end[c] = records claimed by
+ *                                    chunks 0..c (chunk c's are [h_chunk_end[c-1], h_chunk_end[c])); synchronises
  *   scone_shard_gather_pack_range    records [first, first + count) of the plan into d_send_buf, followed by `pad` padding
  *                                    records (row id 0xFFFFFFFF: an all-gather wants equal contributions; receivers skip them)
  *   scone_shard_gather_add_records   receiver: records [record0, record0 + n_records) of the gathered buffer
  *                                    (d_records_base = record 0; the buffer will hold n_total records in all, padding
  *                                    included) join the row map; record0 == 0 starts a new exchange
  *   scone_shard_gather_embed_range   sequences [seq_begin, seq_end) of the planned batch out of [replicated head | records
- *                                    added so far] into their place in d_out ([B, T, d]); every row they reference must
- *                                    have been added.  B, T must be the planned batch's. */
+ *                                    added so far]; every row they reference must have been added.  d_out's first row
+ *                                    is token out_tok0 of the flattened batch (0: d_out is the whole [B, T, d];
+ *                                    seq_begin * T: d_out holds just this run).  B, T must be the planned batch's. */
 int scone_shard_gather_plan_chunks(scone_handle *h, const int32_t *d_tok, int32_t B, int32_t T, int32_t n_chunks,
-                                   uint64_t *h_chunk_end, scone_stream_t stream);
+                                   int32_t dedup_across_chunks, uint64_t *h_chunk_end, scone_stream_t stream);
 int scone_shard_gather_pack_range(scone_handle *h, uint64_t first, uint64_t count, uint64_t pad, void *d_send_buf,
                                   scone_stream_t stream);
 int scone_shard_gather_add_records(scone_handle *h, const void *d_records_base, uint64_t record0, uint64_t n_records,
@@ -303,7 +309,7 @@ int scone_shard_gather_add_records(scone_handle *h, const void *d_records_base, 
 int scone_shard_gather_embed_range(scone_handle *h, const int32_t *d_tok, int32_t B, int32_t T, int32_t seq_begin,
                                    int32_t seq_end, const void *d_records_base, uint64_t n_total, const void *d_wte,
                                    int64_t vocab, const void *d_wpe, int64_t n_pos, const int32_t *d_pos, int32_t reduce,
-                                   void *d_out, int32_t out_dtype, scone_stream_t stream);
+                                   void *d_out, int64_t out_tok0, int32_t out_dtype, scone_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -272,13 +272,15 @@ extern "C" int scone_shard_gather_add_records(scone_handle *h, const void *d_rec
 extern "C" int scone_shard_gather_embed_range(scone_handle *h, const int32_t *d_tok, int32_t B, int32_t T, int32_t seq_begin,
                                               int32_t seq_end, const void *d_records_base, uint64_t n_total, const void *d_wte,
                                               int64_t vocab, const void *d_wpe, int64_t n_pos, const int32_t *d_pos,
-                                              int32_t reduce, void *d_out, int32_t out_dtype, scone_stream_t stream) {
+                                              int32_t reduce, void *d_out, int64_t out_tok0, int32_t out_dtype,
+                                              scone_stream_t stream) {
   int rc = need_table(h, "scone_shard_gather_embed: handle has no table (dim == 0)");
   if (rc) return rc;
   if (!h->shard) return scone_fail(h, SCONE_ESTATE, "scone_shard_gather_embed: call scone_shard_gather_plan first");
   int32_t pB = 0, pT = 0;
   scone_shard_plan_shape(h, &pB, &pT);
-  if (B < 0 || T <= 0 || B != pB || T != pT || seq_begin < 0 || seq_end < seq_begin || seq_end > B || (n_total && !d_records_base))
+  if (B < 0 || T <= 0 || B != pB || T != pT || seq_begin < 0 || seq_end < seq_begin || seq_end > B || (n_total && !d_records_base) ||
+      out_tok0 < 0 || out_tok0 > (long long)seq_begin * T)
     return scone_fail(h, SCONE_EINVAL, "scone_shard_gather_embed: bad argument (B, T must be the planned batch's)");
   if (!scone_wave_kernel_covers(h->cfg.table_fmt, h->cfg.dim))
     return scone_fail(h, SCONE_EINVAL, "scone_shard_gather_embed: needs d % 8 == 0");
@@ -308,7 +310,7 @@ extern "C" int scone_shard_gather_embed_range(scone_handle *h, const int32_t *d_
   a.ell = ell, a.zero_row = h->d_zero_row, a.mode = (int)h->cfg.lookup_mode;
   a.tok = d_tok + t0, a.pos = d_pos ? d_pos + t0 : nullptr;
   a.wte = d_wte, a.vocab = vocab, a.wpe = d_wpe, a.n_pos = n_pos;
-  a.reduce = reduce, a.out = reinterpret_cast<uint8_t *>(d_out) + (size_t)t0 * h->cfg.dim * esz, a.status = h->d_status;
+  a.reduce = reduce, a.out = reinterpret_cast<uint8_t *>(d_out) + (size_t)(t0 - out_tok0) * h->cfg.dim * esz, a.status = h->d_status;
   return launch_fmt(h, a, SRC_HITS, MODE_FULL, out_dtype, s);
 }
 
@@ -320,7 +322,7 @@ extern "C" int scone_shard_gather_embed(scone_handle *h, const int32_t *d_tok, i
   if (rc) return rc;
   if ((long long)B * T == 0) return SCONE_OK;
   return scone_shard_gather_embed_range(h, d_tok, B, T, 0, B, d_records, n_records, d_wte, vocab, d_wpe, n_pos, d_pos, reduce,
-                                        d_out, out_dtype, stream);
+                                        d_out, 0, out_dtype, stream);
 }
 
 extern "C" int scone_embed_partial(scone_handle *h, const int32_t *d_tok, int32_t B, int32_t T, float *d_partial,

@@ -615,7 +615,7 @@ static void chunk_seqs(int32_t B, int32_t n_chunks, int32_t c, int32_t *s0, int3
 }
 
 extern "C" int scone_shard_gather_plan_chunks(scone_handle *h, const int32_t *d_tok, int32_t B, int32_t T, int32_t n_chunks,
-                                              uint64_t *h_chunk_end, scone_stream_t stream) {
+                                              int32_t dedup_across_chunks, uint64_t *h_chunk_end, scone_stream_t stream) {
   if (!h) return SCONE_EINVAL;
   if (h->cfg.dim <= 0 || !h->rows) return scone_fail(h, SCONE_ESTATE, "scone_shard_gather_plan: handle has no table");
   if (B < 0 || T <= 0 || !h_chunk_end || !d_tok || n_chunks < 1 || n_chunks > 64)
@@ -661,11 +661,20 @@ extern "C" int scone_shard_gather_plan_chunks(scone_handle *h, const int32_t *d_
   // ONE match of the whole batch against ALL rows: the lists the lookup kernel will walk, and what the claim passes filter
   rc = scone_launch_match_ell_ex(h, d_tok, B, T, st->ell_slice, 0, (long long)h->cfg.n_rows, 0, s);
   if (rc) return rc;
-  // one claim pass per chunk, in chunk order, all in ONE generation: a row already claimed by an earlier chunk is not
-  // sent again -- the receiver's row map is cumulative, and chunk c is reduced after the records of chunks 0..c arrived
+  // one claim pass per chunk, in chunk order.  dedup_across_chunks (the all-gather form): all in ONE generation -- a row
+  // already claimed by an earlier chunk is not sent again, the receiver's row map is cumulative and chunk c is reduced
+  // after the records of chunks 0..c arrived.  Otherwise (the slice exchange: chunk q = what rank q's slice needs from
+  // me) every chunk claims in a generation of its own: each destination gets every distinct row it references, once.
   for (int c = 0; c < n_chunks; ++c) {
     int32_t s0, s1;
     chunk_seqs(B, n_chunks, c, &s0, &s1);
+    if (c > 0 && !dedup_across_chunks) {
+      st->uniq_gen += 1;
+      if (st->uniq_gen == 0) {
+        SCONE_HIP(h, hipMemsetAsync(st->uniq_claim, 0, (size_t)(h->local_rows ? h->local_rows : 1) * sizeof(uint32_t), s));
+        st->uniq_gen = 1;
+      }
+    }
     const long long nt = (long long)(s1 - s0) * T;
     if (nt > 0) {
       const unsigned blocks = (unsigned)((nt + 255) / 256 < SHARD_BLOCKS ? (nt + 255) / 256 : SHARD_BLOCKS);
@@ -687,7 +696,7 @@ extern "C" int scone_shard_gather_plan_chunks(scone_handle *h, const int32_t *d_
 extern "C" int scone_shard_gather_plan(scone_handle *h, const int32_t *d_tok, int32_t B, int32_t T, uint64_t *h_n_records,
                                        scone_stream_t stream) {
   if (!h_n_records) return h ? scone_fail(h, SCONE_EINVAL, "scone_shard_gather_plan: bad argument") : SCONE_EINVAL;
-  return scone_shard_gather_plan_chunks(h, d_tok, B, T, 1, h_n_records, stream);
+  return scone_shard_gather_plan_chunks(h, d_tok, B, T, 1, 1, h_n_records, stream);
 }
 
 extern "C" int scone_shard_gather_pack_range(scone_handle *h, uint64_t first, uint64_t count, uint64_t pad, void *d_send_buf,

@@ -453,14 +453,17 @@ class SconeTable:
         self._check(rc, "scone_shard_gather_pack")
         return buf
 
-    def shard_gather_plan_chunks(self, tok: torch.Tensor, n_chunks: int) -> list:
+    def shard_gather_plan_chunks(self, tok: torch.Tensor, n_chunks: int, dedup_across_chunks: bool = True) -> list:
         """Chunked plan: ``ends[c]`` = records this shard contributes to chunks ``0..c`` of the batch (chunk c = sequences
-        ``[c * ceil(B / n_chunks), ...)``); a row claimed by an earlier chunk is not claimed again (synchronises)."""
+        ``[c * ceil(B / n_chunks), ...)``).  ``dedup_across_chunks=True`` (all-gather form): a row claimed by an earlier chunk
+        is not claimed again; ``False`` (slice exchange, ``n_chunks = world``): every chunk lists each distinct row it
+        references (synchronises)."""
         tok = self._tok(tok)
         B, T = tok.shape
         ends = (C.c_uint64 * 64)()
         with torch.cuda.device(self.device):
-            rc = L.lib().scone_shard_gather_plan_chunks(self._h, _ptr(tok), B, T, int(n_chunks), ends, _stream())
+            rc = L.lib().scone_shard_gather_plan_chunks(self._h, _ptr(tok), B, T, int(n_chunks), int(bool(dedup_across_chunks)),
+                                                        ends, _stream())
         self._check(rc, "scone_shard_gather_plan_chunks")
         self._shard_keepalive = (tok,)
         return [int(e) for e in ends[:n_chunks]]
@@ -484,16 +487,20 @@ class SconeTable:
 
     def shard_gather_embed_range(self, tok: torch.Tensor, seq_begin: int, seq_end: int, records: torch.Tensor,
                                  out: torch.Tensor, wte: Optional[torch.Tensor] = None, wpe: Optional[torch.Tensor] = None,
-                                 position_ids: Optional[torch.Tensor] = None, reduce: str = "mean") -> None:
-        """Sequences ``[seq_begin, seq_end)`` of the planned batch into their place in ``out [B*T, d]``."""
+                                 position_ids: Optional[torch.Tensor] = None, reduce: str = "mean",
+                                 out_is_slice: bool = False) -> None:
+        """Sequences ``[seq_begin, seq_end)`` of the planned batch into their place in ``out [B*T, d]`` -- or, with
+        ``out_is_slice``, into ``out [>= (seq_end - seq_begin) * T, d]`` whose first row is sequence ``seq_begin``."""
         tok = self._tok(tok)
         B, T = tok.shape
-        assert out.is_cuda and out.is_contiguous() and out.numel() == B * T * self.dim
+        n_out = (seq_end - seq_begin) * T if out_is_slice else B * T
+        assert out.is_cuda and out.is_contiguous() and out.numel() >= n_out * self.dim
         with torch.cuda.device(self.device):
             rc = L.lib().scone_shard_gather_embed_range(self._h, _ptr(tok), B, T, int(seq_begin), int(seq_end), _ptr(records),
                                                         records.shape[0], _ptr(wte), 0 if wte is None else wte.shape[0],
                                                         _ptr(wpe), 0 if wpe is None else wpe.shape[0], _ptr(position_ids),
-                                                        _REDUCE[reduce], _ptr(out), _DT[out.dtype], _stream())
+                                                        _REDUCE[reduce], _ptr(out), int(seq_begin) * T if out_is_slice else 0,
+                                                        _DT[out.dtype], _stream())
         self._shard_keepalive = (records, tok, position_ids, wte, wpe, out)
         self._check(rc, "scone_shard_gather_embed_range")
 

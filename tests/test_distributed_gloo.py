@@ -162,11 +162,13 @@ class OracleShard:
     def shard_record_bytes(self):
         return self.dim * 4 + 8
 
-    def shard_gather_plan_chunks(self, tok, n_chunks):
+    def shard_gather_plan_chunks(self, tok, n_chunks, dedup_across_chunks=True):
         B, T = tok.shape
         per = (B + n_chunks - 1) // n_chunks
         claimed, order, ends = set(), [], []
         for c in range(n_chunks):
+            if not dedup_across_chunks:
+                claimed = set()                                       # every chunk (= destination) gets its own copy
             s0, s1 = min(c * per, B), min(c * per + per, B)
             if s1 > s0:
                 off, ids, tix, jix = self._refs(tok[s0:s1])
@@ -190,6 +192,8 @@ class OracleShard:
     def shard_gather_add_records(self, records, record0, n_records):
         if record0 == 0:
             self._by_id, self._added = {}, 0
+        if n_records == 0:
+            return
         assert record0 == self._added, "records must be added in order"
         r = records.numpy()
         for p in range(record0, record0 + n_records):
@@ -201,7 +205,7 @@ class OracleShard:
         self._added = record0 + n_records
 
     def shard_gather_embed_range(self, tok, seq_begin, seq_end, records, out, wte=None, wpe=None, position_ids=None,
-                                 reduce="mean"):
+                                 reduce="mean", out_is_slice=False):
         assert tuple(tok.shape) == self._planned
         B, T = tok.shape
         sl = tok[seq_begin:seq_end]
@@ -218,7 +222,10 @@ class OracleShard:
         if wpe is not None:
             pos = (torch.arange(flat.numel()) % T) if position_ids is None else position_ids[seq_begin:seq_end].reshape(-1).long()
             x = x + wpe.float()[pos]
-        out.view(B * T, self.dim)[seq_begin * T:seq_end * T] = x.to(out.dtype)
+        if out_is_slice:
+            out.view(-1, self.dim)[:(seq_end - seq_begin) * T] = x.to(out.dtype)
+        else:
+            out.view(B * T, self.dim)[seq_begin * T:seq_end * T] = x.to(out.dtype)
 
     def finalize(self, sums, counts, tok, a, b, wte=None, wpe=None, position_ids=None, reduce="mean",
                  out_dtype=torch.float32, out=None):
@@ -292,7 +299,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("exchange", ["rows", "gather_rows", "partial_sums"])
+@pytest.mark.parametrize("exchange", ["rows", "rows_per_reference", "gather_rows", "partial_sums"])
 @pytest.mark.parametrize("shape,dtype", [((3, 17), "float32"), ((2, 8), "float16"), ((1, 5), "float32")])
 def test_sharded_exchange_world2_gloo(shape, dtype, exchange):
     ctx = mp.get_context("spawn")

@@ -78,7 +78,8 @@ def _worker(rank, world, port, fmt, d, max_n, exchange, head, q):
 @pytest.mark.parametrize("fmt,d,max_n,world,exchange,head", [("int8", 768, 3, 2, "rows", 0), ("int4", 1024, 4, 3, "rows", 100),
                                                              ("int8", 768, 3, 3, "gather_rows", 0),
                                                              ("int4", 1024, 4, 2, "gather_rows", 100),
-                                                             ("int8", 768, 3, 2, "partial_sums", 0)])
+                                                             ("int8", 768, 3, 2, "partial_sums", 0),
+                                                             ("int4", 1024, 3, 3, "rows_per_reference", 100)])
 def test_sharded_cache_across_processes_on_one_gpu(fmt, d, max_n, world, exchange, head):
     if not torch.cuda.is_available():
         pytest.skip("needs an MI355X")
@@ -94,7 +95,7 @@ def test_sharded_cache_across_processes_on_one_gpu(fmt, d, max_n, world, exchang
     for rank, same, err, shape, sl_shape in results:
         assert shape is not None, f"rank {rank} failed: {err}"
         assert shape == (5, 33, d)
-        if exchange in ("rows", "gather_rows"):
+        if exchange in ("rows", "rows_per_reference", "gather_rows"):
             assert same, f"rank {rank}: row exchange must be bit-identical to the unsharded table (rel err {err})"
         else:
             assert err < 1e-3, (rank, err)          # fp32 partial sums are added in shard order, not list order
@@ -187,7 +188,7 @@ def _nccl_worker(rank, world, port, q):
             full = EmbeddingCache(ex, d, table_format=fmt)
             full.cache_embeddings(list(range(len(lens))), torch.from_numpy(table), verbose=False)
             ref = full.embed_tokens(torch.from_numpy(tok), wte=wte_d, wpe=wpe_d)
-            for exchange in ("rows", "gather_rows", "partial_sums"):
+            for exchange in ("rows", "rows_per_reference", "gather_rows", "partial_sums"):
                 got = sh.embed_tokens(torch.from_numpy(tok), wte=wte_d, wpe=wpe_d, exchange=exchange)
                 err = float((got.float() - ref.float()).abs().max() / ref.float().abs().max())
                 res.append((fmt, exchange, bool(torch.equal(got, ref)), err))

@@ -142,7 +142,8 @@ def test_committed_bench_line_follows_the_contract():
     import json
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     prof = os.path.join(root, "profiles")
-    rounds = sorted(d for d in os.listdir(prof) if os.path.exists(os.path.join(prof, d, "bench.json")))
+    import re
+    rounds = sorted(d for d in os.listdir(prof) if re.fullmatch(r"r\d+[a-z]?", d) and os.path.exists(os.path.join(prof, d, "bench.json")))   # the headline runs (rNNx); rNNx_<config> are secondary configs
     r = json.load(open(os.path.join(prof, rounds[-1], "bench.json")))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
@@ -156,3 +157,33 @@ def test_committed_bench_line_follows_the_contract():
     assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["unit"] == "tokens/s" and cb["sample"]
     # value = tokens of all ranks / time
     assert abs(r["value"] - r["config"]["tokens_per_step_per_rank"] * r["n_gpus"] / (r["ms_per_step"] * 1e-3)) / r["value"] < 1e-6
+    # round 2: the brackets of what HBM really moves, the launch-time spread, the cache-defeating variant, the baselines
+    assert 0 < rf["hbm_frac"] <= 1.0 and rf["hbm_bytes_compulsory"] < rf["algorithmic_bytes_per_launch"]
+    if rf["traffic"] is not None:
+        assert rf["hbm_bytes_compulsory"] <= rf["traffic"] and 0 < rf["traffic_frac"] <= 1.0 and not rf["traffic_stale"]
+    km = rf["kernel_ms"]
+    assert km["min"] <= km["median"] <= km["max"] and km["n"] == rf["timed_launches"]
+    hv = rf["hbm_variant"]
+    assert 0 < hv["hbm_frac"] <= 1.0 and hv["hbm_bytes_compulsory"] < hv["algorithmic_bytes_per_launch"]
+    assert cb["python_all_cores"]["cores"] >= 1 and cb["c_oracle_all_cores"]["value"] > cb["value"]
+    assert r["sharded"]["n1_pinned_host"]["value"] > 0
+
+
+def test_host_side_packing_under_sanitizers(tmp_path):
+    """SURVEY section 5 "sanitizers" for the product's own host code: the key packing, probe-sequence and INT4 scale-slot
+    helpers that the index build, the match kernels and the table kernels share between host and device
+    (scone_amd/csrc/scone_common.h), compiled for the host only with -fsanitize=address,undefined and checked for the
+    properties the exact-key index relies on (tests/host_pack_check.cpp).  CPU only: hipcc cross-compiles, nothing runs on
+    a GPU."""
+    import shutil
+    import subprocess
+    if shutil.which("hipcc") is None:
+        pytest.skip("hipcc not on PATH")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "host_pack_check")
+    subprocess.run(["hipcc", "-x", "hip", "--cuda-host-only", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined",
+                    "-fno-sanitize-recover=all", "-fno-omit-frame-pointer", os.path.join(root, "tests", "host_pack_check.cpp"),
+                    "-o", exe], check=True, capture_output=True, timeout=300)
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))    # the HIP runtime's own start-up allocations are not ours
+    assert p.returncode == 0 and "0 problem(s)" in p.stdout, p.stdout + p.stderr[-2000:]

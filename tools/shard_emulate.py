@@ -46,7 +46,7 @@ def main():
     ap.add_argument("--check", action="store_true")
     ap.add_argument("--head", type=int, default=0, help="replicated head: global rows [0, head) kept on every shard")
     ap.add_argument("--chunks", type=int, default=1, help="gather_rows: chunks of the pipelined exchange (1 = one shot)")
-    ap.add_argument("--mode", default="rows", choices=["rows", "gather_rows"],
+    ap.add_argument("--mode", default="rows", choices=["rows", "rows_dedup", "gather_rows"],
                     help="rows: all-to-all of records, every rank reduces its slice; gather_rows: all-gather of records, "
                          "every rank reduces the whole batch")
     a = ap.parse_args()
@@ -72,6 +72,9 @@ def main():
            "replicated_head_rows": a.head, "ranks": []}
     out = torch.empty(B * T, d, dtype=torch.float16, device="cuda")
     best = None
+    if a.mode == "rows_dedup":
+        rows_dedup_mode(a, shards, tok, wte, wpe, out, res, keys, lens)
+        return
     if a.mode == "gather_rows" and a.chunks > 1:
         gather_rows_chunked(a, shards, tok, wte, wpe, out, res, keys, lens)
         return
@@ -175,6 +178,56 @@ def gather_rows_mode(a, shards, tok, wte, wpe, out, res, keys, lens):
     print(json.dumps(res))
 
 
+def rows_dedup_mode(a, shards, tok, wte, wpe, out, res, keys, lens):
+    """The slice exchange with one record per distinct row and destination (ShardedEmbeddingCache._embed_row_exchange_dedup),
+    the all-to-all done by hand."""
+    N, W, d, B, T = a.rows, a.world, a.dim, a.batch, a.seq
+    rec = res["record_bytes"]
+    bper = (B + W - 1) // W
+    best = None
+    for rep in range(a.reps):
+        ends, t_plan, sends, t_pack, t_embed = [], [], [], [], []
+        for s in shards:
+            e, ms = timed(lambda: s.shard_gather_plan_chunks(tok, W, dedup_across_chunks=False))
+            ends.append(e)
+            t_plan.append(ms)
+        cnt = [[e[0]] + [e[q] - e[q - 1] for q in range(1, W)] for e in ends]        # cnt[r][q]: r sends to q
+        for r, s in enumerate(shards):
+            buf = torch.empty((max(ends[r][-1], 1), rec), dtype=torch.uint8, device="cuda")
+            _, ms = timed(lambda: s.shard_gather_pack_range(0, ends[r][-1], buf[:ends[r][-1]]))
+            sends.append(buf)
+            t_pack.append(ms)
+        for q, s in enumerate(shards):
+            parts = []
+            for r in range(W):
+                o = sum(cnt[r][:q])
+                parts.append(sends[r][o:o + cnt[r][q]])
+            recv = torch.cat(parts).contiguous()                                      # the all-to-all, by hand
+            b0, b1 = min(q * bper, B), min(q * bper + bper, B)
+
+            def step():
+                s.shard_gather_add_records(recv, 0, recv.shape[0])
+                s.shard_gather_embed_range(tok, b0, b1, recv, out[b0 * T:b1 * T], wte=wte, wpe=wpe, out_is_slice=True)
+            _, ms = timed(step)
+            t_embed.append(ms)
+        cur = [t_plan, t_pack, t_embed]
+        best = cur if best is None else [[min(x, y) for x, y in zip(b, c_)] for b, c_ in zip(best, cur)]
+    for r in range(W):
+        res["ranks"].append({"rank": r, "plan_ms": best[0][r], "pack_ms": best[1][r], "embed_ms": best[2][r],
+                             "send_records": int(sum(cnt[r])), "send_off_rank_bytes": int((sum(cnt[r]) - cnt[r][r]) * rec)})
+    loc = [x["plan_ms"] + x["pack_ms"] + x["embed_ms"] for x in res["ranks"]]
+    res["mode"] = "rows_dedup"
+    res["local_ms_max"], res["local_ms_mean"] = max(loc), sum(loc) / len(loc)
+    res["wire_bytes_all_ranks"] = sum(x["send_off_rank_bytes"] for x in res["ranks"])
+    if a.check:
+        full_t = SconeTable(3, N, d, a.format)
+        full_t.index_build(keys, lens)
+        full_t.fill_synthetic(7, 0.02 / 127)
+        want = full_t.embed(tok, wte=wte, wpe=wpe).reshape(B * T, d)
+        res["bit_identical_to_unsharded"] = bool(torch.equal(out, want))
+    print(json.dumps(res))
+
+
 def gather_rows_chunked(a, shards, tok, wte, wpe, out, res, keys, lens):
     """The pipelined all-gather form (ShardedEmbeddingCache._embed_gather_rows) with the C all-gathers done by hand: per rank,
     plan (one match + C claim passes), the C packs, and per chunk add_records + embed_range.  What a rank cannot hide behind
@@ -186,7 +239,7 @@ def gather_rows_chunked(a, shards, tok, wte, wpe, out, res, keys, lens):
     for rep in range(a.reps):
         ends, t_plan = [], []
         for s in shards:
-            e, ms = timed(lambda: s.shard_gather_plan_chunks(tok, C))
+            e, ms = timed(lambda: s.shard_gather_plan_chunks(tok, C, dedup_across_chunks=True))
             ends.append(e)
             t_plan.append(ms)
         mine = [[e[0]] + [e[c] - e[c - 1] for c in range(1, C)] for e in ends]

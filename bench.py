@@ -443,6 +443,9 @@ def sharded_record(args, dist, rank, world, backend, sync):
     from scone_amd.distributed import ShardedEmbeddingCache
     d, B, T = 1024, 2048, 512
     free, total = torch.cuda.mem_get_info()
+    fm = torch.tensor([float(free)], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+    dist.all_reduce(fm, op=dist.ReduceOp.MIN)       # every rank must size the table the same way: the tightest GPU decides
+    free = float(fm.item())
     per = args.sharded_rows_per_rank
     N = per * world
     cap = 64

@@ -36,18 +36,41 @@ scone_row_store scone_store_of(const scone_handle *h) {
   return st;
 }
 
+// At most SCONE_MAX_WS workspaces per handle: a process that keeps creating streams re-uses the least recently used
+// idle one (its buffers are freed -- hipFree synchronises the device, so nothing still reads them) instead of growing.
+#define SCONE_MAX_WS 16
 scone_ws *scone_ws_acquire(scone_handle *h, hipStream_t s) {
   scone_ws *w = nullptr;
   {
     std::lock_guard<std::mutex> g(h->ws_mu);
+    h->ws_clock += 1;
     for (scone_ws *c : h->ws)
       if (c->stream == s) w = c;
+    if (!w && h->ws.size() >= SCONE_MAX_WS) {
+      scone_ws *victim = nullptr;
+      for (scone_ws *c : h->ws)
+        if (c->stream != nullptr && (!victim || c->last_use < victim->last_use) && c->mu.try_lock()) {
+          if (victim) victim->mu.unlock();
+          victim = c;
+        }
+      if (victim) {  // locked by the try_lock above
+        if (victim->d_hits) (void)hipFree(victim->d_hits);
+        if (victim->d_ell) (void)hipFree(victim->d_ell);
+        if (victim->d_block_sums) (void)hipFree(victim->d_block_sums);
+        victim->d_hits = victim->d_ell = victim->d_block_sums = nullptr;
+        victim->hits_cap_tokens = victim->ell_cap_tokens = victim->block_sums_cap = 0;
+        victim->stream = s;
+        victim->last_use = h->ws_clock;
+        return victim;  // still locked: the caller's
+      }
+    }
     if (!w) {
       w = new (std::nothrow) scone_ws();
       if (!w) return nullptr;
       w->stream = s;
       h->ws.push_back(w);
     }
+    w->last_use = h->ws_clock;
   }
   w->mu.lock();
   return w;
@@ -185,7 +208,7 @@ extern "C" int scone_create(const scone_cfg *cfg, scone_handle **out) {
   h->local_rows = h->cfg.row_end - h->cfg.row_begin;
   h->slots = nullptr, h->d_counters = nullptr, h->d_status = nullptr, h->d_uni = nullptr, h->d_bloom = nullptr, h->bloom_mask = 0;
   h->rows = nullptr, h->rows_host = nullptr, h->scales = nullptr, h->hot_local = 0;
-  h->d_zero_row = nullptr, h->reserve_tokens = 0;
+  h->d_zero_row = nullptr, h->reserve_tokens = 0, h->ws_clock = 0;
   h->row_payload_bytes = 0, h->scale_bytes_per_row = 0;
   h->stage = nullptr, h->shard = nullptr;
   h->prof_on = false, h->prof_ev = nullptr, h->prof_head = 0, h->prof_n = 0, h->prof_ms = 0.0;

@@ -141,6 +141,7 @@ struct scone_ws {
   int32_t *d_block_sums = nullptr;
   int64_t block_sums_cap = 0;
   int64_t *d_total = nullptr;
+  uint64_t last_use = 0;  // handle clock at the last acquire (least recently used idle workspace is recycled)
 };
 
 // ---------------------------------------------------------------- handle
@@ -169,6 +170,7 @@ struct scone_handle {
   std::mutex ws_mu;             // guards the list
   std::vector<scone_ws *> ws;
   int64_t reserve_tokens;       // scone_reserve: every workspace holds at least this many tokens
+  uint64_t ws_clock;
   void *d_zero_row;  // dim * 4 zero bytes
   scone_stage_state *stage;  // staged host->HBM prefetch (scone_stage.hip), created on first use
   scone_shard_state *shard;  // row exchange between shards (scone_shard.hip), created on first use

@@ -689,6 +689,31 @@ def test_engine_generation_consumes_fgram_embeddings(mode):
     assert stats["tokens_per_second"] > 0
 
 
+def test_workspaces_of_many_streams_are_recycled():
+    """A handle keeps one large-batch workspace per stream, at most 16: a process that keeps creating streams recycles
+    the least recently used idle one instead of growing by 2 MB per stream; results stay exact and device memory flat."""
+    rng = np.random.default_rng(33)
+    vocab, n, d = 41, 1200, 768
+    lens = rng.integers(1, 4, size=n).astype(np.uint8)
+    keys = rng.integers(0, vocab, size=(n, 3)).astype(np.uint32)
+    keys[np.arange(3)[None, :] >= lens[:, None]] = 0
+    cache = _cache(keys, lens, 3, rng.standard_normal((n, d)).astype(np.float32), "int8")
+    tok = torch.from_numpy(rng.integers(0, vocab, size=(128, 512))).to("cuda", torch.int32)      # 64k tokens: two-kernel form
+    want = cache.embed_tokens(tok, out_dtype=torch.float32).clone()
+    torch.cuda.synchronize()
+    free0 = None
+    for i in range(48):
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            got = cache.embed_tokens(tok, out_dtype=torch.float32)
+        st.synchronize()
+        assert torch.equal(got, want), i
+        del got
+        if i == 20:
+            free0 = torch.cuda.mem_get_info()[0]
+    assert free0 - torch.cuda.mem_get_info()[0] < 16 << 20          # 27 more streams, no growth beyond allocator noise
+
+
 def test_staging_buffer_overflow_is_flagged_and_never_reads_out_of_bounds(monkeypatch):
     """k_stage_claim's `slot >= capacity` path.  The staging buffer is sized for the worst case of a chunk, so the path is
     unreachable from scone_embed; the test hook SCONE_STAGE_CAP_ROWS shrinks the buffer to 8 rows while a chunk references

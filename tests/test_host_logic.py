@@ -187,3 +187,15 @@ def test_host_side_packing_under_sanitizers(tmp_path):
     p = subprocess.run([exe], capture_output=True, text=True, timeout=300,
                        env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))    # the HIP runtime's own start-up allocations are not ours
     assert p.returncode == 0 and "0 problem(s)" in p.stdout, p.stdout + p.stderr[-2000:]
+
+
+def test_bench_refuses_more_ranks_than_devices():
+    """`python bench.py --gpus N` without a launcher starts its own ranks -- and exits non-zero, printing no result line,
+    when the box has fewer than N devices (never a 1-GPU line labelled N)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "SCONE_ONE_DEVICE")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "64", "--steps", "1"], env=env, cwd=root,
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and "HIP device" in p.stderr and not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]

@@ -702,13 +702,15 @@ def test_workspaces_of_many_streams_are_recycled():
     want = cache.embed_tokens(tok, out_dtype=torch.float32).clone()
     torch.cuda.synchronize()
     free0 = None
+    got = torch.empty_like(want)                  # one output buffer: torch's allocator keeps a pool PER STREAM otherwise
     for i in range(48):
         st = torch.cuda.Stream()
+        got.zero_()
+        torch.cuda.synchronize()
         with torch.cuda.stream(st):
-            got = cache.embed_tokens(tok, out_dtype=torch.float32)
+            cache.embed_tokens(tok, out_dtype=torch.float32, out=got)
         st.synchronize()
         assert torch.equal(got, want), i
-        del got
         if i == 20:
             free0 = torch.cuda.mem_get_info()[0]
     assert free0 - torch.cuda.mem_get_info()[0] < 16 << 20          # 27 more streams, no growth beyond allocator noise

@@ -299,7 +299,8 @@ int scone_shard_gather_embed(scone_handle *h, const int32_t *d_tok, int32_t B, i
  *   scone_shard_gather_embed_range   sequences [seq_begin, seq_end) of the planned batch out of [replicated head | records
  *                                    added so far]; every row they reference must have been added.  d_out's first row
  *                                    is token out_tok0 of the flattened batch (0: d_out is the whole [B, T, d];
- *                                    seq_begin * T: d_out holds just this run).  B, T must be the planned batch's. */
+ *                                    seq_begin * T: d_out holds just this run).  B, T must be the planned batch's; a run
+ *                                    is reduced ONCE per plan (its id lists are rewritten to record numbers in place). */
 int scone_shard_gather_plan_chunks(scone_handle *h, const int32_t *d_tok, int32_t B, int32_t T, int32_t n_chunks,
                                    int32_t dedup_across_chunks, uint64_t *h_chunk_end, scone_stream_t stream);
 int scone_shard_gather_pack_range(scone_handle *h, uint64_t first, uint64_t count, uint64_t pad, void *d_send_buf,

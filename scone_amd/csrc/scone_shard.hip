@@ -652,7 +652,10 @@ extern "C" int scone_shard_gather_plan_chunks(scone_handle *h, const int32_t *d_
     SCONE_HIP(h, hipMemsetAsync(st->uniq_claim, 0, (size_t)(h->local_rows ? h->local_rows : 1) * sizeof(uint32_t), s));
     st->uniq_gen = 1;
   }
-  long long need = ntok * NC < (long long)h->local_rows ? ntok * NC : (long long)h->local_rows;
+  // list capacity: every reference could be a distinct row of mine; a row is listed once per plan (all-gather form) or
+  // once per CHUNK (slice exchange: every destination gets its own copy)
+  const long long rows_cap = (long long)h->local_rows * (dedup_across_chunks ? 1 : n_chunks);
+  long long need = ntok * NC < rows_cap ? ntok * NC : rows_cap;
   rc = grow(h, &st->uniq_list, &st->cap_uniq, need, 1);
   if (rc) return rc;
   SCONE_HIP(h, hipMemsetAsync(st->counters, 0, 3 * 64 * sizeof(uint32_t), s));
@@ -690,6 +693,10 @@ extern "C" int scone_shard_gather_plan_chunks(scone_handle *h, const int32_t *d_
   SCONE_HIP(h, hipStreamSynchronize(s));
   for (int c = 0; c < n_chunks; ++c) h_chunk_end[c] = ends[c];
   st->n_uniq = ends[n_chunks - 1];
+  if ((long long)st->n_uniq > st->cap_uniq) {  // cannot happen with the capacity above; never hand out records that were not listed
+    st->n_uniq = 0;
+    return scone_fail(h, SCONE_ERANGE, "scone_shard_gather_plan: claim list overflow");
+  }
   return SCONE_OK;
 }
 
@@ -765,6 +772,8 @@ int scone_shard_gather_add(scone_handle *h, const void *d_records, uint64_t n, u
 int scone_shard_gather_remap(scone_handle *h, int32_t T, int32_t seq0, int32_t seq1, const int32_t **ell, const void **scales,
                              hipStream_t s) {
   scone_shard_state *st = h->shard;
+  if (!st->rhash || st->rhash_cap_now <= 0 || !st->ell_slice)
+    return scone_fail(h, SCONE_ESTATE, "scone_shard_gather_embed: plan the batch and add the records first");
   const int W = SCONE_ELL_W(h->cfg.max_n), NC = h->cfg.max_n * (h->cfg.max_n + 1) / 2;
   const long long nt = (long long)(seq1 - seq0) * T;
   int32_t *e = st->ell_slice + (long long)seq0 * T * W;

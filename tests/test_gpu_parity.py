@@ -1085,6 +1085,85 @@ def test_row_exchange_between_shards_is_bit_exact(fmt, d, max_n, world, head):
                 assert torch.equal(got, want[b0 * T:b1 * T]), (B, T, q)
 
 
+@pytest.mark.parametrize("fmt,d,max_n,world,n,head", [("int8", 768, 3, 4, 60, 0), ("int4", 1024, 3, 8, 2000, 37),
+                                                       ("fp16", 768, 4, 3, 500, 0), ("int8", 1024, 3, 8, 24, 5)])
+def test_slice_exchange_one_record_per_distinct_row_and_destination(fmt, d, max_n, world, n, head):
+    """The round-2 slice exchange (scone_shard_gather_plan_chunks with a claim generation per chunk, chunk q = rank q's
+    slice): W shards on one GPU, the all-to-all by hand.  Every destination gets each DISTINCT row it references exactly
+    once from its owner (the record counts equal the oracle's per-slice distinct-row counts; tiny tables where every slice
+    needs nearly every row exercise the per-destination list capacity), every slice is bit-identical to the unsharded
+    table, and the error paths of the new entry points return codes instead of touching memory."""
+    from scone_amd.hip_backend import SconeTable
+    from scone_amd.distributed import shard_range
+    rng = np.random.default_rng(190 + world + n)
+    vocab = 7 if n < 100 else 29
+    lens = rng.integers(1, max_n + 1, size=n).astype(np.uint8)
+    keys = rng.integers(0, vocab, size=(n, max_n)).astype(np.uint32)
+    keys[np.arange(max_n)[None, :] >= lens[:, None]] = 0
+    table = rng.standard_normal((n, d)).astype(np.float32)
+    full = SconeTable(max_n, n, d, fmt)
+    full.index_build(keys, lens)
+    full.store_f32(torch.from_numpy(table))
+    shards = []
+    for r in range(world):
+        a, b = shard_range(n, r, world)
+        s = SconeTable(max_n, n, d, fmt, row_begin=a, row_end=b)
+        s.index_build(keys, lens)
+        if b > a:
+            s.store_f32(torch.from_numpy(table[a:b]), row0=a)
+        if head:
+            s.shard_set_head(head)
+            s.shard_head_store_f32(torch.from_numpy(table[:head]), row0=0)
+        shards.append(s)
+    wte = torch.from_numpy(rng.standard_normal((vocab, d)).astype(np.float32)).half().cuda()
+    wpe = torch.from_numpy(rng.standard_normal((40, d)).astype(np.float32)).half().cuda()
+    rec = shards[0].shard_record_bytes()
+    for B, T in ((16, 40), (3, 7), (64, 3), (1, 40)):
+        tok = torch.from_numpy(rng.integers(0, vocab, size=(B, T)))
+        want = full.embed(tok, wte=wte, wpe=wpe).reshape(B * T, d)
+        off, ids = (x.cpu().numpy() for x in full.match_csr(tok))
+        bper = (B + world - 1) // world
+        ends = [s.shard_gather_plan_chunks(tok, world, dedup_across_chunks=False) for s in shards]
+        cnt = [[e[0]] + [e[q] - e[q - 1] for q in range(1, world)] for e in ends]
+        for q in range(world):                                       # oracle: distinct rows of slice q outside the head, per owner
+            t0, t1 = min(q * bper, B) * T, min(q * bper + bper, B) * T
+            need = np.unique(ids[off[t0]:off[t1]])
+            need = need[need >= head]
+            for r in range(world):
+                a, b = shard_range(n, r, world)
+                assert cnt[r][q] == int(((need >= a) & (need < b)).sum()), (B, T, r, q)
+        sends = []
+        for r, s in enumerate(shards):
+            buf = torch.empty((max(ends[r][-1], 1), rec), dtype=torch.uint8, device="cuda")
+            s.shard_gather_pack_range(0, ends[r][-1], buf[:ends[r][-1]])
+            sends.append(buf)
+        for q, s in enumerate(shards):
+            parts = [sends[r][sum(cnt[r][:q]):sum(cnt[r][:q + 1])] for r in range(world)]
+            recv = torch.cat(parts).contiguous()
+            b0, b1 = min(q * bper, B), min(q * bper + bper, B)
+            out = torch.full(((b1 - b0) * T + 1, d), 7.0, dtype=torch.float16, device="cuda")
+            s.shard_gather_add_records(recv, 0, recv.shape[0])
+            if b1 > b0:
+                s.shard_gather_embed_range(tok, b0, b1, recv, out, wte=wte, wpe=wpe, out_is_slice=True)
+            assert torch.equal(out[:(b1 - b0) * T], want[b0 * T:b1 * T]), (B, T, q)
+            assert bool((out[(b1 - b0) * T:] == 7.0).all())            # nothing written past the slice
+            assert s.status() == 0
+    # error paths
+    s = shards[0]
+    with pytest.raises((ValueError, IndexError, RuntimeError)):
+        s.shard_gather_pack_range(10**9, 5, torch.empty((5, rec), dtype=torch.uint8, device="cuda"))
+    with pytest.raises((ValueError, IndexError, RuntimeError)):
+        s.shard_gather_plan_chunks(tok, 65)
+    fresh = SconeTable(max_n, n, d, fmt, row_begin=0, row_end=n)
+    fresh.index_build(keys, lens)
+    fresh.shard_gather_plan_chunks(tok, 2)
+    with pytest.raises((ValueError, IndexError, RuntimeError)):       # records were never added
+        fresh.shard_gather_embed_range(tok, 0, 1, torch.empty((0, rec), dtype=torch.uint8, device="cuda"),
+                                       torch.empty((tok.numel(), d), dtype=torch.float16, device="cuda"))
+    with pytest.raises((ValueError, IndexError, RuntimeError)):       # another batch shape than the planned one
+        s.shard_gather_embed_range(tok[:, :-1].contiguous(), 0, 1, recv, torch.empty((tok.numel(), d), dtype=torch.float16, device="cuda"))
+
+
 def test_sharded_cache_world1_row_exchange():
     from scone_amd import EmbeddingCache
     from scone_amd.distributed import ShardedEmbeddingCache

@@ -807,7 +807,8 @@ def test_engine_greedy_decoding_equals_hf_gpt2_driven_by_the_oracle(mode):
     assert torch.equal(got, ids)
 
 
-def test_engine_from_pretrained_reads_a_reference_checkpoint_layout(tmp_path):
+@pytest.mark.parametrize("use_mm", [False, True])
+def test_engine_from_pretrained_reads_a_reference_checkpoint_layout(tmp_path, use_mm):
     """SconeInferenceEngine.from_pretrained (engine.py:129-190): config.json + weights under the reference's module names
     (base_model.* = GPT2LMHeadModel, f_gram_projection.weight, f_gram_model.* ignored), n_gram_extractor.npy, the
     reference-format embedding_cache.npy with rows of the f-gram model's size.  The projection is folded into the table;
@@ -826,8 +827,11 @@ def test_engine_from_pretrained_reads_a_reference_checkpoint_layout(tmp_path):
     lens = rng.integers(1, 4, size=n).astype(np.uint8)
     keys = rng.integers(2, vocab, size=(n, 3)).astype(np.uint32)
     keys[np.arange(3)[None, :] >= lens[:, None]] = 0
+    _, first = np.unique(np.concatenate([keys, lens[:, None]], axis=1), axis=0, return_index=True)
+    keys, lens = keys[np.sort(first)], lens[np.sort(first)]          # distinct f-grams: dense ids, as the reference's fit assigns them
     ex = _extractor(keys, lens, max_n)
     keys, lens = ex.key_arrays()
+    assert len(ex.f_gram_to_id) == len(lens)
     d = str(tmp_path / "ckpt")
     os.makedirs(d)
     json.dump({"model_type": "scone", "vocab_size": vocab, "hidden_size": H, "num_hidden_layers": 2, "num_attention_heads": 4,
@@ -841,10 +845,11 @@ def test_engine_from_pretrained_reads_a_reference_checkpoint_layout(tmp_path):
     save_file(state, os.path.join(d, "model.safetensors"))
     ex.save(os.path.join(d, "n_gram_extractor"))
     table = (rng.standard_normal((len(lens), df)) * 0.5).astype(np.float32)
-    host = EmbeddingCache(ex, df)
+    # the cache file in both of the reference's forms: rows inside the .npy, or a raw memory-mapped [N, d] file beside it
+    host = EmbeddingCache(ex, df, cache_dir=str(tmp_path / "mm") if use_mm else None, use_memory_map=use_mm)
     host.cache_embeddings(list(range(len(lens))), torch.from_numpy(table), verbose=False)
     host.save(os.path.join(d, "embedding_cache"))
-    engine = SconeInferenceEngine.from_pretrained(d, tokenizer=StubTokenizer(vocab), use_memory_map=False)
+    engine = SconeInferenceEngine.from_pretrained(d, tokenizer=StubTokenizer(vocab), use_memory_map=use_mm)
     assert engine.embedding_cache.embedding_dim == H and engine.max_n == max_n
     ids = torch.from_numpy(rng.integers(2, vocab, size=(2, 11)))
     ro, ri = R.hits_to_csr(R.match_hits(keys, lens, ids.numpy(), max_n))

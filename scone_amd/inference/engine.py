@@ -96,7 +96,7 @@ class SconeInferenceEngine:
         # rows of the file, in id order, projected to hidden size and stored in the device table's format
         if loaded.use_memory_map:
             ids = np.arange(loaded.memory_mapped_embeddings.shape[0], dtype=np.int64)
-            rows = torch.from_numpy(np.ascontiguousarray(loaded.memory_mapped_embeddings))
+            rows = torch.from_numpy(np.array(loaded.memory_mapped_embeddings, dtype=np.float32))     # a writable copy of the read-only map
         else:
             ids = np.asarray(sorted(loaded.embeddings.keys()), dtype=np.int64)
             rows = torch.from_numpy(np.stack([np.asarray(loaded.embeddings[int(i)], dtype=np.float32).reshape(-1) for i in ids])

@@ -707,16 +707,16 @@ def main():
     if not args.no_sharded_record and not sharded and emu is None:
         del cache, table, out, gpu_out_for_check
         torch.cuda.empty_cache()
-        watchdog = None
-        if rank == 0:
-            # a hung collective must not cost the headline: after 10 minutes rank 0 prints what it has and leaves
-            def bail():
+        # a hung collective must not cost the headline: after 10 minutes rank 0 prints what it has and every rank leaves
+        # (all with status 0, so that the launcher reports the run as what it is: a measured headline without the record)
+        def bail():
+            if rank == 0:
                 res["sharded"] = {"error": "timed out after 600 s"}
                 print(json.dumps(res), flush=True)
-                os._exit(0)
-            watchdog = threading.Timer(600.0, bail)
-            watchdog.daemon = True
-            watchdog.start()
+            os._exit(0)
+        watchdog = threading.Timer(600.0 if rank == 0 else 615.0, bail)
+        watchdog.daemon = True
+        watchdog.start()
         try:
             if world > 1:
                 rec = sharded_record(args, dist, rank, world, backend, sync)
@@ -726,8 +726,7 @@ def main():
                                "HBM; the row-sharded record is printed by the N > 1 lines"}
         except Exception as e:
             rec = {"error": repr(e)}
-        if watchdog is not None:
-            watchdog.cancel()
+        watchdog.cancel()
         if rank == 0:
             res["sharded"] = rec
     if rank == 0:

@@ -138,8 +138,10 @@ class SconeInferenceEngine:
     @torch.no_grad()
     def generate_ids(self, input_ids: torch.Tensor, max_length: int = 50, min_length: int = 0, do_sample: bool = True,
                      temperature: float = 1.0, top_k: int = 50, top_p: float = 1.0, eos_token_id: Optional[int] = None,
-                     generator: Optional[torch.Generator] = None) -> torch.Tensor:
-        """Decode until ``max_length`` total tokens.  Batch of prompts of equal length ``[B, T0]``."""
+                     generator: Optional[torch.Generator] = None, repetition_penalty: float = 1.0) -> torch.Tensor:
+        """Decode until ``max_length`` total tokens.  Batch of prompts of equal length ``[B, T0]``.
+        ``repetition_penalty`` as HF's logits processor: the logit of every token already in the sequence is divided by
+        it when positive, multiplied when negative."""
         ids = input_ids.to(self.device)
         B = ids.shape[0]
         past = None
@@ -173,6 +175,7 @@ class SconeInferenceEngine:
                 out = self.base.transformer(inputs_embeds=x, position_ids=pos, use_cache=True, return_dict=True)
             past = out.past_key_values
             logits = self.base.lm_head(out.last_hidden_state[:, -1, :]).float()
+            logits = self._penalise(logits, ids, repetition_penalty)
             if eos_token_id is not None and T < min_length:
                 logits[:, eos_token_id] = -float("inf")
             nxt = self._pick(logits, do_sample, temperature, top_k, top_p, generator)
@@ -183,6 +186,67 @@ class SconeInferenceEngine:
             if eos_token_id is not None and bool(finished.all()):
                 break
         return ids
+
+    @staticmethod
+    def _penalise(logits: torch.Tensor, ids: torch.Tensor, penalty: float) -> torch.Tensor:
+        if penalty == 1.0:
+            return logits
+        seen = torch.gather(logits, 1, ids)
+        seen = torch.where(seen > 0, seen / penalty, seen * penalty)
+        return logits.scatter(1, ids, seen)
+
+    @torch.no_grad()
+    def _step_logits(self, ids: torch.Tensor) -> torch.Tensor:
+        """Next-token logits ``[N, V]`` for ``N`` sequences of equal length: the lookup over the whole prefix and a full
+        transformer pass (what ``SconeLanguageModel.forward`` does) -- used where sequences are re-ordered between steps."""
+        T = ids.shape[1]
+        pos = torch.arange(T, device=self.device).unsqueeze(0).expand(ids.shape[0], -1)
+        h = self.base.transformer(inputs_embeds=self.embed(ids, position_ids=pos), position_ids=pos, return_dict=True)
+        return self.base.lm_head(h.last_hidden_state[:, -1, :]).float()
+
+    @torch.no_grad()
+    def beam_search_ids(self, input_ids: torch.Tensor, max_length: int = 50, min_length: int = 0, num_beams: int = 4,
+                        num_return_sequences: int = 1, eos_token_id: Optional[int] = None, repetition_penalty: float = 1.0,
+                        length_penalty: float = 1.0):
+        """Beam search over the f-gram-augmented model for ONE prompt ``[1, T0]``: every step scores all beams with the
+        fused lookup over their whole prefix (beams are re-ordered between steps, so no KV cache is carried), keeps the
+        ``num_beams`` best continuations by summed log-probability; a beam that emits ``eos_token_id`` is finished and
+        ranked by ``score / length ** length_penalty`` (HF's convention).  Returns ``(sequences, scores)``, best first."""
+        ids = input_ids.to(self.device)
+        if ids.shape[0] != 1:
+            raise ValueError("beam search takes one prompt")
+        if not 1 <= num_return_sequences <= num_beams:
+            raise ValueError("num_return_sequences must be in 1..num_beams")
+        beams = ids                                          # [n, T]
+        scores = torch.zeros(1, device=self.device)
+        done = []                                            # (normalised score, sequence)
+        while beams.shape[1] < max_length and beams.shape[0] > 0:
+            T = beams.shape[1]
+            logits = self._penalise(self._step_logits(beams), beams, repetition_penalty)
+            if eos_token_id is not None and T < min_length:
+                logits[:, eos_token_id] = -float("inf")
+            logp = torch.log_softmax(logits, dim=-1) + scores[:, None]
+            V = logp.shape[1]
+            top = torch.topk(logp.reshape(-1), min(2 * num_beams, logp.numel()))
+            nb, ns = [], []
+            for sc, flat in zip(top.values.tolist(), top.indices.tolist()):
+                b, tok = divmod(flat, V)
+                seq = torch.cat([beams[b], torch.tensor([tok], device=self.device)])
+                if eos_token_id is not None and tok == eos_token_id:
+                    done.append((sc / (seq.numel() ** length_penalty), seq))
+                else:
+                    nb.append(seq)
+                    ns.append(sc)
+                if len(nb) == num_beams:
+                    break
+            if len(done) >= num_beams and nb and max(d[0] for d in done) >= ns[0] / ((T + 1) ** length_penalty):
+                nb = []                                      # no live beam can still beat the finished ones (scores only fall)
+            beams = torch.stack(nb) if nb else beams[:0]
+            scores = torch.tensor(ns, device=self.device)
+        for sc, seq in zip(scores.tolist(), beams):
+            done.append((sc / (seq.numel() ** length_penalty), seq))
+        done.sort(key=lambda x: -x[0])
+        return [d[1] for d in done[:num_return_sequences]], [d[0] for d in done[:num_return_sequences]]
 
     @staticmethod
     def _pick(logits, do_sample, temperature, top_k, top_p, generator):
@@ -203,14 +267,19 @@ class SconeInferenceEngine:
     def generate(self, text, max_length: int = 50, min_length: int = 0, do_sample: bool = True, num_beams: int = 1,
                  temperature: float = 1.0, top_k: int = 50, top_p: float = 1.0, repetition_penalty: float = 1.0,
                  num_return_sequences: int = 1) -> List:
-        """Same arguments as the reference's ``generate`` (engine.py:192-204); beam search and repetition
-        penalty are not implemented (``num_beams`` must be 1, ``repetition_penalty`` 1.0)."""
-        if num_beams != 1 or repetition_penalty != 1.0:
-            raise NotImplementedError("beam search / repetition penalty are outside the lookup layer")
-        ids = self._encode(text).repeat(num_return_sequences, 1) if num_return_sequences > 1 else self._encode(text)
-        out = self.generate_ids(ids, max_length=max_length, min_length=min_length, do_sample=do_sample,
-                                temperature=temperature, top_k=top_k, top_p=top_p,
-                                eos_token_id=getattr(self.tokenizer, "eos_token_id", None))
+        """Same arguments as the reference's ``generate`` (engine.py:192-204).  ``num_beams > 1`` runs
+        :meth:`beam_search_ids` (deterministic; sampling applies to ``num_beams == 1`` only)."""
+        eos = getattr(self.tokenizer, "eos_token_id", None)
+        if num_beams > 1:
+            seqs, _ = self.beam_search_ids(self._encode(text)[:1], max_length=max_length, min_length=min_length,
+                                           num_beams=num_beams, num_return_sequences=num_return_sequences, eos_token_id=eos,
+                                           repetition_penalty=repetition_penalty)
+            out = seqs
+        else:
+            ids = self._encode(text).repeat(num_return_sequences, 1) if num_return_sequences > 1 else self._encode(text)
+            out = self.generate_ids(ids, max_length=max_length, min_length=min_length, do_sample=do_sample,
+                                    temperature=temperature, top_k=top_k, top_p=top_p, eos_token_id=eos,
+                                    repetition_penalty=repetition_penalty)
         if self.tokenizer is None:
             return [o.tolist() for o in out]
         return [self.tokenizer.decode(o.tolist()) for o in out]

@@ -807,6 +807,59 @@ def test_engine_greedy_decoding_equals_hf_gpt2_driven_by_the_oracle(mode):
     assert torch.equal(got, ids)
 
 
+def test_engine_beam_search_and_repetition_penalty_vs_oracle_scoring():
+    """generate(num_beams=, repetition_penalty=) (engine.py:192-204 passes both to HF generate): beam search keeps the
+    num_beams best prefixes by summed log-probability, checked against an independent beam search in this test whose
+    scoring model is HF GPT-2 fed ORACLE inputs_embeds; with one beam it is greedy decoding; the repetition penalty
+    follows HF's processor (seen logits / penalty if positive, * penalty if negative)."""
+    from transformers import GPT2Config, GPT2LMHeadModel
+    from scone_amd import EmbeddingCache, SconeLanguageModel
+    from scone_amd.inference import SconeInferenceEngine
+    torch.manual_seed(3)
+    rng = np.random.default_rng(14)
+    vocab, H, n, max_n = 23, 768, 200, 3
+    lens = rng.integers(1, 4, size=n).astype(np.uint8)
+    keys = rng.integers(0, vocab, size=(n, 3)).astype(np.uint32)
+    keys[np.arange(3)[None, :] >= lens[:, None]] = 0
+    ex = _extractor(keys, lens, max_n)
+    keys, lens = ex.key_arrays()
+    table = (rng.standard_normal((len(lens), H)) * 0.5).astype(np.float32)
+    cache = EmbeddingCache(ex, H, table_format="fp32")
+    cache.cache_embeddings(list(range(len(lens))), torch.from_numpy(table), verbose=False)
+    base = GPT2LMHeadModel(GPT2Config(vocab_size=vocab, n_positions=32, n_embd=H, n_layer=2, n_head=4)).eval()
+    engine = SconeInferenceEngine(SconeLanguageModel(base, None, cache).cuda().eval(), embedding_cache=cache)
+    wte, wpe = base.transformer.wte.weight.detach().float().cpu(), base.transformer.wpe.weight.detach().float().cpu()
+
+    def oracle_logp(seqs, penalty=1.0):
+        ids = torch.tensor(seqs)
+        x = _oracle_inputs_embeds("cover", keys, lens, max_n, table, ids, wte, wpe).cuda()
+        with torch.no_grad():
+            lg = base.lm_head(base.transformer(inputs_embeds=x, return_dict=True).last_hidden_state[:, -1, :]).float().cpu()
+        if penalty != 1.0:
+            for r, sq in enumerate(seqs):
+                for t in set(sq):
+                    lg[r, t] = lg[r, t] / penalty if lg[r, t] > 0 else lg[r, t] * penalty
+        return torch.log_softmax(lg, dim=-1)
+
+    prompt, L, nb = [3, 7, 7, 1], 10, 3
+    for penalty in (1.0, 1.7):
+        beams, scores = [list(prompt)], [0.0]                            # the test's own beam search
+        while len(beams[0]) < L:
+            lp = oracle_logp(beams, penalty)
+            cand = sorted(((scores[b] + float(lp[b, t]), beams[b] + [t]) for b in range(len(beams)) for t in range(vocab)),
+                          key=lambda c: -c[0])[:nb]
+            scores, beams = [c[0] for c in cand], [c[1] for c in cand]
+        seqs, sc = engine.beam_search_ids(torch.tensor([prompt]), max_length=L, num_beams=nb, num_return_sequences=nb,
+                                          repetition_penalty=penalty)
+        assert [q.tolist() for q in seqs] == beams
+        assert np.allclose(sc, [x / L for x in scores], rtol=1e-4, atol=1e-4)
+        one, _ = engine.beam_search_ids(torch.tensor([prompt]), max_length=L, num_beams=1, repetition_penalty=penalty)
+        greedy = engine.generate_ids(torch.tensor([prompt]), max_length=L, do_sample=False, repetition_penalty=penalty)
+        assert one[0].tolist() == greedy[0].tolist()
+    out = engine.generate(prompt, max_length=L, num_beams=nb, num_return_sequences=2)
+    assert len(out) == 2 and len(out[0]) == L
+
+
 @pytest.mark.parametrize("use_mm", [False, True])
 def test_engine_from_pretrained_reads_a_reference_checkpoint_layout(tmp_path, use_mm):
     """SconeInferenceEngine.from_pretrained (engine.py:129-190): config.json + weights under the reference's module names

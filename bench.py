@@ -389,8 +389,17 @@ def pinned_baseline(args, sync):
     from scone_amd import synthetic as S
     N, d, B, T = args.pinned_rows, 1024, 2048, 512
     need = N * 512 + 8e9
-    if psutil.virtual_memory().available < need:
-        return {"value": None, "skipped": f"needs {need / 1e9:.0f} GB of host memory for the pinned table"}
+    avail = psutil.virtual_memory().available
+    for f_lim, f_use in (("/sys/fs/cgroup/memory.max", "/sys/fs/cgroup/memory.current"),
+                         ("/sys/fs/cgroup/memory/memory.limit_in_bytes", "/sys/fs/cgroup/memory/memory.usage_in_bytes")):
+        try:                                            # a container's own limit counts, not only the host's free memory
+            lim = open(f_lim).read().strip()
+            if lim != "max":
+                avail = min(avail, int(lim) - int(open(f_use).read().strip()))
+        except (OSError, ValueError):
+            pass
+    if avail < need:
+        return {"value": None, "skipped": f"needs {need / 1e9:.0f} GB of host memory for the pinned table ({avail / 1e9:.0f} GB available)"}
     vocab = S.StructuredVocab(N)
     cache = EmbeddingCache.from_synthetic(vocab, d, table_format="int4", seed=7, base_scale=0.02 / 127, n_rows=N,
                                           placement="pinned_host", hot_rows=1_000_000)

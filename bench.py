@@ -704,7 +704,12 @@ def main():
     # ---- the cache-defeating variant, the CPU baselines, the sharded record: outside the timed region -----------
     if rank == 0 and world == 1 and not sharded and emu is None and not args.no_hbm_variant and args.placement == "hbm":
         try:
-            res["roofline"]["hbm_variant"] = hbm_variant(args, wte, wpe, sync)
+            hv = hbm_variant(args, wte, wpe, sync)
+            res["roofline"]["hbm_variant"] = hv
+            # the cache-defeating variant's bracket, lifted to the top of the block: what really touches HBM is at least
+            # `_lower` (compulsory bytes) and at most `_upper` (bytes that left L2, Infinity-Cache hits included) of the peak
+            res["roofline"]["hbm_variant_frac_lower"] = hv["hbm_frac"]
+            res["roofline"]["hbm_variant_frac_upper"] = hv["traffic_frac"]
         except Exception as e:
             res["roofline"]["hbm_variant"] = {"error": repr(e)}
     if rank == 0 and not args.no_cpu_baseline and world == 1 and not sharded:

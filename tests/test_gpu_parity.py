@@ -428,6 +428,36 @@ def test_sharded_cache_world1_equals_plain_cache():
 
 
 # ------------------------------------------------------------------ BASELINE.json full size
+@pytest.mark.parametrize("fmt,d", [("int8", 768), ("fp16", 768), ("int4", 1024), ("int8", 1024), ("int8", 1280)])
+def test_full_batch_high_occupancy_kernel_equals_the_per_token_position_kernel(fmt, d):
+    """The bench's full batch (2048 x 512 = 1M tokens, 1M-row table) through the two instantiations of k_embed_wave that a
+    lookup can take: default positions -> the high-occupancy variant (position row in LDS, 7-8 waves / SIMD); the same
+    positions passed explicitly -> the per-token-position kernel (round-1 register layout).  Size-independent property at
+    BASELINE's full size: the outputs are identical bit for bit, for fp16 and fp32 output, and the one-launch kernel agrees
+    on the first 32k tokens."""
+    from scone_amd import EmbeddingCache
+    from scone_amd import synthetic as S
+    keys, lens = S.make_keys(1_000_000, S.GPT2_VOCAB, 3, seed=11)
+    ex = _extractor(keys, lens, 3)
+    cache = EmbeddingCache.from_synthetic(ex, d, table_format=fmt, seed=7, base_scale=0.02 / 127)
+    B, T = 2048, 512
+    tok = torch.from_numpy(S.stream_uniform_ids(keys, lens, B, T, 1234)).to("cuda", torch.int32)
+    g = torch.Generator().manual_seed(1)
+    wte = (torch.randn(S.GPT2_VOCAB, d, generator=g) * 0.02).half().cuda()
+    wpe = (torch.randn(T, d, generator=g) * 0.01).half().cuda()
+    pos = torch.arange(T, dtype=torch.int32, device="cuda").unsqueeze(0).expand(B, T).contiguous()
+    a = cache.embed_tokens(tok, wte=wte, wpe=wpe)
+    b = cache.embed_tokens(tok, wte=wte, wpe=wpe, position_ids=pos)
+    assert torch.equal(a, b)
+    small = cache.embed_tokens(tok[:64], wte=wte, wpe=wpe)                # 32768 tokens: match + gather in one launch
+    assert torch.equal(small, a[:64])
+    del b, small
+    a32 = cache.embed_tokens(tok[:512], wte=wte.float(), wpe=wpe.float(), out_dtype=torch.float32)
+    b32 = cache.embed_tokens(tok[:512], wte=wte.float(), wpe=wpe.float(), position_ids=pos[:512], out_dtype=torch.float32)
+    assert torch.equal(a32, b32)
+    assert cache.table.status() == 0
+
+
 @pytest.mark.parametrize("fmt,d,n_rows", [("int8", 768, 1_000_000), ("fp16", 768, 1_000_000), ("int4", 1024, 1_000_000)])
 def test_full_size_table_spot_check_vs_oracle(fmt, d, n_rows):
     """Headline-size table (1M rows, synthetic on the GPU): ids bit-exact and embeddings within

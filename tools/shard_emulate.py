@@ -46,6 +46,9 @@ def main():
     ap.add_argument("--check", action="store_true")
     ap.add_argument("--head", type=int, default=0, help="replicated head: global rows [0, head) kept on every shard")
     ap.add_argument("--chunks", type=int, default=1, help="gather_rows: chunks of the pipelined exchange (1 = one shot)")
+    ap.add_argument("--wall", action="store_true",
+                    help="gather_rows: also time rank 0's whole step back to back (no phase synchronisation): the local "
+                         "critical path including launch gaps and the plan's one host synchronisation")
     ap.add_argument("--mode", default="rows", choices=["rows", "rows_dedup", "gather_rows"],
                     help="rows: all-to-all of records, every rank reduces its slice; gather_rows: all-gather of records, "
                          "every rank reduces the whole batch")
@@ -75,7 +78,7 @@ def main():
     if a.mode == "rows_dedup":
         rows_dedup_mode(a, shards, tok, wte, wpe, out, res, keys, lens)
         return
-    if a.mode == "gather_rows" and a.chunks > 1:
+    if a.mode == "gather_rows" and (a.chunks > 1 or a.wall):
         gather_rows_chunked(a, shards, tok, wte, wpe, out, res, keys, lens)
         return
     if a.mode == "gather_rows":
@@ -281,6 +284,35 @@ def gather_rows_chunked(a, shards, tok, wte, wpe, out, res, keys, lens):
     res["mode"], res["chunks"] = "gather_rows", C
     res["local_ms_max"], res["local_ms_mean"] = max(loc), sum(loc) / len(loc)
     res["all_gather_padded_bytes_per_chunk"] = chunk_bytes
+    if a.wall:
+        # rank 0's step as ShardedEmbeddingCache issues it, the other ranks' records already in place
+        import time
+        s = shards[0]
+
+        def whole_step():
+            e = s.shard_gather_plan_chunks(tok, C, dedup_across_chunks=True)          # synchronises (record counts)
+            m = [e[0]] + [e[c] - e[c - 1] for c in range(1, C)]
+            first = 0
+            for c in range(C):
+                if maxc[c]:
+                    s.shard_gather_pack_range(first, m[c], full[base[c]:base[c] + maxc[c]])
+                first += m[c]
+            for c in range(C):
+                s0, s1 = min(c * per, B), min(c * per + per, B)
+                if c == 0 or base[c + 1] > base[c]:
+                    s.shard_gather_add_records(records, base[c], base[c + 1] - base[c])
+                if s1 > s0:
+                    s.shard_gather_embed_range(tok, s0, s1, records, out, wte=wte, wpe=wpe)
+        for _ in range(3):
+            whole_step()
+        torch.cuda.synchronize()
+        walls = []
+        for _ in range(10):
+            t0 = time.perf_counter()
+            whole_step()
+            torch.cuda.synchronize()
+            walls.append((time.perf_counter() - t0) * 1e3)
+        res["rank0_whole_step_wall_ms"] = {"min": min(walls), "median": sorted(walls)[len(walls) // 2], "max": max(walls)}
     if a.check:
         full_t = SconeTable(3, N, d, a.format)
         full_t.index_build(keys, lens)

@@ -39,7 +39,18 @@ scone_row_store scone_store_of(const scone_handle *h) {
 // At most SCONE_MAX_WS workspaces per handle: a process that keeps creating streams re-uses the least recently used
 // idle one (its buffers are freed -- hipFree synchronises the device, so nothing still reads them) instead of growing.
 #define SCONE_MAX_WS 16
+static scone_ws *scone_ws_acquire_once(scone_handle *h, hipStream_t s);
 scone_ws *scone_ws_acquire(scone_handle *h, hipStream_t s) {
+  for (;;) {
+    scone_ws *w = scone_ws_acquire_once(h, s);
+    // between finding the stream's workspace and locking it another thread may have recycled it for ITS stream (all
+    // other workspaces busy): then it is no longer ours -- look again
+    if (!w || w->stream == s) return w;
+    w->mu.unlock();
+  }
+}
+
+static scone_ws *scone_ws_acquire_once(scone_handle *h, hipStream_t s) {
   scone_ws *w = nullptr;
   {
     std::lock_guard<std::mutex> g(h->ws_mu);

@@ -434,7 +434,7 @@ def _rccl_version():
         return f"unknown ({e!r})"
 
 
-def sharded_record(args, dist, rank, world, backend, sync):
+def sharded_record(args, dist, rank, world, backend, sync, rec=None):
     """N > 1: the row-sharded path on the C5-shaped workload -- INT4 d = 1024, `rows_per_rank` x N rows (1e9 at N = 8),
     replicated index built from keys generated on the GPU, every rank its own contiguous row range generated on its GPU,
     replicated head = the unigram rows, ONE 1M-token S_uniform batch that every rank passes in -- for the two exchanges
@@ -444,9 +444,11 @@ def sharded_record(args, dist, rank, world, backend, sync):
       gather_rows       all-gather of the DISTINCT quantised rows the batch references, every rank reduces the whole batch;
                         pipelined over `gather_chunks` chunks of sequences (gather_rows_one_shot: the same in one piece)
     and, for contrast, rows_slices_only: the all-to-all alone, every rank keeps its own slice (a consumer that is
-    data-parallel over the same slices needs no more).
+    data-parallel over the same slices needs no more); last, gather_rows_split_phase: the serving-loop form of gather_rows
+    (ShardedEmbeddingCache.gather_rows_begin / _finish, one piece, two batches in flight: plan, pack and transfers of step
+    s + 1 run on a side stream behind the reduction of step s) -- a throughput figure, a batch's latency is two steps.
     Un-synchronised steps give ms/step; one instrumented step per exchange (device synchronised between phases) gives the
-    phase split."""
+    phase split.  `rec` (optional) is filled in place, so that a caller's watchdog can print what was measured so far."""
     import torch
     from scone_amd import synthetic as S
     from scone_amd.distributed import ShardedEmbeddingCache
@@ -478,12 +480,13 @@ def sharded_record(args, dist, rank, world, backend, sync):
     wte = (torch.randn(S.GPT2_VOCAB, d, generator=g, device="cuda") * 0.02).half()
     wpe = (torch.randn(1024, d, generator=g, device="cuda") * 0.01).half()
     ntok = B * T
-    rec = {"workload": f"{N}-row int4 f-gram table d={d} row-sharded over {world} ranks ({per} rows = {per * 528 / 1e9:.1f} GB per rank), "
+    rec = {} if rec is None else rec
+    rec.update({"workload": f"{N}-row int4 f-gram table d={d} row-sharded over {world} ranks ({per} rows = {per * 528 / 1e9:.1f} GB per rank), "
                        f"replicated {cap}-slot index, replicated head {S.GPT2_VOCAB} rows, structured vocabulary, S_uniform, "
                        f"{B}x{T} tokens/step (the same batch on every rank), whole [B,T,d] fp16 output on every rank",
            "world_size": dist.get_world_size(), "device_count": torch.cuda.device_count(), "backend": backend,
            "rccl_version": _rccl_version() if backend == "nccl" else None,
-           "build_s": t_build, "note": note, "exchanges": {}}
+           "build_s": t_build, "note": note, "exchanges": {}})
     checks = {}
     chunks = cache.gather_chunks
     for name, kw in (("rows+all_gather", {"exchange": "rows", "gather_output": True}),
@@ -517,6 +520,32 @@ def sharded_record(args, dist, rank, world, backend, sync):
             }
         except Exception as e:                                                        # the record never takes the line down
             rec["exchanges"][name] = {"error": repr(e)}
+    try:
+        cache.gather_chunks = 1
+        def loop(n):
+            o = None
+            tk = cache.gather_rows_begin(tok)
+            for i in range(n):
+                o = cache.gather_rows_finish(tk, wte=wte, wpe=wpe)      # queues the reduction of step i ...
+                tk = cache.gather_rows_begin(tok) if i + 1 < n else None   # ... plan / pack / transfers of step i + 1 overlap it
+            return o
+        out = loop(3)
+        sync()
+        t0 = time.perf_counter()
+        out = loop(args.sharded_steps)
+        sync()
+        dt = time.perf_counter() - t0
+        tm = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        dt = float(tm.item())
+        rec["exchanges"]["gather_rows_split_phase"] = {
+            "ms_per_step": dt / args.sharded_steps * 1e3, "tokens_per_s": ntok * args.sharded_steps / dt,
+            "steps": args.sharded_steps, "batches_in_flight": 2,
+            "same_output_as_gather_rows": bool(float(out.float().abs().sum().item()) == checks.get("gather_rows")),
+        }
+    except Exception as e:
+        rec["exchanges"]["gather_rows_split_phase"] = {"error": repr(e)}
+    cache.gather_chunks = chunks
     if len(checks) == 3:                                # all bit-identical to the unsharded table, hence to each other
         rec["exchanges_agree"] = bool(len(set(checks.values())) == 1)
     rec["gather_chunks"] = chunks
@@ -723,17 +752,19 @@ def main():
         torch.cuda.empty_cache()
         # a hung collective must not cost the headline: after 10 minutes rank 0 prints what it has and every rank leaves
         # (all with status 0, so that the launcher reports the run as what it is: a measured headline without the record)
+        partial = {}
         def bail():
             if rank == 0:
-                res["sharded"] = {"error": "timed out after 600 s"}
-                print(json.dumps(res), flush=True)
+                partial["error"] = "timed out after 600 s; what was measured until then is kept"
+                res["sharded"] = partial
+                print(json.dumps(res, default=str), flush=True)
             os._exit(0)
         watchdog = threading.Timer(600.0 if rank == 0 else 615.0, bail)
         watchdog.daemon = True
         watchdog.start()
         try:
             if world > 1:
-                rec = sharded_record(args, dist, rank, world, backend, sync)
+                rec = sharded_record(args, dist, rank, world, backend, sync, partial)
             else:
                 rec = {"n1_pinned_host": pinned_baseline(args, sync),
                        "note": "one GPU: nothing to exchange.  This is the single-GPU alternative for a table that does not fit "

@@ -301,6 +301,13 @@ int scone_shard_gather_embed(scone_handle *h, const int32_t *d_tok, int32_t B, i
  *                                    is token out_tok0 of the flattened batch (0: d_out is the whole [B, T, d];
  *                                    seq_begin * T: d_out holds just this run).  B, T must be the planned batch's; a run
  *                                    is reduced ONCE per plan (its id lists are rewritten to record numbers in place). */
+/* Two plan slots (0 and 1; 0 is active at first): the receiver-side state of a planned batch (its id lists, the scales of
+ * [head | records], the row map) exists twice, so that a serving loop can plan, pack and exchange batch b + 1 on a side
+ * stream while batch b is still being reduced on the main stream.  A host-side switch, no device work; the
+ * scone_shard_gather_plan* / _add_records / _embed_range / _embed calls that follow work on the selected slot (the
+ * per-reference exchange scone_shard_plan / _pack / _embed is not slot-aware: use slot 0).  The sender-side scratch is
+ * shared: plan and pack of one batch must be enqueued before the next plan.  New here (the reference is one process). */
+int scone_shard_select_slot(scone_handle *h, int32_t slot);
 int scone_shard_gather_plan_chunks(scone_handle *h, const int32_t *d_tok, int32_t B, int32_t T, int32_t n_chunks,
                                    int32_t dedup_across_chunks, uint64_t *h_chunk_end, scone_stream_t stream);
 int scone_shard_gather_pack_range(scone_handle *h, uint64_t first, uint64_t count, uint64_t pad, void *d_send_buf,

@@ -24,6 +24,7 @@
 #include "scone_common.h"
 
 #include <new>
+#include <utility>
 
 struct scone_shard_state {
   long long cap_tok = 0, cap_slice = 0, cap_slot = 0, cap_recv = 0;
@@ -48,6 +49,19 @@ struct scone_shard_state {
   long long rhash_cap_now = 0;     // capacity the receiver's map was cleared for (current exchange)
   unsigned long long *rhash = nullptr;  // receiver: open-addressing map row id -> record number
   long long cap_rhash = 0;
+  // Plan slots (scone_shard_select_slot): the receiver-side state of a planned batch -- its id lists, the scales of
+  // [head | received records], the row map -- exists twice, so that batch b + 1 can be planned, packed and exchanged on a
+  // side stream while batch b is still being reduced.  The fields above are the ACTIVE slot's; the other one is parked.
+  struct plan_slot {
+    int32_t *ell_slice = nullptr;
+    long long cap_slice = 0;
+    uint8_t *scales = nullptr;
+    long long cap_recv = 0;
+    unsigned long long *rhash = nullptr;
+    long long cap_rhash = 0, rhash_cap_now = 0;
+    int32_t plan_B = 0, plan_T = 0, plan_chunks = 0;
+  } parked;
+  int slot = 0;
 };
 
 namespace {
@@ -256,7 +270,8 @@ void scone_shard_destroy(scone_handle *h) {
   scone_shard_state *st = h->shard;
   if (!st) return;
   void *ptrs[] = {st->ell_send, st->ell_slice, st->counters, st->send_src, st->slot_of_ref, st->scales,
-                  st->head_rows, st->head_scales, st->uniq_claim, st->uniq_list, st->rhash, st->chunk_ends};
+                  st->head_rows, st->head_scales, st->uniq_claim, st->uniq_list, st->rhash, st->chunk_ends,
+                  st->parked.ell_slice, st->parked.scales, st->parked.rhash};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   delete st;
@@ -697,6 +712,34 @@ extern "C" int scone_shard_gather_plan_chunks(scone_handle *h, const int32_t *d_
     st->n_uniq = 0;
     return scone_fail(h, SCONE_ERANGE, "scone_shard_gather_plan: claim list overflow");
   }
+  return SCONE_OK;
+}
+
+// Two plan slots: everything a planned batch needs on the RECEIVING side until it has been reduced (scone_shard_state::
+// plan_slot).  Selecting a slot is a host-side swap; the calls that follow -- plan, add_records, embed_range -- work on
+// it.  Sender-side scratch (claim table, record list, counters) is shared: plan + pack of one batch are finished (in
+// stream order) before the next plan starts.
+extern "C" int scone_shard_select_slot(scone_handle *h, int32_t slot) {
+  if (!h) return SCONE_EINVAL;
+  if (slot != 0 && slot != 1) return scone_fail(h, SCONE_EINVAL, "scone_shard_select_slot: slot must be 0 or 1");
+  if (!h->shard) {
+    h->shard = new (std::nothrow) scone_shard_state();
+    if (!h->shard) return scone_fail(h, SCONE_ENOMEM, "scone_shard_select_slot: out of memory");
+  }
+  scone_shard_state *st = h->shard;
+  if (st->slot == slot) return SCONE_OK;
+  scone_shard_state::plan_slot &p = st->parked;
+  std::swap(st->ell_slice, p.ell_slice);
+  std::swap(st->cap_slice, p.cap_slice);
+  std::swap(st->scales, p.scales);
+  std::swap(st->cap_recv, p.cap_recv);
+  std::swap(st->rhash, p.rhash);
+  std::swap(st->cap_rhash, p.cap_rhash);
+  std::swap(st->rhash_cap_now, p.rhash_cap_now);
+  std::swap(st->plan_B, p.plan_B);
+  std::swap(st->plan_T, p.plan_T);
+  std::swap(st->plan_chunks, p.plan_chunks);
+  st->slot = slot;
   return SCONE_OK;
 }
 

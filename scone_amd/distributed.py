@@ -141,6 +141,11 @@ class ShardedEmbeddingCache:
         self.replicated_rows = min(int(replicated_rows), self.n_rows)
         self._prof = None
         self._keep = None
+        # split-phase "gather_rows" (gather_rows_begin / gather_rows_finish): side stream, two plan slots
+        self._side = None
+        self._slot_next = 0
+        self._slot_done = [None, None]
+        self._slot_full = [None, None]
 
     @classmethod
     def from_synthetic(cls, n_gram_extractor: NGramExtractor, embedding_dim: int, *, table_format: str = "int8",
@@ -265,20 +270,68 @@ class ShardedEmbeddingCache:
         chunks c+1.. overlap the reduction of chunk c, which is what every rank spends most of the step on (it reduces the
         whole batch).  The receive buffer is one allocation ``[sum_c W * max_c, record]`` (a contribution is padded to
         the largest of its chunk; padding records carry row id 0xFFFFFFFF and are skipped), so the lookup kernel reads
-        all records received so far as one row store."""
+        all records received so far as one row store.
+
+        The two halves are also public -- :meth:`gather_rows_begin` / :meth:`gather_rows_finish` -- so that a serving loop
+        can run the first half of batch b + 1 on a side stream while batch b is being reduced."""
+        if not hasattr(self.table, "shard_gather_plan_chunks"):          # stand-in handles (CPU tests of the exchange logic)
+            return self._embed_gather_rows_unchunked(tok, reduce, wte, wpe, position_ids, out_dtype)
+        ticket = self.gather_rows_begin(tok, overlap=False)
+        return self.gather_rows_finish(ticket, reduce=reduce, wte=wte, wpe=wpe, position_ids=position_ids,
+                                       out_dtype=out_dtype).reshape(-1, self.embedding_dim)
+
+    # -- split-phase form of "gather_rows": plan + pack + collectives | reduction ------------------------------
+    def gather_rows_begin(self, input_ids: torch.Tensor, *, overlap: bool = True) -> dict:
+        """First half of the ``"gather_rows"`` exchange for one batch (the same ``[B, T]`` on every rank): match + claim
+        passes, the exchange of the record counts, the packs, and the all-gathers of the records (asynchronous over RCCL).
+        Returns a ticket for :meth:`gather_rows_finish`.
+
+        ``overlap=True``: the work is queued on a side stream of this cache (it starts after everything already queued on
+        the caller's stream, so the tokens may be produced there) and uses the plan slot the previous ``begin`` did not,
+        so a loop ::
+
+            ticket = cache.gather_rows_begin(batch[0])
+            for b in range(n):
+                out = cache.gather_rows_finish(ticket, wte=wte, wpe=wpe)        # queues the reduction of batch b
+                ticket = cache.gather_rows_begin(batch[b + 1]) if b + 1 < n else None   # ... and this overlaps it
+
+        hides plan, pack and the transfers of batch b + 1 behind the reduction of batch b: the step is then bound by the
+        reduction alone.  At most two batches in flight (two plan slots); tickets are finished in the order they were
+        begun.  ``begin`` blocks the host until the side stream has planned the batch (the record counts size the
+        buffers), not until the device is idle."""
+        if self._prof is not None and overlap:
+            raise ValueError("profile=True measures the phases one after the other: use overlap=False")
         import time
-        t0 = time.perf_counter() if self._prof is not None else 0.0
+        t = self.table
+        tok = torch.as_tensor(input_ids)
+        if tok.dim() == 1:
+            tok = tok.unsqueeze(0)
+        tok = t._tok(tok)
+        if not overlap:
+            return self._gather_begin(tok, 0, time.perf_counter() if self._prof is not None else 0.0)
+        slot = self._slot_next
+        self._slot_next ^= 1
+        if not tok.is_cuda:                                   # stand-in tables of the CPU tests: two slots, no streams
+            return self._gather_begin(tok, slot, 0.0)
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=tok.device)
+        side = self._side
+        side.wait_stream(torch.cuda.current_stream())
+        if self._slot_done[slot] is not None:                 # the slot's buffers are free once ITS last batch has been reduced
+            side.wait_event(self._slot_done[slot])
+        with torch.cuda.stream(side):
+            ticket = self._gather_begin(tok, slot, 0.0)
+            ticket["ready"] = torch.cuda.Event()
+            ticket["ready"].record(side)
+        return ticket
+
+    def _gather_begin(self, tok, slot, t0):
         B, T = tok.shape
         W, t = self.world, self.table
-        d = self.embedding_dim
-        if not hasattr(t, "shard_gather_plan_chunks"):          # stand-in handles (CPU tests of the exchange logic)
-            return self._embed_gather_rows_unchunked(tok, reduce, wte, wpe, position_ids, out_dtype)
-        tok = t._tok(tok)
-        if position_ids is not None:
-            position_ids = position_ids.to(device=tok.device, dtype=torch.int32).expand(B, T).contiguous()
         C = max(1, min(self.gather_chunks, B, 64))
         per = (B + C - 1) // C
-        ends = t.shard_gather_plan_chunks(tok, C)                       # synchronises: this rank's record counts
+        t.shard_select_slot(slot)
+        ends = t.shard_gather_plan_chunks(tok, C)                       # synchronises its stream: this rank's record counts
         mine = [ends[0]] + [ends[c] - ends[c - 1] for c in range(1, C)]
         t0 = self._tick("plan_ms", t0)
         if W > 1:
@@ -293,7 +346,13 @@ class ShardedEmbeddingCache:
             base.append(base[-1] + W * int(maxc[c]))
         total = base[-1]
         rec = t.shard_record_bytes()
-        full = torch.empty((max(total, 1), rec), dtype=torch.uint8, device=tok.device)
+        full = self._slot_full[slot]
+        if full is None or full.shape[0] < max(total, 1) or full.shape[1] != rec or full.device != tok.device:
+            # one receive buffer per slot, kept between steps and grown with some room (the counts move a little from
+            # batch to batch); a dropped buffer returns to the allocator only after this stream has waited for the
+            # slot's last reduction
+            full = torch.empty((max(total + total // 8, 1), rec), dtype=torch.uint8, device=tok.device)
+            self._slot_full[slot] = full
         t0 = self._tick("collective_ms", t0)
         works = []
         first = 0
@@ -318,8 +377,32 @@ class ShardedEmbeddingCache:
             first += mine[c]
         if self._prof is not None:
             self._prof["bytes_received"] = float(total * rec * (W - 1) // max(W, 1))
-        out = torch.empty((B * T, d), dtype=out_dtype, device=tok.device)
-        records = full[:total]
+        return {"slot": slot, "tok": tok, "C": C, "per": per, "base": base, "total": total, "records": full[:total],
+                "works": works, "ready": None, "t0": t0}
+
+    def gather_rows_finish(self, ticket: dict, *, reduce: str = "mean", wte: Optional[torch.Tensor] = None,
+                           wpe: Optional[torch.Tensor] = None, position_ids: Optional[torch.Tensor] = None,
+                           out_dtype: Optional[torch.dtype] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Second half: chunk by chunk, the caller's stream waits for the chunk's records, adds them to the row map and
+        reduces the chunk's sequences out of ``[replicated head | records received so far]``.  Returns ``[B, T, d]`` --
+        bit-identical to ``EmbeddingCache.embed_tokens`` on the unsharded table."""
+        t, d = self.table, self.embedding_dim
+        tok = ticket["tok"]
+        B, T = tok.shape
+        if out_dtype is None:
+            out_dtype = wte.dtype if wte is not None else (wpe.dtype if wpe is not None else torch.float32)
+        if position_ids is not None:
+            position_ids = position_ids.to(device=tok.device, dtype=torch.int32).expand(B, T).contiguous()
+        cur = torch.cuda.current_stream() if tok.is_cuda else None
+        if ticket["ready"] is not None:                                  # begun on the side stream
+            cur.wait_event(ticket["ready"])
+        t.shard_select_slot(ticket["slot"])
+        if out is None:
+            out = torch.empty((B * T, d), dtype=out_dtype, device=tok.device)
+        else:
+            assert out.is_contiguous() and out.dtype == out_dtype and out.numel() == B * T * d
+        C, per, base, records, works = ticket["C"], ticket["per"], ticket["base"], ticket["records"], ticket["works"]
+        t0 = ticket["t0"]
         for c in range(C):
             if works[c] is not None:
                 works[c][0].wait()                                       # the current stream waits for chunk c's records
@@ -331,8 +414,12 @@ class ShardedEmbeddingCache:
                 t.shard_gather_embed_range(tok, s0, s1, records, out, wte=wte, wpe=wpe, position_ids=position_ids,
                                            reduce=reduce)
             t0 = self._tick("embed_ms", t0)
-        self._keep = (full, works)                                       # read in place until the stream has passed
-        return out
+        if cur is not None:
+            done = torch.cuda.Event()
+            done.record(cur)
+            self._slot_done[ticket["slot"]] = done
+        self._keep = (ticket, position_ids, wte, wpe, out)               # read in place until the stream has passed
+        return out.view(B, T, d)
 
     def _embed_gather_rows_unchunked(self, tok, reduce, wte, wpe, position_ids, out_dtype):
         """One plan, one all-gather, one reduction (the form the chunked path degenerates to with one chunk)."""

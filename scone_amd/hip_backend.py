@@ -453,6 +453,11 @@ class SconeTable:
         self._check(rc, "scone_shard_gather_pack")
         return buf
 
+    def shard_select_slot(self, slot: int) -> None:
+        """Plan slot 0 / 1 for the scone_shard_gather_* calls that follow (host-side switch): the receiver-side state of a
+        planned batch exists twice, so batch b + 1 can be planned and exchanged while batch b is being reduced."""
+        self._check(L.lib().scone_shard_select_slot(self._h, int(slot)), "scone_shard_select_slot")
+
     def shard_gather_plan_chunks(self, tok: torch.Tensor, n_chunks: int, dedup_across_chunks: bool = True) -> list:
         """Chunked plan: ``ends[c]`` = records this shard contributes to chunks ``0..c`` of the batch (chunk c = sequences
         ``[c * ceil(B / n_chunks), ...)``).  ``dedup_across_chunks=True`` (all-gather form): a row claimed by an earlier chunk

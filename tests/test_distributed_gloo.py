@@ -159,6 +159,16 @@ class OracleShard:
     def _tok(self, tok):
         return tok
 
+    def shard_select_slot(self, slot):
+        # the receiver-side state of a planned batch exists twice (scone_shard_select_slot)
+        st = self.__dict__.setdefault("_slots", {0: {}, 1: {}})
+        cur = self.__dict__.setdefault("_slot", 0)
+        if slot == cur:
+            return
+        st[cur] = {k: self.__dict__.pop(k) for k in ("_planned", "_by_id", "_added") if k in self.__dict__}
+        self.__dict__.update(st[slot])
+        self._slot = slot
+
     def shard_record_bytes(self):
         return self.dim * 4 + 8
 
@@ -337,6 +347,66 @@ def test_gather_rows_chunked_pipeline_world2_gloo(chunks, head):
     for rank, err, out_shape, ok_slice in results:
         assert isinstance(err, float), f"rank {rank} failed: {err}"
         assert out_shape == (shape[0], shape[1], 32) and err < 1e-6 and ok_slice
+
+
+def _worker_split_phase(rank, world, port, q):
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from oracle import ref_port as R
+        from scone_amd import NGramExtractor
+        from scone_amd.distributed import ShardedEmbeddingCache, shard_range
+        rng = np.random.default_rng(7)
+        vocab, n, d, max_n = 19, 301, 32, 3
+        lens = rng.integers(1, max_n + 1, size=n).astype(np.uint8)
+        keys = rng.integers(0, vocab, size=(n, max_n)).astype(np.uint32)
+        keys[np.arange(max_n)[None, :] >= lens[:, None]] = 0
+        table = rng.standard_normal((n, d)).astype(np.float32)
+        B, T = 4, 11
+        batches = [torch.from_numpy(rng.integers(0, vocab, size=(B, T))) for _ in range(4)]
+        wte = torch.from_numpy(rng.standard_normal((vocab, d)).astype(np.float32))
+        wpe = torch.from_numpy(rng.standard_normal((T, d)).astype(np.float32))
+        ex = NGramExtractor.from_arrays(keys, lens, max_n=max_n)
+        a, b = shard_range(n, rank, world)
+        shard = OracleShard(keys, lens, max_n, table, a, b)
+        shard.shard_set_head(30)
+        cache = ShardedEmbeddingCache(ex, d, rank=rank, world=world, n_rows=n, table=shard, replicated_rows=30, gather_chunks=2)
+        outs = []
+        ticket = cache.gather_rows_begin(batches[0])
+        for i in range(len(batches)):
+            nxt = cache.gather_rows_begin(batches[i + 1]) if i + 1 < len(batches) else None   # batch i+1 planned and
+            outs.append(cache.gather_rows_finish(ticket, wte=wte, wpe=wpe))                    # exchanged before batch i is reduced
+            ticket = nxt
+        worst = 0.0
+        for tok, out in zip(batches, outs):
+            ro, ri = R.hits_to_csr(R.match_hits(keys, lens, tok.numpy(), max_n))
+            fg = torch.from_numpy(R.embed_numpy(table, ro, ri, "mean").reshape(B, T, d))
+            ref = R.combine(tok, fg, wte, wpe)
+            worst = max(worst, float((out.float() - ref).abs().max() / ref.abs().max()))
+        same = torch.equal(outs[1], cache.embed_tokens(batches[1], wte=wte, wpe=wpe, exchange="gather_rows"))
+        q.put((rank, worst, same))
+        dist.destroy_process_group()
+    except Exception as e:
+        import traceback
+        q.put((rank, repr(e) + traceback.format_exc(), False))
+
+
+def test_gather_rows_split_phase_two_batches_in_flight_world2_gloo():
+    """gather_rows_begin / gather_rows_finish with the next batch begun (planned, packed, gathered) BEFORE the current one is
+    reduced: the two plan slots keep the batches apart; every output equals the unsharded lookup of ITS batch and the
+    one-call form."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_split_phase, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, err, same in results:
+        assert isinstance(err, float), f"rank {rank} failed: {err}"
+        assert err < 1e-6 and same
 
 
 def test_load_rows_stores_owned_range_and_replicated_head():

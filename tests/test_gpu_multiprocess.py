@@ -101,6 +101,61 @@ def test_sharded_cache_across_processes_on_one_gpu(fmt, d, max_n, world, exchang
             assert err < 1e-3, (rank, err)          # fp32 partial sums are added in shard order, not list order
 
 
+def _worker_split_phase(rank, world, port, fmt, d, max_n, head, chunks, q):
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        torch.cuda.set_device(0)
+        from scone_amd import EmbeddingCache, NGramExtractor
+        from scone_amd.distributed import ShardedEmbeddingCache
+        keys, lens, table, tok0, wte, wpe = _problem(fmt, d, max_n)
+        rng = np.random.default_rng(99)
+        batches = [tok0] + [rng.integers(0, 24, size=tok0.shape) for _ in range(4)]
+        ex = NGramExtractor.from_arrays(keys, lens, max_n=max_n)
+        sh = ShardedEmbeddingCache(ex, d, table_format=fmt, rank=rank, world=world, replicated_rows=head, gather_chunks=chunks)
+        sh.load_rows(torch.from_numpy(table), 0)
+        wte_d, wpe_d = torch.from_numpy(wte).half().cuda(), torch.from_numpy(wpe).half().cuda()
+        full = EmbeddingCache(ex, d, table_format=fmt)
+        full.cache_embeddings(list(range(len(lens))), torch.from_numpy(table), verbose=False)
+        outs = []
+        ticket = sh.gather_rows_begin(torch.from_numpy(batches[0]))
+        for i in range(len(batches)):                                   # two batches in flight: begin(i + 1) is queued on the side
+            outs.append(sh.gather_rows_finish(ticket, wte=wte_d, wpe=wpe_d))   # stream behind finish(i) on the main one
+            ticket = sh.gather_rows_begin(torch.from_numpy(batches[i + 1])) if i + 1 < len(batches) else None
+        torch.cuda.synchronize()
+        same = all(bool(torch.equal(o, full.embed_tokens(torch.from_numpy(b), wte=wte_d, wpe=wpe_d))) for o, b in zip(outs, batches))
+        # the one-call form still works afterwards (slot 0, current stream)
+        again = bool(torch.equal(sh.embed_tokens(torch.from_numpy(batches[2]), wte=wte_d, wpe=wpe_d, exchange="gather_rows"), outs[2]))
+        q.put((rank, same and again, "", tuple(outs[0].shape), None))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:
+        import traceback
+        q.put((rank, False, repr(e) + traceback.format_exc(), None, None))
+
+
+@pytest.mark.parametrize("fmt,d,max_n,world,head,chunks", [("int4", 1024, 3, 3, 100, 1), ("int8", 768, 4, 2, 0, 3)])
+def test_split_phase_gather_two_batches_in_flight_across_processes(fmt, d, max_n, world, head, chunks):
+    """gather_rows_begin / gather_rows_finish as a serving loop issues them: batch i + 1 is planned, packed and gathered on
+    the cache's side stream (plan slot i + 1 mod 2) while batch i is reduced on the main stream.  Five different batches,
+    real kernels, separate processes (gloo over one GPU): every output is bit-identical to the unsharded lookup of ITS batch."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_split_phase, args=(r, world, port, fmt, d, max_n, head, chunks, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, same, err, shape, _ in results:
+        assert shape is not None, f"rank {rank} failed: {err}"
+        assert shape == (5, 33, d) and same, rank
+
+
 @pytest.mark.parametrize("mode", ["replicated", "sharded", "sharded-slices"])
 def test_bench_two_ranks_launched_like_the_driver(mode):
     """`python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2` with the rehearsal knobs
@@ -145,6 +200,9 @@ def _check_sharded_record(rec, world):
             assert e["phase_ms_slowest_rank"][ph] >= 0.0, (name, ph)
     assert "gather_out_ms" in rec["exchanges"]["rows+all_gather"]["phase_ms_slowest_rank"]
     assert rec["exchanges_agree"] is True
+    sp = rec["exchanges"]["gather_rows_split_phase"]
+    assert "error" not in sp, sp
+    assert sp["ms_per_step"] > 0 and sp["batches_in_flight"] == 2 and sp["same_output_as_gather_rows"] is True
 
 
 def test_bench_starts_its_own_ranks_when_no_launcher_did():
@@ -192,6 +250,12 @@ def _nccl_worker(rank, world, port, q):
                 got = sh.embed_tokens(torch.from_numpy(tok), wte=wte_d, wpe=wpe_d, exchange=exchange)
                 err = float((got.float() - ref.float()).abs().max() / ref.float().abs().max())
                 res.append((fmt, exchange, bool(torch.equal(got, ref)), err))
+            # the split-phase loop: two batches in flight, the second one's transfers behind the first one's reduction
+            tk = sh.gather_rows_begin(torch.from_numpy(tok))
+            for i in range(3):
+                got = sh.gather_rows_finish(tk, wte=wte_d, wpe=wpe_d)
+                tk = sh.gather_rows_begin(torch.from_numpy(tok)) if i < 2 else None
+                res.append((fmt, f"gather_rows split-phase step {i}", bool(torch.equal(got, ref)), 0.0))
         q.put((rank, res, None))
         dist.barrier()
         dist.destroy_process_group()

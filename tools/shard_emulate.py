@@ -313,6 +313,65 @@ def gather_rows_chunked(a, shards, tok, wte, wpe, out, res, keys, lens):
             torch.cuda.synchronize()
             walls.append((time.perf_counter() - t0) * 1e3)
         res["rank0_whole_step_wall_ms"] = {"min": min(walls), "median": sorted(walls)[len(walls) // 2], "max": max(walls)}
+        # ... and as the split-phase loop issues it (gather_rows_begin of batch b + 1 on a side stream, on the other plan
+        # slot, while batch b is reduced on the main stream)
+        side = torch.cuda.Stream()
+        fulls = [full, full.clone()]
+        done = [None, None]
+
+        def begin(slot):
+            side.wait_stream(torch.cuda.current_stream())
+            if done[slot] is not None:
+                side.wait_event(done[slot])
+            with torch.cuda.stream(side):
+                s.shard_select_slot(slot)
+                e = s.shard_gather_plan_chunks(tok, C, dedup_across_chunks=True)
+                m = [e[0]] + [e[c] - e[c - 1] for c in range(1, C)]
+                first = 0
+                for c in range(C):
+                    if maxc[c]:
+                        s.shard_gather_pack_range(first, m[c], fulls[slot][base[c]:base[c] + maxc[c]])
+                    first += m[c]
+                ready = torch.cuda.Event()
+                ready.record(side)
+            return slot, ready
+
+        def finish(ticket):
+            slot, ready = ticket
+            cur = torch.cuda.current_stream()
+            cur.wait_event(ready)
+            s.shard_select_slot(slot)
+            recs = fulls[slot][:base[-1]]
+            for c in range(C):
+                s0, s1 = min(c * per, B), min(c * per + per, B)
+                if c == 0 or base[c + 1] > base[c]:
+                    s.shard_gather_add_records(recs, base[c], base[c + 1] - base[c])
+                if s1 > s0:
+                    s.shard_gather_embed_range(tok, s0, s1, recs, out, wte=wte, wpe=wpe)
+            done[slot] = torch.cuda.Event()
+            done[slot].record(cur)
+
+        def loop(n):
+            slot = 0
+            t = begin(slot)
+            for i in range(n):
+                finish(t)
+                slot ^= 1
+                t = begin(slot) if i + 1 < n else None
+        loop(4)
+        torch.cuda.synchronize()
+        n = 20
+        t0 = time.perf_counter()
+        loop(n)
+        torch.cuda.synchronize()
+        res["rank0_split_phase_loop_ms_per_step"] = (time.perf_counter() - t0) * 1e3 / n
+        s.shard_select_slot(0)
+        if a.check:
+            full_c = SconeTable(3, N, d, a.format)
+            full_c.index_build(keys, lens)
+            full_c.fill_synthetic(7, 0.02 / 127)
+            res["split_phase_bit_identical_to_unsharded"] = bool(torch.equal(out, full_c.embed(tok, wte=wte, wpe=wpe).reshape(B * T, d)))
+            del full_c
     if a.check:
         full_t = SconeTable(3, N, d, a.format)
         full_t.index_build(keys, lens)

@@ -31,6 +31,9 @@ here and only needed when the table does not fit one GPU's 288 GB (BASELINE conf
   contribution), and ``scone_shard_gather_embed`` indexes them by row id and reduces the whole batch out of
   ``[replicated head | gathered records]`` -- bit-identical again, ~0.25 GB into every rank per 1M-token step instead
   of ~1.9 GB;
+* split-phase form of ``"gather_rows"`` for a serving loop: ``gather_rows_begin`` (plan, packs, transfers -- on a side stream,
+  on the other of the handle's two plan slots) / ``gather_rows_finish`` (the reduction, on the caller's stream): two batches in
+  flight, the next batch's exchange hidden behind the current batch's reduction;
 * exchange ``"partial_sums"`` (kept for comparison): every rank sums the rows it owns
   (``scone_embed_partial``) -> ``reduce_scatter`` -> ``scone_finalize``;
 * finally an ``all_gather`` of the finished vectors in the output dtype (skippable when the

@@ -524,10 +524,10 @@ def sharded_record(args, dist, rank, world, backend, sync, rec=None):
         cache.gather_chunks = 1
         def loop(n):
             o = None
-            tk = cache.gather_rows_begin(tok)
+            tk = cache.gather_rows_begin(tok, tokens_ready=None)         # (the batch has been on the device since the build)
             for i in range(n):
                 o = cache.gather_rows_finish(tk, wte=wte, wpe=wpe)      # queues the reduction of step i ...
-                tk = cache.gather_rows_begin(tok) if i + 1 < n else None   # ... plan / pack / transfers of step i + 1 overlap it
+                tk = cache.gather_rows_begin(tok, tokens_ready=None) if i + 1 < n else None   # ... plan / pack / transfers of step i + 1 overlap it
             return o
         out = loop(3)
         sync()

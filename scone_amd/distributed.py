@@ -284,14 +284,13 @@ class ShardedEmbeddingCache:
                                        out_dtype=out_dtype).reshape(-1, self.embedding_dim)
 
     # -- split-phase form of "gather_rows": plan + pack + collectives | reduction ------------------------------
-    def gather_rows_begin(self, input_ids: torch.Tensor, *, overlap: bool = True) -> dict:
+    def gather_rows_begin(self, input_ids: torch.Tensor, *, overlap: bool = True, tokens_ready="current") -> dict:
         """First half of the ``"gather_rows"`` exchange for one batch (the same ``[B, T]`` on every rank): match + claim
         passes, the exchange of the record counts, the packs, and the all-gathers of the records (asynchronous over RCCL).
         Returns a ticket for :meth:`gather_rows_finish`.
 
-        ``overlap=True``: the work is queued on a side stream of this cache (it starts after everything already queued on
-        the caller's stream, so the tokens may be produced there) and uses the plan slot the previous ``begin`` did not,
-        so a loop ::
+        ``overlap=True``: the work is queued on a side stream of this cache and uses the plan slot the previous ``begin``
+        did not, so a loop ::
 
             ticket = cache.gather_rows_begin(batch[0])
             for b in range(n):
@@ -301,7 +300,14 @@ class ShardedEmbeddingCache:
         hides plan, pack and the transfers of batch b + 1 behind the reduction of batch b: the step is then bound by the
         reduction alone.  At most two batches in flight (two plan slots); tickets are finished in the order they were
         begun.  ``begin`` blocks the host until the side stream has planned the batch (the record counts size the
-        buffers), not until the device is idle."""
+        buffers), not until the device is idle.
+
+        ``tokens_ready`` says what the side stream must wait for before it reads the tokens: a ``torch.cuda.Event``
+        recorded where they were produced; ``None`` -- nothing, they are complete (uploaded earlier, or produced by work the
+        host has synchronised with); ``"current"`` (the default for a device tensor: always safe) -- everything queued on the
+        caller's stream so far.  NB the default puts the plan BEHIND a reduction queued just before it and with it most of the
+        overlap is lost: a serving loop passes the event of its token producer, or host tokens (copied on the side stream,
+        nothing to wait for)."""
         if self._prof is not None and overlap:
             raise ValueError("profile=True measures the phases one after the other: use overlap=False")
         import time
@@ -309,21 +315,27 @@ class ShardedEmbeddingCache:
         tok = torch.as_tensor(input_ids)
         if tok.dim() == 1:
             tok = tok.unsqueeze(0)
-        tok = t._tok(tok)
         if not overlap:
-            return self._gather_begin(tok, 0, time.perf_counter() if self._prof is not None else 0.0)
+            return self._gather_begin(t._tok(tok), 0, time.perf_counter() if self._prof is not None else 0.0)
         slot = self._slot_next
         self._slot_next ^= 1
-        if not tok.is_cuda:                                   # stand-in tables of the CPU tests: two slots, no streams
-            return self._gather_begin(tok, slot, 0.0)
+        dev = getattr(t, "device", None)
+        if dev is None or torch.device(dev).type != "cuda":   # stand-in tables of the CPU tests: two slots, no streams
+            return self._gather_begin(t._tok(tok), slot, 0.0)
         if self._side is None:
-            self._side = torch.cuda.Stream(device=tok.device)
+            self._side = torch.cuda.Stream(device=dev)
         side = self._side
-        side.wait_stream(torch.cuda.current_stream())
+        if tok.is_cuda:
+            if isinstance(tokens_ready, str):
+                if tokens_ready != "current":
+                    raise ValueError("tokens_ready must be an event, None or 'current'")
+                side.wait_stream(torch.cuda.current_stream())
+            elif tokens_ready is not None:
+                side.wait_event(tokens_ready)
         if self._slot_done[slot] is not None:                 # the slot's buffers are free once ITS last batch has been reduced
             side.wait_event(self._slot_done[slot])
         with torch.cuda.stream(side):
-            ticket = self._gather_begin(tok, slot, 0.0)
+            ticket = self._gather_begin(t._tok(tok), slot, 0.0)   # host tokens are uploaded here, on the side stream
             ticket["ready"] = torch.cuda.Event()
             ticket["ready"].record(side)
         return ticket
@@ -399,6 +411,7 @@ class ShardedEmbeddingCache:
         cur = torch.cuda.current_stream() if tok.is_cuda else None
         if ticket["ready"] is not None:                                  # begun on the side stream
             cur.wait_event(ticket["ready"])
+            tok.record_stream(cur)                                       # (allocated there, read here)
         t.shard_select_slot(ticket["slot"])
         if out is None:
             out = torch.empty((B * T, d), dtype=out_dtype, device=tok.device)

@@ -125,6 +125,18 @@ def _worker_split_phase(rank, world, port, fmt, d, max_n, head, chunks, q):
             ticket = sh.gather_rows_begin(torch.from_numpy(batches[i + 1])) if i + 1 < len(batches) else None
         torch.cuda.synchronize()
         same = all(bool(torch.equal(o, full.embed_tokens(torch.from_numpy(b), wte=wte_d, wpe=wpe_d))) for o, b in zip(outs, batches))
+        # device tokens: produced on the caller's stream (default: the side stream waits for that stream), or with the
+        # producer's event / nothing to wait for
+        dev = [torch.from_numpy(b).cuda() for b in batches[:3]]
+        ev = torch.cuda.Event()
+        ev.record()
+        outs2 = []
+        ticket = sh.gather_rows_begin(dev[0])
+        for i, ready in enumerate((ev, None, "current")):
+            outs2.append(sh.gather_rows_finish(ticket, wte=wte_d, wpe=wpe_d))
+            ticket = sh.gather_rows_begin(dev[i + 1], tokens_ready=ready) if i + 1 < 3 else None
+        torch.cuda.synchronize()
+        same = same and all(bool(torch.equal(a, b)) for a, b in zip(outs2, outs[:3]))
         # the one-call form still works afterwards (slot 0, current stream)
         again = bool(torch.equal(sh.embed_tokens(torch.from_numpy(batches[2]), wte=wte_d, wpe=wpe_d, exchange="gather_rows"), outs[2]))
         q.put((rank, same and again, "", tuple(outs[0].shape), None))

@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--check", action="store_true")
     ap.add_argument("--head", type=int, default=0, help="replicated head: global rows [0, head) kept on every shard")
     ap.add_argument("--chunks", type=int, default=1, help="gather_rows: chunks of the pipelined exchange (1 = one shot)")
+    ap.add_argument("--side-high-priority", action="store_true", help="--wall: the split-phase loop's side stream gets high priority")
     ap.add_argument("--wall", action="store_true",
                     help="gather_rows: also time rank 0's whole step back to back (no phase synchronisation): the local "
                          "critical path including launch gaps and the plan's one host synchronisation")
@@ -315,12 +316,13 @@ def gather_rows_chunked(a, shards, tok, wte, wpe, out, res, keys, lens):
         res["rank0_whole_step_wall_ms"] = {"min": min(walls), "median": sorted(walls)[len(walls) // 2], "max": max(walls)}
         # ... and as the split-phase loop issues it (gather_rows_begin of batch b + 1 on a side stream, on the other plan
         # slot, while batch b is reduced on the main stream)
-        side = torch.cuda.Stream()
+        side = torch.cuda.Stream(priority=-1 if a.side_high_priority else 0)
         fulls = [full, full.clone()]
         done = [None, None]
 
         def begin(slot):
-            side.wait_stream(torch.cuda.current_stream())
+            # (no wait for the caller's stream: the tokens of the next batch are ready long before -- gather_rows_begin(...,
+            # tokens_ready=None); waiting for the current stream would put the plan BEHIND the reduction queued just before)
             if done[slot] is not None:
                 side.wait_event(done[slot])
             with torch.cuda.stream(side):
@@ -365,6 +367,7 @@ def gather_rows_chunked(a, shards, tok, wte, wpe, out, res, keys, lens):
         loop(n)
         torch.cuda.synchronize()
         res["rank0_split_phase_loop_ms_per_step"] = (time.perf_counter() - t0) * 1e3 / n
+        res["side_stream_high_priority"] = bool(a.side_high_priority)
         s.shard_select_slot(0)
         if a.check:
             full_c = SconeTable(3, N, d, a.format)

@@ -269,7 +269,7 @@ class EmbeddingCache:
     def embed_tokens(self, input_ids: torch.Tensor, *, reduce: str = "mean", wte: Optional[torch.Tensor] = None,
                      wpe: Optional[torch.Tensor] = None, position_ids: Optional[torch.Tensor] = None,
                      out_dtype: Optional[torch.dtype] = None, out: Optional[torch.Tensor] = None,
-                     check: bool = False) -> torch.Tensor:
+                     check: bool = False, base: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Fused lookup for ``input_ids [B, T]`` -> ``[B, T, d]``:
 
             out[b, t] = (wte[input_ids[b, t]] + reduce_k row(f_gram_k)) + wpe[position_ids[b, t]]
@@ -279,7 +279,26 @@ class EmbeddingCache:
         ``SconeLanguageModel.forward`` (language_model.py:239-254) with the bias-free
         projection folded into the table.  ``check=True`` synchronises and raises
         ``IndexError`` for token / position ids outside ``wte`` / ``wpe``.
+
+        ``base [B, T, d]`` instead of ``wte`` / ``wpe``: a dense tensor the caller has already computed (the
+        ``inputs_embeds`` of language_model.py:239-243, say) -- ``out = base + reduce_k row(f_gram_k)``, one rounding to
+        ``out_dtype`` (default: ``base``'s dtype); the match produces CSR lists and ``scone_gather_reduce`` consumes them.
         """
+        if base is not None:
+            if wte is not None or wpe is not None or position_ids is not None or out is not None:
+                raise ValueError("base= replaces wte / wpe / position_ids (and takes no out=)")
+            table = self.to_device()
+            tok = torch.as_tensor(input_ids)
+            if tok.dim() == 1:
+                tok = tok.unsqueeze(0)
+            B, T = tok.shape
+            if tuple(base.shape) != (B, T, self.embedding_dim):
+                raise ValueError(f"base must be [{B}, {T}, {self.embedding_dim}]")
+            if out_dtype is None:
+                out_dtype = base.dtype
+            offsets, ids = table.match_csr(tok)
+            return table.gather_reduce(offsets, ids, reduce, base=base.reshape(B * T, self.embedding_dim),
+                                       out_dtype=out_dtype).view(B, T, self.embedding_dim)
         table = self.to_device()
         result = table.embed(torch.as_tensor(input_ids), wte=wte, wpe=wpe, position_ids=position_ids, reduce=reduce,
                              out_dtype=out_dtype, out=out)

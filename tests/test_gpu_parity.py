@@ -1657,6 +1657,40 @@ def test_gather_reduce_csr_entry_point(fmt, d):
         assert np.array_equal(got, R.embed_numpy(deq, off_b, bad[keep], "sum"))
 
 
+@pytest.mark.parametrize("fmt", ["fp32", "int8", "int4"])
+def test_embed_tokens_with_a_dense_base_vs_oracle(fmt):
+    """embed_tokens(base=[B, T, d]) (SURVEY 8b's additive API: the caller's own inputs_embeds): base + mean of the rows, fp32
+    bit-exact against the oracle on the dequantised table, fp16 within 1e-3; and equal to wte[tok] passed as the base."""
+    from scone_amd import EmbeddingCache
+    rng = np.random.default_rng(12)
+    vocab, n, d, max_n = 40, 900, 1024, 3
+    lens = rng.integers(1, max_n + 1, size=n).astype(np.uint8)
+    keys = rng.integers(0, vocab, size=(n, max_n)).astype(np.uint32)
+    keys[np.arange(max_n)[None, :] >= lens[:, None]] = 0
+    ex = _extractor(keys, lens, max_n)
+    keys, lens = ex.key_arrays()
+    table = (rng.standard_normal((len(lens), d)) * 0.3).astype(np.float32)
+    cache = EmbeddingCache(ex, d, table_format=fmt)
+    cache.cache_embeddings(list(range(len(lens))), torch.from_numpy(table), verbose=False)
+    deq = {"fp32": table, "int8": R.dequantize_i8(*R.quantize_i8(table)), "int4": R.dequantize_i4(*R.quantize_i4(table))}[fmt]
+    B, T = 6, 37
+    tok = rng.integers(0, vocab + 2, size=(B, T))
+    base = rng.standard_normal((B, T, d)).astype(np.float32)
+    ro, ri = R.hits_to_csr(R.match_hits(keys, lens, tok, max_n))
+    fg = R.embed_numpy(deq, ro, ri, "mean").reshape(B, T, d)
+    got = cache.embed_tokens(torch.from_numpy(tok), base=torch.from_numpy(base).cuda())
+    assert got.dtype == torch.float32 and np.array_equal(got.cpu().numpy(), base + fg)
+    got16 = cache.embed_tokens(torch.from_numpy(tok), base=torch.from_numpy(base).cuda().half())
+    assert got16.dtype == torch.float16
+    assert _rel(got16.float().cpu().numpy(), torch.from_numpy(base).half().float().numpy() + fg) < REL_TOL
+    sums = cache.embed_tokens(torch.from_numpy(tok), base=torch.zeros(B, T, d).cuda(), reduce="sum")
+    assert np.array_equal(sums.cpu().numpy(), R.embed_numpy(deq, ro, ri, "sum").reshape(B, T, d))
+    with pytest.raises(ValueError):
+        cache.embed_tokens(torch.from_numpy(tok), base=torch.zeros(B, T, d + 8).cuda())
+    with pytest.raises(ValueError):
+        cache.embed_tokens(torch.from_numpy(tok), base=torch.zeros(B, T, d).cuda(), wte=torch.zeros(vocab + 2, d).cuda())
+
+
 def test_one_handle_from_two_host_threads():
     """Batches that take the one-launch kernel touch no handle state: two host threads, each on its own HIP stream,
     hammer ONE handle concurrently; every result equals the single-threaded answer."""

@@ -442,7 +442,10 @@ def sharded_record(args, dist, rank, world, backend, sync, rec=None):
       rows+all_gather   all-to-all of the quantised rows each slice needs, rank r reduces slice r, all-gather of the
                         finished fp16 vectors (the north-star's wording)
       gather_rows       all-gather of the DISTINCT quantised rows the batch references, every rank reduces the whole batch;
-                        pipelined over `gather_chunks` chunks of sequences (gather_rows_one_shot: the same in one piece)
+                        pipelined over `gather_chunks` chunks of sequences (gather_rows_one_shot: the same in one piece);
+                        the records travel as exact point-to-point ranges (batch_isend_irecv: one RCCL group, each link
+                        carries one peer's records) -- gather_rows_padded_all_gather: through all_gather_into_tensor
+                        instead, every contribution padded to the largest
     and, for contrast, rows_slices_only: the all-to-all alone, every rank keeps its own slice (a consumer that is
     data-parallel over the same slices needs no more); last, gather_rows_split_phase: the serving-loop form of gather_rows
     (ShardedEmbeddingCache.gather_rows_begin / _finish, one piece, two batches in flight: plan, pack and transfers of step
@@ -492,9 +495,13 @@ def sharded_record(args, dist, rank, world, backend, sync, rec=None):
     for name, kw in (("rows+all_gather", {"exchange": "rows", "gather_output": True}),
                      ("gather_rows", {"exchange": "gather_rows", "gather_output": True}),
                      ("gather_rows_one_shot", {"exchange": "gather_rows", "gather_output": True}),
+                     ("gather_rows_padded_all_gather", {"exchange": "gather_rows", "gather_output": True}),
                      ("rows_slices_only", {"exchange": "rows", "gather_output": False})):
         try:
             cache.gather_chunks = 1 if name == "gather_rows_one_shot" else chunks
+            # the records travel as exact point-to-point ranges; ..._padded_all_gather: all_gather_into_tensor, every
+            # contribution padded to the largest (twice the mean on this workload at 8 ranks)
+            cache.gather_transport = "all_gather" if name == "gather_rows_padded_all_gather" else "p2p"
             out = cache.embed_tokens(tok, wte=wte, wpe=wpe, **kw)                  # warm-up (allocations, RCCL channels)
             out = cache.embed_tokens(tok, wte=wte, wpe=wpe, **kw)
             sync()
@@ -546,7 +553,8 @@ def sharded_record(args, dist, rank, world, backend, sync, rec=None):
     except Exception as e:
         rec["exchanges"]["gather_rows_split_phase"] = {"error": repr(e)}
     cache.gather_chunks = chunks
-    if len(checks) == 3:                                # all bit-identical to the unsharded table, hence to each other
+    cache.gather_transport = "p2p"
+    if len(checks) == 4:                                # all bit-identical to the unsharded table, hence to each other
         rec["exchanges_agree"] = bool(len(set(checks.values())) == 1)
     rec["gather_chunks"] = chunks
     rec["n1_baseline"] = ("the N = 1 line's `sharded.n1_pinned_host` (one GPU cannot hold this table: rows in pinned host DRAM, "

@@ -257,7 +257,7 @@ class OracleShard:
         return x
 
 
-def _worker(rank, world, port, ntok_shape, out_dtype_name, exchange, q, chunks=4, head=0):
+def _worker(rank, world, port, ntok_shape, out_dtype_name, exchange, q, chunks=4, head=0, transport="p2p"):
     try:
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -283,7 +283,7 @@ def _worker(rank, world, port, ntok_shape, out_dtype_name, exchange, q, chunks=4
         if head:
             shard.shard_set_head(head)
         cache = ShardedEmbeddingCache(ex, d, rank=rank, world=world, n_rows=n, table=shard, replicated_rows=head,
-                                      gather_chunks=max(chunks, 1))
+                                      gather_chunks=max(chunks, 1), gather_transport=transport)
         assert (cache.row_begin, cache.row_end) == (a, b)
         out = cache.embed_tokens(tok, wte=wte.to(out_dtype), wpe=wpe.to(out_dtype), out_dtype=out_dtype,
                                  exchange=exchange)
@@ -328,17 +328,38 @@ def test_sharded_exchange_world2_gloo(shape, dtype, exchange):
         assert ok_slice
 
 
-@pytest.mark.parametrize("chunks,head", [(0, 0), (1, 0), (2, 40), (3, 0), (8, 25)])
-def test_gather_rows_chunked_pipeline_world2_gloo(chunks, head):
+@pytest.mark.parametrize("chunks,head,transport", [(0, 0, "p2p"), (1, 0, "p2p"), (2, 40, "p2p"), (3, 0, "p2p"), (8, 25, "p2p"),
+                                                   (1, 0, "all_gather"), (2, 40, "all_gather"), (8, 25, "all_gather")])
+def test_gather_rows_chunked_pipeline_world2_gloo(chunks, head, transport):
     """The pipelined all-gather form: one plan with a claim pass per chunk (a row sent by an earlier chunk is not sent
-    again), per-chunk all-gathers padded to the largest contribution (padding records skipped), records added and
-    sequences reduced chunk by chunk -- same output as the unsharded table for any chunk count (0 = the one-shot form),
-    with and without a replicated head."""
+    again); the records of a chunk travel as exact point-to-point ranges (``p2p``: every rank's contribution at its own
+    size) or through per-chunk all-gathers padded to the largest contribution (``all_gather``: padding records skipped);
+    records added and sequences reduced chunk by chunk -- same output as the unsharded table for any chunk count (0 = the
+    one-shot form), with and without a replicated head."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
     shape = (5, 13)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, shape, "float32", "gather_rows", q, chunks, head)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, shape, "float32", "gather_rows", q, chunks, head, transport))
+             for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, err, out_shape, ok_slice in results:
+        assert isinstance(err, float), f"rank {rank} failed: {err}"
+        assert out_shape == (shape[0], shape[1], 32) and err < 1e-6 and ok_slice
+
+
+@pytest.mark.parametrize("transport", ["p2p", "all_gather"])
+def test_gather_rows_world3_gloo(transport):
+    """Three ranks: with ``p2p`` every rank sends its records to two peers and receives two ranges of different sizes."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    shape = (4, 19)
+    procs = [ctx.Process(target=_worker, args=(r, 3, port, shape, "float32", "gather_rows", q, 2, 20, transport)) for r in range(3)]
     for p in procs:
         p.start()
     results = [q.get(timeout=180) for _ in procs]

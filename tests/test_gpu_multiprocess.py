@@ -56,7 +56,9 @@ def _worker(rank, world, port, fmt, d, max_n, exchange, head, q):
         from scone_amd.distributed import ShardedEmbeddingCache
         keys, lens, table, tok, wte, wpe = _problem(fmt, d, max_n)
         ex = NGramExtractor.from_arrays(keys, lens, max_n=max_n)
-        sh = ShardedEmbeddingCache(ex, d, table_format=fmt, rank=rank, world=world, replicated_rows=head)
+        exchange, _, transport = exchange.partition(":")          # "gather_rows:all_gather" = the padded all-gather transport
+        sh = ShardedEmbeddingCache(ex, d, table_format=fmt, rank=rank, world=world, replicated_rows=head,
+                                   gather_transport=transport or "p2p")
         sh.load_rows(torch.from_numpy(table), 0)
         wte_d, wpe_d = torch.from_numpy(wte).half().cuda(), torch.from_numpy(wpe).half().cuda()
         got = sh.embed_tokens(torch.from_numpy(tok), wte=wte_d, wpe=wpe_d, exchange=exchange)
@@ -78,6 +80,7 @@ def _worker(rank, world, port, fmt, d, max_n, exchange, head, q):
 @pytest.mark.parametrize("fmt,d,max_n,world,exchange,head", [("int8", 768, 3, 2, "rows", 0), ("int4", 1024, 4, 3, "rows", 100),
                                                              ("int8", 768, 3, 3, "gather_rows", 0),
                                                              ("int4", 1024, 4, 2, "gather_rows", 100),
+                                                             ("int4", 1024, 3, 3, "gather_rows:all_gather", 100),
                                                              ("int8", 768, 3, 2, "partial_sums", 0),
                                                              ("int4", 1024, 3, 3, "rows_per_reference", 100)])
 def test_sharded_cache_across_processes_on_one_gpu(fmt, d, max_n, world, exchange, head):
@@ -95,7 +98,7 @@ def test_sharded_cache_across_processes_on_one_gpu(fmt, d, max_n, world, exchang
     for rank, same, err, shape, sl_shape in results:
         assert shape is not None, f"rank {rank} failed: {err}"
         assert shape == (5, 33, d)
-        if exchange in ("rows", "rows_per_reference", "gather_rows"):
+        if exchange.partition(":")[0] in ("rows", "rows_per_reference", "gather_rows"):
             assert same, f"rank {rank}: row exchange must be bit-identical to the unsharded table (rel err {err})"
         else:
             assert err < 1e-3, (rank, err)          # fp32 partial sums are added in shard order, not list order
@@ -204,7 +207,7 @@ def _check_sharded_record(rec, world):
     wire bytes are there, and they produced the same output."""
     assert "error" not in rec, rec
     assert rec["world_size"] == world and rec["device_count"] >= 1 and "n1_baseline" in rec
-    for name in ("rows+all_gather", "gather_rows", "gather_rows_one_shot", "rows_slices_only"):
+    for name in ("rows+all_gather", "gather_rows", "gather_rows_one_shot", "gather_rows_padded_all_gather", "rows_slices_only"):
         e = rec["exchanges"][name]
         assert "error" not in e, e
         assert e["ms_per_step"] > 0 and e["tokens_per_s"] > 0 and e["wire_bytes_received_rank0"] > 0
@@ -258,10 +261,12 @@ def _nccl_worker(rank, world, port, q):
             full = EmbeddingCache(ex, d, table_format=fmt)
             full.cache_embeddings(list(range(len(lens))), torch.from_numpy(table), verbose=False)
             ref = full.embed_tokens(torch.from_numpy(tok), wte=wte_d, wpe=wpe_d)
-            for exchange in ("rows", "rows_per_reference", "gather_rows", "partial_sums"):
-                got = sh.embed_tokens(torch.from_numpy(tok), wte=wte_d, wpe=wpe_d, exchange=exchange)
+            for exchange in ("rows", "rows_per_reference", "gather_rows", "gather_rows:all_gather", "partial_sums"):
+                sh.gather_transport = exchange.partition(":")[2] or "p2p"       # records as exact point-to-point ranges / padded all-gather
+                got = sh.embed_tokens(torch.from_numpy(tok), wte=wte_d, wpe=wpe_d, exchange=exchange.partition(":")[0])
                 err = float((got.float() - ref.float()).abs().max() / ref.float().abs().max())
                 res.append((fmt, exchange, bool(torch.equal(got, ref)), err))
+            sh.gather_transport = "p2p"
             # the split-phase loop: two batches in flight, the second one's transfers behind the first one's reduction
             tk = sh.gather_rows_begin(torch.from_numpy(tok))
             for i in range(3):

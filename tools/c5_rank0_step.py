@@ -1,0 +1,140 @@
+#!/usr/bin/env python3
+"""Rank 0's local step of the C5 exchange at C5's TRUE scale, on one GPU: shard 0 of the 1e9-row INT4 d = 1024 table
+(125M rows = 66 GB) with the full replicated 1e9-key index (2^31 slots, 34 GB) and the replicated unigram head, a
+1M-token S_uniform batch, `exchange="gather_rows"` in one piece.  The records of the other seven ranks cannot be produced
+here (their rows are not on this GPU), but everything rank 0 does with them can be timed: they are laid out in the
+all-gather's receive buffer with the RIGHT row ids (every distinct non-head row of ranks 1..7 that the batch references,
+grouped by owner, padded like the all-gather pads) and zero payloads -- the lookup reads the same bytes from the same
+places, only the values differ.
+
+Prints rank 0's step (a) issued back to back on one stream and (b) as the split-phase loop issues it
+(gather_rows_begin of the next batch on a side stream / second plan slot behind gather_rows_finish of this one), in ms.
+tools/shard_emulate.py does the same for ALL eight ranks of a 100M-row table, with real payloads and the bit-exactness check.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from scone_amd import synthetic as S
+from scone_amd.distributed import ShardedEmbeddingCache
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rows", type=int, default=1_000_000_000)
+    ap.add_argument("--world", type=int, default=8)
+    ap.add_argument("--batch", type=int, default=2048)
+    ap.add_argument("--seq", type=int, default=512)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--padded", action="store_true", help="the padded all-gather's receive layout instead of exact ranges")
+    a = ap.parse_args()
+    N, W, d, B, T = a.rows, a.world, 1024, a.batch, a.seq
+    vocab = S.StructuredVocab(N)
+    t0 = time.perf_counter()
+    cache = ShardedEmbeddingCache.from_synthetic(vocab, d, table_format="int4", seed=7, base_scale=0.02 / 127, rank=0, world=W,
+                                                 replicated_rows=S.GPT2_VOCAB, n_rows=N)
+    torch.cuda.synchronize()
+    build_s = time.perf_counter() - t0
+    s = cache.table
+    tok = torch.from_numpy(S.stream_uniform_ids(vocab, None, B, T, 1234)).to("cuda", torch.int32)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    wte = (torch.randn(S.GPT2_VOCAB, d, generator=g, device="cuda") * 0.02).half()
+    wpe = (torch.randn(1024, d, generator=g, device="cuda") * 0.01).half()
+    out = torch.empty((B * T, d), dtype=torch.float16, device="cuda")
+    rec = s.shard_record_bytes()
+    per = N // W
+    # what the other ranks contribute: the distinct rows outside my range (and outside the head) the batch references
+    _, ids = s.match_csr(tok)
+    other = torch.unique(ids[ids >= cache.row_end].to(torch.int64))
+    owner = torch.div((other + 1) * W - 1, N, rounding_mode="floor")
+    counts = [int((owner == r).sum().item()) for r in range(W)]
+    mine = s.shard_gather_plan_chunks(tok, 1)[0]
+    counts[0] = mine
+    # receive-buffer layout: exact point-to-point ranges back to back (the default transport), or -- --padded -- every
+    # contribution padded to the largest as all_gather_into_tensor needs
+    size = [max(counts)] * W if a.padded else counts
+    offs = [0]
+    for r in range(W):
+        offs.append(offs[-1] + size[r])
+    total = offs[-1]
+    full = torch.zeros((total, rec), dtype=torch.uint8, device="cuda")
+    hdr = full.view(torch.int32).view(total, rec // 4)
+    hdr[:, rec // 4 - 2] = -1                                            # every record is padding ...
+    hdr[:, rec // 4 - 1] = -1
+    for r in range(1, W):
+        rows_r = other[owner == r]
+        hdr[offs[r]:offs[r] + rows_r.numel(), rec // 4 - 2] = rows_r.to(torch.int32)     # ... except the real ones: row id
+    del ids, other, owner
+    fulls = [full, full.clone()]
+    maxc = size[0]
+
+    def begin(slot):
+        s.shard_select_slot(slot)
+        n = s.shard_gather_plan_chunks(tok, 1)[0]
+        s.shard_gather_pack_range(0, n, fulls[slot][:maxc])
+
+    def finish(slot):
+        s.shard_select_slot(slot)
+        s.shard_gather_add_records(fulls[slot][:total], 0, total)
+        s.shard_gather_embed_range(tok, 0, B, fulls[slot][:total], out, wte=wte, wpe=wpe)
+
+    for _ in range(3):
+        begin(0)
+        finish(0)
+    torch.cuda.synchronize()
+    assert s.status() == 0, "a referenced row is missing from the synthesised records"
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        begin(0)
+        finish(0)
+    torch.cuda.synchronize()
+    one_stream = (time.perf_counter() - t0) * 1e3 / a.steps
+
+    side = torch.cuda.Stream()
+    done = [None, None]
+
+    def begin_side(slot):
+        if done[slot] is not None:
+            side.wait_event(done[slot])
+        with torch.cuda.stream(side):
+            begin(slot)
+            ready = torch.cuda.Event()
+            ready.record(side)
+        return slot, ready
+
+    def finish_main(ticket):
+        slot, ready = ticket
+        cur = torch.cuda.current_stream()
+        cur.wait_event(ready)
+        finish(slot)
+        done[slot] = torch.cuda.Event()
+        done[slot].record(cur)
+
+    def loop(n):
+        slot = 0
+        tk = begin_side(slot)
+        for i in range(n):
+            finish_main(tk)
+            slot ^= 1
+            tk = begin_side(slot) if i + 1 < n else None
+    loop(4)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    loop(a.steps)
+    torch.cuda.synchronize()
+    split = (time.perf_counter() - t0) * 1e3 / a.steps
+    assert s.status() == 0
+    print(json.dumps({"rows": N, "world": W, "rank": 0, "tokens": B * T, "build_s": build_s, "records_per_rank": counts,
+                      "layout": "padded to the largest contribution" if a.padded else "exact ranges",
+                      "bytes_into_rank0": int((total - size[0]) * rec),
+                      "rank0_step_one_stream_ms": one_stream, "rank0_step_split_phase_loop_ms": split,
+                      "note": "other ranks' records carry the right row ids and zero payloads"}))
+
+
+if __name__ == "__main__":
+    main()

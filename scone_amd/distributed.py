@@ -27,8 +27,10 @@ here and only needed when the table does not fit one GPU's 288 GB (BASELINE conf
   aggregated vectors), gathering the 2 KB fp16 vector of every token costs four times the bytes of gathering the
   quantised ROWS the batch references, and every DISTINCT row crosses once however many tokens reference it:
   ``scone_shard_gather_plan`` claims the distinct rows this rank owns that the batch references, ``scone_shard_gather_pack``
-  writes one record ``[row | scales | row id]`` per claimed row, ONE all-gather of records (padded to the largest
-  contribution), and ``scone_shard_gather_embed`` indexes them by row id and reduces the whole batch out of
+  writes one record ``[row | scales | row id]`` per claimed row, the records of all ranks are gathered -- as exact
+  point-to-point ranges (``gather_transport="p2p"``: one ``batch_isend_irecv``, each xGMI link carries one peer's records) or
+  through ``all_gather_into_tensor`` with every contribution padded to the largest (``"all_gather"``) -- and
+  ``scone_shard_gather_embed`` indexes them by row id and reduces the whole batch out of
   ``[replicated head | gathered records]`` -- bit-identical again, ~0.25 GB into every rank per 1M-token step instead
   of ~1.9 GB;
 * split-phase form of ``"gather_rows"`` for a serving loop: ``gather_rows_begin`` (plan, packs, transfers -- on a side stream,

@@ -492,11 +492,13 @@ def sharded_record(args, dist, rank, world, backend, sync, rec=None):
            "build_s": t_build, "note": note, "exchanges": {}})
     checks = {}
     chunks = cache.gather_chunks
+    # order: the plainest collectives first (all_to_all_single, all_gather_into_tensor), the batched point-to-point
+    # transport after them -- should one of them hang under RCCL, the watchdog still prints everything measured before it
     for name, kw in (("rows+all_gather", {"exchange": "rows", "gather_output": True}),
-                     ("gather_rows", {"exchange": "gather_rows", "gather_output": True}),
-                     ("gather_rows_one_shot", {"exchange": "gather_rows", "gather_output": True}),
+                     ("rows_slices_only", {"exchange": "rows", "gather_output": False}),
                      ("gather_rows_padded_all_gather", {"exchange": "gather_rows", "gather_output": True}),
-                     ("rows_slices_only", {"exchange": "rows", "gather_output": False})):
+                     ("gather_rows", {"exchange": "gather_rows", "gather_output": True}),
+                     ("gather_rows_one_shot", {"exchange": "gather_rows", "gather_output": True})):
         try:
             cache.gather_chunks = 1 if name == "gather_rows_one_shot" else chunks
             # the records travel as exact point-to-point ranges; ..._padded_all_gather: all_gather_into_tensor, every

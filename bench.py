@@ -526,6 +526,9 @@ def sharded_record(args, dist, rank, world, backend, sync, rec=None):
                 "steps": args.sharded_steps,
                 "phase_ms_slowest_rank": {k: float(v) for k, v in zip(sorted(phases), ph.tolist()) if not k.startswith("bytes")},
                 "wire_bytes_received_rank0": int(phases.get("bytes_received", 0)),
+                "chunks": cache.gather_chunks if kw["exchange"] == "gather_rows" else None,
+                "records_transport": ({"p2p": "batch_isend_irecv, exact ranges", "all_gather": "all_gather_into_tensor, padded"}
+                                      [cache.gather_transport] if kw["exchange"] == "gather_rows" else "all_to_all_single"),
             }
         except Exception as e:                                                        # the record never takes the line down
             rec["exchanges"][name] = {"error": repr(e)}
@@ -549,7 +552,8 @@ def sharded_record(args, dist, rank, world, backend, sync, rec=None):
         dt = float(tm.item())
         rec["exchanges"]["gather_rows_split_phase"] = {
             "ms_per_step": dt / args.sharded_steps * 1e3, "tokens_per_s": ntok * args.sharded_steps / dt,
-            "steps": args.sharded_steps, "batches_in_flight": 2,
+            "steps": args.sharded_steps, "batches_in_flight": 2, "chunks": 1,
+            "records_transport": "batch_isend_irecv, exact ranges",
             "same_output_as_gather_rows": bool(float(out.float().abs().sum().item()) == checks.get("gather_rows")),
         }
     except Exception as e:

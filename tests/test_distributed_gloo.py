@@ -430,6 +430,19 @@ def test_gather_rows_split_phase_two_batches_in_flight_world2_gloo():
         assert err < 1e-6 and same
 
 
+def test_gather_transport_is_validated():
+    from scone_amd import NGramExtractor
+    from scone_amd.distributed import ShardedEmbeddingCache
+    keys = np.array([[1, 0, 0], [2, 3, 0]], dtype=np.uint32)
+    lens = np.array([1, 2], dtype=np.uint8)
+    ex = NGramExtractor.from_arrays(keys, lens, max_n=3)
+    shard = OracleShard(keys, lens, 3, np.zeros((2, 8), dtype=np.float32), 0, 2)
+    with pytest.raises(ValueError):
+        ShardedEmbeddingCache(ex, 8, rank=0, world=1, n_rows=2, table=shard, gather_transport="ring")
+    c = ShardedEmbeddingCache(ex, 8, rank=0, world=1, n_rows=2, table=shard, gather_transport="all_gather")
+    assert c.gather_transport == "all_gather" and c.gather_chunks == 4
+
+
 def test_load_rows_stores_owned_range_and_replicated_head():
     """ShardedEmbeddingCache.load_rows: every rank keeps its own row range and, with replicated_rows, the head of
     the table, whatever chunking the rows arrive in (no process group needed: rank / world are given)."""

@@ -16,22 +16,35 @@ which starts the N ranks itself (fresh child processes, before this process touc
 fails unless the line it forwards says n_gpus == N.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with
-  roofline      the gather/reduce kernel, HIP-event timed on its launch stream: algorithmic GB/s and its
-                fraction of the 8 TB/s HBM peak, min / median / max launch time, the compulsory-byte lower bound and the
-                PMC upper bound on what really came from HBM (`hbm_frac`, `traffic_frac`), and the same figures for a
-                cache-defeating variant of the workload (`hbm_variant`: 10M rows, token ids uniform over the vocabulary)
-  cpu_baseline  the line-for-line Python port of the reference loop (oracle/ref_port.py), 1 core; beside it the same
-                port on all host cores (multiprocessing over sequences) and the plain-C oracle with OpenMP
+  roofline      the gather/reduce kernel, HIP-event timed on its launch stream.  `frac` is a PHYSICAL fraction of the
+                8 TB/s HBM peak, never above 1: the bytes that left L2 (committed rocprofv3 PMC passes, quoted only while
+                the kernel's sources are the ones they were taken on) / kernel time / peak -- or, without such an entry,
+                the compulsory bytes (every distinct row once + output + ids).  SURVEY 8d's algorithmic figure (every
+                row REFERENCE counted; cache reuse can carry it past the peak) is `algorithmic_frac`.  Also: min /
+                median / max launch time, `match_us`, and the same figures for a cache-defeating variant (`hbm_variant`)
+  cpu_baseline  the line-for-line Python port of the reference loop (oracle/ref_port.py), 1 core; at N = 1 beside it the
+                same port on all host cores (multiprocessing over sequences) and the plain-C oracle with OpenMP; the GPU
+                output of 8 sequences drawn from the whole batch is checked against it
   sharded       N > 1: the row-sharded path on the C5-shaped workload (INT4 d = 1024, 125M rows per rank, replicated
-                index, 1M-token batch) for both exchanges, with the phase split, wire bytes and RCCL facts;
-                N = 1: the single-GPU way to serve a table that does not fit HBM (pinned host DRAM, C4-shaped) -- the
-                baseline the north-star's ">= 4x at 8 GPUs" is computed against
+                index, 1M-token batch) for every exchange, each with phase split, wire bytes, a roofline block (per-rank
+                HBM bytes / step / 8 TB/s; wire bytes / collective time / xGMI peak) and `speedup_vs_n1_pinned_host`:
+                rank 0 measures the single-GPU alternative (pinned host DRAM, C4-shaped) in the same process, so the
+                north-star's ">= 4x at 8 GPUs vs 1 GPU" is readable from ONE record.  N = 1: that baseline alone, on the
+                S_uniform stream (rows read in place over PCIe) and on a Zipf stream (staged, de-duplicated prefetch)
+
+Time budget.  `--time-budget S` (default 420 s, inside the driver's 600 s) is ABSOLUTE, from the start of the first
+process of the job.  A watchdog thread on every rank enforces it and the per-stage limits inside it (every collective
+of the `sharded` record runs in a stage): on expiry rank 0 prints the line with everything measured so far -- marked
+`incomplete` -- and every rank leaves through os._exit (a hung RCCL collective cannot be cancelled; no process that
+touched the GPU is ever replaced by another program).  The exit status is 0 when the headline metric was measured
+(the line is valid; the record says what is missing) and 3 when it was not.
 """
 
 import argparse
 import hashlib
 import json
 import os
+import re
 import socket
 import subprocess
 import sys
@@ -45,6 +58,10 @@ if ROOT not in sys.path:
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 HBM_PEAK_GBPS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# xGMI: 7 links per GPU, ~153.6 GB/s each counting both directions (task statement / DESIGN section 6) = 76.8 GB/s into a
+# GPU per link; a rank receives over min(W - 1, 7) links at once on the fully connected node
+XGMI_LINK_GBPS_PER_DIRECTION = 76.8
+T0_ENV = "SCONE_BENCH_T0"   # wall-clock start of the job's FIRST process: children of `self_launch` inherit the deadline
 
 
 def parse(argv=None):
@@ -85,9 +102,16 @@ def parse(argv=None):
     ap.add_argument("--sharded-rows-per-rank", type=int, default=125_000_000,
                     help="sharded record: table rows per rank (C5: 1e9 rows over 8 GPUs)")
     ap.add_argument("--sharded-steps", type=int, default=5)
-    ap.add_argument("--pinned-rows", type=int, default=100_000_000, help="N = 1 sharded baseline: rows of the pinned-host table (C4)")
+    ap.add_argument("--pinned-rows", type=int, default=100_000_000, help="rows of the pinned-host table (C4) behind "
+                    "sharded.n1_pinned_host: the single-GPU baseline of the row-sharded record")
     ap.add_argument("--force-dist", action="store_true", help="init torch.distributed even with one rank (tests the N>1 code path)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--time-budget", type=float, default=420.0,
+                    help="absolute limit in seconds from the start of the job's first process (driver timeout: 600): when "
+                         "it is used up rank 0 prints the line with what has been measured and every rank exits")
+    ap.add_argument("--stage-limit", type=float, default=90.0,
+                    help="limit in seconds for one stage of the sharded record (one exchange with its collectives)")
+    ap.add_argument("--selftest", default="", choices=["", "hang", "ok"], help=argparse.SUPPRESS)   # CPU rehearsal of the watchdog
     a = ap.parse_args(argv)
     if a.quick:
         a.no_cpu_baseline = a.no_hbm_variant = a.no_sharded_record = True
@@ -95,62 +119,213 @@ def parse(argv=None):
 
 
 # ----------------------------------------------------------------------------------------------------------------
+# the time budget, the line, the watchdog
+class Budget:
+    """One absolute deadline for the whole job (wall clock, shared with the ranks `self_launch` starts)."""
+
+    def __init__(self, seconds: float) -> None:
+        self.t0 = float(os.environ.get(T0_ENV) or time.time())
+        self.seconds = float(seconds)
+        self.deadline = self.t0 + self.seconds
+
+    def remaining(self) -> float:
+        return self.deadline - time.time()
+
+    def used(self) -> float:
+        return time.time() - self.t0
+
+
+class Line:
+    """The one JSON line.  `publish` hands over the headline record; from then on every change of it (or of a dict hanging
+    off it) is made inside `with line.lock`, and `emit` serialises it inside the same lock -- the watchdog thread can print
+    at any moment without meeting a half-built dictionary.  Printed at most once."""
+
+    def __init__(self, rank: int) -> None:
+        self.lock = threading.RLock()
+        self.rank = rank
+        self.res = None
+        self.headline_done = False        # set on every rank once the timed region and its max-over-ranks are through
+        self.emitted = False
+
+    def publish(self, res) -> None:
+        with self.lock:
+            self.res = res
+
+    def set(self, d, key, value) -> None:
+        with self.lock:
+            d[key] = value
+
+    def emit(self, incomplete=None) -> bool:
+        with self.lock:
+            if self.emitted or self.res is None or self.rank != 0:
+                return False
+            if incomplete:
+                self.res["incomplete"] = incomplete
+            try:
+                text = json.dumps(self.res, default=str)
+            except Exception as e:          # never lose the headline to a value json cannot take
+                keep = {k: v for k, v in self.res.items() if isinstance(v, (str, int, float, bool, type(None)))}
+                keep["incomplete"] = f"{incomplete or ''} (record dropped: {e!r})"
+                text = json.dumps(keep)
+            try:                            # RCCL prints its banner through C stdio: flush it so the line comes last
+                import ctypes
+                ctypes.CDLL(None).fflush(None)
+            except Exception:
+                pass
+            sys.stdout.write(text + "\n")
+            sys.stdout.flush()
+            self.emitted = True
+            return True
+
+
+class Watchdog(threading.Thread):
+    """Enforces the job's deadline and the limit of the current stage.  On expiry: rank 0 prints the line (what was
+    measured so far, `incomplete` says why), then the process ends through os._exit -- status 0 if the headline was
+    measured, 3 if not.  The other ranks follow two seconds later with the same rule.  Nothing is restarted."""
+
+    def __init__(self, budget: Budget, line: Line, rank: int) -> None:
+        super().__init__(daemon=True, name="bench-watchdog")
+        self.budget, self.line, self.rank = budget, line, rank
+        self.stage = None                   # (name, deadline, limit)
+        self.grace = 0.0 if rank == 0 else 2.0
+
+    def arm(self, name: str, seconds: float) -> None:
+        self.stage = (name, time.time() + seconds, seconds)
+
+    def disarm(self) -> None:
+        self.stage = None
+
+    def run(self) -> None:
+        while True:
+            time.sleep(0.2)
+            now = time.time()
+            st = self.stage
+            if st is not None and now > st[1] + self.grace:
+                self.bail(f"stage '{st[0]}' did not complete within its {st[2]:.0f} s; what was measured before it is kept")
+            if now > self.budget.deadline + self.grace:
+                self.bail(f"time budget of {self.budget.seconds:.0f} s used up"
+                          + (f" in stage '{st[0]}'" if st else "") + "; what was measured until then is kept")
+
+    def bail(self, why: str) -> None:
+        code = 3
+        try:
+            code = 0 if self.line.headline_done else 3
+            sys.stderr.write(f"bench.py[rank {self.rank}]: {why}\n")
+            sys.stderr.flush()
+            self.line.emit(incomplete=why)
+        finally:
+            os._exit(code)
+
+
+# ----------------------------------------------------------------------------------------------------------------
 # `python bench.py --gpus N` without a launcher: start the N ranks here
-def self_launch(args) -> int:
-    """Spawn N fresh child processes (one rank per GPU) BEFORE this process touches a GPU -- nothing here calls into HIP,
-    and no process that has is ever replaced by another program.  Rank 0's stdout is captured; its last JSON line is
-    checked (n_gpus == N) and forwarded as this process's single output line."""
-    import torch                                   # device_count() does not initialise the GPU on this image
-    n = args.gpus
-    one_device = os.environ.get("SCONE_ONE_DEVICE") == "1"
-    have = torch.cuda.device_count()
-    if have < n and not one_device:
-        print(f"bench.py: --gpus {n} but only {have} HIP device(s) visible", file=sys.stderr)
-        return 2
+def _launch_once(args, n, deadline):
+    """One attempt: N fresh children, rank 0's stdout captured.  Returns (rcs, rank-0 stdout, seconds until the first exit)."""
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
+    t_start = time.time()
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out, _ = procs[0].communicate()
-    rcs = [procs[0].returncode]
-    for p in procs[1:]:
-        try:
-            rcs.append(p.wait(timeout=120))
-        except subprocess.TimeoutExpired:
-            p.kill()
-            rcs.append(-9)
+    out_box = {}
+    reader = threading.Thread(target=lambda: out_box.setdefault("out", procs[0].stdout.read()), daemon=True)
+    reader.start()                                           # drain the pipe while polling, or rank 0 blocks on a full one
+    first_exit = None
+    while True:
+        rcs = [p.poll() for p in procs]
+        if first_exit is None and any(rc is not None for rc in rcs):
+            first_exit = time.time() - t_start
+        if all(rc is not None for rc in rcs):
+            break
+        # a rank died with an error: the others would sit in their next collective until its own timeout
+        if any(rc not in (None, 0) for rc in rcs) or time.time() > deadline:
+            time.sleep(3.0)                                  # (ranks that are on their way out through the watchdog)
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            rcs = [p.wait() for p in procs]
+            break
+        time.sleep(0.2)
+    reader.join(timeout=10)
+    return rcs, out_box.get("out") or "", first_exit or 0.0
+
+
+def self_launch(args) -> int:
+    """Spawn N fresh child processes (one rank per GPU) BEFORE this process touches a GPU -- nothing here calls into HIP,
+    and no process that has is ever replaced by another program.  Rank 0's stdout is captured; its last JSON line is
+    checked (n_gpus == N) and forwarded as this process's single output line.  The children are polled: as soon as one
+    exits non-zero the rest are killed, and nothing outlives the job's time budget (+ 20 s for the ranks' own watchdogs
+    to print and leave first).  A line rank 0 did print is forwarded even when a rank failed; the status stays non-zero."""
+    n = args.gpus
+    one_device = os.environ.get("SCONE_ONE_DEVICE") == "1"
+    if not args.selftest:
+        import torch                               # device_count() does not initialise the GPU on this image
+        have = torch.cuda.device_count()
+        if have < n and not one_device:
+            print(f"bench.py: --gpus {n} but only {have} HIP device(s) visible", file=sys.stderr)
+            return 2
+    os.environ.setdefault(T0_ENV, repr(time.time()))
+    deadline = float(os.environ[T0_ENV]) + args.time_budget + 20.0
+    rcs, out, first_exit = _launch_once(args, n, deadline)
+    if rcs[0] not in (0, None) and '{"metric"' not in out and first_exit < 30.0 and time.time() + 60.0 < deadline:
+        # the rendezvous port was picked by bind-then-close: another process may have taken it in between.  One retry
+        sys.stderr.write(f"bench.py: ranks exited with {rcs} after {first_exit:.0f} s without a result; retrying once on a new port\n")
+        rcs, out, first_exit = _launch_once(args, n, deadline)
     line = None
-    for ln in (out or "").splitlines():
+    for ln in out.splitlines():
         if ln.startswith('{"metric"'):
             line = ln
-    if any(rcs) or line is None:
-        sys.stderr.write(f"bench.py: ranks exited with {rcs}; rank 0 printed {'no' if line is None else 'a'} result line\n")
-        if out:
-            sys.stderr.write(out[-2000:])
-        return 1
-    res = json.loads(line)
-    if res.get("n_gpus") != n:
+    res = None
+    if line is not None:
+        try:
+            res = json.loads(line)
+        except ValueError:
+            res = None
+    ok = not any(rcs) and res is not None
+    if res is not None and res.get("n_gpus") != n:
         sys.stderr.write(f"bench.py: --gpus {n} but the result line says n_gpus = {res.get('n_gpus')}\n")
         return 1
-    res["launcher"] = f"bench.py started {n} ranks itself (WORLD_SIZE was unset)"
-    print(json.dumps(res), flush=True)
+    if res is not None:
+        res["launcher"] = f"bench.py started {n} ranks itself (WORLD_SIZE was unset)"
+        if not ok:
+            res["launcher"] += f"; ranks exited with {rcs}"
+        print(json.dumps(res), flush=True)
+    if not ok:
+        sys.stderr.write(f"bench.py: ranks exited with {rcs}; rank 0 printed {'no' if res is None else 'a'} result line\n")
+        if out and res is None:
+            sys.stderr.write(out[-2000:])
+        return 1
     return 0
 
 
 # ----------------------------------------------------------------------------------------------------------------
-def kernel_source_sha() -> str:
-    """Hash of the kernel sources: a committed PMC traffic figure is only quoted for the code it was measured on."""
-    h = hashlib.sha256()
+def kernel_source_files():
+    """The files the timed kernel (k_embed_wave and its siblings) is compiled from: the scone_gather*.hip translation
+    units, every header they include (transitively) and the Makefile with the compiler flags."""
     d = os.path.join(ROOT, "scone_amd", "csrc")
-    for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".h")):
-            h.update(f.encode())
-            h.update(open(os.path.join(d, f), "rb").read())
+    todo = sorted(f for f in os.listdir(d) if f.startswith("scone_gather") and f.endswith(".hip"))
+    seen = []
+    while todo:
+        f = todo.pop(0)
+        if f in seen or not os.path.exists(os.path.join(d, f)):
+            continue
+        seen.append(f)
+        for inc in re.findall(r'^\s*#\s*include\s*"([^"]+)"', open(os.path.join(d, f), errors="ignore").read(), flags=re.M):
+            todo.append(os.path.normpath(inc))
+    return [os.path.join(d, f) for f in sorted(seen)] + [os.path.join(d, "Makefile")]
+
+
+def kernel_source_sha() -> str:
+    """Hash of the timed kernel's sources: a committed PMC traffic figure is only quoted for the code it was measured on."""
+    h = hashlib.sha256()
+    for p in kernel_source_files():
+        if os.path.exists(p):
+            h.update(os.path.basename(p).encode())
+            h.update(open(p, "rb").read())
     return h.hexdigest()[:16]
 
 
@@ -189,11 +364,13 @@ def _cpu_pool_work(seqs):
     return len(seqs)
 
 
-def cpu_baseline(args, keys, lens, tok, seed, base_scale, gpu_out, wte, wpe):
+def cpu_baseline(args, keys, lens, tok, seed, base_scale, gpu_out, wte, wpe, seconds=None, all_cores=True):
     """Time the reference loop (set-of-tuples match -> dict id map -> torch.stack of fp32 rows
     -> mean -> zero-filled [1,T,d]; n_gram_extractor.py:106-126, embedding_cache.py:113-181,
     engine.py:234-266) on a bounded sample of the same stream, 1 core, and use its output to
-    sanity-check the GPU result for the first sequence."""
+    check the GPU result of 8 sequences drawn from the WHOLE batch (the last one always among them: every part of the
+    large-batch kernel's walk -- first, middle and last iteration of a workgroup, the partial last block -- is looked at).
+    `all_cores=False` (N > 1 lines): the 1-core figure and the check only."""
     import numpy as np
     import torch
     if keys.shape[0] > 20_000_000:
@@ -201,6 +378,7 @@ def cpu_baseline(args, keys, lens, tok, seed, base_scale, gpu_out, wte, wpe):
     from oracle import ref_port as R
     torch.set_num_threads(1)
     d = args.dim
+    seconds = args.cpu_seconds if seconds is None else seconds
     f2id = R._key_dict(keys, lens)
     cache = R.RefCache(f2id, 3, d)
 
@@ -226,69 +404,78 @@ def cpu_baseline(args, keys, lens, tok, seed, base_scale, gpu_out, wte, wpe):
             for i, r in zip(ids.tolist(), deq):
                 cache.embeddings[i] = r
 
-    seqs = [tok[b].tolist() for b in range(min(tok.shape[0], 128))]
+    B = tok.shape[0]
+    seqs = [tok[b].tolist() for b in range(min(B, 128 if all_cores else 32))]
     load_rows(seqs)                       # host copies of the rows the sample touches (not timed)
-    first = R.aggregate(cache, seqs[0], d)
-    # whole passes over the sample until ~cpu_seconds of CPU work have been timed
+    # whole passes over the sample until ~seconds of CPU work have been timed
     done, dt = 0, 0.0
     t0 = time.perf_counter()
-    while dt < args.cpu_seconds:
+    while dt < seconds:
         for s in seqs:
             R.aggregate(cache, s, d)
         done += len(seqs)
         dt = time.perf_counter() - t0
     nseq = done
-    refs = np.asarray(sorted(cache.embeddings.keys()), dtype=np.int64)
-    sub = np.stack([cache.embeddings[int(i)] for i in refs])
-    # courtesy upper bound 1: the SAME Python port on all host cores, multiprocessing over
-    # independent sequences (spawned workers -- this process holds a GPU context -- each with the sample's vocabulary)
-    py_all = None
-    try:
-        import multiprocessing as mp
-        ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-        nw = max(1, min(ncpu, 16))
-        ctx = mp.get_context("spawn")
-        with ctx.Pool(nw, initializer=_cpu_pool_init, initargs=(keys[refs], lens[refs], refs, sub, d)) as pool:
-            pool.map(_cpu_pool_work, [seqs[:1]] * nw)           # workers up and warm
+    py_all = c_line = None
+    if all_cores:
+        refs = np.asarray(sorted(cache.embeddings.keys()), dtype=np.int64)
+        sub = np.stack([cache.embeddings[int(i)] for i in refs])
+        # courtesy upper bound 1: the SAME Python port on all host cores, multiprocessing over
+        # independent sequences (spawned workers -- this process holds a GPU context -- each with the sample's vocabulary)
+        try:
+            import multiprocessing as mp
+            ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            nw = max(1, min(ncpu, 16))
+            ctx = mp.get_context("spawn")
+            with ctx.Pool(nw, initializer=_cpu_pool_init, initargs=(keys[refs], lens[refs], refs, sub, d)) as pool:
+                pool.map(_cpu_pool_work, [seqs[:1]] * nw)           # workers up and warm
+                reps, t0 = 0, time.perf_counter()
+                while time.perf_counter() - t0 < 5.0:
+                    pool.map(_cpu_pool_work, [seqs[i::nw] for i in range(nw)])
+                    reps += 1
+                el = time.perf_counter() - t0
+            py_all = {"value": reps * len(seqs) * tok.shape[1] / el, "unit": "tokens/s", "cores": nw,
+                      "kind": "port (oracle/ref_port.py aggregate(), multiprocessing over sequences)",
+                      "sample": f"{reps} passes over {len(seqs)} sequences x {tok.shape[1]} tokens ({el:.1f} s)"}
+        except Exception as e:
+            py_all = {"value": None, "error": repr(e)}
+        # courtesy upper bound 2: the plain-C oracle (oracle/oracle.c), OpenMP over independent sequences on all host
+        # cores, on the same sample (vocabulary and table restricted to the f-grams the sample references)
+        try:
+            from oracle.c_oracle import COracle
+            co = COracle(keys[refs], lens[refs], 3)
+            tok_s = np.asarray(seqs, dtype=np.int64)
+            nthr = min(os.cpu_count() or 1, 64)
+            co.embed(sub, tok_s[:8], "mean", nthr)
             reps, t0 = 0, time.perf_counter()
-            while time.perf_counter() - t0 < 5.0:
-                pool.map(_cpu_pool_work, [seqs[i::nw] for i in range(nw)])
+            while time.perf_counter() - t0 < 3.0:
+                co.embed(sub, tok_s, "mean", nthr)
                 reps += 1
-            el = time.perf_counter() - t0
-        py_all = {"value": reps * len(seqs) * tok.shape[1] / el, "unit": "tokens/s", "cores": nw,
-                  "kind": "port (oracle/ref_port.py aggregate(), multiprocessing over sequences)",
-                  "sample": f"{reps} passes over {len(seqs)} sequences x {tok.shape[1]} tokens ({el:.1f} s)"}
-    except Exception as e:
-        py_all = {"value": None, "error": repr(e)}
-    # courtesy upper bound 2: the plain-C oracle (oracle/oracle.c), OpenMP over independent sequences on all host
-    # cores, on the same sample (vocabulary and table restricted to the f-grams the sample references)
-    c_line = None
-    try:
-        from oracle.c_oracle import COracle
-        co = COracle(keys[refs], lens[refs], 3)
-        tok_s = np.asarray(seqs, dtype=np.int64)
-        nthr = min(os.cpu_count() or 1, 64)
-        co.embed(sub, tok_s[:8], "mean", nthr)
-        reps, t0 = 0, time.perf_counter()
-        while time.perf_counter() - t0 < 3.0:
-            co.embed(sub, tok_s, "mean", nthr)
-            reps += 1
-        c_line = {"value": reps * tok_s.size / (time.perf_counter() - t0), "unit": "tokens/s", "cores": nthr,
-                  "kind": "port (plain C, OpenMP over sequences; oracle/oracle.c)"}
-    except Exception as e:
-        c_line = {"value": None, "error": repr(e)}
-    # parity spot check of the GPU output (first sequence) against the oracle
-    ref = R.combine(torch.from_numpy(tok[:1]), first, wte.float().cpu(), wpe.float().cpu()).numpy()
-    err = float(np.abs(gpu_out[:1].float().cpu().numpy() - ref).max() / np.abs(ref).max())
-    return {
+            c_line = {"value": reps * tok_s.size / (time.perf_counter() - t0), "unit": "tokens/s", "cores": nthr,
+                      "kind": "port (plain C, OpenMP over sequences; oracle/oracle.c)"}
+        except Exception as e:
+            c_line = {"value": None, "error": repr(e)}
+    # parity check of the GPU output against the oracle: 8 sequences from all over the batch
+    rng = np.random.default_rng(20260304)
+    picks = sorted(set(int(x) for x in rng.choice(B, size=min(7, B), replace=False)) | {B - 1})
+    check = [tok[b].tolist() for b in picks]
+    load_rows(check)
+    err = 0.0
+    for b, s in zip(picks, check):
+        fg = R.aggregate(cache, s, d)
+        ref = R.combine(torch.from_numpy(tok[b:b + 1]), fg, wte.float().cpu(), wpe.float().cpu()).numpy()
+        err = max(err, float(np.abs(gpu_out[b:b + 1].float().cpu().numpy() - ref).max() / np.abs(ref).max()))
+    res = {
         "value": nseq * tok.shape[1] / dt, "unit": "tokens/s", "cores": 1, "kind": "port",
         "sample": f"{nseq} sequences x {tok.shape[1]} tokens ({len(seqs)} distinct sequences of the same stream, repeated) "
                   f"({dt:.1f} s; oracle/ref_port.py aggregate(), python {sys.version_info.major}.{sys.version_info.minor}, "
                   f"torch {torch.__version__}, host cpus {os.cpu_count()})",
-        "gpu_vs_oracle_max_rel_err_seq0": err,
-        "python_all_cores": py_all,
-        "c_oracle_all_cores": c_line,
+        "gpu_vs_oracle_max_rel_err": err, "gpu_vs_oracle_sequences": picks,
     }
+    if all_cores:
+        res["python_all_cores"] = py_all
+        res["c_oracle_all_cores"] = c_line
+    return res
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -378,17 +565,8 @@ def hbm_variant(args, wte, wpe, sync):
     return res
 
 
-def pinned_baseline(args, sync):
-    """N = 1: how ONE GPU serves a table that does not fit its HBM -- rows in pinned host DRAM read in place over PCIe
-    (BASELINE config C4: 100M rows INT4 d = 1024 = 52.8 GB, first 1M rows hot in HBM), on the batch shape of the
-    sharded record.  PCIe-bound, so the rate barely depends on the table's size; this is what ">= 4x at 8 GPUs vs 1 GPU
-    on the 1B-row sharded table" is computed against."""
+def _host_memory_available():
     import psutil
-    import torch
-    from scone_amd import EmbeddingCache
-    from scone_amd import synthetic as S
-    N, d, B, T = args.pinned_rows, 1024, 2048, 512
-    need = N * 512 + 8e9
     avail = psutil.virtual_memory().available
     for f_lim, f_use in (("/sys/fs/cgroup/memory.max", "/sys/fs/cgroup/memory.current"),
                          ("/sys/fs/cgroup/memory/memory.limit_in_bytes", "/sys/fs/cgroup/memory/memory.usage_in_bytes")):
@@ -398,32 +576,78 @@ def pinned_baseline(args, sync):
                 avail = min(avail, int(lim) - int(open(f_use).read().strip()))
         except (OSError, ValueError):
             pass
+    return avail
+
+
+def pinned_baseline(args, sync, zipf_too=True):
+    """How ONE GPU serves a table that does not fit its HBM -- rows in pinned host DRAM (BASELINE config C4: 100M rows
+    INT4 d = 1024 = 52.8 GB, first 1M rows hot in HBM), on the batch shape of the sharded record.  PCIe-bound, so the
+    rate barely depends on the table's size; this is what ">= 4x at 8 GPUs vs 1 GPU on the 1B-row sharded table" is
+    computed against.  Returns (record for the S_uniform stream with the rows read in place over PCIe -- the faster
+    mechanism on that stream --, record for a Zipf token stream through the staged, de-duplicated prefetch -- the
+    north-star's "async prefetch" on the kind of stream where a chunk's rows recur; None unless `zipf_too`)."""
+    import torch
+    from scone_amd import EmbeddingCache
+    from scone_amd import synthetic as S
+    N, d, B, T = args.pinned_rows, 1024, 2048, 512
+    need = N * 512 + 8e9
+    avail = _host_memory_available()
     if avail < need:
-        return {"value": None, "skipped": f"needs {need / 1e9:.0f} GB of host memory for the pinned table ({avail / 1e9:.0f} GB available)"}
+        skip = {"value": None, "skipped": f"needs {need / 1e9:.0f} GB of host memory for the pinned table ({avail / 1e9:.0f} GB available)"}
+        return skip, (dict(skip) if zipf_too else None)
+    hot = min(1_000_000, max(N // 100, 1))
     vocab = S.StructuredVocab(N)
-    cache = EmbeddingCache.from_synthetic(vocab, d, table_format="int4", seed=7, base_scale=0.02 / 127, n_rows=N,
-                                          placement="pinned_host", hot_rows=1_000_000)
-    tok = torch.from_numpy(S.stream_uniform_ids(vocab, None, B, T, 1234)).to("cuda", torch.int32)
     g = torch.Generator(device="cuda").manual_seed(5)
     wte = (torch.randn(S.GPT2_VOCAB, d, generator=g, device="cuda") * 0.02).half()
     wpe = (torch.randn(1024, d, generator=g, device="cuda") * 0.01).half()
     out = torch.empty(B, T, d, dtype=torch.float16, device="cuda")
-    cache.table.reserve(B * T)
-    cache.embed_tokens(tok, wte=wte, wpe=wpe, out=out)
-    sync()
-    steps = 4
-    t0 = time.perf_counter()
-    for _ in range(steps):
+
+    def run(cache, tok, steps=4):
+        cache.table.reserve(B * T)
         cache.embed_tokens(tok, wte=wte, wpe=wpe, out=out)
-    sync()
-    dt = time.perf_counter() - t0
-    res = {"value": B * T * steps / dt, "unit": "tokens/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
-           "workload": f"{N}-row int4 table d={d} in pinned host DRAM (rows read in place over PCIe), first 1000000 rows in HBM, "
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            cache.embed_tokens(tok, wte=wte, wpe=wpe, out=out)
+        sync()
+        return (time.perf_counter() - t0) / steps
+
+    cache = EmbeddingCache.from_synthetic(vocab, d, table_format="int4", seed=7, base_scale=0.02 / 127, n_rows=N,
+                                          placement="pinned_host", hot_rows=hot)
+    tok = torch.from_numpy(S.stream_uniform_ids(vocab, None, B, T, 1234)).to("cuda", torch.int32)
+    dt = run(cache, tok)
+    res = {"value": B * T / dt, "unit": "tokens/s", "ms_per_step": dt * 1e3, "steps": 4,
+           "workload": f"{N}-row int4 table d={d} in pinned host DRAM (rows read in place over PCIe), first {hot} rows in HBM, "
                        f"structured vocabulary, S_uniform, {B}x{T} tokens/step",
            "bound": "PCIe Gen5 x16 (~64 GB/s)"}
+    zres = None
+    if zipf_too:
+        try:
+            ztok = torch.from_numpy(S.stream_zipf(S.GPT2_VOCAB, B, T, 1234)).to("cuda", torch.int32)
+            off, ids = cache.table.match_csr(ztok)
+            cold = ids[ids >= hot]
+            stats = {"mean_hits_per_token": float(ids.numel()) / (B * T), "cold_row_references": int(cold.numel()),
+                     "distinct_cold_rows": int(torch.unique(cold).numel())}
+            del off, ids, cold
+            dt_zero = run(cache, ztok)
+            del cache
+            torch.cuda.empty_cache()
+            # the same table again with the staged prefetch (stage_tokens is a property of the handle)
+            cache = EmbeddingCache.from_synthetic(vocab, d, table_format="int4", seed=7, base_scale=0.02 / 127, n_rows=N,
+                                                  placement="pinned_host", hot_rows=hot, stage_tokens=262144)
+            dt_staged = run(cache, ztok)
+            zres = {"value": B * T / dt_staged, "unit": "tokens/s", "ms_per_step": dt_staged * 1e3, "steps": 4,
+                    "mechanism": "staged prefetch: 262144-token chunks, each chunk's distinct cold rows copied once host -> HBM "
+                                 "on side streams while the previous chunk is reduced",
+                    "zero_copy_same_stream": {"value": B * T / dt_zero, "ms_per_step": dt_zero * 1e3},
+                    "workload": f"{N}-row int4 table d={d} in pinned host DRAM, first {hot} rows in HBM, structured vocabulary, "
+                                f"S_zipf (iid Zipf(1.1) tokens), {B}x{T} tokens/step", **stats,
+                    "bound": "PCIe Gen5 x16 (~64 GB/s)"}
+        except Exception as e:
+            zres = {"value": None, "error": repr(e)}
     del cache, tok, out, wte, wpe
     torch.cuda.empty_cache()
-    return res
+    return res, zres
 
 
 def _rccl_version():
@@ -434,30 +658,74 @@ def _rccl_version():
         return f"unknown ({e!r})"
 
 
-def sharded_record(args, dist, rank, world, backend, sync, rec=None):
+def run_stages(rec, line, watchdog, budget, stage_limit, stages, n1_value=None, on_done=None):
+    """The exchanges of the sharded record, one STAGE each: `stages` = [(name, callable -> dict)].  A stage runs under the
+    watchdog with `stage_limit` seconds (less when the job's budget is nearly used up); one that raises is recorded as an
+    error and the next one runs; one that HANGS (a collective that never completes) ends the job through the watchdog,
+    which prints everything recorded before it -- hence the order of `stages`: the plainest collectives first.  Every
+    finished stage is entered into `rec["exchanges"]` under the line's lock, with its speed-up over the N = 1 baseline."""
+    for name, fn in stages:
+        left = budget.remaining() - 15.0          # keep 15 s for the rest of the line
+        if left < 10.0:
+            with line.lock:
+                rec["exchanges"][name] = {"skipped": f"time budget: {budget.remaining():.0f} s left"}
+            continue
+        watchdog.arm(f"sharded.exchanges.{name}", min(stage_limit, left))
+        try:
+            e = fn()
+        except Exception as ex:                    # the record never takes the line down
+            e = {"error": repr(ex)}
+        watchdog.disarm()
+        if n1_value and isinstance(e, dict) and e.get("tokens_per_s"):
+            e["speedup_vs_n1_pinned_host"] = e["tokens_per_s"] / n1_value
+        with line.lock:
+            rec["exchanges"][name] = e
+            if on_done is not None:
+                on_done(name, e)
+
+
+def sharded_record(args, dist, rank, world, backend, sync, rec, line, watchdog, budget):
     """N > 1: the row-sharded path on the C5-shaped workload -- INT4 d = 1024, `rows_per_rank` x N rows (1e9 at N = 8),
     replicated index built from keys generated on the GPU, every rank its own contiguous row range generated on its GPU,
-    replicated head = the unigram rows, ONE 1M-token S_uniform batch that every rank passes in -- for the two exchanges
+    replicated head = the unigram rows, ONE 1M-token S_uniform batch that every rank passes in -- for the exchanges
     that leave the whole [B, T, d] output on every rank:
       rows+all_gather   all-to-all of the quantised rows each slice needs, rank r reduces slice r, all-gather of the
                         finished fp16 vectors (the north-star's wording)
       gather_rows       all-gather of the DISTINCT quantised rows the batch references, every rank reduces the whole batch;
                         pipelined over `gather_chunks` chunks of sequences (gather_rows_one_shot: the same in one piece);
                         the records travel as exact point-to-point ranges (batch_isend_irecv: one RCCL group, each link
-                        carries one peer's records) -- gather_rows_padded_all_gather: through all_gather_into_tensor
+                        carries one peer's records) -- ..._padded_all_gather: through all_gather_into_tensor
                         instead, every contribution padded to the largest
+      gather_rows_split_phase[_padded_all_gather]  the serving-loop form (ShardedEmbeddingCache.gather_rows_begin / _finish,
+                        one piece, two batches in flight: plan, pack and transfers of step s + 1 run on a side stream behind
+                        the reduction of step s) -- a throughput figure, a batch's latency is two steps
     and, for contrast, rows_slices_only: the all-to-all alone, every rank keeps its own slice (a consumer that is
-    data-parallel over the same slices needs no more); last, gather_rows_split_phase: the serving-loop form of gather_rows
-    (ShardedEmbeddingCache.gather_rows_begin / _finish, one piece, two batches in flight: plan, pack and transfers of step
-    s + 1 run on a side stream behind the reduction of step s) -- a throughput figure, a batch's latency is two steps.
-    Un-synchronised steps give ms/step; one instrumented step per exchange (device synchronised between phases) gives the
-    phase split.  `rec` (optional) is filled in place, so that a caller's watchdog can print what was measured so far."""
+    data-parallel over the same slices needs no more).  Order: the plainest collectives first (all_to_all_single,
+    all_gather_into_tensor), everything that needs the batched point-to-point transport after them -- should that
+    transport hang under RCCL, the watchdog prints every figure measured before it and the padded all-gather figures stand
+    in (`transport_fallback`).  Before any of it rank 0 alone measures the N = 1 baseline (pinned host DRAM), so every
+    exchange carries `speedup_vs_n1_pinned_host`.  Un-synchronised steps give ms/step; one instrumented step per exchange
+    (device synchronised between phases) gives the phase split.  `rec` is filled in place under `line.lock`."""
     import torch
     from scone_amd import synthetic as S
     from scone_amd.distributed import ShardedEmbeddingCache
-    d, B, T = 1024, 2048, 512
+    from scone_amd.hip_backend import format_code, row_bytes
+    d, B, T = 1024, args.batch, args.seq
+    cdev = "cuda" if backend == "nccl" else "cpu"
+    # ---- the N = 1 baseline, rank 0 alone (the others wait in the first collective below)
+    n1 = None
+    if rank == 0:
+        watchdog.arm("sharded.n1_pinned_host", min(150.0, max(budget.remaining() - 60.0, 10.0)))
+        try:
+            n1, _ = pinned_baseline(args, lambda: torch.cuda.synchronize(), zipf_too=False)
+        except Exception as e:
+            n1 = {"value": None, "error": repr(e)}
+        watchdog.disarm()
+        line.set(rec, "n1_pinned_host", n1)
+    n1_value = (n1 or {}).get("value")
+    watchdog.arm("sharded.build", min(200.0, max(budget.remaining() - 30.0, 10.0)))
     free, total = torch.cuda.mem_get_info()
-    fm = torch.tensor([float(free)], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+    fm = torch.tensor([float(free)], dtype=torch.float64, device=cdev)
     dist.all_reduce(fm, op=dist.ReduceOp.MIN)       # every rank must size the table the same way: the tightest GPU decides
     free = float(fm.item())
     per = args.sharded_rows_per_rank
@@ -483,27 +751,52 @@ def sharded_record(args, dist, rank, world, backend, sync, rec=None):
     wte = (torch.randn(S.GPT2_VOCAB, d, generator=g, device="cuda") * 0.02).half()
     wpe = (torch.randn(1024, d, generator=g, device="cuda") * 0.01).half()
     ntok = B * T
-    rec = {} if rec is None else rec
-    rec.update({"workload": f"{N}-row int4 f-gram table d={d} row-sharded over {world} ranks ({per} rows = {per * 528 / 1e9:.1f} GB per rank), "
-                       f"replicated {cap}-slot index, replicated head {S.GPT2_VOCAB} rows, structured vocabulary, S_uniform, "
-                       f"{B}x{T} tokens/step (the same batch on every rank), whole [B,T,d] fp16 output on every rank",
-           "world_size": dist.get_world_size(), "device_count": torch.cuda.device_count(), "backend": backend,
-           "rccl_version": _rccl_version() if backend == "nccl" else None,
-           "build_s": t_build, "note": note, "exchanges": {}})
+    # per-rank HBM bytes of a step (SURVEY 8d's accounting): the whole batch when every rank reduces it, rank 0's slice
+    # when every rank reduces its own
+    fmt = format_code("int4")
+    alg_all, comp_all, sum_k, _, nr_all, nt_all = workload_bytes(cache.table, tok, fmt, d)
+    bper = (B + world - 1) // world
+    alg_sl, comp_sl, _, _, _, _ = workload_bytes(cache.table, tok[:bper], fmt, d)
+    links = max(1, min(world - 1, 7))
+    xgmi_peak = links * XGMI_LINK_GBPS_PER_DIRECTION
+    with line.lock:
+        rec.update({"workload": f"{N}-row int4 f-gram table d={d} row-sharded over {world} ranks ({per} rows = {per * 528 / 1e9:.1f} GB per rank; "
+                                f"{args.sharded_rows_per_rank} rows per rank requested: N = 2 / 4 / 8 ranks hold {2 * per} / {4 * per} / {8 * per} rows), "
+                                f"replicated {cap}-slot index, replicated head {S.GPT2_VOCAB} rows, structured vocabulary, S_uniform, "
+                                f"{B}x{T} tokens/step (the same batch on every rank), whole [B,T,d] fp16 output on every rank",
+                    "rows_total": N, "rows_per_rank": per, "mean_hits_per_token": sum_k / ntok,
+                    "world_size": dist.get_world_size(), "device_count": torch.cuda.device_count(), "backend": backend,
+                    "rccl_version": _rccl_version() if backend == "nccl" else None,
+                    "build_s": t_build, "note": note,
+                    "xgmi_peak_GBps": xgmi_peak,
+                    "xgmi_peak_kind": f"into one GPU: {links} links x {XGMI_LINK_GBPS_PER_DIRECTION} GB/s per direction "
+                                      "(153.6 GB/s per link counting both directions)"})
+    watchdog.disarm()
     checks = {}
     chunks = cache.gather_chunks
-    # order: the plainest collectives first (all_to_all_single, all_gather_into_tensor), the batched point-to-point
-    # transport after them -- should one of them hang under RCCL, the watchdog still prints everything measured before it
-    for name, kw in (("rows+all_gather", {"exchange": "rows", "gather_output": True}),
-                     ("rows_slices_only", {"exchange": "rows", "gather_output": False}),
-                     ("gather_rows_padded_all_gather", {"exchange": "gather_rows", "gather_output": True}),
-                     ("gather_rows", {"exchange": "gather_rows", "gather_output": True}),
-                     ("gather_rows_one_shot", {"exchange": "gather_rows", "gather_output": True})):
-        try:
-            cache.gather_chunks = 1 if name == "gather_rows_one_shot" else chunks
-            # the records travel as exact point-to-point ranges; ..._padded_all_gather: all_gather_into_tensor, every
-            # contribution padded to the largest (twice the mean on this workload at 8 ranks)
-            cache.gather_transport = "all_gather" if name == "gather_rows_padded_all_gather" else "p2p"
+
+    def roofline_of(kw, ms_per_step, phases, wire_bytes):
+        whole = kw["exchange"] == "gather_rows"
+        alg, comp = (alg_all, comp_all) if whole else (alg_sl, comp_sl)
+        if not whole and kw["gather_output"]:
+            comp += (world - 1) * bper * T * d * 2                      # the other slices arrive and are written too
+            alg += (world - 1) * bper * T * d * 2
+        coll_ms = (phases.get("collective_ms", 0.0) + phases.get("gather_out_ms", 0.0)) if phases else None
+        return {"bound": "hbm", "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "per_rank_tokens_reduced": ntok if whole else bper * T,
+                "per_rank_algorithmic_bytes": alg, "per_rank_compulsory_bytes": comp,
+                "achieved": comp / (ms_per_step * 1e-3) / 1e9, "frac": comp / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                "frac_kind": "compulsory HBM bytes of one rank's step (distinct rows + wte rows + output + ids) / ms_per_step / 8 TB/s: "
+                             "the whole exchange step, not one kernel",
+                "algorithmic_frac": alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                "wire": {"bytes_received_rank0": wire_bytes, "collective_ms_instrumented": coll_ms,
+                         "GBps": (wire_bytes / (coll_ms * 1e-3) / 1e9) if coll_ms else None,
+                         "frac_of_xgmi_peak": (wire_bytes / (coll_ms * 1e-3) / 1e9 / xgmi_peak) if coll_ms else None}}
+
+    def one_call(name, kw, chunks_, transport):
+        def fn():
+            cache.gather_chunks = chunks_
+            cache.gather_transport = transport
             out = cache.embed_tokens(tok, wte=wte, wpe=wpe, **kw)                  # warm-up (allocations, RCCL channels)
             out = cache.embed_tokens(tok, wte=wte, wpe=wpe, **kw)
             sync()
@@ -512,62 +805,158 @@ def sharded_record(args, dist, rank, world, backend, sync, rec=None):
                 out = cache.embed_tokens(tok, wte=wte, wpe=wpe, **kw)
             sync()
             dt = time.perf_counter() - t0
-            tm = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+            tm = torch.tensor([dt], dtype=torch.float64, device=cdev)
             dist.all_reduce(tm, op=dist.ReduceOp.MAX)
             dt = float(tm.item())
             phases = cache.embed_tokens(tok, wte=wte, wpe=wpe, profile=True, **kw)[1]
-            ph = torch.tensor([phases[k] for k in sorted(phases)], dtype=torch.float64,
-                              device="cuda" if backend == "nccl" else "cpu")
+            ph = torch.tensor([phases[k] for k in sorted(phases)], dtype=torch.float64, device=cdev)
             dist.all_reduce(ph, op=dist.ReduceOp.MAX)                                 # slowest rank per phase
+            phm = {k: float(v) for k, v in zip(sorted(phases), ph.tolist()) if not k.startswith("bytes")}
             if kw["gather_output"]:
                 checks[name] = float(out.float().abs().sum().item())
-            rec["exchanges"][name] = {
-                "ms_per_step": dt / args.sharded_steps * 1e3, "tokens_per_s": ntok * args.sharded_steps / dt,
-                "steps": args.sharded_steps,
-                "phase_ms_slowest_rank": {k: float(v) for k, v in zip(sorted(phases), ph.tolist()) if not k.startswith("bytes")},
-                "wire_bytes_received_rank0": int(phases.get("bytes_received", 0)),
-                "chunks": cache.gather_chunks if kw["exchange"] == "gather_rows" else None,
-                "records_transport": ({"p2p": "batch_isend_irecv, exact ranges", "all_gather": "all_gather_into_tensor, padded"}
-                                      [cache.gather_transport] if kw["exchange"] == "gather_rows" else "all_to_all_single"),
-            }
-        except Exception as e:                                                        # the record never takes the line down
-            rec["exchanges"][name] = {"error": repr(e)}
-    try:
-        cache.gather_chunks = 1
-        def loop(n):
-            o = None
-            tk = cache.gather_rows_begin(tok, tokens_ready=None)         # (the batch has been on the device since the build)
-            for i in range(n):
-                o = cache.gather_rows_finish(tk, wte=wte, wpe=wpe)      # queues the reduction of step i ...
-                tk = cache.gather_rows_begin(tok, tokens_ready=None) if i + 1 < n else None   # ... plan / pack / transfers of step i + 1 overlap it
-            return o
-        out = loop(3)
-        sync()
-        t0 = time.perf_counter()
-        out = loop(args.sharded_steps)
-        sync()
-        dt = time.perf_counter() - t0
-        tm = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
-        dt = float(tm.item())
-        rec["exchanges"]["gather_rows_split_phase"] = {
-            "ms_per_step": dt / args.sharded_steps * 1e3, "tokens_per_s": ntok * args.sharded_steps / dt,
-            "steps": args.sharded_steps, "batches_in_flight": 2, "chunks": 1,
-            "records_transport": "batch_isend_irecv, exact ranges",
-            "same_output_as_gather_rows": bool(float(out.float().abs().sum().item()) == checks.get("gather_rows")),
-        }
-    except Exception as e:
-        rec["exchanges"]["gather_rows_split_phase"] = {"error": repr(e)}
+            ms = dt / args.sharded_steps * 1e3
+            wire = int(phases.get("bytes_received", 0))
+            return {"ms_per_step": ms, "tokens_per_s": ntok * args.sharded_steps / dt, "steps": args.sharded_steps,
+                    "phase_ms_slowest_rank": phm, "wire_bytes_received_rank0": wire,
+                    "chunks": chunks_ if kw["exchange"] == "gather_rows" else None,
+                    "records_transport": ({"p2p": "batch_isend_irecv, exact ranges", "all_gather": "all_gather_into_tensor, padded"}
+                                          [transport] if kw["exchange"] == "gather_rows" else "all_to_all_single"),
+                    "roofline": roofline_of(kw, ms, phm, wire)}
+        return name, fn
+
+    def split_phase(name, transport, same_as):
+        def fn():
+            cache.gather_chunks = 1
+            cache.gather_transport = transport
+
+            def loop(n):
+                o = None
+                tk = cache.gather_rows_begin(tok, tokens_ready=None)         # (the batch has been on the device since the build)
+                for i in range(n):
+                    o = cache.gather_rows_finish(tk, wte=wte, wpe=wpe)      # queues the reduction of step i ...
+                    tk = cache.gather_rows_begin(tok, tokens_ready=None) if i + 1 < n else None   # ... plan / pack / transfers of step i + 1 overlap it
+                return o
+            out = loop(3)
+            sync()
+            t0 = time.perf_counter()
+            out = loop(args.sharded_steps)
+            sync()
+            dt = time.perf_counter() - t0
+            tm = torch.tensor([dt], dtype=torch.float64, device=cdev)
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            dt = float(tm.item())
+            ms = dt / args.sharded_steps * 1e3
+            kw = {"exchange": "gather_rows", "gather_output": True}
+            one = rec["exchanges"].get(same_as, {})
+            return {"ms_per_step": ms, "tokens_per_s": ntok * args.sharded_steps / dt,
+                    "steps": args.sharded_steps, "batches_in_flight": 2, "chunks": 1,
+                    "records_transport": {"p2p": "batch_isend_irecv, exact ranges", "all_gather": "all_gather_into_tensor, padded"}[transport],
+                    "same_output_as_gather_rows": bool(float(out.float().abs().sum().item()) == checks.get(same_as)),
+                    "roofline": roofline_of(kw, ms, None, int(one.get("wire_bytes_received_rank0", 0)))}
+        return name, fn
+
+    whole = {"gather_output": True}
+    stages = [one_call("rows+all_gather", {"exchange": "rows", **whole}, chunks, "p2p"),
+              one_call("rows_slices_only", {"exchange": "rows", "gather_output": False}, chunks, "p2p"),
+              one_call("gather_rows_padded_all_gather", {"exchange": "gather_rows", **whole}, chunks, "all_gather"),
+              one_call("gather_rows_one_shot_padded_all_gather", {"exchange": "gather_rows", **whole}, 1, "all_gather"),
+              split_phase("gather_rows_split_phase_padded_all_gather", "all_gather", "gather_rows_one_shot_padded_all_gather"),
+              # ---- from here on: the batched point-to-point transport
+              one_call("gather_rows", {"exchange": "gather_rows", **whole}, chunks, "p2p"),
+              one_call("gather_rows_one_shot", {"exchange": "gather_rows", **whole}, 1, "p2p"),
+              split_phase("gather_rows_split_phase", "p2p", "gather_rows_one_shot")]
+    p2p_names = ("gather_rows", "gather_rows_one_shot", "gather_rows_split_phase")
+    with line.lock:
+        rec["exchanges"] = {}
+        rec["transport_fallback"] = ("records over batch_isend_irecv (exact ranges) not measured yet: the ..._padded_all_gather "
+                                     "figures (all_gather_into_tensor) are the ones that stand if it does not complete")
+
+    def on_done(name, e):                                  # (inside line.lock)
+        ok = {k: v for k, v in rec["exchanges"].items() if isinstance(v, dict) and v.get("tokens_per_s")
+              and k != "rows_slices_only"}
+        if ok:
+            best = max(ok, key=lambda k: ok[k]["tokens_per_s"])
+            rec["best_whole_output"] = {"exchange": best, "tokens_per_s": ok[best]["tokens_per_s"],
+                                        "ms_per_step": ok[best]["ms_per_step"],
+                                        "speedup_vs_n1_pinned_host": ok[best].get("speedup_vs_n1_pinned_host")}
+        if name in p2p_names:
+            done = [k for k in p2p_names if rec["exchanges"].get(k, {}).get("tokens_per_s")]
+            failed = [k for k in p2p_names if "error" in rec["exchanges"].get(k, {})]
+            rec["transport_fallback"] = (None if done and not failed else
+                                         f"batch_isend_irecv transport failed in {failed}: the ..._padded_all_gather figures stand")
+
+    run_stages(rec, line, watchdog, budget, args.stage_limit, stages, n1_value, on_done)
     cache.gather_chunks = chunks
     cache.gather_transport = "p2p"
-    if len(checks) == 4:                                # all bit-identical to the unsharded table, hence to each other
-        rec["exchanges_agree"] = bool(len(set(checks.values())) == 1)
-    rec["gather_chunks"] = chunks
-    rec["n1_baseline"] = ("the N = 1 line's `sharded.n1_pinned_host` (one GPU cannot hold this table: rows in pinned host DRAM, "
-                          "PCIe-bound, ~0.24 G tokens/s on MI355X); '>= 4x at 8 GPUs' is tokens_per_s here / that value")
+    with line.lock:
+        if len(checks) >= 2:                             # all bit-identical to the unsharded table, hence to each other
+            rec["exchanges_agree"] = bool(len(set(checks.values())) == 1)
+            rec["exchanges_compared"] = sorted(checks)
+        rec["gather_chunks"] = chunks
+        rec["n1_baseline"] = ("`n1_pinned_host` of THIS record (rank 0, same process, before the exchanges): one GPU cannot hold the "
+                              "table, so its rows sit in pinned host DRAM and cross PCIe; '>= 4x at 8 GPUs vs 1 GPU' = "
+                              "exchanges.<name>.speedup_vs_n1_pinned_host")
     del cache, tok, wte, wpe
     torch.cuda.empty_cache()
     return rec
+
+
+# ----------------------------------------------------------------------------------------------------------------
+def selftest_main(args):
+    """CPU rehearsal of the time budget (tests/test_bench_budget.py): no GPU, gloo, a made-up headline clearly marked as
+    such, then two stages of `run_stages` -- the second one a collective that rank 1 never joins when `--selftest hang`.
+    Everything that matters is the real code: Budget, Line, Watchdog, run_stages, self_launch, the exit path."""
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    budget = Budget(args.time_budget)
+    line = Line(rank)
+    watchdog = Watchdog(budget, line, rank)
+    watchdog.start()
+    time.sleep(0.5)                                # (a budget that is already gone ends the job here, before any "headline")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+    res = {"metric": "selftest (no measurement: watchdog rehearsal on CPU)", "value": 0.0, "unit": "tokens/s", "n_gpus": world,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": 0.0, "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "none", "data": "selftest", "config": {"workload": "none"}, "selftest": args.selftest,
+           "time_budget_s": budget.seconds}
+    line.headline_done = True
+    rec = {"exchanges": {}}
+    if rank == 0:
+        res["sharded"] = rec
+    line.publish(res)
+
+    def fine():
+        t = torch.ones(1)
+        if world > 1:
+            dist.all_reduce(t)
+        return {"ms_per_step": 1.0, "tokens_per_s": 1000.0 * float(t.item())}
+
+    def hangs():
+        if os.environ.get("SCONE_SELFTEST_DIE_RANK") == str(rank):
+            os._exit(7)                            # a rank that crashes in the middle of the record
+        if rank != 0 and args.selftest == "hang":
+            time.sleep(3600)                       # never joins: rank 0 waits in the collective for ever
+        return fine()
+
+    def mutate():                                  # keeps changing the record while the watchdog may be printing it
+        i = 0
+        while True:
+            with line.lock:
+                rec.setdefault("noise", {})[f"k{i % 64}"] = i
+            i += 1
+            time.sleep(0.0005)
+    threading.Thread(target=mutate, daemon=True).start()
+    run_stages(rec, line, watchdog, budget, args.stage_limit, [("fine", fine), ("second", hangs), ("third", fine)], 500.0)
+    line.emit()
+    if world > 1:
+        watchdog.arm("final barrier", 20.0)
+        dist.barrier()
+        dist.destroy_process_group()
+    sys.stdout.flush()
+    os._exit(0)
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -575,6 +964,8 @@ def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
+    if args.selftest:
+        selftest_main(args)
     import numpy as np
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -584,6 +975,10 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no HIP device visible)")
+    budget = Budget(args.time_budget)
+    line = Line(rank)
+    watchdog = Watchdog(budget, line, rank)
+    watchdog.start()
     # Rehearsal knobs (never set by the driver): SCONE_DIST_BACKEND=gloo + SCONE_ONE_DEVICE=1 let several
     # ranks share ONE GPU so that the N > 1 code path can be exercised on a 1-GPU box (RCCL refuses two
     # ranks on one device).  Numbers from such a run are not scaling results.
@@ -598,6 +993,8 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
+        if rank == 0 and world > 1:
+            os.environ.setdefault("SCONE_DIST_TRACE", "1")     # one stderr line per collective of the sharded record (rank 0)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -675,6 +1072,7 @@ def main():
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+    line.headline_done = True         # from here on a time-out still leaves a valid line (exit status 0)
 
     units = ntok * args.steps * (1 if sharded else world)
     value = units / dt
@@ -685,13 +1083,23 @@ def main():
         # back to the whole step so that the line stays well-formed
         per_step = max(1, n_launch // max(args.steps, 1)) if n_launch else 1
         step_kernel_ms = kern_ms / args.steps if n_launch else dt / args.steps * 1e3
-        achieved = bytes_per_launch / (step_kernel_ms * 1e-3) / 1e9
         sig = (f"{args.format}-d{d}-N{N}-B{B}-T{T}-{args.stream}-{args.placement}" + ("-sharded" if sharded else "") + (f"-shard{args.shard_of}" if emu else "")
                + (f"-hot{args.hot_rows}-stage{args.stage_tokens}" if args.placement != "hbm" else "")
                + ("-structured" if args.keygen == "structured" else ""))
         tr, stale = read_traffic(sig)
         traffic = None if (tr is None or stale) else tr.get("hbm_bytes_per_launch")
         in_hbm = args.placement == "hbm"
+        per_s = step_kernel_ms * 1e-3
+        algorithmic = bytes_per_launch / per_s / 1e9
+        # the physical fraction: bytes that left L2 (PMC passes of THIS kernel source) if there is such an entry, else the
+        # compulsory bytes -- both are byte counts of the launch that do not depend on the box; never above the peak
+        if traffic is not None:
+            phys_bytes, phys_kind = traffic, ("bytes that left L2 per launch (2 x FETCH_SIZE + WRITE_SIZE, rocprofv3 PMC passes of this "
+                                              "kernel source: an upper bound on HBM bytes, Infinity-Cache hits included)")
+        else:
+            phys_bytes, phys_kind = bytes_compulsory, ("compulsory bytes per launch (every distinct table row and wte row once + output + "
+                                                       "ids: a lower bound on HBM bytes; no PMC entry for this workload and kernel source)")
+        achieved = phys_bytes / per_s / 1e9
         res = {
             "metric": "f-gram embed tokens/sec (1M-row INT8 table @ d=768)" if (N, d, args.format) == (1_000_000, 768, "int8")
                       else f"f-gram embed tokens/sec ({N}-row {args.format} table @ d={d})",
@@ -719,85 +1127,113 @@ def main():
                                 else f"replicated table, tokens sharded over {world} rank(s), no collective"),
             },
             "roofline": {
-                "bound": "hbm", "kernel": ("scone_gather::k_embed_wave (gather+dequant+reduce+combine), HIP-event timed" if n_launch
-                                           else "whole step (sharded path: match + pack + RCCL + gather)"),
+                "bound": "hbm" if in_hbm else "pcie",
+                "kernel": ("scone_gather::k_embed_wave (gather+dequant+reduce+combine), HIP-event timed" if n_launch
+                           else "whole step (sharded path: match + pack + RCCL + gather)"),
+                # `frac` = achieved / peak is PHYSICAL: bytes of the launch that crossed the L2 <-> fabric boundary (or, without
+                # a counter entry, that must cross it) over the HIP-event kernel time; it cannot exceed 1
+                "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                "frac_kind": phys_kind + f" / avg_kernel_ms ({step_kernel_ms:.4f} ms, HIP events) / 8 TB/s",
+                "frac_bytes": phys_bytes,
                 # SURVEY 8d's figure: every row REFERENCE counted (K_t rows + out + wte + id per token).  Adjacent tokens
                 # share f-gram rows and hot wte rows are re-referenced, so part of these bytes is served by L2 / the
-                # Infinity Cache: `frac` is the algorithmic rate over the HBM peak, not an HBM utilisation
-                "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                "frac_kind": "algorithmic bytes (SURVEY.md 8d: every reference) / kernel time / 8 TB/s",
-                "algorithmic_above_peak": bool(achieved > HBM_PEAK_GBPS),
-                "algorithmic_bytes_per_launch": bytes_per_launch, "avg_kernel_ms": step_kernel_ms,
+                # Infinity Cache: the algorithmic rate can exceed the HBM peak and is not an HBM utilisation
+                "algorithmic_bytes_per_launch": bytes_per_launch, "algorithmic_GBps": algorithmic,
+                "algorithmic_frac": algorithmic / HBM_PEAK_GBPS,
+                "avg_kernel_ms": step_kernel_ms,
                 "kernel_ms": kernel_stats(samples, per_step), "timed_launches": n_launch, "launches_per_step": per_step,
                 # what HBM must at least move: every DISTINCT table row and wte row once + the output + the ids
                 # (<= the truth; can never exceed the peak) ...
                 "hbm_bytes_compulsory": bytes_compulsory if in_hbm else None,
-                "hbm_frac": bytes_compulsory / (step_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS if in_hbm else None,
+                "hbm_frac": bytes_compulsory / per_s / 1e9 / HBM_PEAK_GBPS if in_hbm else None,
                 # ... and what left L2 (rocprofv3 PMC passes of THIS code, committed: >= the truth, it includes
                 # Infinity-Cache hits); null when the kernels have changed since the passes were taken
                 "traffic": traffic,
                 "traffic_source": None if tr is None else tr.get("source"),
                 "traffic_stale": bool(stale),
-                "traffic_GBps": None if traffic is None else traffic / (step_kernel_ms * 1e-3) / 1e9,
-                "traffic_frac": None if traffic is None else traffic / (step_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                "traffic_GBps": None if traffic is None else traffic / per_s / 1e9,
+                "traffic_frac": None if traffic is None else traffic / per_s / 1e9 / HBM_PEAK_GBPS,
                 "kernel_source_sha": kernel_source_sha(),
             },
+            "time_budget_s": budget.seconds,
         }
+        if n_launch and not sharded and emu is None and args.placement == "hbm":
+            # the match kernel's share of the step: stream time of whole steps (torch events on the launch stream) minus
+            # the gather kernel's own HIP-event time over the same steps
+            try:
+                table.profile_enable(True)
+                table.profile_read(reset=True)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(10):
+                    step()
+                e1.record()
+                torch.cuda.synchronize()
+                nl, km = table.profile_read(reset=True)
+                table.profile_enable(False)
+                res["roofline"]["match_us"] = (e0.elapsed_time(e1) - km) / 10 * 1e3
+                res["roofline"]["match_us_kind"] = ("stream time of 10 back-to-back steps minus their gather-kernel time, per step: "
+                                                    "k_match_ell + the gap between the two launches")
+            except Exception as e:
+                res["roofline"]["match_us"] = None
+                res["roofline"]["match_us_error"] = repr(e)
+        line.publish(res)
     gpu_out_for_check = out
     # ---- the cache-defeating variant, the CPU baselines, the sharded record: outside the timed region -----------
-    if rank == 0 and world == 1 and not sharded and emu is None and not args.no_hbm_variant and args.placement == "hbm":
+    if rank == 0 and world == 1 and not sharded and emu is None and not args.no_hbm_variant and args.placement == "hbm" \
+            and budget.remaining() > 150.0:
+        watchdog.arm("roofline.hbm_variant", min(150.0, budget.remaining() - 60.0))
         try:
             hv = hbm_variant(args, wte, wpe, sync)
-            res["roofline"]["hbm_variant"] = hv
-            # the cache-defeating variant's bracket, lifted to the top of the block: what really touches HBM is at least
-            # `_lower` (compulsory bytes) and at most `_upper` (bytes that left L2, Infinity-Cache hits included) of the peak
-            res["roofline"]["hbm_variant_frac_lower"] = hv["hbm_frac"]
-            res["roofline"]["hbm_variant_frac_upper"] = hv["traffic_frac"]
+            with line.lock:
+                res["roofline"]["hbm_variant"] = hv
+                # the cache-defeating variant's bracket, lifted to the top of the block: what really touches HBM is at least
+                # `_lower` (compulsory bytes) and at most `_upper` (bytes that left L2, Infinity-Cache hits included) of the peak
+                res["roofline"]["hbm_variant_frac_lower"] = hv["hbm_frac"]
+                res["roofline"]["hbm_variant_frac_upper"] = hv["traffic_frac"]
         except Exception as e:
-            res["roofline"]["hbm_variant"] = {"error": repr(e)}
-    if rank == 0 and not args.no_cpu_baseline and world == 1 and not sharded:
-        try:
-            res["cpu_baseline"] = cpu_baseline(args, keys, lens, tok_np, seed, base_scale, gpu_out_for_check, wte, wpe)
-        except Exception as e:      # the baseline is reported, never the product
-            res["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": 1, "kind": "port",
-                                   "sample": f"failed: {e!r}"}
+            line.set(res["roofline"], "hbm_variant", {"error": repr(e)})
+        watchdog.disarm()
+    if rank == 0 and not args.no_cpu_baseline and not sharded and emu is None:
+        short = world > 1                     # N > 1: a 3-second 1-core sample; the all-cores figures are on the N = 1 line
+        if budget.remaining() > (40.0 if short else 100.0):
+            watchdog.arm("cpu_baseline", 60.0 if short else 120.0)
+            try:
+                cb = cpu_baseline(args, keys, lens, tok_np, seed, base_scale, gpu_out_for_check, wte, wpe,
+                                  seconds=3.0 if short else None, all_cores=not short)
+            except Exception as e:      # the baseline is reported, never the product
+                cb = {"value": None, "unit": "tokens/s", "cores": 1, "kind": "port", "sample": f"failed: {e!r}"}
+            watchdog.disarm()
+        else:
+            cb = {"value": None, "unit": "tokens/s", "cores": 1, "kind": "port", "sample": "skipped: time budget"}
+        line.set(res, "cpu_baseline", cb)
     if not args.no_sharded_record and not sharded and emu is None:
         del cache, table, out, gpu_out_for_check
         torch.cuda.empty_cache()
-        # a hung collective must not cost the headline: after 10 minutes rank 0 prints what it has and every rank leaves
-        # (all with status 0, so that the launcher reports the run as what it is: a measured headline without the record)
-        partial = {}
-        def bail():
-            if rank == 0:
-                partial["error"] = "timed out after 600 s; what was measured until then is kept"
-                res["sharded"] = partial
-                print(json.dumps(res, default=str), flush=True)
-            os._exit(0)
-        watchdog = threading.Timer(600.0 if rank == 0 else 615.0, bail)
-        watchdog.daemon = True
-        watchdog.start()
+        rec = {}
+        if rank == 0:
+            line.set(res, "sharded", rec)
         try:
             if world > 1:
-                rec = sharded_record(args, dist, rank, world, backend, sync, partial)
+                sharded_record(args, dist, rank, world, backend, sync, rec, line, watchdog, budget)
+            elif budget.remaining() > 90.0:
+                watchdog.arm("sharded.n1_pinned_host", min(240.0, budget.remaining() - 20.0))
+                n1, n1z = pinned_baseline(args, sync, zipf_too=True)
+                watchdog.disarm()
+                with line.lock:
+                    rec["n1_pinned_host"] = n1
+                    rec["n1_pinned_host_zipf"] = n1z
+                    rec["note"] = ("one GPU: nothing to exchange.  This is the single-GPU alternative for a table that does not fit "
+                                   "HBM; the row-sharded record (with this baseline measured again by its rank 0) is printed by the "
+                                   "N > 1 lines")
             else:
-                rec = {"n1_pinned_host": pinned_baseline(args, sync),
-                       "note": "one GPU: nothing to exchange.  This is the single-GPU alternative for a table that does not fit "
-                               "HBM; the row-sharded record is printed by the N > 1 lines"}
+                line.set(rec, "skipped", f"time budget: {budget.remaining():.0f} s left")
         except Exception as e:
-            rec = {"error": repr(e)}
-        watchdog.cancel()
-        if rank == 0:
-            res["sharded"] = rec
-    if rank == 0:
-        # RCCL prints its version banner through C stdio; flush it first so that the JSON line is
-        # the last thing on stdout
-        try:
-            import ctypes
-            ctypes.CDLL(None).fflush(None)
-        except Exception:
-            pass
-        print(json.dumps(res), flush=True)
+            watchdog.disarm()
+            line.set(rec, "error", repr(e))
+    line.emit()
     if dist is not None:
+        watchdog.arm("final barrier", 30.0)       # the line is out: a rank that never arrives costs 30 s, not the job
         dist.barrier()
         dist.destroy_process_group()
     sys.stdout.flush()

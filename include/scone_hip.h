@@ -299,8 +299,16 @@ int scone_shard_gather_embed(scone_handle *h, const int32_t *d_tok, int32_t B, i
  *   scone_shard_gather_embed_range   sequences [seq_begin, seq_end) of the planned batch out of [replicated head | records
  *                                    added so far]; every row they reference must have been added.  d_out's first row
  *                                    is token out_tok0 of the flattened batch (0: d_out is the whole [B, T, d];
- *                                    seq_begin * T: d_out holds just this run).  B, T must be the planned batch's; a run
- *                                    is reduced ONCE per plan (its id lists are rewritten to record numbers in place). */
+ *                                    seq_begin * T: d_out holds just this run).  B, T must be the planned batch's.  The
+ *                                    id lists of a run are rewritten to record numbers in place, ONCE per plan: the slot
+ *                                    remembers which sequences already hold record numbers, so a second call over the
+ *                                    same or an overlapping range (a retry, other chunk bounds) reduces them as they are;
+ *                                    a new exchange (_add_records with record0 == 0) on lists that were already rewritten
+ *                                    is refused (SCONE_ESTATE): plan the batch again first.
+ * The receiver's row map (row id -> record number) is a direct-mapped array over all table rows (4 B per row and plan
+ * slot, generation-tagged: nothing is cleared between exchanges) when both slots' maps stay under 1/8 of the device's
+ * memory and the exchange has fewer than 2^24 records, else an open-addressing hash map; environment variable
+ * SCONE_SHARD_ROW_MAP=hash|direct overrides the choice. */
 /* Two plan slots (0 and 1; 0 is active at first): the receiver-side state of a planned batch (its id lists, the scales of
  * [head | records], the row map) exists twice, so that a serving loop can plan, pack and exchange batch b + 1 on a side
  * stream while batch b is still being reduced on the main stream.  A host-side switch, no device work; the
@@ -310,6 +318,23 @@ int scone_shard_gather_embed(scone_handle *h, const int32_t *d_tok, int32_t B, i
 int scone_shard_select_slot(scone_handle *h, int32_t slot);
 int scone_shard_gather_plan_chunks(scone_handle *h, const int32_t *d_tok, int32_t B, int32_t T, int32_t n_chunks,
                                    int32_t dedup_across_chunks, uint64_t *h_chunk_end, scone_stream_t stream);
+/* The match of a plan, sharded over the ranks.  In the all-gather form every rank needs the id lists of the WHOLE batch
+ * (it reduces all of it), which makes the match against a 1e9-key index the largest helper kernel of the step.  Index and
+ * tokens are replicated and matching is per sequence, so rank r matches only ITS run of sequences, the runs are
+ * all-gathered by the caller (32 B per token for max_n <= 3: scone_ell_width ints per token) and the claim passes run over
+ * the gathered lists:
+ *   scone_shard_gather_match      sequences [seq_begin, seq_end) of the batch d_tok [B, T] against ALL rows -> their list
+ *                                 records, (seq_end - seq_begin) * T * width int32 at d_ell_out; stream-ordered, no state
+ *   scone_shard_gather_plan_ell   the claim passes of scone_shard_gather_plan_chunks over lists the caller supplies:
+ *                                 d_ell [B * T, width] int32, records of the whole batch in token order.  The buffer is
+ *                                 BORROWED by the selected plan slot until the batch has been reduced (_embed_range
+ *                                 rewrites it in place); same chunk semantics, synchronises
+ * New here (the reference matches one sequence at a time in one process: n_gram_extractor.py:106-126). */
+int scone_ell_width(scone_handle *h, uint32_t *ints_per_token);
+int scone_shard_gather_match(scone_handle *h, const int32_t *d_tok, int32_t B, int32_t T, int32_t seq_begin,
+                             int32_t seq_end, int32_t *d_ell_out, scone_stream_t stream);
+int scone_shard_gather_plan_ell(scone_handle *h, int32_t *d_ell, int32_t B, int32_t T, int32_t n_chunks,
+                                int32_t dedup_across_chunks, uint64_t *h_chunk_end, scone_stream_t stream);
 int scone_shard_gather_pack_range(scone_handle *h, uint64_t first, uint64_t count, uint64_t pad, void *d_send_buf,
                                   scone_stream_t stream);
 int scone_shard_gather_add_records(scone_handle *h, const void *d_records_base, uint64_t record0, uint64_t n_records,

@@ -23,8 +23,11 @@
 // On the C5-shaped workload that removes half of all records and the 10x send imbalance of the rank owning the head.
 #include "scone_common.h"
 
+#include <cstdlib>
+#include <cstring>
 #include <new>
 #include <utility>
+#include <vector>
 
 struct scone_shard_state {
   long long cap_tok = 0, cap_slice = 0, cap_slot = 0, cap_recv = 0;
@@ -49,6 +52,17 @@ struct scone_shard_state {
   long long rhash_cap_now = 0;     // capacity the receiver's map was cleared for (current exchange)
   unsigned long long *rhash = nullptr;  // receiver: open-addressing map row id -> record number
   long long cap_rhash = 0;
+  // The lists of the planned batch live in ell_slice -- or in a buffer the CALLER owns (scone_shard_gather_plan_ell:
+  // the lists were matched slice by slice on several ranks and all-gathered), borrowed until the batch has been reduced.
+  int32_t *ell_ext = nullptr;
+  // Receiver's row map, direct-mapped form: rmap[global row id] = generation << 24 | record number.  Plain stores and
+  // loads instead of an open-addressing table filled by 64-bit CAS; a new exchange bumps the generation instead of
+  // clearing (cleared once every 255 exchanges).  4 B per table row and plan slot (8 GB of the 288 at 1e9 rows);
+  // exchanges of >= 2^24 records, or SCONE_SHARD_ROW_MAP=hash, use the hash map.
+  uint32_t *rmap = nullptr;
+  uint32_t rmap_gen = 0;
+  bool rmap_active = false;        // the CURRENT exchange uses rmap (else rhash)
+  std::vector<uint8_t> remapped;   // per sequence of the planned batch: its lists already hold record numbers
   // Plan slots (scone_shard_select_slot): the receiver-side state of a planned batch -- its id lists, the scales of
   // [head | received records], the row map -- exists twice, so that batch b + 1 can be planned, packed and exchanged on a
   // side stream while batch b is still being reduced.  The fields above are the ACTIVE slot's; the other one is parked.
@@ -60,8 +74,14 @@ struct scone_shard_state {
     unsigned long long *rhash = nullptr;
     long long cap_rhash = 0, rhash_cap_now = 0;
     int32_t plan_B = 0, plan_T = 0, plan_chunks = 0;
+    int32_t *ell_ext = nullptr;
+    uint32_t *rmap = nullptr;
+    uint32_t rmap_gen = 0;
+    bool rmap_active = false;
+    std::vector<uint8_t> remapped;
   } parked;
   int slot = 0;
+  int rmap_policy = -1;            // -1 undecided, 0 hash, 1 direct
 };
 
 namespace {
@@ -271,7 +291,7 @@ void scone_shard_destroy(scone_handle *h) {
   if (!st) return;
   void *ptrs[] = {st->ell_send, st->ell_slice, st->counters, st->send_src, st->slot_of_ref, st->scales,
                   st->head_rows, st->head_scales, st->uniq_claim, st->uniq_list, st->rhash, st->chunk_ends,
-                  st->parked.ell_slice, st->parked.scales, st->parked.rhash};
+                  st->parked.ell_slice, st->parked.scales, st->parked.rhash, st->rmap, st->parked.rmap};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   delete st;
@@ -587,6 +607,67 @@ __global__ __launch_bounds__(256) void k_gather_index(const uint8_t *__restrict_
   }
 }
 
+// The same two steps on the direct-mapped row map: record p holding row `id` -> rmap[id] = gen << 24 | p (the smallest p
+// wins should a row arrive twice, as in the hash map), and a list entry is looked up with ONE load.
+#define RMAP_REC_BITS 24
+#define RMAP_REC_MASK ((1u << RMAP_REC_BITS) - 1u)
+__global__ __launch_bounds__(256) void k_gather_index_direct(const uint8_t *__restrict__ recv, unsigned long long n_recv, int rec_bytes,
+                                                             int row_bytes, int scale_bytes, uint32_t *__restrict__ rmap,
+                                                             unsigned long long n_rows, uint32_t gen, uint8_t *__restrict__ scales,
+                                                             unsigned long long record0, uint32_t *__restrict__ status) {
+  unsigned long long p = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_recv) return;
+  const uint8_t *rec = recv + p * (unsigned long long)rec_bytes;
+  const uint32_t id = reinterpret_cast<const uint32_t *>(rec + rec_bytes - 8)[0];
+  if (id == 0xFFFFFFFFu) return;  // padding
+  if (id >= n_rows) {             // not a row of this table: never index outside the map
+    atomicOr(status, SCONE_ST_BAD_ID);
+    return;
+  }
+  for (int b = 0; b < scale_bytes / 2; ++b)
+    reinterpret_cast<unsigned short *>(scales + p * scale_bytes)[b] = reinterpret_cast<const unsigned short *>(rec + row_bytes)[b];
+  p += record0;
+  const uint32_t mine = (gen << RMAP_REC_BITS) | (uint32_t)p;
+  uint32_t old = rmap[id];
+  while (!((old >> RMAP_REC_BITS) == gen && old <= mine)) {
+    const uint32_t prev = atomicCAS(&rmap[id], old, mine);
+    if (prev == old) break;
+    old = prev;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_gather_remap_direct(int32_t *__restrict__ ell, long long ntok, int W, int NC,
+                                                             const uint32_t *__restrict__ rmap, uint32_t gen, long long n_head,
+                                                             long long n_rows, uint32_t *__restrict__ status) {
+  const long long per = (ntok + gridDim.x - 1) / gridDim.x;
+  const long long t0 = (long long)blockIdx.x * per, t1 = t0 + per < ntok ? t0 + per : ntok;
+  for (long long t = t0 + threadIdx.x; t < t1; t += blockDim.x) {
+    int4 *rp = reinterpret_cast<int4 *>(ell + t * W);
+    int4 a = rp[0], b = rp[1];  // (W = 16: ids 8.. are handled below through memory)
+    int32_t r[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    const int kown = (W == 8 ? r[6] : ell[t * W + W - 2]) & 0xFF;
+    bool dirty = false;
+    for (int j = 0; j < NC; ++j) {
+      if (j >= kown) break;
+      const long long id = j < 8 && W == 8 ? r[j] : ell[t * W + j];
+      if (id < n_head) continue;  // a head row: its id is its row number in the lookup's row store
+      long long slot = 0;
+      const uint32_t v = (id >= 0 && id < n_rows) ? rmap[id] : 0u;
+      if ((v >> RMAP_REC_BITS) == gen) {
+        slot = (long long)(v & RMAP_REC_MASK);
+      } else {  // the row did not arrive (the ranks disagree about the batch): report, never read out of bounds
+        atomicOr(status, SCONE_ST_BAD_ID);
+      }
+      if (W == 8 && j < 8) r[j] = (int32_t)(n_head + slot), dirty = true;
+      else ell[t * W + j] = (int32_t)(n_head + slot);
+    }
+    if (W == 8 && dirty) {
+      rp[0] = make_int4(r[0], r[1], r[2], r[3]);
+      rp[1] = make_int4(r[4], r[5], r[6], r[7]);
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void k_gather_remap(int32_t *__restrict__ ell, long long ntok, int W, int NC,
                                                       const unsigned long long *__restrict__ rhash, unsigned long long hmask,
                                                       long long n_head, uint32_t *__restrict__ status) {
@@ -629,32 +710,23 @@ static void chunk_seqs(int32_t B, int32_t n_chunks, int32_t c, int32_t *s0, int3
   *s1 = (int32_t)(b < B ? b : B);
 }
 
-extern "C" int scone_shard_gather_plan_chunks(scone_handle *h, const int32_t *d_tok, int32_t B, int32_t T, int32_t n_chunks,
-                                              int32_t dedup_across_chunks, uint64_t *h_chunk_end, scone_stream_t stream) {
-  if (!h) return SCONE_EINVAL;
-  if (h->cfg.dim <= 0 || !h->rows) return scone_fail(h, SCONE_ESTATE, "scone_shard_gather_plan: handle has no table");
-  if (B < 0 || T <= 0 || !h_chunk_end || !d_tok || n_chunks < 1 || n_chunks > 64)
-    return scone_fail(h, SCONE_EINVAL, "scone_shard_gather_plan: bad argument (1 <= n_chunks <= 64)");
-  if (h->cfg.placement != SCONE_PLACE_HBM) return scone_fail(h, SCONE_EINVAL, "scone_shard_gather_plan: HBM tables only");
-  SCONE_ON_DEVICE(h);
-  hipStream_t s = (hipStream_t)stream;
-  if (!h->shard) {
-    h->shard = new (std::nothrow) scone_shard_state();
-    if (!h->shard) return scone_fail(h, SCONE_ENOMEM, "scone_shard_gather_plan: out of memory");
-  }
-  scone_shard_state *st = h->shard;
-  for (int c = 0; c < n_chunks; ++c) h_chunk_end[c] = 0;
-  st->n_uniq = 0;
-  st->plan_B = B, st->plan_T = T, st->plan_chunks = n_chunks;
+static scone_shard_state *shard_state(scone_handle *h) {
+  if (!h->shard) h->shard = new (std::nothrow) scone_shard_state();
+  return h->shard;
+}
+
+// the lists of the planned batch: the library's own buffer, or the one the caller lent (scone_shard_gather_plan_ell)
+static inline int32_t *plan_lists(scone_shard_state *st) { return st->ell_ext ? st->ell_ext : st->ell_slice; }
+
+// The claim passes of a plan over the lists `ell` [B*T, W] (matched against ALL rows, compacted).  One claim pass per
+// chunk, in chunk order.  dedup_across_chunks (the all-gather form): all in ONE generation -- a row already claimed by an
+// earlier chunk is not sent again, the receiver's row map is cumulative and chunk c is reduced after the records of
+// chunks 0..c arrived.  Otherwise (the slice exchange: chunk q = what rank q's slice needs from me) every chunk claims
+// in a generation of its own: each destination gets every distinct row it references, once.
+static int plan_claims(scone_handle *h, scone_shard_state *st, const int32_t *ell, int32_t B, int32_t T, int32_t n_chunks,
+                       int32_t dedup_across_chunks, uint64_t *h_chunk_end, hipStream_t s) {
   const int W = SCONE_ELL_W(h->cfg.max_n), NC = h->cfg.max_n * (h->cfg.max_n + 1) / 2;
   const long long ntok = (long long)B * T;
-  if (ntok == 0) return SCONE_OK;
-  if (!scone_grid_fits((unsigned long long)(ntok + 255) / 256, 256))
-    return scone_fail(h, SCONE_EINVAL, "scone_shard_gather_plan: too many tokens for one launch");
-  long long cs = st->cap_slice;
-  int rc = grow(h, &st->ell_slice, &cs, ntok, (size_t)W);
-  if (rc) return rc;
-  st->cap_slice = cs;
   if (!st->counters) SCONE_HIP(h, hipMalloc(&st->counters, 3 * 64 * sizeof(uint32_t)));
   if (!st->chunk_ends) SCONE_HIP(h, hipMalloc(&st->chunk_ends, 64 * sizeof(uint32_t)));
   if (!st->uniq_claim) {
@@ -671,18 +743,11 @@ extern "C" int scone_shard_gather_plan_chunks(scone_handle *h, const int32_t *d_
   // once per CHUNK (slice exchange: every destination gets its own copy)
   const long long rows_cap = (long long)h->local_rows * (dedup_across_chunks ? 1 : n_chunks);
   long long need = ntok * NC < rows_cap ? ntok * NC : rows_cap;
-  rc = grow(h, &st->uniq_list, &st->cap_uniq, need, 1);
+  int rc = grow(h, &st->uniq_list, &st->cap_uniq, need, 1);
   if (rc) return rc;
   SCONE_HIP(h, hipMemsetAsync(st->counters, 0, 3 * 64 * sizeof(uint32_t), s));
   const long long n_head = (long long)st->n_head;
   const long long send_begin = (long long)h->cfg.row_begin > n_head ? (long long)h->cfg.row_begin : n_head;
-  // ONE match of the whole batch against ALL rows: the lists the lookup kernel will walk, and what the claim passes filter
-  rc = scone_launch_match_ell_ex(h, d_tok, B, T, st->ell_slice, 0, (long long)h->cfg.n_rows, 0, s);
-  if (rc) return rc;
-  // one claim pass per chunk, in chunk order.  dedup_across_chunks (the all-gather form): all in ONE generation -- a row
-  // already claimed by an earlier chunk is not sent again, the receiver's row map is cumulative and chunk c is reduced
-  // after the records of chunks 0..c arrived.  Otherwise (the slice exchange: chunk q = what rank q's slice needs from
-  // me) every chunk claims in a generation of its own: each destination gets every distinct row it references, once.
   for (int c = 0; c < n_chunks; ++c) {
     int32_t s0, s1;
     chunk_seqs(B, n_chunks, c, &s0, &s1);
@@ -696,7 +761,7 @@ extern "C" int scone_shard_gather_plan_chunks(scone_handle *h, const int32_t *d_
     const long long nt = (long long)(s1 - s0) * T;
     if (nt > 0) {
       const unsigned blocks = (unsigned)((nt + 255) / 256 < SHARD_BLOCKS ? (nt + 255) / 256 : SHARD_BLOCKS);
-      hipLaunchKernelGGL(k_gather_claim, dim3(blocks), dim3(256), 0, s, st->ell_slice + (long long)s0 * T * W, nt, W, NC,
+      hipLaunchKernelGGL(k_gather_claim, dim3(blocks), dim3(256), 0, s, ell + (long long)s0 * T * W, nt, W, NC,
                          (long long)h->cfg.row_begin, send_begin, (long long)h->cfg.row_end, st->uniq_claim, st->uniq_gen,
                          st->counters, st->uniq_list, st->cap_uniq);
     }
@@ -712,6 +777,84 @@ extern "C" int scone_shard_gather_plan_chunks(scone_handle *h, const int32_t *d_
     st->n_uniq = 0;
     return scone_fail(h, SCONE_ERANGE, "scone_shard_gather_plan: claim list overflow");
   }
+  return SCONE_OK;
+}
+
+static int plan_check(scone_handle *h, int32_t B, int32_t T, int32_t n_chunks, const void *p1, const void *p2) {
+  if (!h) return SCONE_EINVAL;
+  if (h->cfg.dim <= 0 || !h->rows) return scone_fail(h, SCONE_ESTATE, "scone_shard_gather_plan: handle has no table");
+  if (B < 0 || T <= 0 || !p1 || !p2 || n_chunks < 1 || n_chunks > 64)
+    return scone_fail(h, SCONE_EINVAL, "scone_shard_gather_plan: bad argument (1 <= n_chunks <= 64)");
+  if (h->cfg.placement != SCONE_PLACE_HBM) return scone_fail(h, SCONE_EINVAL, "scone_shard_gather_plan: HBM tables only");
+  if (!scone_grid_fits((unsigned long long)((long long)B * T + 255) / 256, 256))
+    return scone_fail(h, SCONE_EINVAL, "scone_shard_gather_plan: too many tokens for one launch");
+  return SCONE_OK;
+}
+
+static void plan_reset(scone_shard_state *st, int32_t B, int32_t T, int32_t n_chunks, int32_t *ell_ext) {
+  st->n_uniq = 0;
+  st->plan_B = B, st->plan_T = T, st->plan_chunks = n_chunks;
+  st->ell_ext = ell_ext;
+  st->remapped.assign((size_t)(B > 0 ? B : 0), 0);
+}
+
+extern "C" int scone_shard_gather_plan_chunks(scone_handle *h, const int32_t *d_tok, int32_t B, int32_t T, int32_t n_chunks,
+                                              int32_t dedup_across_chunks, uint64_t *h_chunk_end, scone_stream_t stream) {
+  int rc = plan_check(h, B, T, n_chunks, d_tok, h_chunk_end);
+  if (rc) return rc;
+  SCONE_ON_DEVICE(h);
+  hipStream_t s = (hipStream_t)stream;
+  scone_shard_state *st = shard_state(h);
+  if (!st) return scone_fail(h, SCONE_ENOMEM, "scone_shard_gather_plan: out of memory");
+  for (int c = 0; c < n_chunks; ++c) h_chunk_end[c] = 0;
+  plan_reset(st, B, T, n_chunks, nullptr);
+  const int W = SCONE_ELL_W(h->cfg.max_n);
+  const long long ntok = (long long)B * T;
+  if (ntok == 0) return SCONE_OK;
+  long long cs = st->cap_slice;
+  rc = grow(h, &st->ell_slice, &cs, ntok, (size_t)W);
+  if (rc) return rc;
+  st->cap_slice = cs;
+  // ONE match of the whole batch against ALL rows: the lists the lookup kernel will walk, and what the claim passes filter
+  rc = scone_launch_match_ell_ex(h, d_tok, B, T, st->ell_slice, 0, (long long)h->cfg.n_rows, 0, s);
+  if (rc) return rc;
+  return plan_claims(h, st, st->ell_slice, B, T, n_chunks, dedup_across_chunks, h_chunk_end, s);
+}
+
+// The match of a plan, SHARDED over the ranks.  Index and tokens are replicated, so every rank can match any part of the
+// batch -- and in the all-gather form every rank needs the lists of the WHOLE batch (it reduces all of it), which made
+// the match the largest helper kernel of the step: 98 us per rank against the 34 GB index of 1e9 keys, every probe an
+// HBM miss.  Matching is per sequence, so rank r matches slice r only (scone_shard_gather_match: sequences
+// [seq_begin, seq_end) of the batch, 32 B per token into a buffer of the caller), the slices are all-gathered (32 MB per
+// 1M tokens: a transfer, not GPU work) and the claim passes run over the gathered lists (scone_shard_gather_plan_ell).
+extern "C" int scone_shard_gather_match(scone_handle *h, const int32_t *d_tok, int32_t B, int32_t T, int32_t seq_begin,
+                                        int32_t seq_end, int32_t *d_ell_out, scone_stream_t stream) {
+  if (!h) return SCONE_EINVAL;
+  if (B < 0 || T <= 0 || seq_begin < 0 || seq_end < seq_begin || seq_end > B)
+    return scone_fail(h, SCONE_EINVAL, "scone_shard_gather_match: bad sequence range");
+  if (seq_end == seq_begin) return SCONE_OK;
+  if (!d_tok || !d_ell_out) return scone_fail(h, SCONE_EINVAL, "scone_shard_gather_match: null pointer");
+  SCONE_ON_DEVICE(h);
+  return scone_launch_match_ell_ex(h, d_tok + (long long)seq_begin * T, seq_end - seq_begin, T, d_ell_out, 0,
+                                   (long long)h->cfg.n_rows, 0, (hipStream_t)stream);
+}
+
+extern "C" int scone_shard_gather_plan_ell(scone_handle *h, int32_t *d_ell, int32_t B, int32_t T, int32_t n_chunks,
+                                           int32_t dedup_across_chunks, uint64_t *h_chunk_end, scone_stream_t stream) {
+  int rc = plan_check(h, B, T, n_chunks, d_ell, h_chunk_end);
+  if (rc) return rc;
+  SCONE_ON_DEVICE(h);
+  scone_shard_state *st = shard_state(h);
+  if (!st) return scone_fail(h, SCONE_ENOMEM, "scone_shard_gather_plan: out of memory");
+  for (int c = 0; c < n_chunks; ++c) h_chunk_end[c] = 0;
+  plan_reset(st, B, T, n_chunks, d_ell);
+  if ((long long)B * T == 0) return SCONE_OK;
+  return plan_claims(h, st, d_ell, B, T, n_chunks, dedup_across_chunks, h_chunk_end, (hipStream_t)stream);
+}
+
+extern "C" int scone_ell_width(scone_handle *h, uint32_t *ints_per_token) {
+  if (!h || !ints_per_token) return SCONE_EINVAL;
+  *ints_per_token = (uint32_t)SCONE_ELL_W(h->cfg.max_n);
   return SCONE_OK;
 }
 
@@ -739,6 +882,11 @@ extern "C" int scone_shard_select_slot(scone_handle *h, int32_t slot) {
   std::swap(st->plan_B, p.plan_B);
   std::swap(st->plan_T, p.plan_T);
   std::swap(st->plan_chunks, p.plan_chunks);
+  std::swap(st->ell_ext, p.ell_ext);
+  std::swap(st->rmap, p.rmap);
+  std::swap(st->rmap_gen, p.rmap_gen);
+  std::swap(st->rmap_active, p.rmap_active);
+  st->remapped.swap(p.remapped);
   st->slot = slot;
   return SCONE_OK;
 }
@@ -777,7 +925,22 @@ extern "C" int scone_shard_gather_pack(scone_handle *h, void *d_send_buf, scone_
 }
 
 // Receiver, step 1: records [record0, record0 + n) of the gathered buffer (d_records points at record record0; the
-// whole buffer will hold n_total) join the row map; record0 == 0 starts a new exchange (the map is cleared).
+// whole buffer will hold n_total) join the row map; record0 == 0 starts a new exchange (a new generation of the
+// direct-mapped map / the hash map is cleared).
+static int rmap_policy(scone_handle *h, scone_shard_state *st) {
+  // read when an exchange starts (cheap; lets one process compare the two forms): SCONE_SHARD_ROW_MAP=hash|direct, else
+  // auto: 4 B per table row and plan slot, taken when both slots' maps are under 1/8 of the device's memory
+  const char *e = getenv("SCONE_SHARD_ROW_MAP");
+  if (e && !strcmp(e, "hash")) return 0;
+  if (e && !strcmp(e, "direct")) return h->cfg.n_rows < 0xFFFFFFFFull ? 1 : 0;
+  if (st->rmap_policy < 0) {
+    size_t free_b = 0, total_b = 0;
+    (void)hipMemGetInfo(&free_b, &total_b);
+    st->rmap_policy = ((unsigned long long)h->cfg.n_rows * 8ull <= (unsigned long long)total_b / 8ull && h->cfg.n_rows < 0xFFFFFFFFull) ? 1 : 0;
+  }
+  return st->rmap_policy;
+}
+
 int scone_shard_gather_add(scone_handle *h, const void *d_records, uint64_t n, uint64_t record0, uint64_t n_total,
                            hipStream_t s) {
   scone_shard_state *st = h->shard;
@@ -785,6 +948,9 @@ int scone_shard_gather_add(scone_handle *h, const void *d_records, uint64_t n, u
   const unsigned long long n_head = st->n_head;
   if (n_total > 0xFFFFFFF0ull || record0 + n > n_total) return scone_fail(h, SCONE_EINVAL, "scone_shard_gather_embed: bad record range");
   if (record0 == 0) {
+    for (uint8_t r : st->remapped)
+      if (r) return scone_fail(h, SCONE_ESTATE, "scone_shard_gather_add_records: lists of this plan already hold record numbers of "
+                                                "an earlier exchange (plan the batch again before a new exchange)");
     if (sb) {
       long long cap = st->cap_recv;
       uint8_t *p = st->scales;
@@ -793,40 +959,78 @@ int scone_shard_gather_add(scone_handle *h, const void *d_records, uint64_t n, u
       if (rc) return rc;
       if (n_head) SCONE_HIP(h, hipMemcpyAsync(st->scales, st->head_scales, (size_t)n_head * sb, hipMemcpyDeviceToDevice, s));
     }
-    long long hcap = 1024;
-    while (hcap < 2 * (long long)n_total) hcap <<= 1;
-    int rc = grow(h, &st->rhash, &st->cap_rhash, hcap, 1);
-    if (rc) return rc;
-    SCONE_HIP(h, hipMemsetAsync(st->rhash, 0, (size_t)hcap * sizeof(unsigned long long), s));
-    st->rhash_cap_now = hcap;
+    st->rmap_active = rmap_policy(h, st) == 1 && n_total < (1ull << RMAP_REC_BITS);
+    if (st->rmap_active) {
+      const size_t bytes = (size_t)(h->cfg.n_rows ? h->cfg.n_rows : 1) * sizeof(uint32_t);
+      if (!st->rmap) {
+        SCONE_HIP(h, hipMalloc(&st->rmap, bytes));
+        st->rmap_gen = 0;
+      }
+      st->rmap_gen += 1;
+      if (st->rmap_gen == 1 || st->rmap_gen > 0xFFu) {  // first use / the 8-bit generation wraps: forget every entry
+        SCONE_HIP(h, hipMemsetAsync(st->rmap, 0, bytes, s));
+        st->rmap_gen = 1;
+      }
+      st->rhash_cap_now = 2 * (long long)n_total + 2;     // (kept consistent for the out-of-order check below)
+    } else {
+      long long hcap = 1024;
+      while (hcap < 2 * (long long)n_total) hcap <<= 1;
+      int rc = grow(h, &st->rhash, &st->cap_rhash, hcap, 1);
+      if (rc) return rc;
+      SCONE_HIP(h, hipMemsetAsync(st->rhash, 0, (size_t)hcap * sizeof(unsigned long long), s));
+      st->rhash_cap_now = hcap;
+    }
   } else if (st->rhash_cap_now < 2 * (long long)n_total || (sb && st->cap_recv < (long long)(n_head + n_total))) {
     return scone_fail(h, SCONE_ESTATE, "scone_shard_gather_embed: records added out of order (start with record 0)");
   }
-  if (n)
-    hipLaunchKernelGGL(k_gather_index, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const uint8_t *)d_records,
-                       (unsigned long long)n, scone_shard_rec_bytes(h), (int)h->row_payload_bytes, (int)sb, st->rhash,
-                       (unsigned long long)st->rhash_cap_now - 1,
-                       st->scales ? st->scales + (size_t)(n_head + record0) * sb : nullptr, (unsigned long long)record0);
+  if (n) {
+    uint8_t *sc = st->scales ? st->scales + (size_t)(n_head + record0) * sb : nullptr;
+    if (st->rmap_active)
+      hipLaunchKernelGGL(k_gather_index_direct, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const uint8_t *)d_records,
+                         (unsigned long long)n, scone_shard_rec_bytes(h), (int)h->row_payload_bytes, (int)sb, st->rmap,
+                         (unsigned long long)h->cfg.n_rows, st->rmap_gen, sc, (unsigned long long)record0, h->d_status);
+    else
+      hipLaunchKernelGGL(k_gather_index, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const uint8_t *)d_records,
+                         (unsigned long long)n, scone_shard_rec_bytes(h), (int)h->row_payload_bytes, (int)sb, st->rhash,
+                         (unsigned long long)st->rhash_cap_now - 1, sc, (unsigned long long)record0);
+  }
   SCONE_HIP(h, hipGetLastError());
   return SCONE_OK;
 }
 
-// Receiver, step 2: the lists of sequences [seq0, seq1) of the planned batch are remapped to record numbers.
+// Receiver, step 2: the lists of sequences [seq0, seq1) of the planned batch are remapped to record numbers -- in place,
+// so every sequence exactly ONCE per plan: the slot remembers which ones already hold record numbers (a second
+// scone_shard_gather_embed_range over the same or an overlapping range reduces them as they are).
 int scone_shard_gather_remap(scone_handle *h, int32_t T, int32_t seq0, int32_t seq1, const int32_t **ell, const void **scales,
                              hipStream_t s) {
   scone_shard_state *st = h->shard;
-  if (!st->rhash || st->rhash_cap_now <= 0 || !st->ell_slice)
+  int32_t *lists = plan_lists(st);
+  const bool have_map = st->rmap_active ? st->rmap != nullptr : (st->rhash && st->rhash_cap_now > 0);
+  if (!have_map || !lists)
     return scone_fail(h, SCONE_ESTATE, "scone_shard_gather_embed: plan the batch and add the records first");
+  if ((size_t)seq1 > st->remapped.size()) return scone_fail(h, SCONE_ESTATE, "scone_shard_gather_embed: sequences outside the planned batch");
   const int W = SCONE_ELL_W(h->cfg.max_n), NC = h->cfg.max_n * (h->cfg.max_n + 1) / 2;
-  const long long nt = (long long)(seq1 - seq0) * T;
-  int32_t *e = st->ell_slice + (long long)seq0 * T * W;
-  if (nt > 0) {
+  for (int32_t a = seq0; a < seq1;) {
+    if (st->remapped[a]) {
+      ++a;
+      continue;
+    }
+    int32_t b = a;
+    while (b < seq1 && !st->remapped[b]) ++b;  // a run of sequences whose lists still hold row ids
+    const long long nt = (long long)(b - a) * T;
+    int32_t *e = lists + (long long)a * T * W;
     const unsigned blocks = (unsigned)((nt + 255) / 256 < SHARD_BLOCKS ? (nt + 255) / 256 : SHARD_BLOCKS);
-    hipLaunchKernelGGL(k_gather_remap, dim3(blocks), dim3(256), 0, s, e, nt, W, NC, st->rhash,
-                       (unsigned long long)st->rhash_cap_now - 1, (long long)st->n_head, h->d_status);
+    if (st->rmap_active)
+      hipLaunchKernelGGL(k_gather_remap_direct, dim3(blocks), dim3(256), 0, s, e, nt, W, NC, st->rmap, st->rmap_gen,
+                         (long long)st->n_head, (long long)h->cfg.n_rows, h->d_status);
+    else
+      hipLaunchKernelGGL(k_gather_remap, dim3(blocks), dim3(256), 0, s, e, nt, W, NC, st->rhash,
+                         (unsigned long long)st->rhash_cap_now - 1, (long long)st->n_head, h->d_status);
+    for (int32_t q = a; q < b; ++q) st->remapped[q] = 1;
+    a = b;
   }
   SCONE_HIP(h, hipGetLastError());
-  *ell = e;
+  *ell = lists + (long long)seq0 * T * W;
   *scales = st->scales;
   return SCONE_OK;
 }

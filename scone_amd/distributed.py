@@ -45,12 +45,32 @@ Sequences are independent, so when the table DOES fit one GPU the path needs no 
 at all: replicate the table and shard the tokens (bench.py's default at N > 1).
 """
 
+import os
+import sys
+import time
 from typing import Optional, Tuple
 
 import torch
 import torch.distributed as dist
 
 from scone_amd.tokenization.n_gram_extractor import NGramExtractor
+
+_T_IMPORT = time.time()
+
+
+def _trace(name: str, group=None, **facts) -> None:
+    """``SCONE_DIST_TRACE=1``: one stderr line per collective -- its name, element counts and bytes -- written BEFORE the
+    call, so that the last line of a hung job's stderr names the collective it hangs in (bench.py switches it on for
+    rank 0 of an N > 1 run; the driver keeps the tail of stderr)."""
+    if os.environ.get("SCONE_DIST_TRACE") != "1":
+        return
+    try:
+        r = dist.get_rank(group)
+    except Exception:
+        r = -1
+    sys.stderr.write(f"[scone dist +{time.time() - _T_IMPORT:8.3f}s r{r}] {name} "
+                     + " ".join(f"{k}={v}" for k, v in facts.items()) + "\n")
+    sys.stderr.flush()
 
 
 def _host_staged(group) -> bool:
@@ -62,6 +82,8 @@ def _host_staged(group) -> bool:
 
 
 def _reduce_scatter_sum(out: torch.Tensor, inp: torch.Tensor, group) -> None:
+    _trace("reduce_scatter_tensor(sum)", group, dtype=inp.dtype, in_elems=inp.numel(), out_elems=out.numel(),
+           in_bytes=inp.numel() * inp.element_size())
     if _host_staged(group) and inp.is_cuda:
         o = torch.empty(out.shape, dtype=out.dtype)
         dist.reduce_scatter_tensor(o, inp.cpu(), op=dist.ReduceOp.SUM, group=group)
@@ -71,6 +93,7 @@ def _reduce_scatter_sum(out: torch.Tensor, inp: torch.Tensor, group) -> None:
 
 
 def _all_gather(out: torch.Tensor, inp: torch.Tensor, group) -> None:
+    _trace("all_gather_into_tensor", group, dtype=inp.dtype, in_elems=inp.numel(), out_bytes=out.numel() * out.element_size())
     if _host_staged(group) and inp.is_cuda:
         o = torch.empty(out.shape, dtype=out.dtype)
         dist.all_gather_into_tensor(o, inp.cpu(), group=group)
@@ -93,6 +116,7 @@ def _all_gather_async(out: torch.Tensor, inp: torch.Tensor, group):
     if _host_staged(group) and inp.is_cuda:
         _all_gather(out, inp, group)
         return _Done()
+    _trace("all_gather_into_tensor(async)", group, dtype=inp.dtype, in_elems=inp.numel(), out_bytes=out.numel() * out.element_size())
     return dist.all_gather_into_tensor(out, inp, group=group, async_op=True)
 
 
@@ -115,6 +139,8 @@ def _exchange_exact_async(region: torch.Tensor, offs, counts, rank: int, group):
     the largest; on the C5-shaped batch the largest is twice the mean (511 MB against 258 MB into every rank)."""
     W = len(counts)
     me = region[offs[rank]:offs[rank] + counts[rank]]
+    _trace("batch_isend_irecv(exact ranges)", group, record_bytes=region.shape[1], counts=list(counts),
+           send_bytes_per_peer=counts[rank] * region.shape[1], recv_bytes=(sum(counts) - counts[rank]) * region.shape[1])
     if _host_staged(group) and region.is_cuda:
         src = me.cpu()
         bufs = {r: torch.empty((counts[r], region.shape[1]), dtype=region.dtype) for r in range(W) if r != rank and counts[r]}
@@ -145,6 +171,8 @@ def _exchange_exact_async(region: torch.Tensor, offs, counts, rank: int, group):
 
 
 def _all_to_all(out: torch.Tensor, inp: torch.Tensor, out_splits, in_splits, group) -> None:
+    _trace("all_to_all_single", group, dtype=inp.dtype, row_bytes=inp.shape[1] * inp.element_size() if inp.dim() == 2 else inp.element_size(),
+           in_splits=list(in_splits), out_splits=list(out_splits))
     if _host_staged(group) and inp.is_cuda:
         o = torch.empty(out.shape, dtype=out.dtype)
         dist.all_to_all_single(o, inp.cpu(), output_split_sizes=out_splits, input_split_sizes=in_splits, group=group)
@@ -174,8 +202,14 @@ class ShardedEmbeddingCache:
     def __init__(self, n_gram_extractor: NGramExtractor, embedding_dim: int, *, table_format: str = "int8",
                  rank: Optional[int] = None, world: Optional[int] = None, group=None, device=None,
                  n_rows: Optional[int] = None, placement: str = "hbm", table=None, replicated_rows: int = 0,
-                 gather_chunks: int = 4, gather_transport: str = "p2p") -> None:
+                 gather_chunks: int = 4, gather_transport: str = "p2p", shard_match="auto") -> None:
         self.group = group
+        # The match of a plan sharded over the ranks (rank r matches slice r, the 32-B list records are all-gathered) instead
+        # of every rank matching the whole batch: True / False / "auto" (on for batches of >= 65,536 tokens with at least one
+        # sequence per rank -- below that the extra small collective costs more than the match it saves)
+        if shard_match not in (True, False, "auto"):
+            raise ValueError("shard_match must be True, False or 'auto'")
+        self.shard_match = shard_match
         self.gather_chunks = int(gather_chunks)    # "gather_rows": the batch is exchanged and reduced in this many chunks
         if gather_transport not in ("p2p", "all_gather"):
             raise ValueError("gather_transport must be 'p2p' or 'all_gather'")
@@ -203,6 +237,14 @@ class ShardedEmbeddingCache:
         self._slot_next = 0
         self._slot_done = [None, None]
         self._slot_full = [None, None]
+        # The SENDER-side scratch of a plan (list of claimed rows, counters, chunk ends) exists once per handle, whatever the
+        # slot: the next plan may only overwrite it after the last pack of the previous one has read it, on whichever stream
+        # that pack ran -> an event after every plan's last pack, waited for by the stream of the next plan.  And a slot
+        # whose ticket has not been finished must not be planned into again.
+        self._plan_packed = None
+        self._slot_open = [False, False]
+        self._slot_ell = [None, None]        # sharded match: the gathered list records of the batch a slot holds
+        self._ell_send = None
 
     @classmethod
     def from_synthetic(cls, n_gram_extractor: NGramExtractor, embedding_dim: int, *, table_format: str = "int8",
@@ -394,13 +436,55 @@ class ShardedEmbeddingCache:
             ticket["ready"].record(side)
         return ticket
 
+    def _plan_enter(self, slot: int, tok) -> None:
+        """Before a plan: the slot must be free, and this stream must not overwrite the sender-side scratch while the
+        previous plan's last pack (possibly on another stream) is still reading it."""
+        if self._slot_open[slot]:
+            raise RuntimeError(f"plan slot {slot} still holds a batch begun with gather_rows_begin: call gather_rows_finish "
+                               "for it first (at most two batches in flight, finished in the order they were begun)")
+        if self._plan_packed is not None and tok.is_cuda:
+            torch.cuda.current_stream().wait_event(self._plan_packed)
+        self.table.shard_select_slot(slot)
+
+    def _plan_packed_here(self, tok) -> None:
+        if tok.is_cuda:
+            self._plan_packed = torch.cuda.Event()
+            self._plan_packed.record(torch.cuda.current_stream())
+
+    def _plan(self, tok, slot: int, n_chunks: int, dedup_across_chunks: bool) -> list:
+        """Match + claim passes of one batch on plan slot ``slot``; returns the chunk ends (synchronises the stream).
+        With the sharded match this rank matches only its own run of sequences and the list records of all runs are
+        all-gathered -- index and tokens are replicated, so the gathered lists are what a local match of the whole batch
+        would have produced, at 1/W of the probes per rank."""
+        B, T = tok.shape
+        W, t = self.world, self.table
+        on = self.shard_match
+        if on == "auto":
+            on = B * T >= 65536
+        if not (on and W > 1 and B >= W and hasattr(t, "shard_gather_match")):
+            return t.shard_gather_plan_chunks(tok, n_chunks, dedup_across_chunks)
+        bper = (B + W - 1) // W                                           # the slice convention of every exchange here
+        b0, b1 = min(self.rank * bper, B), min(self.rank * bper + bper, B)
+        wd = t.ell_width()
+        ell = self._slot_ell[slot]
+        if ell is None or ell.shape[0] < W * bper * T or ell.shape[1] != wd or ell.device != tok.device:
+            ell = torch.empty((W * bper * T, wd), dtype=torch.int32, device=tok.device)
+            self._slot_ell[slot] = ell
+        send = self._ell_send
+        if send is None or send.shape[0] != bper * T or send.shape[1] != wd or send.device != tok.device:
+            send = torch.zeros((bper * T, wd), dtype=torch.int32, device=tok.device)   # (a short last slice leaves zero records:
+            self._ell_send = send                                                       #  tokens past B * T, never read)
+        t.shard_gather_match(tok, b0, b1, send)
+        _all_gather(ell[:W * bper * T].view(-1), send.view(-1), self.group)             # 32 B per token: W * bper * T * 32 B in all
+        return t.shard_gather_plan_ell(ell, B, T, n_chunks, dedup_across_chunks)
+
     def _gather_begin(self, tok, slot, t0):
         B, T = tok.shape
         W, t = self.world, self.table
         C = max(1, min(self.gather_chunks, B, 64))
         per = (B + C - 1) // C
-        t.shard_select_slot(slot)
-        ends = t.shard_gather_plan_chunks(tok, C)                       # synchronises its stream: this rank's record counts
+        self._plan_enter(slot, tok)
+        ends = self._plan(tok, slot, C, True)                           # synchronises its stream: this rank's record counts
         mine = [ends[0]] + [ends[c] - ends[c - 1] for c in range(1, C)]
         t0 = self._tick("plan_ms", t0)
         exact = W > 1 and self.gather_transport == "p2p"
@@ -461,6 +545,8 @@ class ShardedEmbeddingCache:
                 t0 = self._tick("pack_ms", t0)
                 works.append(None)
             first += mine[c]
+        self._plan_packed_here(tok)
+        self._slot_open[slot] = True
         if self._prof is not None:
             self._prof["bytes_received"] = float((total - sum(mine)) * rec if exact else total * rec * (W - 1) // max(W, 1))
         return {"slot": slot, "tok": tok, "C": C, "per": per, "base": base, "total": total, "records": full[:total],
@@ -484,6 +570,7 @@ class ShardedEmbeddingCache:
             cur.wait_event(ticket["ready"])
             tok.record_stream(cur)                                       # (allocated there, read here)
         t.shard_select_slot(ticket["slot"])
+        self._slot_open[ticket["slot"]] = False
         if out is None:
             out = torch.empty((B * T, d), dtype=out_dtype, device=tok.device)
         else:
@@ -550,7 +637,8 @@ class ShardedEmbeddingCache:
         if position_ids is not None:
             position_ids = position_ids.to(device=tok.device, dtype=torch.int32).expand(B, T).contiguous()
         bper = (B + W - 1) // W
-        ends = t.shard_gather_plan_chunks(tok, W, dedup_across_chunks=False)     # chunk q = slice q (ceil(B / W) sequences)
+        self._plan_enter(0, tok)                                                 # one-call form: slot 0, the caller's stream
+        ends = self._plan(tok, 0, W, False)                                      # chunk q = slice q (ceil(B / W) sequences)
         send_counts = [ends[0]] + [ends[q] - ends[q - 1] for q in range(1, W)]
         t0 = self._tick("plan_ms", t0)
         rec = t.shard_record_bytes()
@@ -566,6 +654,7 @@ class ShardedEmbeddingCache:
         send = torch.empty((max(n_send, 1), rec), dtype=torch.uint8, device=tok.device)
         if n_send:
             t.shard_gather_pack_range(0, n_send, send[:n_send])
+        self._plan_packed_here(tok)
         t0 = self._tick("pack_ms", t0)
         if W > 1:
             recv = torch.empty((max(n_recv, 1), rec), dtype=torch.uint8, device=tok.device)

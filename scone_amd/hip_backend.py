@@ -473,6 +473,38 @@ class SconeTable:
         self._shard_keepalive = (tok,)
         return [int(e) for e in ends[:n_chunks]]
 
+    def ell_width(self) -> int:
+        """int32 words of one token's list record (8 for max_n <= 3, 16 for max_n = 4)."""
+        n = C.c_uint32(0)
+        self._check(L.lib().scone_ell_width(self._h, C.byref(n)), "scone_ell_width")
+        return n.value
+
+    def shard_gather_match(self, tok: torch.Tensor, seq_begin: int, seq_end: int, out_ell: torch.Tensor) -> None:
+        """List records of sequences ``[seq_begin, seq_end)`` of the batch (matched against ALL rows) into
+        ``out_ell[:(seq_end - seq_begin) * T]`` (int32 ``[., ell_width()]``): this rank's share of a plan whose match is
+        sharded over the ranks."""
+        tok = self._tok(tok)
+        B, T = tok.shape
+        n = (seq_end - seq_begin) * T
+        assert out_ell.is_cuda and out_ell.is_contiguous() and out_ell.dtype == torch.int32 and out_ell.numel() >= n * self.ell_width()
+        with torch.cuda.device(self.device):
+            rc = L.lib().scone_shard_gather_match(self._h, _ptr(tok), B, T, int(seq_begin), int(seq_end), _ptr(out_ell), _stream())
+        self._check(rc, "scone_shard_gather_match")
+        self._shard_keepalive = (tok, out_ell)
+
+    def shard_gather_plan_ell(self, ell: torch.Tensor, B: int, T: int, n_chunks: int, dedup_across_chunks: bool = True) -> list:
+        """The claim passes of :meth:`shard_gather_plan_chunks` over list records the caller gathered (``ell`` int32
+        ``[>= B * T, ell_width()]``, token order); ``ell`` is borrowed by the plan slot until the batch has been reduced
+        (synchronises)."""
+        assert ell.is_cuda and ell.is_contiguous() and ell.dtype == torch.int32 and ell.numel() >= B * T * self.ell_width()
+        ends = (C.c_uint64 * 64)()
+        with torch.cuda.device(self.device):
+            rc = L.lib().scone_shard_gather_plan_ell(self._h, _ptr(ell), int(B), int(T), int(n_chunks),
+                                                     int(bool(dedup_across_chunks)), ends, _stream())
+        self._check(rc, "scone_shard_gather_plan_ell")
+        self._shard_keepalive = (ell,)
+        return [int(e) for e in ends[:n_chunks]]
+
     def shard_gather_pack_range(self, first: int, count: int, out: torch.Tensor) -> None:
         """Records ``[first, first + count)`` of the plan into ``out[:count]``; the rest of ``out`` becomes padding."""
         assert out.is_cuda and out.is_contiguous() and out.dtype == torch.uint8 and out.shape[1] == self.shard_record_bytes()

@@ -1,0 +1,92 @@
+"""bench.py's time budget, rehearsed on CPU (gloo, no GPU): a collective that never completes must still leave ONE
+parseable JSON line and exit status 0 inside the budget -- launched both ways the driver / a user launches bench.py
+(`python -m torch.distributed.run ... bench.py --gpus 2` and plain `python bench.py --gpus 2`).  `--selftest` swaps the GPU
+measurements for a made-up, clearly marked headline; the Budget / Line / Watchdog / run_stages / self_launch / exit code is
+the code every real run executes."""
+
+import json
+import os
+import socket
+import subprocess
+import sys
+import time
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _env():
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "SCONE_BENCH_T0")}
+    env["MASTER_ADDR"] = "127.0.0.1"
+    return env
+
+
+def _line(stdout):
+    lines = [ln for ln in stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1, stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("launcher", ["self", "torchrun"])
+def test_hung_collective_still_yields_a_line_and_status_0(launcher):
+    """Stage 2 of 3 hangs (rank 1 never joins the all-reduce).  The stage limit (4 s) ends the job: rank 0 prints what was
+    measured before the hang, marked incomplete, both ranks leave with status 0 -- well inside the 60 s budget.  A thread
+    keeps changing the record all the while: the line is serialised under the lock (round-2 ADVICE: a 'dictionary
+    changed size during iteration' on the timer thread used to hang the job for ever)."""
+    args = ["--gpus", "2", "--selftest", "hang", "--time-budget", "60", "--stage-limit", "4"]
+    if launcher == "self":
+        cmd = [sys.executable, BENCH] + args
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), BENCH] + args
+    t0 = time.time()
+    p = subprocess.run(cmd, env=_env(), cwd=ROOT, capture_output=True, text=True, timeout=180)
+    took = time.time() - t0
+    assert p.returncode == 0, (p.returncode, p.stderr[-3000:])
+    assert took < 60, took
+    r = _line(p.stdout)
+    assert r["n_gpus"] == 2 and r["data"] == "selftest"
+    assert "second" in r["incomplete"] and "did not complete" in r["incomplete"]
+    ex = r["sharded"]["exchanges"]
+    assert ex["fine"]["tokens_per_s"] == 2000.0 and ex["fine"]["speedup_vs_n1_pinned_host"] == 4.0
+    assert "second" not in ex and "third" not in ex                   # nothing after the hang ran; nothing before it was lost
+    assert "did not complete" in p.stderr
+
+
+def test_no_hang_prints_the_complete_line():
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--selftest", "ok", "--time-budget", "60", "--stage-limit", "10"],
+                       env=_env(), cwd=ROOT, capture_output=True, text=True, timeout=180)
+    assert p.returncode == 0, p.stderr[-3000:]
+    r = _line(p.stdout)
+    assert "incomplete" not in r and sorted(k for k in r["sharded"]["exchanges"]) == ["fine", "second", "third"]
+    assert "started 2 ranks itself" in r["launcher"]
+
+
+def test_budget_used_up_before_the_headline_is_status_3_and_no_line():
+    """The whole budget gone before anything was measured (here: the job 'started' 1000 s ago): no line, status 3 from the
+    ranks, and `self_launch` reports failure instead of forwarding something made up."""
+    env = _env()
+    env["SCONE_BENCH_T0"] = repr(time.time() - 1000.0)                # the job 'started' 1000 s ago
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--selftest", "hang", "--time-budget", "5", "--stage-limit", "4"],
+                       env=env, cwd=ROOT, capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0 and not [ln for ln in p.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert "time budget of 5 s used up" in p.stderr
+
+
+def test_a_rank_that_dies_takes_the_job_down_quickly():
+    """`self_launch` polls its children: when one exits non-zero the others are killed instead of sitting in their next
+    collective until its own timeout (round-2 ADVICE bench.py:86)."""
+    env = _env()
+    env["SCONE_SELFTEST_DIE_RANK"] = "1"
+    t0 = time.time()
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--selftest", "hang", "--time-budget", "120", "--stage-limit", "100"],
+                       env=env, cwd=ROOT, capture_output=True, text=True, timeout=180)
+    assert p.returncode != 0 and time.time() - t0 < 60

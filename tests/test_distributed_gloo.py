@@ -165,7 +165,7 @@ class OracleShard:
         cur = self.__dict__.setdefault("_slot", 0)
         if slot == cur:
             return
-        st[cur] = {k: self.__dict__.pop(k) for k in ("_planned", "_by_id", "_added") if k in self.__dict__}
+        st[cur] = {k: self.__dict__.pop(k) for k in ("_planned", "_by_id", "_added", "_planned_ell") if k in self.__dict__}
         self.__dict__.update(st[slot])
         self._slot = slot
 
@@ -188,6 +188,46 @@ class OracleShard:
                         order.append(i)
             ends.append(len(order))
         self._uniq, self._planned = np.asarray(order, dtype=np.int64), tuple(tok.shape)
+        self._planned_ell = None
+        return ends
+
+    # ---- the match of a plan, sharded over the ranks (scone_shard_gather_match / _plan_ell): list records as the device
+    #      writes them -- ids in the reference's order, -1 padding, K_own | K_full << 8 in word W - 2
+    def ell_width(self):
+        return 8 if self.max_n <= 3 else 16
+
+    def shard_gather_match(self, tok, seq_begin, seq_end, out_ell):
+        W = self.ell_width()
+        off, ids, tix, jix = self._refs(tok[seq_begin:seq_end])
+        rec = np.full((len(off) - 1, W), -1, dtype=np.int32)
+        rec[tix, jix] = ids
+        k = np.diff(off).astype(np.int32)
+        rec[:, W - 2] = k | (k << 8)
+        rec[:, W - 1] = 0
+        out_ell.numpy()[:rec.shape[0]] = rec
+
+    def shard_gather_plan_ell(self, ell, B, T, n_chunks, dedup_across_chunks=True):
+        # the claim passes over the GATHERED lists (no match of its own: what the all-gather delivered is what counts)
+        W = self.ell_width()
+        e = ell.numpy()[:B * T].reshape(B, T, W)
+        per = (B + n_chunks - 1) // n_chunks
+        claimed, order, ends = set(), [], []
+        for c in range(n_chunks):
+            if not dedup_across_chunks:
+                claimed = set()
+            s0, s1 = min(c * per, B), min(c * per + per, B)
+            if s1 > s0:
+                r = e[s0:s1].reshape(-1, W)
+                k = r[:, W - 2] & 0xFF
+                ids = np.concatenate([r[i, :k[i]] for i in range(r.shape[0])]) if r.shape[0] else np.zeros(0, dtype=np.int32)
+                for i in np.unique(ids[(ids >= max(self.row_begin, self.n_head)) & (ids < self.row_end)])[::-1].tolist():
+                    if i not in claimed:
+                        claimed.add(i)
+                        order.append(i)
+            ends.append(len(order))
+        self._uniq, self._planned = np.asarray(order, dtype=np.int64), (B, T)
+        self._planned_ell = e.copy()
+        self.plans_from_gathered_lists = getattr(self, "plans_from_gathered_lists", 0) + 1
         return ends
 
     def shard_gather_pack_range(self, first, count, out):
@@ -220,6 +260,9 @@ class OracleShard:
         B, T = tok.shape
         sl = tok[seq_begin:seq_end]
         off, ids, tix, jix = self._refs(sl)
+        if getattr(self, "_planned_ell", None) is not None:            # sharded match: the gathered lists ARE these lists
+            e = self._planned_ell[seq_begin:seq_end].reshape(-1, self.ell_width())
+            assert np.array_equal(e[:, self.ell_width() - 2] & 0xFF, np.diff(off)) and np.array_equal(e[tix, jix], ids)
         r = records.numpy()
         rows = np.zeros((len(ids), self.dim), dtype=np.float32)
         for k, i in enumerate(ids.tolist()):                          # KeyError = a needed row has not arrived yet
@@ -257,7 +300,7 @@ class OracleShard:
         return x
 
 
-def _worker(rank, world, port, ntok_shape, out_dtype_name, exchange, q, chunks=4, head=0, transport="p2p"):
+def _worker(rank, world, port, ntok_shape, out_dtype_name, exchange, q, chunks=4, head=0, transport="p2p", shard_match="auto"):
     try:
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -283,7 +326,7 @@ def _worker(rank, world, port, ntok_shape, out_dtype_name, exchange, q, chunks=4
         if head:
             shard.shard_set_head(head)
         cache = ShardedEmbeddingCache(ex, d, rank=rank, world=world, n_rows=n, table=shard, replicated_rows=head,
-                                      gather_chunks=max(chunks, 1), gather_transport=transport)
+                                      gather_chunks=max(chunks, 1), gather_transport=transport, shard_match=shard_match)
         assert (cache.row_begin, cache.row_end) == (a, b)
         out = cache.embed_tokens(tok, wte=wte.to(out_dtype), wpe=wpe.to(out_dtype), out_dtype=out_dtype,
                                  exchange=exchange)
@@ -297,6 +340,10 @@ def _worker(rank, world, port, ntok_shape, out_dtype_name, exchange, q, chunks=4
         per = (B * T + world - 1) // world if exchange == "partial_sums" else ((B + world - 1) // world) * T
         lo, hi = min(rank * per, B * T), min(rank * per + per, B * T)
         ok_slice = torch.equal(sl[:hi - lo], out.reshape(-1, d)[lo:hi])
+        if shard_match is True and world > 1 and B >= world and exchange in ("rows", "gather_rows") and chunks > 0:
+            ok_slice = ok_slice and getattr(shard, "plans_from_gathered_lists", 0) == 2     # both calls planned from gathered lists
+        elif shard_match == "auto":
+            ok_slice = ok_slice and not hasattr(shard, "plans_from_gathered_lists")         # (tiny batches: every rank matches)
         q.put((rank, err, tuple(out.shape), ok_slice))
         dist.destroy_process_group()
     except Exception as e:      # surface the failure in the parent
@@ -352,6 +399,29 @@ def test_gather_rows_chunked_pipeline_world2_gloo(chunks, head, transport):
         assert out_shape == (shape[0], shape[1], 32) and err < 1e-6 and ok_slice
 
 
+@pytest.mark.parametrize("exchange,chunks,head,world,shape", [("gather_rows", 1, 0, 2, (5, 13)), ("gather_rows", 3, 25, 3, (4, 19)),
+                                                               ("gather_rows", 2, 40, 2, (2, 8)), ("rows", 4, 25, 3, (7, 9)),
+                                                               ("rows", 4, 0, 2, (1, 5)), ("gather_rows", 2, 10, 3, (2, 7))])
+def test_match_sharded_over_the_ranks_world_gloo(exchange, chunks, head, world, shape):
+    """The plan's match sharded over the ranks: rank r matches only its own run of sequences (`shard_gather_match`), the
+    list records are all-gathered, and the claim passes, the reduction and the slice exchange work from the GATHERED lists
+    (`shard_gather_plan_ell`) -- same output as the unsharded table, B not a multiple of W, fewer sequences than ranks
+    (falls back to matching everything everywhere), chunked, with and without head."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, shape, "float32", exchange, q, chunks, head, "p2p", True))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, err, out_shape, ok_slice in results:
+        assert isinstance(err, float), f"rank {rank} failed: {err}"
+        assert out_shape == (shape[0], shape[1], 32) and err < 1e-6 and ok_slice
+
+
 @pytest.mark.parametrize("transport", ["p2p", "all_gather"])
 def test_gather_rows_world3_gloo(transport):
     """Three ranks: with ``p2p`` every rank sends its records to two peers and receives two ranges of different sizes."""
@@ -391,7 +461,8 @@ def _worker_split_phase(rank, world, port, q):
         a, b = shard_range(n, rank, world)
         shard = OracleShard(keys, lens, max_n, table, a, b)
         shard.shard_set_head(30)
-        cache = ShardedEmbeddingCache(ex, d, rank=rank, world=world, n_rows=n, table=shard, replicated_rows=30, gather_chunks=2)
+        cache = ShardedEmbeddingCache(ex, d, rank=rank, world=world, n_rows=n, table=shard, replicated_rows=30, gather_chunks=2,
+                                      shard_match=True)       # both slots plan from gathered lists: each needs its own buffer
         outs = []
         ticket = cache.gather_rows_begin(batches[0])
         for i in range(len(batches)):

@@ -97,6 +97,8 @@ def test_fuzz_row_exchange_vs_unsharded():
         tok = torch.from_numpy(rng.integers(0, vocab + 1, size=(B, T)))
         wte = torch.from_numpy(rng.standard_normal((vocab + 1, d)).astype(np.float32)).half().cuda()
         wpe = torch.from_numpy(rng.standard_normal((T, d)).astype(np.float32)).half().cuda()
+        # the receiver's row map: direct-mapped array / hash map, alternating (read when a handle first adds records)
+        os.environ["SCONE_SHARD_ROW_MAP"] = ("direct", "hash")[case % 2]
         full = SconeTable(max_n, n, d, fmt)
         full.index_build(keys, lens)
         full.store_f32(torch.from_numpy(table))
@@ -133,7 +135,17 @@ def test_fuzz_row_exchange_vs_unsharded():
         recv = torch.cat([sends[r] for r in order]).contiguous()
         assert recv.shape[0] == int(torch.unique(ids[ids >= head]).numel()), tag
         for q in {int(rng.integers(world)), 0}:
-            shards[q].shard_gather_plan(tok)                                 # a rank embeds after ITS OWN plan of this batch
+            if case % 3 == 0:
+                # the plan's match sharded over the ranks: shard r matches run r of the sequences, the list records laid end
+                # to end are what the all-gather delivers, shard q plans from them (same claims as its own match gives)
+                wd = shards[q].ell_width()
+                ell = torch.empty((B * T, wd), dtype=torch.int32, device="cuda")
+                for r in range(world):
+                    b0, b1 = min(r * bper, B), min(r * bper + bper, B)
+                    shards[r].shard_gather_match(tok, b0, b1, ell[b0 * T:max(b1, b0) * T])
+                assert shards[q].shard_gather_plan_ell(ell, B, T, 1) == [sends[q].shape[0]], tag
+            else:
+                shards[q].shard_gather_plan(tok)                             # a rank embeds after ITS OWN plan of this batch
             got = shards[q].shard_gather_embed(tok, recv, wte=wte, wpe=wpe, out_dtype=torch.float16)
             assert torch.equal(got, want), tag + ("gather_rows", q)
             assert shards[q].status() == 0, tag

@@ -56,9 +56,10 @@ def _worker(rank, world, port, fmt, d, max_n, exchange, head, q):
         from scone_amd.distributed import ShardedEmbeddingCache
         keys, lens, table, tok, wte, wpe = _problem(fmt, d, max_n)
         ex = NGramExtractor.from_arrays(keys, lens, max_n=max_n)
-        exchange, _, transport = exchange.partition(":")          # "gather_rows:all_gather" = the padded all-gather transport
+        exchange, _, rest = exchange.partition(":")               # "gather_rows:all_gather" = the padded all-gather transport,
+        transport, _, sm = rest.partition(":")                    # "...:sm" = the plan's match sharded over the ranks
         sh = ShardedEmbeddingCache(ex, d, table_format=fmt, rank=rank, world=world, replicated_rows=head,
-                                   gather_transport=transport or "p2p")
+                                   gather_transport=transport or "p2p", shard_match=True if sm == "sm" else "auto")
         sh.load_rows(torch.from_numpy(table), 0)
         wte_d, wpe_d = torch.from_numpy(wte).half().cuda(), torch.from_numpy(wpe).half().cuda()
         got = sh.embed_tokens(torch.from_numpy(tok), wte=wte_d, wpe=wpe_d, exchange=exchange)
@@ -81,6 +82,9 @@ def _worker(rank, world, port, fmt, d, max_n, exchange, head, q):
                                                              ("int8", 768, 3, 3, "gather_rows", 0),
                                                              ("int4", 1024, 4, 2, "gather_rows", 100),
                                                              ("int4", 1024, 3, 3, "gather_rows:all_gather", 100),
+                                                             ("int4", 1024, 3, 3, "gather_rows:p2p:sm", 100),
+                                                             ("int8", 768, 4, 2, "gather_rows:all_gather:sm", 0),
+                                                             ("fp16", 768, 3, 3, "rows:p2p:sm", 100),
                                                              ("int8", 768, 3, 2, "partial_sums", 0),
                                                              ("int4", 1024, 3, 3, "rows_per_reference", 100)])
 def test_sharded_cache_across_processes_on_one_gpu(fmt, d, max_n, world, exchange, head):
@@ -116,7 +120,8 @@ def _worker_split_phase(rank, world, port, fmt, d, max_n, head, chunks, q):
         rng = np.random.default_rng(99)
         batches = [tok0] + [rng.integers(0, 24, size=tok0.shape) for _ in range(4)]
         ex = NGramExtractor.from_arrays(keys, lens, max_n=max_n)
-        sh = ShardedEmbeddingCache(ex, d, table_format=fmt, rank=rank, world=world, replicated_rows=head, gather_chunks=chunks)
+        sh = ShardedEmbeddingCache(ex, d, table_format=fmt, rank=rank, world=world, replicated_rows=head, gather_chunks=chunks,
+                                   shard_match=chunks == 1)                  # (one of the two cases: match sharded over the ranks)
         sh.load_rows(torch.from_numpy(table), 0)
         wte_d, wpe_d = torch.from_numpy(wte).half().cuda(), torch.from_numpy(wpe).half().cuda()
         full = EmbeddingCache(ex, d, table_format=fmt)
@@ -181,7 +186,7 @@ def test_bench_two_ranks_launched_like_the_driver(mode):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
            "--gpus", "2", "--steps", "5", "--warmup", "2", "--rows", "200000", "--batch", "256", "--table-mode", mode.split("-")[0],
-           "--sharded-rows-per-rank", "300000", "--sharded-steps", "2"]
+           "--sharded-rows-per-rank", "300000", "--sharded-steps", "2", "--pinned-rows", "300000", "--cpu-seconds", "1"]
     if mode == "sharded-slices":
         cmd.append("--no-gather-output")
     p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
@@ -189,7 +194,7 @@ def test_bench_two_ranks_launched_like_the_driver(mode):
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, p.stdout[-2000:]
     r = json.loads(lines[0])
-    assert r["n_gpus"] == 2 and r["steps"] == 5 and "cpu_baseline" not in r
+    assert r["n_gpus"] == 2 and r["steps"] == 5 and "incomplete" not in r
     ranks_counted = 2 if mode == "replicated" else 1      # sharded: every rank embeds the SAME batch (strong scaling)
     assert r["scaling"] == ("weak" if mode == "replicated" else "strong")
     assert abs(r["value"] - ranks_counted * 256 * 512 * 5 / (r["ms_per_step"] * 5e-3)) / r["value"] < 1e-6
@@ -197,27 +202,48 @@ def test_bench_two_ranks_launched_like_the_driver(mode):
         assert r["roofline"]["timed_launches"] == 5
         km = r["roofline"]["kernel_ms"]
         assert km["n"] == 5 and km["min"] <= km["median"] <= km["max"]
+        assert 0 < r["roofline"]["frac"] <= 1.0 and r["roofline"]["algorithmic_frac"] > 0
+        cb = r["cpu_baseline"]                                   # N > 1: the short 1-core sample + the 8-sequence check
+        assert cb["value"] > 0 and cb["cores"] == 1 and "python_all_cores" not in cb and cb["gpu_vs_oracle_max_rel_err"] < 1e-3
         _check_sharded_record(r["sharded"], 2)
     else:
-        assert "sharded" not in r
+        assert "sharded" not in r and "cpu_baseline" not in r
 
 
 def _check_sharded_record(rec, world):
-    """The C5-shaped sub-record of an N > 1 line: both whole-output exchanges ran on `world` ranks, their phase split and
-    wire bytes are there, and they produced the same output."""
+    """The C5-shaped sub-record of an N > 1 line: every exchange ran on `world` ranks -- phase split, wire bytes, a roofline
+    block with physical fractions, the speed-up over the N = 1 baseline measured by rank 0 in the same process -- and
+    they produced the same output."""
     assert "error" not in rec, rec
     assert rec["world_size"] == world and rec["device_count"] >= 1 and "n1_baseline" in rec
-    for name in ("rows+all_gather", "gather_rows", "gather_rows_one_shot", "gather_rows_padded_all_gather", "rows_slices_only"):
+    assert rec["n1_pinned_host"]["value"] > 0 and rec["rows_total"] == world * rec["rows_per_rank"]
+    assert "N = 2 / 4 / 8 ranks hold" in rec["workload"]
+    one_call = ("rows+all_gather", "rows_slices_only", "gather_rows_padded_all_gather", "gather_rows_one_shot_padded_all_gather",
+                "gather_rows", "gather_rows_one_shot")
+    assert list(rec["exchanges"])[:len(one_call) + 2] == list(one_call[:4]) + ["gather_rows_split_phase_padded_all_gather"] + \
+        list(one_call[4:]) + ["gather_rows_split_phase"]                  # plain collectives first, point-to-point last
+    for name in one_call:
         e = rec["exchanges"][name]
         assert "error" not in e, e
         assert e["ms_per_step"] > 0 and e["tokens_per_s"] > 0 and e["wire_bytes_received_rank0"] > 0
         for ph in ("plan_ms", "pack_ms", "collective_ms", "embed_ms"):
             assert e["phase_ms_slowest_rank"][ph] >= 0.0, (name, ph)
+        assert abs(e["speedup_vs_n1_pinned_host"] - e["tokens_per_s"] / rec["n1_pinned_host"]["value"]) < 1e-9
+        rf = e["roofline"]
+        assert 0 < rf["frac"] <= 1.0 and rf["per_rank_compulsory_bytes"] <= rf["per_rank_algorithmic_bytes"]
+        assert rf["wire"]["bytes_received_rank0"] == e["wire_bytes_received_rank0"] and rf["wire"]["GBps"] > 0
+    assert rec["exchanges"]["rows_slices_only"]["roofline"]["per_rank_tokens_reduced"] < \
+        rec["exchanges"]["gather_rows"]["roofline"]["per_rank_tokens_reduced"]
     assert "gather_out_ms" in rec["exchanges"]["rows+all_gather"]["phase_ms_slowest_rank"]
-    assert rec["exchanges_agree"] is True
-    sp = rec["exchanges"]["gather_rows_split_phase"]
-    assert "error" not in sp, sp
-    assert sp["ms_per_step"] > 0 and sp["batches_in_flight"] == 2 and sp["same_output_as_gather_rows"] is True
+    assert rec["exchanges_agree"] is True and len(rec["exchanges_compared"]) == 5
+    for name in ("gather_rows_split_phase_padded_all_gather", "gather_rows_split_phase"):
+        sp = rec["exchanges"][name]
+        assert "error" not in sp, sp
+        assert sp["ms_per_step"] > 0 and sp["batches_in_flight"] == 2 and sp["same_output_as_gather_rows"] is True
+        assert sp["speedup_vs_n1_pinned_host"] > 0 and 0 < sp["roofline"]["frac"] <= 1.0
+    assert rec["transport_fallback"] is None
+    best = rec["best_whole_output"]
+    assert best["exchange"] != "rows_slices_only" and best["tokens_per_s"] == rec["exchanges"][best["exchange"]]["tokens_per_s"]
 
 
 def test_bench_starts_its_own_ranks_when_no_launcher_did():
@@ -228,7 +254,8 @@ def test_bench_starts_its_own_ranks_when_no_launcher_did():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     env.update(SCONE_DIST_BACKEND="gloo", SCONE_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--rows", "200000",
-           "--batch", "128", "--sharded-rows-per-rank", "200000", "--sharded-steps", "1"]
+           "--batch", "128", "--sharded-rows-per-rank", "200000", "--sharded-steps", "1", "--pinned-rows", "200000",
+           "--cpu-seconds", "1"]
     p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
@@ -261,12 +288,14 @@ def _nccl_worker(rank, world, port, q):
             full = EmbeddingCache(ex, d, table_format=fmt)
             full.cache_embeddings(list(range(len(lens))), torch.from_numpy(table), verbose=False)
             ref = full.embed_tokens(torch.from_numpy(tok), wte=wte_d, wpe=wpe_d)
-            for exchange in ("rows", "rows_per_reference", "gather_rows", "gather_rows:all_gather", "partial_sums"):
-                sh.gather_transport = exchange.partition(":")[2] or "p2p"       # records as exact point-to-point ranges / padded all-gather
+            for exchange in ("rows", "rows_per_reference", "gather_rows", "gather_rows:all_gather", "partial_sums",
+                             "rows::sm", "gather_rows::sm", "gather_rows:all_gather:sm"):
+                sh.gather_transport = exchange.split(":")[1] if ":" in exchange and exchange.split(":")[1] else "p2p"   # exact p2p ranges / padded all-gather
+                sh.shard_match = exchange.endswith(":sm")                        # the plan's match sharded over the ranks (+ one all-gather)
                 got = sh.embed_tokens(torch.from_numpy(tok), wte=wte_d, wpe=wpe_d, exchange=exchange.partition(":")[0])
                 err = float((got.float() - ref.float()).abs().max() / ref.float().abs().max())
                 res.append((fmt, exchange, bool(torch.equal(got, ref)), err))
-            sh.gather_transport = "p2p"
+            sh.gather_transport, sh.shard_match = "p2p", True
             # the split-phase loop: two batches in flight, the second one's transfers behind the first one's reduction
             tk = sh.gather_rows_begin(torch.from_numpy(tok))
             for i in range(3):
@@ -301,7 +330,7 @@ def test_sharded_exchanges_under_rccl_one_rank_per_gpu():
     for rank, res, err in results:
         assert res is not None, f"rank {rank} failed: {err}"
         for fmt, exchange, same, e in res:
-            if exchange == "partial_sums":
+            if exchange.startswith("partial_sums"):
                 assert e < 1e-3, (rank, fmt, exchange, e)
             else:
                 assert same, (rank, fmt, exchange, e)

@@ -167,6 +167,26 @@ def test_committed_bench_line_follows_the_contract():
     assert 0 < hv["hbm_frac"] <= 1.0 and hv["hbm_bytes_compulsory"] < hv["algorithmic_bytes_per_launch"]
     assert cb["python_all_cores"]["cores"] >= 1 and cb["c_oracle_all_cores"]["value"] > cb["value"]
     assert r["sharded"]["n1_pinned_host"]["value"] > 0
+    if int(re.match(r"r(\d+)", rounds[-1]).group(1)) >= 3:
+        # round 3: `frac` is a PHYSICAL fraction of the HBM peak -- priced by the bytes that left L2 (PMC passes of this kernel
+        # source) or, without such an entry, by the compulsory bytes -- and never above 1; SURVEY 8d's every-reference figure
+        # is `algorithmic_frac`; the line says which byte count `frac` used and the kernel time it was divided by
+        assert 0 < rf["frac"] <= 1.0
+        assert rf["frac_bytes"] == (rf["traffic"] if rf["traffic"] is not None else rf["hbm_bytes_compulsory"])
+        assert abs(rf["achieved"] - rf["frac_bytes"] / (rf["avg_kernel_ms"] * 1e-3) / 1e9) / rf["achieved"] < 1e-9
+        assert abs(rf["algorithmic_frac"] - rf["algorithmic_bytes_per_launch"] / (rf["avg_kernel_ms"] * 1e-3) / 1e9 / 8000.0) < 1e-9
+        assert "avg_kernel_ms" in rf["frac_kind"] and ("left L2" in rf["frac_kind"] or "compulsory" in rf["frac_kind"])
+        assert rf["match_us"] > 0
+        assert len(cb["gpu_vs_oracle_sequences"]) == 8 and cb["gpu_vs_oracle_max_rel_err"] < 1e-3
+        assert r["sharded"]["n1_pinned_host_zipf"]["value"] > 0
+        # every other committed line of the round (tools/run_configs.sh) obeys the same rule
+        for d in os.listdir(prof):
+            cj = os.path.join(prof, d, "configs.jsonl")
+            if d.startswith("r03") and os.path.exists(cj):
+                for ln in open(cj):
+                    if ln.strip():
+                        c = json.loads(ln)
+                        assert 0 < c["roofline"]["frac"] <= 1.0, (d, c.get("config_name"))
 
 
 def test_bench_refuses_more_ranks_than_devices():

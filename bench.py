@@ -584,7 +584,8 @@ def pinned_baseline(args, sync, zipf_too=True):
     INT4 d = 1024 = 52.8 GB, first 1M rows hot in HBM), on the batch shape of the sharded record.  PCIe-bound, so the
     rate barely depends on the table's size; this is what ">= 4x at 8 GPUs vs 1 GPU on the 1B-row sharded table" is
     computed against.  Returns (record for the S_uniform stream with the rows read in place over PCIe -- the faster
-    mechanism on that stream --, record for a Zipf token stream through the staged, de-duplicated prefetch -- the
+    mechanism on that stream --, record for the Zipf-ids stream (f-gram ids drawn from a power law over the
+    frequency-ordered table: what real text looks like to such a table) through the staged, de-duplicated prefetch -- the
     north-star's "async prefetch" on the kind of stream where a chunk's rows recur; None unless `zipf_too`)."""
     import torch
     from scone_amd import EmbeddingCache
@@ -623,7 +624,7 @@ def pinned_baseline(args, sync, zipf_too=True):
     zres = None
     if zipf_too:
         try:
-            ztok = torch.from_numpy(S.stream_zipf(S.GPT2_VOCAB, B, T, 1234)).to("cuda", torch.int32)
+            ztok = torch.from_numpy(S.stream_zipf_ids(vocab, None, B, T, 1234)).to("cuda", torch.int32)
             off, ids = cache.table.match_csr(ztok)
             cold = ids[ids >= hot]
             stats = {"mean_hits_per_token": float(ids.numel()) / (B * T), "cold_row_references": int(cold.numel()),
@@ -641,7 +642,8 @@ def pinned_baseline(args, sync, zipf_too=True):
                                  "on side streams while the previous chunk is reduced",
                     "zero_copy_same_stream": {"value": B * T / dt_zero, "ms_per_step": dt_zero * 1e3},
                     "workload": f"{N}-row int4 table d={d} in pinned host DRAM, first {hot} rows in HBM, structured vocabulary, "
-                                f"S_zipf (iid Zipf(1.1) tokens), {B}x{T} tokens/step", **stats,
+                                f"S_zipf_ids (f-grams laid end to end, ids ~ bounded power law with exponent 1.1 over the "
+                                f"frequency-ordered table: the realistic stream), {B}x{T} tokens/step", **stats,
                     "bound": "PCIe Gen5 x16 (~64 GB/s)"}
         except Exception as e:
             zres = {"value": None, "error": repr(e)}
@@ -696,9 +698,10 @@ def sharded_record(args, dist, rank, world, backend, sync, rec, line, watchdog, 
                         the records travel as exact point-to-point ranges (batch_isend_irecv: one RCCL group, each link
                         carries one peer's records) -- ..._padded_all_gather: through all_gather_into_tensor
                         instead, every contribution padded to the largest
-      gather_rows_split_phase[_padded_all_gather]  the serving-loop form (ShardedEmbeddingCache.gather_rows_begin / _finish,
-                        one piece, two batches in flight: plan, pack and transfers of step s + 1 run on a side stream behind
-                        the reduction of step s) -- a throughput figure, a batch's latency is two steps
+      gather_rows_split_phase[_3_in_flight][_padded_all_gather]  the serving-loop form (ShardedEmbeddingCache.gather_rows_begin /
+                        _finish, one piece, two or three batches in flight: plan, pack and transfers of step s + 1 (s + 2) run
+                        on side streams behind the reduction of step s; with three, that chain may take two reductions'
+                        time) -- a throughput figure, a batch's latency is two (three) steps
     and, for contrast, rows_slices_only: the all-to-all alone, every rank keeps its own slice (a consumer that is
     data-parallel over the same slices needs no more).  Order: the plainest collectives first (all_to_all_single,
     all_gather_into_tensor), everything that needs the batched point-to-point transport after them -- should that
@@ -824,17 +827,22 @@ def sharded_record(args, dist, rank, world, backend, sync, rec, line, watchdog, 
                     "roofline": roofline_of(kw, ms, phm, wire)}
         return name, fn
 
-    def split_phase(name, transport, same_as):
+    def split_phase(name, transport, same_as, slots=2):
         def fn():
             cache.gather_chunks = 1
             cache.gather_transport = transport
+            cache.plan_slots = slots
 
             def loop(n):
-                o = None
-                tk = cache.gather_rows_begin(tok, tokens_ready=None)         # (the batch has been on the device since the build)
+                o, nxt, q = None, 0, []
+                for _ in range(min(slots - 1, n)):                          # slots - 1 batches ahead of the one being reduced
+                    q.append(cache.gather_rows_begin(tok, tokens_ready=None))   # (the batch has been on the device since the build)
+                    nxt += 1
                 for i in range(n):
-                    o = cache.gather_rows_finish(tk, wte=wte, wpe=wpe)      # queues the reduction of step i ...
-                    tk = cache.gather_rows_begin(tok, tokens_ready=None) if i + 1 < n else None   # ... plan / pack / transfers of step i + 1 overlap it
+                    o = cache.gather_rows_finish(q.pop(0), wte=wte, wpe=wpe)    # queues the reduction of step i ...
+                    if nxt < n:                                             # ... plan / pack / transfers of a later step overlap it
+                        q.append(cache.gather_rows_begin(tok, tokens_ready=None))
+                        nxt += 1
                 return o
             out = loop(3)
             sync()
@@ -842,6 +850,7 @@ def sharded_record(args, dist, rank, world, backend, sync, rec, line, watchdog, 
             out = loop(args.sharded_steps)
             sync()
             dt = time.perf_counter() - t0
+            cache.plan_slots = 2
             tm = torch.tensor([dt], dtype=torch.float64, device=cdev)
             dist.all_reduce(tm, op=dist.ReduceOp.MAX)
             dt = float(tm.item())
@@ -849,7 +858,7 @@ def sharded_record(args, dist, rank, world, backend, sync, rec, line, watchdog, 
             kw = {"exchange": "gather_rows", "gather_output": True}
             one = rec["exchanges"].get(same_as, {})
             return {"ms_per_step": ms, "tokens_per_s": ntok * args.sharded_steps / dt,
-                    "steps": args.sharded_steps, "batches_in_flight": 2, "chunks": 1,
+                    "steps": args.sharded_steps, "batches_in_flight": slots, "chunks": 1,
                     "records_transport": {"p2p": "batch_isend_irecv, exact ranges", "all_gather": "all_gather_into_tensor, padded"}[transport],
                     "same_output_as_gather_rows": bool(float(out.float().abs().sum().item()) == checks.get(same_as)),
                     "roofline": roofline_of(kw, ms, None, int(one.get("wire_bytes_received_rank0", 0)))}
@@ -861,11 +870,13 @@ def sharded_record(args, dist, rank, world, backend, sync, rec, line, watchdog, 
               one_call("gather_rows_padded_all_gather", {"exchange": "gather_rows", **whole}, chunks, "all_gather"),
               one_call("gather_rows_one_shot_padded_all_gather", {"exchange": "gather_rows", **whole}, 1, "all_gather"),
               split_phase("gather_rows_split_phase_padded_all_gather", "all_gather", "gather_rows_one_shot_padded_all_gather"),
+              split_phase("gather_rows_split_phase_3_in_flight_padded_all_gather", "all_gather", "gather_rows_one_shot_padded_all_gather", 3),
               # ---- from here on: the batched point-to-point transport
               one_call("gather_rows", {"exchange": "gather_rows", **whole}, chunks, "p2p"),
               one_call("gather_rows_one_shot", {"exchange": "gather_rows", **whole}, 1, "p2p"),
-              split_phase("gather_rows_split_phase", "p2p", "gather_rows_one_shot")]
-    p2p_names = ("gather_rows", "gather_rows_one_shot", "gather_rows_split_phase")
+              split_phase("gather_rows_split_phase", "p2p", "gather_rows_one_shot"),
+              split_phase("gather_rows_split_phase_3_in_flight", "p2p", "gather_rows_one_shot", 3)]
+    p2p_names = ("gather_rows", "gather_rows_one_shot", "gather_rows_split_phase", "gather_rows_split_phase_3_in_flight")
     with line.lock:
         rec["exchanges"] = {}
         rec["transport_fallback"] = ("records over batch_isend_irecv (exact ranges) not measured yet: the ..._padded_all_gather "

@@ -305,13 +305,14 @@ int scone_shard_gather_embed(scone_handle *h, const int32_t *d_tok, int32_t B, i
  *                                    same or an overlapping range (a retry, other chunk bounds) reduces them as they are;
  *                                    a new exchange (_add_records with record0 == 0) on lists that were already rewritten
  *                                    is refused (SCONE_ESTATE): plan the batch again first.
- * The receiver's row map (row id -> record number) is a direct-mapped array over all table rows (4 B per row and plan
- * slot, generation-tagged: nothing is cleared between exchanges) when both slots' maps stay under 1/8 of the device's
- * memory and the exchange has fewer than 2^24 records, else an open-addressing hash map; environment variable
- * SCONE_SHARD_ROW_MAP=hash|direct overrides the choice. */
-/* Two plan slots (0 and 1; 0 is active at first): the receiver-side state of a planned batch (its id lists, the scales of
- * [head | records], the row map) exists twice, so that a serving loop can plan, pack and exchange batch b + 1 on a side
- * stream while batch b is still being reduced on the main stream.  A host-side switch, no device work; the
+ * The receiver's row map (row id -> record number) is an open-addressing hash map sized by the exchange (cache-resident);
+ * SCONE_SHARD_ROW_MAP=direct selects a direct-mapped array over all table rows instead (4 B per row and plan slot,
+ * generation-tagged; exchanges under 2^24 records) -- built on the round-2 review's suggestion and measured slower at 1e9
+ * rows (every lookup a TLB miss), kept for tables small enough to stay in cache. */
+/* Plan slots (0 .. 3; 0 is active at first): the receiver-side state of a planned batch (its id lists, the scales of
+ * [head | records], the row map) exists once per slot, so that a serving loop can plan, pack and exchange batch b + 1 (and
+ * b + 2: the chain plan -> transfers must then fit TWO reductions, not one) on side streams while batch b is still being
+ * reduced on the main stream.  A host-side switch, no device work; the
  * scone_shard_gather_plan* / _add_records / _embed_range / _embed calls that follow work on the selected slot (the
  * per-reference exchange scone_shard_plan / _pack / _embed is not slot-aware: use slot 0).  The sender-side scratch is
  * shared: plan and pack of one batch must be enqueued before the next plan.  New here (the reference is one process). */
@@ -339,6 +340,10 @@ int scone_shard_gather_pack_range(scone_handle *h, uint64_t first, uint64_t coun
                                   scone_stream_t stream);
 int scone_shard_gather_add_records(scone_handle *h, const void *d_records_base, uint64_t record0, uint64_t n_records,
                                    uint64_t n_total, scone_stream_t stream);
+/* Rewrite the id lists of sequences [seq_begin, seq_end) of the planned batch to record numbers now, on `stream` (every row
+ * they reference must have been added): a loop that receives on one stream and reduces on another does this where the
+ * records arrive, so that scone_shard_gather_embed_range finds the lists done and only launches the lookup. */
+int scone_shard_gather_remap_range(scone_handle *h, int32_t seq_begin, int32_t seq_end, scone_stream_t stream);
 int scone_shard_gather_embed_range(scone_handle *h, const int32_t *d_tok, int32_t B, int32_t T, int32_t seq_begin,
                                    int32_t seq_end, const void *d_records_base, uint64_t n_total, const void *d_wte,
                                    int64_t vocab, const void *d_wpe, int64_t n_pos, const int32_t *d_pos, int32_t reduce,

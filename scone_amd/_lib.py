@@ -89,6 +89,7 @@ SIGNATURES = {
     "scone_shard_gather_plan_ell": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, C.POINTER(_U64), _P]),
     "scone_shard_gather_pack_range": (C.c_int, [_P, _U64, _U64, _U64, _P, _P]),
     "scone_shard_gather_add_records": (C.c_int, [_P, _P, _U64, _U64, _U64, _P]),
+    "scone_shard_gather_remap_range": (C.c_int, [_P, _I32, _I32, _P]),
     "scone_shard_gather_embed_range": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _P, _U64, _P, _I64, _P, _I64, _P, _I32, _P,
                                                  _I64, _I32, _P]),
     "scone_shard_set_head": (C.c_int, [_P, _U64]),

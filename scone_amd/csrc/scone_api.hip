@@ -257,6 +257,12 @@ extern "C" int scone_create(const scone_cfg *cfg, scone_handle **out) {
     h->fused_max_tokens = 32768;
     const char *ev = getenv("SCONE_FUSED_MAX_TOKENS");
     if (ev && *ev) h->fused_max_tokens = atoll(ev);
+    h->match_tile = 0;
+    ev = getenv("SCONE_MATCH_TILE");
+    if (ev && *ev) h->match_tile = atoll(ev);
+    h->shard_rec_align = 16;
+    ev = getenv("SCONE_SHARD_REC_ALIGN");
+    if (ev && (atoi(ev) == 64 || atoi(ev) == 128)) h->shard_rec_align = atoi(ev);
   }
   CREATE_HIP(hipMalloc(&h->slots, cap * sizeof(scone_slot)));
   CREATE_HIP(hipMemset(h->slots, 0, cap * sizeof(scone_slot)));
@@ -406,9 +412,18 @@ static int prof_drain(scone_handle *h) {
   return SCONE_OK;
 }
 
+// Whether THIS launch is timed is decided once, in scone_prof_begin, under prof_mu -- scone_profile_enable may flip
+// prof_on between the begin and the end of a launch on another thread, and an end / abort that re-read the flag would
+// then unlock a mutex its begin never took (or skip the unlock of one it did).  begin and end of a launch run on one
+// host thread: the decision is latched in a thread-local (the handle it belongs to: a thread may interleave handles).
+static thread_local scone_handle *prof_held_by_this_thread = nullptr;
+
 int scone_prof_begin(scone_handle *h, hipStream_t s) {
-  if (!h->prof_on) return SCONE_OK;
   h->prof_mu.lock();  // until scone_prof_end / scone_prof_abort: the ring slot belongs to this launch
+  if (!h->prof_on) {
+    h->prof_mu.unlock();
+    return SCONE_OK;
+  }
   if (h->prof_head == SCONE_PROF_RING) {
     int rc = prof_drain(h);
     if (rc) {
@@ -421,11 +436,13 @@ int scone_prof_begin(scone_handle *h, hipStream_t s) {
     h->prof_mu.unlock();
     return scone_hip_fail(h, e, "hipEventRecord");
   }
+  prof_held_by_this_thread = h;
   return SCONE_OK;
 }
 
 int scone_prof_end(scone_handle *h, hipStream_t s) {
-  if (!h->prof_on) return SCONE_OK;
+  if (prof_held_by_this_thread != h) return SCONE_OK;  // this launch's begin did not start a measurement
+  prof_held_by_this_thread = nullptr;
   hipError_t e = hipEventRecord(h->prof_ev[2 * h->prof_head + 1], s);
   if (e == hipSuccess) h->prof_head += 1;
   h->prof_mu.unlock();
@@ -433,7 +450,9 @@ int scone_prof_end(scone_handle *h, hipStream_t s) {
 }
 
 void scone_prof_abort(scone_handle *h) {
-  if (h->prof_on) h->prof_mu.unlock();
+  if (prof_held_by_this_thread != h) return;
+  prof_held_by_this_thread = nullptr;
+  h->prof_mu.unlock();
 }
 
 extern "C" int scone_profile_enable(scone_handle *h, int enable) {

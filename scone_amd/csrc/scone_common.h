@@ -150,6 +150,8 @@ struct scone_handle {
   int device;
   int n_cus;  // compute units of the device (256 on MI355X)
   long long fused_max_tokens;  // batches up to this many tokens take the one-launch kernel (env SCONE_FUSED_MAX_TOKENS overrides)
+  int shard_rec_align;         // record alignment of the shard exchanges (env SCONE_SHARD_REC_ALIGN: 16 (default), 64, 128)
+  long long match_tile;        // > 0: positions per workgroup of k_match_ell fixed by env SCONE_MATCH_TILE (else whole residency rounds)
   // index
   scone_slot *slots;
   uint64_t cap;  // power of two

@@ -223,10 +223,11 @@ __global__ __launch_bounds__(ELL_TILE) void k_match_ell(const scone_slot *__rest
                                                         const uint32_t *__restrict__ bloom, unsigned long long bloom_mask,
                                                         const int32_t *__restrict__ tok, long long BT, int T, int max_n,
                                                         long long row_begin, long long row_end, int mode,
-                                                        int keep_pos, int32_t *__restrict__ ell) {
+                                                        int keep_pos, int32_t *__restrict__ ell, int tile) {
   constexpr int HALO = MAXN - 1;
   constexpr int W = MAXN <= 3 ? 8 : 16;
-  constexpr int TILE = ELL_TILE - HALO;  // positions per workgroup
+  // `tile` <= ELL_TILE - HALO positions per workgroup (the launcher sizes it so that the grid is a whole number of
+  // residency rounds); threads past tile + HALO only keep the barriers company
   __shared__ int32_t win[MAXN][ELL_TILE];
   __shared__ probe_req queue[MAXN * ELL_TILE];  // worst case: every window survives the bitmap
   __shared__ uint32_t q_count;
@@ -235,16 +236,16 @@ __global__ __launch_bounds__(ELL_TILE) void k_match_ell(const scone_slot *__rest
   // candidates covering p; the first HALO threads only supply the starts in front of the tile (one pass
   // per thread: a second, 2-lane pass for the halo would double wave 0's dependent-load chain and with
   // it, through the barrier, the whole workgroup's).
-  const long long p = (long long)blockIdx.x * TILE - HALO + t;
+  const long long p = (long long)blockIdx.x * tile - HALO + t;
 
   if (t == 0) q_count = 0;
   __syncthreads();
-  stage_starts<MAXN>(uni, uni_cap, bloom, bloom_mask, tok, BT, T, max_n, p, t, win, queue, &q_count);
+  stage_starts<MAXN>(uni, uni_cap, bloom, bloom_mask, tok, BT, T, max_n, t < tile + HALO ? p : -1ll, t, win, queue, &q_count);
   __syncthreads();
   resolve_queue(slots, mask, t, &win[0][0], queue, q_count);
   __syncthreads();
 
-  if (t < HALO || p >= BT) return;
+  if (t < HALO || t >= tile + HALO || p >= BT) return;
   const int i = BT <= 0x7FFFFFFFll ? (int)((unsigned)p % (unsigned)T) : (int)(p % T);
   int32_t rec[W];
 #pragma unroll
@@ -434,15 +435,28 @@ int scone_launch_match_ell_ex(scone_handle *h, const int32_t *d_tok, int32_t B, 
                               long long re, int keep_pos, hipStream_t s) {
   const long long BT = (long long)B * T;
   if (BT == 0) return SCONE_OK;
-  const long long tile = ELL_TILE - (h->cfg.max_n <= 3 ? 2 : 3);  // k_match_ell<MAXN>::TILE
-  const long long blocks = (BT + tile - 1) / tile;
+  // Positions per workgroup: at most ELL_TILE - halo, and such that the grid is a whole number of residency rounds (a
+  // workgroup is 4 waves of 27 VGPRs and 15 KB of LDS: 8 fit a CU).  ceil(BT / 254) workgroups at 2048 x 512 tokens is
+  // 4129 = two rounds of 2048 and a third that is nearly empty (profiles/r02g/match_tail.md); smaller tiles, one more
+  // FULL round.  SCONE_MATCH_TILE=<n> fixes the tile (A/B experiments).
+  const long long tile_max = ELL_TILE - (h->cfg.max_n <= 3 ? 2 : 3);
+  const long long resident = (long long)h->n_cus * 8;
+  long long blocks = (BT + tile_max - 1) / tile_max;
+  long long tile = tile_max;
+  if (blocks > resident) {
+    const long long rounds = (blocks + resident - 1) / resident;
+    tile = (BT + rounds * resident - 1) / (rounds * resident);
+    if (tile > tile_max) tile = tile_max;
+  }
+  if (h->match_tile > 0 && h->match_tile <= tile_max) tile = h->match_tile;
+  blocks = (BT + tile - 1) / tile;
   if (!scone_grid_fits((unsigned long long)blocks, ELL_TILE)) return scone_fail(h, SCONE_EINVAL, "scone_embed: too many tokens for one launch");
   if (h->cfg.max_n <= 3)
     hipLaunchKernelGGL((k_match_ell<3>), dim3((unsigned)blocks), dim3(ELL_TILE), 0, s, h->slots, h->cap - 1, h->d_uni,
-                       SCONE_UNI_CAP, h->d_bloom, h->bloom_mask, d_tok, BT, T, h->cfg.max_n, rb, re, (int)h->cfg.lookup_mode, keep_pos, d_ell);
+                       SCONE_UNI_CAP, h->d_bloom, h->bloom_mask, d_tok, BT, T, h->cfg.max_n, rb, re, (int)h->cfg.lookup_mode, keep_pos, d_ell, (int)tile);
   else
     hipLaunchKernelGGL((k_match_ell<4>), dim3((unsigned)blocks), dim3(ELL_TILE), 0, s, h->slots, h->cap - 1, h->d_uni,
-                       SCONE_UNI_CAP, h->d_bloom, h->bloom_mask, d_tok, BT, T, h->cfg.max_n, rb, re, (int)h->cfg.lookup_mode, keep_pos, d_ell);
+                       SCONE_UNI_CAP, h->d_bloom, h->bloom_mask, d_tok, BT, T, h->cfg.max_n, rb, re, (int)h->cfg.lookup_mode, keep_pos, d_ell, (int)tile);
   SCONE_HIP(h, hipGetLastError());
   return SCONE_OK;
 }

@@ -55,17 +55,18 @@ struct scone_shard_state {
   // The lists of the planned batch live in ell_slice -- or in a buffer the CALLER owns (scone_shard_gather_plan_ell:
   // the lists were matched slice by slice on several ranks and all-gathered), borrowed until the batch has been reduced.
   int32_t *ell_ext = nullptr;
-  // Receiver's row map, direct-mapped form: rmap[global row id] = generation << 24 | record number.  Plain stores and
-  // loads instead of an open-addressing table filled by 64-bit CAS; a new exchange bumps the generation instead of
-  // clearing (cleared once every 255 exchanges).  4 B per table row and plan slot (8 GB of the 288 at 1e9 rows);
-  // exchanges of >= 2^24 records, or SCONE_SHARD_ROW_MAP=hash, use the hash map.
+  // Receiver's row map, direct-mapped form (SCONE_SHARD_ROW_MAP=direct; measured SLOWER than the hash map at 1e9 rows, see
+  // rmap_policy): rmap[global row id] = generation << 24 | record number.  Plain stores and loads instead of an
+  // open-addressing table filled by 64-bit CAS; a new exchange bumps the generation instead of clearing (cleared once
+  // every 255 exchanges).  4 B per table row and plan slot; exchanges of >= 2^24 records use the hash map.
   uint32_t *rmap = nullptr;
   uint32_t rmap_gen = 0;
   bool rmap_active = false;        // the CURRENT exchange uses rmap (else rhash)
   std::vector<uint8_t> remapped;   // per sequence of the planned batch: its lists already hold record numbers
   // Plan slots (scone_shard_select_slot): the receiver-side state of a planned batch -- its id lists, the scales of
-  // [head | received records], the row map -- exists twice, so that batch b + 1 can be planned, packed and exchanged on a
-  // side stream while batch b is still being reduced.  The fields above are the ACTIVE slot's; the other one is parked.
+  // [head | received records], the row map -- exists up to SCONE_SHARD_SLOTS times, so that batches b + 1 (and b + 2) can be
+  // planned, packed and exchanged on side streams while batch b is still being reduced.  The fields above are the ACTIVE
+  // slot's; the others are parked.
   struct plan_slot {
     int32_t *ell_slice = nullptr;
     long long cap_slice = 0;
@@ -79,9 +80,10 @@ struct scone_shard_state {
     uint32_t rmap_gen = 0;
     bool rmap_active = false;
     std::vector<uint8_t> remapped;
-  } parked;
+  };
+#define SCONE_SHARD_SLOTS 4
+  plan_slot parked[SCONE_SHARD_SLOTS];  // parked[k]: state of slot k while it is not the active one (parked[slot] is unused)
   int slot = 0;
-  int rmap_policy = -1;            // -1 undecided, 0 hash, 1 direct
 };
 
 namespace {
@@ -291,9 +293,15 @@ void scone_shard_destroy(scone_handle *h) {
   if (!st) return;
   void *ptrs[] = {st->ell_send, st->ell_slice, st->counters, st->send_src, st->slot_of_ref, st->scales,
                   st->head_rows, st->head_scales, st->uniq_claim, st->uniq_list, st->rhash, st->chunk_ends,
-                  st->parked.ell_slice, st->parked.scales, st->parked.rhash, st->rmap, st->parked.rmap};
+                  st->rmap};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
+  for (int k = 0; k < SCONE_SHARD_SLOTS; ++k) {
+    if (k == st->slot) continue;
+    void *pp[] = {st->parked[k].ell_slice, st->parked[k].scales, st->parked[k].rhash, st->parked[k].rmap};
+    for (void *p : pp)
+      if (p) (void)hipFree(p);
+  }
   delete st;
   h->shard = nullptr;
 }
@@ -304,7 +312,11 @@ uint8_t *scone_shard_head(const scone_handle *h, unsigned long long *n_head) {
 }
 
 int scone_shard_rec_bytes(const scone_handle *h) {
-  return (int)((h->row_payload_bytes + h->scale_bytes_per_row + 8 + 15) / 16 * 16);
+  // [payload | scales | 8-byte header], rounded up to the record alignment (16 B; SCONE_SHARD_REC_ALIGN = 64 / 128 makes
+  // every record -- hence every row the lookup reads in place -- start on a sector / cache-line boundary, at the price of
+  // the padding on the wire)
+  const size_t al = h->shard_rec_align >= 16 ? (size_t)h->shard_rec_align : 16;
+  return (int)((h->row_payload_bytes + h->scale_bytes_per_row + 8 + al - 1) / al * al);
 }
 
 static void slice_of(int32_t B, int32_t world, int32_t rank, int32_t *bper, int32_t *b0, int32_t *b1) {
@@ -504,8 +516,13 @@ namespace {
 
 // every reference of the batch to a row I own claims the row for this batch; the first claimer of a row appends it to
 // the list.  One CAS per reference at most, nobody waits.
-#define GATHER_STASH 2048
-__global__ __launch_bounds__(256) void k_gather_claim(const int32_t *__restrict__ ell, long long ntok, int W, int NC,
+#define GATHER_STASH 4096
+// 1024-thread workgroups: every workgroup ends with ONE global atomic on the one list counter (~90 retire per microsecond
+// on one address: 1024 workgroups of 256 spent 11 us of a 25 us pass there); 256 workgroups of 1024 keep the same number
+// of threads in flight with a quarter of those atomics
+#define CLAIM_THREADS 1024
+#define CLAIM_BLOCKS 512
+__global__ __launch_bounds__(CLAIM_THREADS) void k_gather_claim(const int32_t *__restrict__ ell, long long ntok, int W, int NC,
                                                       long long row_begin, long long send_begin, long long row_end,
                                                       uint32_t *__restrict__ claim, uint32_t gen,
                                                       uint32_t *__restrict__ count, int32_t *__restrict__ list, long long cap) {
@@ -518,10 +535,22 @@ __global__ __launch_bounds__(256) void k_gather_claim(const int32_t *__restrict_
   const long long per = (ntok + gridDim.x - 1) / gridDim.x;
   const long long t0 = (long long)blockIdx.x * per, t1 = t0 + per < ntok ? t0 + per : ntok;
   for (long long t = t0 + threadIdx.x; t < t1; t += blockDim.x) {
-    const int kown = ell[t * W + W - 2] & 0xFF;  // the lists against ALL rows (compacted): pick the ids I own
+    int32_t r8[8];
+    if (W == 8) {  // the whole record with two 16-B loads instead of up to seven 4-B ones
+      const int4 a = reinterpret_cast<const int4 *>(ell + t * 8)[0], b = reinterpret_cast<const int4 *>(ell + t * 8)[1];
+      r8[0] = a.x, r8[1] = a.y, r8[2] = a.z, r8[3] = a.w, r8[4] = b.x, r8[5] = b.y, r8[6] = b.z, r8[7] = b.w;
+    }
+    const int kown = (W == 8 ? r8[6] : ell[t * W + W - 2]) & 0xFF;  // the lists against ALL rows (compacted): pick the ids I own
     for (int j = 0; j < NC; ++j) {
       if (j >= kown) break;
-      const long long id = ell[t * W + j];
+      long long id;
+      if (W == 8) {
+        id = r8[0];
+#pragma unroll
+        for (int q = 1; q < 6; ++q) id = j == q ? r8[q] : id;
+      } else {
+        id = ell[t * W + j];
+      }
       if (id < send_begin || id >= row_end) continue;  // another shard's row, or a row of the replicated head
       uint32_t *e = &claim[id - row_begin];
       const uint32_t v = *e;
@@ -548,20 +577,24 @@ __global__ __launch_bounds__(256) void k_gather_claim(const int32_t *__restrict_
 // one wave per claimed row: [payload | scales | row id, marker]
 __global__ __launch_bounds__(256) void k_gather_pack(const int32_t *__restrict__ list, unsigned long long n, scone_row_store st,
                                                      long long row_begin, const uint8_t *__restrict__ scales, int scale_bytes,
-                                                     int rec_bytes, uint8_t *__restrict__ out) {
-  const int lane = threadIdx.x & 63;
+                                                     int rec_bytes, uint8_t *__restrict__ out, int lanes_per_rec) {
+  // `lanes_per_rec` lanes (16, 32 or 64: a 512-B INT4 row is 32 x 16 B) copy one record, so a wave carries 64 / lanes_per_rec
+  // records at once: the pack is a chain of two dependent misses per record (list entry -> row), its time the number of
+  // rounds the records take through the resident waves
+  const unsigned sub = (threadIdx.x & 63) / lanes_per_rec, l = (threadIdx.x & 63) % lanes_per_rec;
+  const unsigned per_wave = 64 / lanes_per_rec;
+  const unsigned long long wave = (unsigned long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const unsigned long long nwaves = (unsigned long long)gridDim.x * (blockDim.x >> 6);
-  for (unsigned long long p = (unsigned long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); p < n; p += nwaves) {
+  for (unsigned long long p = wave * per_wave + sub; p < n; p += nwaves * per_wave) {
     const long long id = list[p];
     const unsigned long long lr = (unsigned long long)(id - row_begin);
     const uint4 *src = reinterpret_cast<const uint4 *>(st.row(lr));
     uint8_t *rec = out + p * (unsigned long long)rec_bytes;
     uint4 *dst = reinterpret_cast<uint4 *>(rec);
-    for (unsigned v = lane; v < st.row_bytes / 16; v += 64) dst[v] = src[v];
-    if (lane < scale_bytes / 2)
-      reinterpret_cast<unsigned short *>(rec + st.row_bytes)[lane] =
-          reinterpret_cast<const unsigned short *>(scales + lr * scale_bytes)[lane];
-    if (lane == 0) {
+    for (unsigned v = l; v < st.row_bytes / 16; v += lanes_per_rec) dst[v] = src[v];
+    for (unsigned b = l; b < (unsigned)scale_bytes / 2; b += lanes_per_rec)
+      reinterpret_cast<unsigned short *>(rec + st.row_bytes)[b] = reinterpret_cast<const unsigned short *>(scales + lr * scale_bytes)[b];
+    if (l == 0) {
       uint32_t *hdr = reinterpret_cast<uint32_t *>(rec + rec_bytes - 8);
       hdr[0] = (uint32_t)id;
       hdr[1] = 0xFFFFFFFFu;
@@ -591,8 +624,12 @@ __global__ __launch_bounds__(256) void k_gather_index(const uint8_t *__restrict_
   const uint8_t *rec = recv + p * (unsigned long long)rec_bytes;
   const uint32_t id = reinterpret_cast<const uint32_t *>(rec + rec_bytes - 8)[0];
   if (id == 0xFFFFFFFFu) return;
-  for (int b = 0; b < scale_bytes / 2; ++b)
-    reinterpret_cast<unsigned short *>(scales + p * scale_bytes)[b] = reinterpret_cast<const unsigned short *>(rec + row_bytes)[b];
+  if (scale_bytes == 16) {
+    *reinterpret_cast<uint4 *>(scales + p * 16) = *reinterpret_cast<const uint4 *>(rec + row_bytes);
+  } else {
+    for (int b = 0; b < scale_bytes / 2; ++b)
+      reinterpret_cast<unsigned short *>(scales + p * scale_bytes)[b] = reinterpret_cast<const unsigned short *>(rec + row_bytes)[b];
+  }
   p += record0;
   const unsigned long long key = (unsigned long long)id + 1ull, mine = (key << 32) | p;
   unsigned long long s = scone_hash_key(key, 0u) & hmask;
@@ -607,8 +644,8 @@ __global__ __launch_bounds__(256) void k_gather_index(const uint8_t *__restrict_
   }
 }
 
-// The same two steps on the direct-mapped row map: record p holding row `id` -> rmap[id] = gen << 24 | p (the smallest p
-// wins should a row arrive twice, as in the hash map), and a list entry is looked up with ONE load.
+// The same two steps on the direct-mapped row map: record p holding row `id` -> rmap[id] = gen << 24 | p, and a list entry
+// is looked up with ONE load.
 #define RMAP_REC_BITS 24
 #define RMAP_REC_MASK ((1u << RMAP_REC_BITS) - 1u)
 __global__ __launch_bounds__(256) void k_gather_index_direct(const uint8_t *__restrict__ recv, unsigned long long n_recv, int rec_bytes,
@@ -627,13 +664,9 @@ __global__ __launch_bounds__(256) void k_gather_index_direct(const uint8_t *__re
   for (int b = 0; b < scale_bytes / 2; ++b)
     reinterpret_cast<unsigned short *>(scales + p * scale_bytes)[b] = reinterpret_cast<const unsigned short *>(rec + row_bytes)[b];
   p += record0;
-  const uint32_t mine = (gen << RMAP_REC_BITS) | (uint32_t)p;
-  uint32_t old = rmap[id];
-  while (!((old >> RMAP_REC_BITS) == gen && old <= mine)) {
-    const uint32_t prev = atomicCAS(&rmap[id], old, mine);
-    if (prev == old) break;
-    old = prev;
-  }
+  // ONE plain store (no read-modify-write: a row arrives once per exchange; should the ranks disagree and send it twice,
+  // either record holds the same bytes)
+  rmap[id] = (gen << RMAP_REC_BITS) | (uint32_t)p;
 }
 
 __global__ __launch_bounds__(256) void k_gather_remap_direct(int32_t *__restrict__ ell, long long ntok, int W, int NC,
@@ -674,10 +707,23 @@ __global__ __launch_bounds__(256) void k_gather_remap(int32_t *__restrict__ ell,
   const long long per = (ntok + gridDim.x - 1) / gridDim.x;
   const long long t0 = (long long)blockIdx.x * per, t1 = t0 + per < ntok ? t0 + per : ntok;
   for (long long t = t0 + threadIdx.x; t < t1; t += blockDim.x) {
-    const int kown = ell[t * W + W - 2] & 0xFF;
+    int32_t r8[8];
+    if (W == 8) {  // W = 8 (max_n <= 3): the record travels as two 16-B accesses each way, written back only if it changed
+      const int4 a = reinterpret_cast<const int4 *>(ell + t * 8)[0], b = reinterpret_cast<const int4 *>(ell + t * 8)[1];
+      r8[0] = a.x, r8[1] = a.y, r8[2] = a.z, r8[3] = a.w, r8[4] = b.x, r8[5] = b.y, r8[6] = b.z, r8[7] = b.w;
+    }
+    const int kown = (W == 8 ? r8[6] : ell[t * W + W - 2]) & 0xFF;
+    bool dirty = false;
     for (int j = 0; j < NC; ++j) {
       if (j >= kown) break;
-      const long long id = ell[t * W + j];
+      long long id;
+      if (W == 8) {
+        id = r8[0];
+#pragma unroll
+        for (int q = 1; q < 6; ++q) id = j == q ? r8[q] : id;
+      } else {
+        id = ell[t * W + j];
+      }
       if (id < n_head) continue;  // a head row: its id is its row number in the lookup's row store
       const unsigned long long key = (unsigned long long)id + 1ull;
       unsigned long long s = scone_hash_key(key, 0u) & hmask;
@@ -695,7 +741,18 @@ __global__ __launch_bounds__(256) void k_gather_remap(int32_t *__restrict__ ell,
         atomicOr(status, SCONE_ST_BAD_ID);
         slot = 0;
       }
-      ell[t * W + j] = (int32_t)(n_head + slot);
+      if (W == 8) {
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+          if (j == q) r8[q] = (int32_t)(n_head + slot);
+        dirty = true;
+      } else {
+        ell[t * W + j] = (int32_t)(n_head + slot);
+      }
+    }
+    if (W == 8 && dirty) {
+      reinterpret_cast<int4 *>(ell + t * 8)[0] = make_int4(r8[0], r8[1], r8[2], r8[3]);
+      reinterpret_cast<int4 *>(ell + t * 8)[1] = make_int4(r8[4], r8[5], r8[6], r8[7]);
     }
   }
 }
@@ -760,8 +817,9 @@ static int plan_claims(scone_handle *h, scone_shard_state *st, const int32_t *el
     }
     const long long nt = (long long)(s1 - s0) * T;
     if (nt > 0) {
-      const unsigned blocks = (unsigned)((nt + 255) / 256 < SHARD_BLOCKS ? (nt + 255) / 256 : SHARD_BLOCKS);
-      hipLaunchKernelGGL(k_gather_claim, dim3(blocks), dim3(256), 0, s, ell + (long long)s0 * T * W, nt, W, NC,
+      const long long want = (nt + CLAIM_THREADS - 1) / CLAIM_THREADS;
+      const unsigned blocks = (unsigned)(want < CLAIM_BLOCKS ? want : CLAIM_BLOCKS);
+      hipLaunchKernelGGL(k_gather_claim, dim3(blocks), dim3(CLAIM_THREADS), 0, s, ell + (long long)s0 * T * W, nt, W, NC,
                          (long long)h->cfg.row_begin, send_begin, (long long)h->cfg.row_end, st->uniq_claim, st->uniq_gen,
                          st->counters, st->uniq_list, st->cap_uniq);
     }
@@ -862,16 +920,7 @@ extern "C" int scone_ell_width(scone_handle *h, uint32_t *ints_per_token) {
 // plan_slot).  Selecting a slot is a host-side swap; the calls that follow -- plan, add_records, embed_range -- work on
 // it.  Sender-side scratch (claim table, record list, counters) is shared: plan + pack of one batch are finished (in
 // stream order) before the next plan starts.
-extern "C" int scone_shard_select_slot(scone_handle *h, int32_t slot) {
-  if (!h) return SCONE_EINVAL;
-  if (slot != 0 && slot != 1) return scone_fail(h, SCONE_EINVAL, "scone_shard_select_slot: slot must be 0 or 1");
-  if (!h->shard) {
-    h->shard = new (std::nothrow) scone_shard_state();
-    if (!h->shard) return scone_fail(h, SCONE_ENOMEM, "scone_shard_select_slot: out of memory");
-  }
-  scone_shard_state *st = h->shard;
-  if (st->slot == slot) return SCONE_OK;
-  scone_shard_state::plan_slot &p = st->parked;
+static void swap_slot(scone_shard_state *st, scone_shard_state::plan_slot &p) {
   std::swap(st->ell_slice, p.ell_slice);
   std::swap(st->cap_slice, p.cap_slice);
   std::swap(st->scales, p.scales);
@@ -887,8 +936,34 @@ extern "C" int scone_shard_select_slot(scone_handle *h, int32_t slot) {
   std::swap(st->rmap_gen, p.rmap_gen);
   std::swap(st->rmap_active, p.rmap_active);
   st->remapped.swap(p.remapped);
+}
+
+extern "C" int scone_shard_select_slot(scone_handle *h, int32_t slot) {
+  if (!h) return SCONE_EINVAL;
+  if (slot < 0 || slot >= SCONE_SHARD_SLOTS) return scone_fail(h, SCONE_EINVAL, "scone_shard_select_slot: slot must be 0 .. 3");
+  scone_shard_state *st = shard_state(h);
+  if (!st) return scone_fail(h, SCONE_ENOMEM, "scone_shard_select_slot: out of memory");
+  if (st->slot == slot) return SCONE_OK;
+  swap_slot(st, st->parked[st->slot]);  // the active state goes to ITS parking place (now holds the active slot's state) ...
+  swap_slot(st, st->parked[slot]);      // ... and the wanted slot's state becomes the active one
   st->slot = slot;
   return SCONE_OK;
+}
+
+// Receiver: rewrite the id lists of sequences [seq_begin, seq_end) of the planned batch to record numbers NOW (every row
+// they reference must have been added), e.g. on the stream that waited for the records, so that the later
+// scone_shard_gather_embed_range -- on the stream that reduces -- finds them done and launches the lookup alone.
+extern "C" int scone_shard_gather_remap_range(scone_handle *h, int32_t seq_begin, int32_t seq_end, scone_stream_t stream) {
+  if (!h) return SCONE_EINVAL;
+  if (!h->shard) return scone_fail(h, SCONE_ESTATE, "scone_shard_gather_remap_range: call scone_shard_gather_plan first");
+  scone_shard_state *st = h->shard;
+  if (seq_begin < 0 || seq_end < seq_begin || seq_end > st->plan_B)
+    return scone_fail(h, SCONE_EINVAL, "scone_shard_gather_remap_range: sequences outside the planned batch");
+  if (seq_end == seq_begin) return SCONE_OK;
+  SCONE_ON_DEVICE(h);
+  const int32_t *ell = nullptr;
+  const void *scales = nullptr;
+  return scone_shard_gather_remap(h, st->plan_T, seq_begin, seq_end, &ell, &scales, (hipStream_t)stream);
 }
 
 extern "C" int scone_shard_gather_plan(scone_handle *h, const int32_t *d_tok, int32_t B, int32_t T, uint64_t *h_n_records,
@@ -906,11 +981,14 @@ extern "C" int scone_shard_gather_pack_range(scone_handle *h, uint64_t first, ui
   if (!d_send_buf) return scone_fail(h, SCONE_EINVAL, "scone_shard_gather_pack: null send buffer");
   SCONE_ON_DEVICE(h);
   if (count) {
-    unsigned pb = (unsigned)((count + 3) / 4);
-    if (pb > 4096) pb = 4096;
+    const size_t vecs = h->row_payload_bytes / 16;
+    const int lpr = vecs <= 16 ? 16 : vecs <= 32 ? 32 : 64;
+    const unsigned long long rec_per_block = 4ull * (64 / lpr);
+    unsigned pb = (unsigned)((count + rec_per_block - 1) / rec_per_block);
+    if (pb > 32768) pb = 32768;  // every row read of the pack in flight at once up to 131k waves
     hipLaunchKernelGGL(k_gather_pack, dim3(pb), dim3(256), 0, (hipStream_t)stream, st->uniq_list + first, count,
                        scone_store_of(h), (long long)h->cfg.row_begin, (const uint8_t *)h->scales, (int)h->scale_bytes_per_row,
-                       scone_shard_rec_bytes(h), (uint8_t *)d_send_buf);
+                       scone_shard_rec_bytes(h), (uint8_t *)d_send_buf, lpr);
   }
   if (pad)
     hipLaunchKernelGGL(k_gather_mark_pad, dim3((unsigned)((pad + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
@@ -928,17 +1006,14 @@ extern "C" int scone_shard_gather_pack(scone_handle *h, void *d_send_buf, scone_
 // whole buffer will hold n_total) join the row map; record0 == 0 starts a new exchange (a new generation of the
 // direct-mapped map / the hash map is cleared).
 static int rmap_policy(scone_handle *h, scone_shard_state *st) {
-  // read when an exchange starts (cheap; lets one process compare the two forms): SCONE_SHARD_ROW_MAP=hash|direct, else
-  // auto: 4 B per table row and plan slot, taken when both slots' maps are under 1/8 of the device's memory
+  // read when an exchange starts (cheap; lets one process compare the two forms).  Default: the HASH map -- sized by the
+  // exchange (8 MB for 0.45M records) it lives in L2 / the Infinity Cache, while the direct-mapped array over all table rows
+  // (4 GB at 1e9 rows) turns every lookup into a TLB miss + an HBM access: measured at C5's true scale, alternating on one
+  // box (profiles/r03e): 0.927 against 0.909 ms per step.  SCONE_SHARD_ROW_MAP=direct selects it all the same.
+  (void)st;
   const char *e = getenv("SCONE_SHARD_ROW_MAP");
-  if (e && !strcmp(e, "hash")) return 0;
   if (e && !strcmp(e, "direct")) return h->cfg.n_rows < 0xFFFFFFFFull ? 1 : 0;
-  if (st->rmap_policy < 0) {
-    size_t free_b = 0, total_b = 0;
-    (void)hipMemGetInfo(&free_b, &total_b);
-    st->rmap_policy = ((unsigned long long)h->cfg.n_rows * 8ull <= (unsigned long long)total_b / 8ull && h->cfg.n_rows < 0xFFFFFFFFull) ? 1 : 0;
-  }
-  return st->rmap_policy;
+  return 0;
 }
 
 int scone_shard_gather_add(scone_handle *h, const void *d_records, uint64_t n, uint64_t record0, uint64_t n_total,

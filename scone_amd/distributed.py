@@ -202,8 +202,14 @@ class ShardedEmbeddingCache:
     def __init__(self, n_gram_extractor: NGramExtractor, embedding_dim: int, *, table_format: str = "int8",
                  rank: Optional[int] = None, world: Optional[int] = None, group=None, device=None,
                  n_rows: Optional[int] = None, placement: str = "hbm", table=None, replicated_rows: int = 0,
-                 gather_chunks: int = 4, gather_transport: str = "p2p", shard_match="auto") -> None:
+                 gather_chunks: int = 4, gather_transport: str = "p2p", shard_match="auto", plan_slots: int = 2) -> None:
         self.group = group
+        # split-phase "gather_rows": batches in flight (2 .. 4).  The chain plan -> count exchange -> pack -> transfers of
+        # a batch must fit (plan_slots - 1) reductions: with 2 it has ONE reduction's time, with 3 it has two -- the
+        # setting for links on which a step's 0.26 GB of records take about as long as its reduction
+        if not 2 <= int(plan_slots) <= 4:
+            raise ValueError("plan_slots must be 2, 3 or 4")
+        self.plan_slots = int(plan_slots)
         # The match of a plan sharded over the ranks (rank r matches slice r, the 32-B list records are all-gathered) instead
         # of every rank matching the whole batch: True / False / "auto" (on for batches of >= 65,536 tokens with at least one
         # sequence per rank -- below that the extra small collective costs more than the match it saves)
@@ -235,15 +241,15 @@ class ShardedEmbeddingCache:
         # split-phase "gather_rows" (gather_rows_begin / gather_rows_finish): side stream, two plan slots
         self._side = None
         self._slot_next = 0
-        self._slot_done = [None, None]
-        self._slot_full = [None, None]
+        self._slot_done = [None] * 4
+        self._slot_full = [None] * 4
         # The SENDER-side scratch of a plan (list of claimed rows, counters, chunk ends) exists once per handle, whatever the
         # slot: the next plan may only overwrite it after the last pack of the previous one has read it, on whichever stream
         # that pack ran -> an event after every plan's last pack, waited for by the stream of the next plan.  And a slot
         # whose ticket has not been finished must not be planned into again.
         self._plan_packed = None
-        self._slot_open = [False, False]
-        self._slot_ell = [None, None]        # sharded match: the gathered list records of the batch a slot holds
+        self._slot_open = [False] * 4
+        self._slot_ell = [None] * 4          # sharded match: the gathered list records of the batch a slot holds
         self._ell_send = None
 
     @classmethod
@@ -394,9 +400,13 @@ class ShardedEmbeddingCache:
                 ticket = cache.gather_rows_begin(batch[b + 1]) if b + 1 < n else None   # ... and this overlaps it
 
         hides plan, pack and the transfers of batch b + 1 behind the reduction of batch b: the step is then bound by the
-        reduction alone.  At most two batches in flight (two plan slots); tickets are finished in the order they were
+        reduction alone.  At most ``plan_slots`` batches in flight (2 by default; with 3, ``begin`` is called two batches
+        ahead and the chain plan -> transfers may take two reductions' time); tickets are finished in the order they were
         begun.  ``begin`` blocks the host until the side stream has planned the batch (the record counts size the
-        buffers), not until the device is idle.
+        buffers), not until the device is idle.  (Tried in round 3 and dropped: indexing the records and rewriting the id
+        lists on a third stream behind the transfers, so that ``finish`` launches the reduction alone -- at C5's true scale
+        the step did not move, 0.926 against 0.921 ms, ``profiles/r03f``; the side stream never waits for the transfers
+        either way, the caller's stream does.)
 
         ``tokens_ready`` says what the side stream must wait for before it reads the tokens: a ``torch.cuda.Event``
         recorded where they were produced; ``None`` -- nothing, they are complete (uploaded earlier, or produced by work the
@@ -414,9 +424,9 @@ class ShardedEmbeddingCache:
         if not overlap:
             return self._gather_begin(t._tok(tok), 0, time.perf_counter() if self._prof is not None else 0.0)
         slot = self._slot_next
-        self._slot_next ^= 1
+        self._slot_next = (slot + 1) % self.plan_slots
         dev = getattr(t, "device", None)
-        if dev is None or torch.device(dev).type != "cuda":   # stand-in tables of the CPU tests: two slots, no streams
+        if dev is None or torch.device(dev).type != "cuda":   # stand-in tables of the CPU tests: the slots, no streams
             return self._gather_begin(t._tok(tok), slot, 0.0)
         if self._side is None:
             self._side = torch.cuda.Stream(device=dev)

@@ -169,13 +169,24 @@ class SconeTable:
         self._check(L.lib().scone_index_stats(self._h, C.byref(a), C.byref(b), C.byref(c)), "scone_index_stats")
         return a.value, b.value, c.value
 
-    def index_export(self):
-        """The built index as host arrays ``(slots uint8, uni int32, bloom uint8, n_keys, capacity)``."""
+    def index_blob_sizes(self) -> Tuple[int, int, int]:
+        """Bytes of the three blobs of the built index: hash slots, unigram table, presence bitmap."""
         a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
         self._check(L.lib().scone_index_blob_sizes(self._h, C.byref(a), C.byref(b), C.byref(c)), "scone_index_blob_sizes")
-        slots = np.empty(a.value, dtype=np.uint8)
-        uni = np.empty(b.value // 4, dtype=np.int32)
-        bloom = np.empty(c.value, dtype=np.uint8)
+        return a.value, b.value, c.value
+
+    def index_export(self, out=None):
+        """The built index as host arrays ``(slots uint8, uni int32, bloom uint8, n_keys, capacity)``.  ``out = (slots, uni,
+        bloom)``: write into these arrays (e.g. sections of a memory-mapped file) instead of allocating."""
+        a, b, c = (C.c_uint64(x) for x in self.index_blob_sizes())
+        if out is None:
+            slots = np.empty(a.value, dtype=np.uint8)
+            uni = np.empty(b.value // 4, dtype=np.int32)
+            bloom = np.empty(c.value, dtype=np.uint8)
+        else:
+            slots, uni, bloom = out
+            assert (slots.nbytes, uni.nbytes, bloom.nbytes) == (a.value, b.value, c.value)
+            assert all(x.flags["C_CONTIGUOUS"] and x.flags["WRITEABLE"] for x in out)
         n = C.c_uint64(0)
         rc = L.lib().scone_index_export(self._h, slots.ctypes.data_as(C.c_void_p), uni.ctypes.data_as(C.c_void_p),
                                         bloom.ctypes.data_as(C.c_void_p), C.byref(n))
@@ -216,11 +227,19 @@ class SconeTable:
     def scales_per_row(self) -> int:
         return {L.FMT_F32: 0, L.FMT_F16: 0, L.FMT_I8: 1, L.FMT_I4: self.dim // I4_GROUP}[self.fmt]
 
-    def download(self, row0: int, nrows: int) -> Tuple[np.ndarray, Optional[np.ndarray]]:
-        """Raw payload rows ``uint8 [nrows, payload_bytes]`` and fp16 scales of global rows ``row0 ..``."""
-        rows = np.empty((nrows, self.payload_bytes()), dtype=np.uint8)
+    def download(self, row0: int, nrows: int, rows: Optional[np.ndarray] = None,
+                 scales: Optional[np.ndarray] = None) -> Tuple[np.ndarray, Optional[np.ndarray]]:
+        """Raw payload rows ``uint8 [nrows, payload_bytes]`` and fp16 scales of global rows ``row0 ..`` -- into ``rows`` /
+        ``scales`` when given (contiguous host arrays of those shapes, e.g. slices of a memory-mapped file)."""
         spr = self.scales_per_row()
-        scales = np.empty((nrows, spr), dtype=np.float16) if spr else None
+        if rows is None:
+            rows = np.empty((nrows, self.payload_bytes()), dtype=np.uint8)
+        if scales is None and spr:
+            scales = np.empty((nrows, spr), dtype=np.float16)
+        assert rows.shape == (nrows, self.payload_bytes()) and rows.dtype == np.uint8 and rows.flags["C_CONTIGUOUS"]
+        assert not spr or (scales.shape == (nrows, spr) and scales.dtype == np.float16 and scales.flags["C_CONTIGUOUS"])
+        if not spr:
+            scales = None
         with torch.cuda.device(self.device):
             rc = L.lib().scone_table_download(self._h, rows.ctypes.data_as(C.c_void_p),
                                               scales.ctypes.data_as(C.c_void_p) if spr else None, int(row0), int(nrows),
@@ -454,8 +473,8 @@ class SconeTable:
         return buf
 
     def shard_select_slot(self, slot: int) -> None:
-        """Plan slot 0 / 1 for the scone_shard_gather_* calls that follow (host-side switch): the receiver-side state of a
-        planned batch exists twice, so batch b + 1 can be planned and exchanged while batch b is being reduced."""
+        """Plan slot 0 .. 3 for the scone_shard_gather_* calls that follow (host-side switch): the receiver-side state of a
+        planned batch exists once per slot, so batches b + 1, b + 2 can be planned and exchanged while batch b is being reduced."""
         self._check(L.lib().scone_shard_select_slot(self._h, int(slot)), "scone_shard_select_slot")
 
     def shard_gather_plan_chunks(self, tok: torch.Tensor, n_chunks: int, dedup_across_chunks: bool = True) -> list:
@@ -521,6 +540,13 @@ class SconeTable:
             rc = L.lib().scone_shard_gather_add_records(self._h, _ptr(records), int(record0), int(n_records),
                                                         records.shape[0], _stream())
         self._check(rc, "scone_shard_gather_add_records")
+
+    def shard_gather_remap_range(self, seq_begin: int, seq_end: int) -> None:
+        """Rewrite the lists of sequences ``[seq_begin, seq_end)`` of the planned batch to record numbers on the current
+        stream (their rows must have been added); :meth:`shard_gather_embed_range` then only launches the lookup."""
+        with torch.cuda.device(self.device):
+            rc = L.lib().scone_shard_gather_remap_range(self._h, int(seq_begin), int(seq_end), _stream())
+        self._check(rc, "scone_shard_gather_remap_range")
 
     def shard_gather_embed_range(self, tok: torch.Tensor, seq_begin: int, seq_end: int, records: torch.Tensor,
                                  out: torch.Tensor, wte: Optional[torch.Tensor] = None, wpe: Optional[torch.Tensor] = None,

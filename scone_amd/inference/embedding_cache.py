@@ -307,45 +307,154 @@ class EmbeddingCache:
         return result
 
     # ------------------------------------------------------------------ native shard format
-    NATIVE_MAGIC = "scone_amd.table.v1"
+    NATIVE_MAGIC = "scone_amd.table.v1"          # round 1-2: one uncompressed .npz, whole arrays in host memory
+    NATIVE_MAGIC_V2 = "scone_amd.table.v2"       # round 3: one memory-mapped .npy, written and read in chunks
+
+    @staticmethod
+    def _native_layout(sections):
+        """Byte offsets of the sections of a v2 file inside the payload of its ``.npy``: ``[u64 header length | json
+        header | pad to 4096 | section | pad | section ...]``; returns (offset of every section, total bytes)."""
+        off, pos = {}, 0
+        for name, (dtype, shape) in sections.items():
+            pos = (pos + 4095) // 4096 * 4096
+            off[name] = pos
+            pos += int(np.prod(shape, dtype=np.int64)) * np.dtype(dtype).itemsize
+        return off, (pos + 4095) // 4096 * 4096
 
     def save_native(self, path: str, chunk_rows: int = 1 << 18, with_index: bool = False) -> None:
-        """Write the device table as it is stored (quantised rows + scales) together with the
-        f-gram keys, so :meth:`load_native` restores it without re-quantising.  One ``.npz``
-        (uncompressed): ``meta`` (json), ``keys [N, max_n] uint32``, ``lens [N] uint8``,
-        ``rows [row_end - row_begin, payload_bytes] uint8``, ``scales [row_end - row_begin, scales_per_row] float16``
-        -- the rows THIS handle owns only (a shard of a 1e9-row table writes its 125M rows, not a 528 GB array) --
-        and, with ``with_index=True``, the built device index (``index_slots / index_uni / index_bloom``) so that a load
-        copies it back instead of re-inserting every key (1e9 keys: ~16 s)."""
+        """Write the device table as it is stored (quantised rows + scales) together with the f-gram keys, so
+        :meth:`load_native` restores it without re-quantising -- the rows THIS handle owns only (a shard of a 1e9-row table
+        writes its 125M rows, not a 528 GB array) and, with ``with_index=True``, the built device index (hash slots,
+        unigram table, presence bitmap) so that a load copies it back instead of re-inserting every key (1e9 keys: ~16 s).
+
+        ONE file, a valid ``.npy`` of bytes whose payload is ``[header | keys | lens | rows | scales | index blobs]``
+        (4096-aligned sections, described by the json header), created as a memory map and filled ``chunk_rows`` rows at
+        a time straight from the device: the host never holds more than one chunk beside the file's own page cache, whatever
+        the shard's size (a C5 shard: 66 GB of rows + a 34 GB index).  A vocabulary without key arrays (the synthetic
+        ``StructuredVocab``) is recorded by its parameters."""
         import json
         table = self.to_device()
         n, a, b = table.n_rows, table.row_begin, table.row_end
-        rows = np.empty((b - a, table.payload_bytes()), dtype=np.uint8)
         spr = table.scales_per_row()
-        scales = np.empty((b - a, spr), dtype=np.float16)
+        ex = self.n_gram_extractor
+        meta = {"magic": self.NATIVE_MAGIC_V2, "table_format": self.table_format, "embedding_dim": self.embedding_dim,
+                "max_n": ex.max_n, "n_rows": n, "row_begin": a, "row_end": b, "rows_are_local": True}
+        sections = {}
+        keys = lens = None
+        if hasattr(ex, "key_arrays"):
+            keys, lens = ex.key_arrays()
+            sections["keys"] = ("uint32", tuple(keys.shape))
+            sections["lens"] = ("uint8", tuple(lens.shape))
+        else:                                             # closed-form vocabulary: its parameters are the keys
+            meta["vocabulary"] = {"kind": type(ex).__name__, "n_rows": len(ex), "vocab": getattr(ex, "vocab", None)}
+        sections["rows"] = ("uint8", (b - a, table.payload_bytes()))
+        sections["scales"] = ("float16", (b - a, spr))
+        if with_index:
+            sb, ub, bb = table.index_blob_sizes()
+            sections["index_slots"] = ("uint8", (sb,))
+            sections["index_uni"] = ("int32", (ub // 4,))
+            sections["index_bloom"] = ("uint8", (bb,))
+            meta["index_capacity"] = sb // 16
+        for _ in range(2):                                # (the header's own length moves the first section once)
+            meta["sections"] = {k: {"dtype": v[0], "shape": list(v[1])} for k, v in sections.items()}
+            hdr = json.dumps(meta).encode()
+            hdr_room = (8 + len(hdr) + 4095 + 64) // 4096 * 4096      # 64 B of slack for "index_keys" below
+            off, body = self._native_layout(sections)
+            meta["section_offsets"] = {k: hdr_room + v for k, v in off.items()}
+        if not str(path).endswith(".npy"):
+            path = str(path) + ".npy"
+        mm = np.lib.format.open_memmap(path, mode="w+", dtype=np.uint8, shape=(hdr_room + body,))
+
+        def section(name):
+            dtype, shape = sections[name]
+            o = meta["section_offsets"][name]
+            nbytes = int(np.prod(shape, dtype=np.int64)) * np.dtype(dtype).itemsize
+            return mm[o:o + nbytes].view(dtype).reshape(shape)
+
+        if keys is not None:
+            section("keys")[:] = keys
+            section("lens")[:] = lens
+        rows, scales = section("rows"), section("scales")
         for r0 in range(a, b, chunk_rows):
             m = min(chunk_rows, b - r0)
-            r, sc = table.download(r0, m)
-            rows[r0 - a:r0 - a + m] = r
-            if spr:
-                scales[r0 - a:r0 - a + m] = sc
-        keys, lens = self.n_gram_extractor.key_arrays()
-        meta = {"magic": self.NATIVE_MAGIC, "table_format": self.table_format, "embedding_dim": self.embedding_dim,
-                "max_n": self.n_gram_extractor.max_n, "n_rows": n, "row_begin": a, "row_end": b, "rows_are_local": True}
-        extra = {}
+            table.download(r0, m, rows=rows[r0 - a:r0 - a + m], scales=scales[r0 - a:r0 - a + m] if spr else None)
         if with_index:
-            slots, uni, bloom, n_keys, cap = table.index_export()
-            meta.update(index_keys=int(n_keys), index_capacity=int(cap))
-            extra = {"index_slots": slots, "index_uni": uni, "index_bloom": bloom}
-        np.savez(path, meta=np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8), keys=keys, lens=lens, rows=rows,
-                 scales=scales, **extra)
+            _, _, _, n_keys, cap = table.index_export(out=(section("index_slots"), section("index_uni"), section("index_bloom")))
+            meta["index_keys"] = int(n_keys)
+        hdr = json.dumps(meta).encode()
+        assert 8 + len(hdr) <= hdr_room
+        mm[:8] = np.frombuffer(np.uint64(len(hdr)).tobytes(), dtype=np.uint8)
+        mm[8:8 + len(hdr)] = np.frombuffer(hdr, dtype=np.uint8)
+        mm.flush()
+        del mm
 
     @classmethod
-    def load_native(cls, path: str, *, placement: str = "hbm", device=None, hot_rows: int = 0) -> "EmbeddingCache":
-        """Restore a cache written by :meth:`save_native` (extractor included; the index from the file when it is there)."""
+    def load_native(cls, path: str, *, placement: str = "hbm", device=None, hot_rows: int = 0,
+                    chunk_rows: int = 1 << 18) -> "EmbeddingCache":
+        """Restore a cache written by :meth:`save_native` (extractor included; the index from the file when it is there).
+        The file is memory-mapped and uploaded ``chunk_rows`` rows at a time (v1 ``.npz`` files of rounds 1-2 are still read,
+        whole)."""
         import json
         from scone_amd.hip_backend import SconeTable
-        z = np.load(path if str(path).endswith(".npz") else str(path) + ".npz")
+        path = str(path)
+        if not os.path.exists(path):
+            path = path + (".npy" if os.path.exists(path + ".npy") else ".npz")
+        if path.endswith(".npz"):
+            return cls._load_native_v1(path, placement=placement, device=device, hot_rows=hot_rows)
+        mm = np.load(path, mmap_mode="r")
+        if mm.dtype != np.uint8 or mm.ndim != 1 or mm.shape[0] < 4096:
+            raise ValueError("not a scone_amd native table file")
+        hlen = int(np.frombuffer(bytes(mm[:8]), dtype=np.uint64)[0])
+        if hlen <= 0 or 8 + hlen > mm.shape[0]:
+            raise ValueError("not a scone_amd native table file")
+        try:
+            meta = json.loads(bytes(mm[8:8 + hlen]).decode())
+        except ValueError:
+            meta = {}
+        if meta.get("magic") != cls.NATIVE_MAGIC_V2:
+            raise ValueError("not a scone_amd native table file")
+
+        def section(name):
+            sec = meta["sections"][name]
+            o = meta["section_offsets"][name]
+            nbytes = int(np.prod(sec["shape"], dtype=np.int64)) * np.dtype(sec["dtype"]).itemsize
+            return mm[o:o + nbytes].view(sec["dtype"]).reshape(sec["shape"])
+
+        if "keys" in meta["sections"]:
+            ex = NGramExtractor.from_arrays(np.array(section("keys")), np.array(section("lens")), max_n=meta["max_n"])
+        else:
+            voc = meta["vocabulary"]
+            if voc["kind"] != "StructuredVocab":
+                raise ValueError(f"native table file without keys for an unknown vocabulary kind {voc['kind']!r}")
+            from scone_amd.synthetic import StructuredVocab
+            ex = StructuredVocab(voc["n_rows"], voc["vocab"], meta["max_n"])
+        cache = cls(ex, meta["embedding_dim"], table_format=meta["table_format"], placement=placement, device=device,
+                    keep_host_copy=False, hot_rows=hot_rows)
+        a, b = meta["row_begin"], meta["row_end"]
+        if "index_slots" in meta["sections"]:
+            table = SconeTable(ex.max_n, meta["n_rows"], dim=cache.embedding_dim, table_format=cache.table_format,
+                               placement=placement, device=device, hot_rows=hot_rows, lookup_mode=cache.lookup_mode,
+                               index_capacity=meta["index_capacity"], row_begin=a, row_end=b)
+            table.index_import(section("index_slots"), section("index_uni"), section("index_bloom"), meta["index_keys"])
+        else:
+            table = SconeTable(ex.max_n, meta["n_rows"], dim=cache.embedding_dim, table_format=cache.table_format,
+                               placement=placement, device=device, hot_rows=hot_rows, lookup_mode=cache.lookup_mode,
+                               row_begin=a, row_end=b)
+            ex.build_index(table)
+        rows, scales = section("rows"), section("scales")
+        for r0 in range(a, b, chunk_rows):
+            m = min(chunk_rows, b - r0)
+            table.upload(rows[r0 - a:r0 - a + m], scales[r0 - a:r0 - a + m] if scales.shape[1] else None, row0=r0)
+        cache._table, cache._dirty = table, False
+        cache._present = np.ones(meta["n_rows"], dtype=bool)
+        del mm
+        return cache
+
+    @classmethod
+    def _load_native_v1(cls, path: str, *, placement: str = "hbm", device=None, hot_rows: int = 0) -> "EmbeddingCache":
+        import json
+        from scone_amd.hip_backend import SconeTable
+        z = np.load(path)
         meta = json.loads(bytes(z["meta"]).decode())
         if meta.get("magic") != cls.NATIVE_MAGIC:
             raise ValueError("not a scone_amd native table file")

@@ -153,6 +153,30 @@ def stream_uniform_ids(keys, lens, B: int, T: int, seed: int) -> np.ndarray:
     return out[:need].reshape(B, T)
 
 
+def stream_zipf_ids(keys, lens, B: int, T: int, seed: int, s: float = 1.1) -> np.ndarray:
+    """S_zipf_ids: f-grams laid end to end like :func:`stream_uniform_ids`, their ids drawn from a Zipf-like law over
+    ``[0, N)`` (bounded power law, exponent ``s``) instead of uniformly.  f-gram ids are FREQUENCY-ordered (the reference
+    assigns them in ``Counter.most_common`` order, ``n_gram_extractor.py:91-99``), so this is what a table sorted by
+    frequency sees from real text: the head of the table takes most references, the tail is long and its rows recur
+    within a batch -- the stream on which a hot head in HBM and a de-duplicating prefetch pay."""
+    rng = np.random.default_rng(seed)
+    need = B * T
+    n_rows = len(keys) if isinstance(keys, StructuredVocab) else keys.shape[0]
+    out = np.empty(0, dtype=np.int64)
+    e = 1.0 - s
+    while out.size < need:
+        u = rng.random(max(1024, int((need - out.size) / 1.5) + 1024))
+        x = ((float(n_rows + 1) ** e - 1.0) * u + 1.0) ** (1.0 / e)          # inverse CDF of the bounded power law on [1, N + 1)
+        ids = np.minimum(x.astype(np.int64) - 1, n_rows - 1)
+        if isinstance(keys, StructuredVocab):
+            k, l = keys.keys_for(ids)
+        else:
+            k, l = keys[ids], lens[ids]
+        mask = np.arange(k.shape[1])[None, :] < l[:, None]
+        out = np.concatenate([out, k[mask].astype(np.int64)])
+    return out[:need].reshape(B, T)
+
+
 def stream_zipf(vocab: int, B: int, T: int, seed: int) -> np.ndarray:
     """S_zipf: iid Zipf(1.1) tokens (the realistic stream of the reference's C1 probe)."""
     rng = np.random.default_rng(seed)

@@ -161,7 +161,7 @@ class OracleShard:
 
     def shard_select_slot(self, slot):
         # the receiver-side state of a planned batch exists twice (scone_shard_select_slot)
-        st = self.__dict__.setdefault("_slots", {0: {}, 1: {}})
+        st = self.__dict__.setdefault("_slots", {0: {}, 1: {}, 2: {}, 3: {}})
         cur = self.__dict__.setdefault("_slot", 0)
         if slot == cur:
             return
@@ -440,7 +440,7 @@ def test_gather_rows_world3_gloo(transport):
         assert out_shape == (shape[0], shape[1], 32) and err < 1e-6 and ok_slice
 
 
-def _worker_split_phase(rank, world, port, q):
+def _worker_split_phase(rank, world, port, q, slots=2):
     try:
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -462,13 +462,20 @@ def _worker_split_phase(rank, world, port, q):
         shard = OracleShard(keys, lens, max_n, table, a, b)
         shard.shard_set_head(30)
         cache = ShardedEmbeddingCache(ex, d, rank=rank, world=world, n_rows=n, table=shard, replicated_rows=30, gather_chunks=2,
-                                      shard_match=True)       # both slots plan from gathered lists: each needs its own buffer
-        outs = []
-        ticket = cache.gather_rows_begin(batches[0])
+                                      shard_match=True, plan_slots=slots)   # every slot plans from gathered lists: each needs its own buffer
+        outs, tickets, nxt = [], [cache.gather_rows_begin(batches[0])], 1
         for i in range(len(batches)):
-            nxt = cache.gather_rows_begin(batches[i + 1]) if i + 1 < len(batches) else None   # batch i+1 planned and
-            outs.append(cache.gather_rows_finish(ticket, wte=wte, wpe=wpe))                    # exchanged before batch i is reduced
-            ticket = nxt
+            while nxt < len(batches) and len(tickets) < slots:        # batches i+1 (.. i+slots-1) planned and exchanged
+                tickets.append(cache.gather_rows_begin(batches[nxt]))     # before batch i is reduced
+                nxt += 1
+            outs.append(cache.gather_rows_finish(tickets.pop(0), wte=wte, wpe=wpe))
+        ts = []
+        with pytest.raises(RuntimeError):                              # more batches in flight than slots: refused, not corrupted
+            for _ in range(slots + 1):
+                ts.append(cache.gather_rows_begin(batches[0]))
+        assert len(ts) == slots
+        for tk in ts:                                                  # (finished in order: the slots are free again)
+            assert torch.equal(cache.gather_rows_finish(tk, wte=wte, wpe=wpe), outs[0])
         worst = 0.0
         for tok, out in zip(batches, outs):
             ro, ri = R.hits_to_csr(R.match_hits(keys, lens, tok.numpy(), max_n))
@@ -483,14 +490,15 @@ def _worker_split_phase(rank, world, port, q):
         q.put((rank, repr(e) + traceback.format_exc(), False))
 
 
-def test_gather_rows_split_phase_two_batches_in_flight_world2_gloo():
+@pytest.mark.parametrize("slots", [2, 3])
+def test_gather_rows_split_phase_two_batches_in_flight_world2_gloo(slots):
     """gather_rows_begin / gather_rows_finish with the next batch begun (planned, packed, gathered) BEFORE the current one is
     reduced: the two plan slots keep the batches apart; every output equals the unsharded lookup of ITS batch and the
     one-call form."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker_split_phase, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker_split_phase, args=(r, 2, port, q, slots)) for r in range(2)]
     for p in procs:
         p.start()
     results = [q.get(timeout=180) for _ in procs]

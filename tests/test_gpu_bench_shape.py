@@ -122,9 +122,9 @@ def test_whole_bench_batch_against_the_c_oracle(name, fmt, d, n_rows, keygen, B)
     assert cache.table.status() == 0
 
 
-@pytest.mark.parametrize("chunks,match,row_map", [(1, "local", "direct"), (3, "local", "hash"), (1, "sharded", "hash"),
-                                                  (3, "sharded", "direct")])
-def test_eight_shard_gather_rows_step_against_the_c_oracle(chunks, match, row_map, monkeypatch):
+@pytest.mark.parametrize("chunks,match,row_map,align", [(1, "local", "direct", 16), (3, "local", "hash", 64), (1, "sharded", "hash", 16),
+                                                        (3, "sharded", "direct", 128)])
+def test_eight_shard_gather_rows_step_against_the_c_oracle(chunks, match, row_map, align, monkeypatch):
     """One `gather_rows` step of the 8-way exchange (tools/shard_emulate.py's loop: eight real shards on this GPU, every shard
     plans and packs its distinct rows, the all-gather is a concatenation, every shard reduces the WHOLE 256 x 512 batch out of
     [replicated head | gathered records]) -- compared with the ORACLE, not with the unsharded handle: fp32 bit-exact on every
@@ -136,6 +136,7 @@ def test_eight_shard_gather_rows_step_against_the_c_oracle(chunks, match, row_ma
     from scone_amd.distributed import shard_range
     from scone_amd.hip_backend import SconeError, SconeTable
     monkeypatch.setenv("SCONE_SHARD_ROW_MAP", row_map)
+    monkeypatch.setenv("SCONE_SHARD_REC_ALIGN", str(align))          # record stride 544 / 576 / 640 B (read when a handle is created)
     N, W, d, B, T, head = 1_000_000, 8, 1024, 256, 512, S.GPT2_VOCAB
     keys, lens = _keys(N, "zipf")
     tok_np = S.stream_uniform_ids(keys, lens, B, T, 4321)
@@ -153,6 +154,7 @@ def test_eight_shard_gather_rows_step_against_the_c_oracle(chunks, match, row_ma
         s.fill_synthetic(SEED, BASE_SCALE)
         shards.append(s)
     rec = shards[0].shard_record_bytes()
+    assert rec == (536 + align - 1) // align * align
     per = (B + chunks - 1) // chunks
     bper = B // W
     wd = shards[0].ell_width()

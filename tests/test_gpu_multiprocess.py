@@ -108,7 +108,7 @@ def test_sharded_cache_across_processes_on_one_gpu(fmt, d, max_n, world, exchang
             assert err < 1e-3, (rank, err)          # fp32 partial sums are added in shard order, not list order
 
 
-def _worker_split_phase(rank, world, port, fmt, d, max_n, head, chunks, q):
+def _worker_split_phase(rank, world, port, fmt, d, max_n, head, chunks, q, slots=2):
     try:
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         import torch.distributed as dist
@@ -121,16 +121,20 @@ def _worker_split_phase(rank, world, port, fmt, d, max_n, head, chunks, q):
         batches = [tok0] + [rng.integers(0, 24, size=tok0.shape) for _ in range(4)]
         ex = NGramExtractor.from_arrays(keys, lens, max_n=max_n)
         sh = ShardedEmbeddingCache(ex, d, table_format=fmt, rank=rank, world=world, replicated_rows=head, gather_chunks=chunks,
-                                   shard_match=chunks == 1)                  # (one of the two cases: match sharded over the ranks)
+                                   shard_match=chunks == 1, plan_slots=slots)   # (one of the cases: match sharded over the ranks)
         sh.load_rows(torch.from_numpy(table), 0)
         wte_d, wpe_d = torch.from_numpy(wte).half().cuda(), torch.from_numpy(wpe).half().cuda()
         full = EmbeddingCache(ex, d, table_format=fmt)
         full.cache_embeddings(list(range(len(lens))), torch.from_numpy(table), verbose=False)
-        outs = []
-        ticket = sh.gather_rows_begin(torch.from_numpy(batches[0]))
-        for i in range(len(batches)):                                   # two batches in flight: begin(i + 1) is queued on the side
-            outs.append(sh.gather_rows_finish(ticket, wte=wte_d, wpe=wpe_d))   # stream behind finish(i) on the main one
-            ticket = sh.gather_rows_begin(torch.from_numpy(batches[i + 1])) if i + 1 < len(batches) else None
+        outs, tickets, nxt = [], [], 0
+        for _ in range(slots - 1):                                      # slots - 1 batches ahead of the one being reduced
+            tickets.append(sh.gather_rows_begin(torch.from_numpy(batches[nxt])))
+            nxt += 1
+        for i in range(len(batches)):                                   # begin(i + slots - 1) is queued on the side streams
+            outs.append(sh.gather_rows_finish(tickets.pop(0), wte=wte_d, wpe=wpe_d))   # behind finish(i) on the main one
+            if nxt < len(batches):
+                tickets.append(sh.gather_rows_begin(torch.from_numpy(batches[nxt])))
+                nxt += 1
         torch.cuda.synchronize()
         same = all(bool(torch.equal(o, full.embed_tokens(torch.from_numpy(b), wte=wte_d, wpe=wpe_d))) for o, b in zip(outs, batches))
         # device tokens: produced on the caller's stream (default: the side stream waits for that stream), or with the
@@ -155,8 +159,9 @@ def _worker_split_phase(rank, world, port, fmt, d, max_n, head, chunks, q):
         q.put((rank, False, repr(e) + traceback.format_exc(), None, None))
 
 
-@pytest.mark.parametrize("fmt,d,max_n,world,head,chunks", [("int4", 1024, 3, 3, 100, 1), ("int8", 768, 4, 2, 0, 3)])
-def test_split_phase_gather_two_batches_in_flight_across_processes(fmt, d, max_n, world, head, chunks):
+@pytest.mark.parametrize("fmt,d,max_n,world,head,chunks,slots", [("int4", 1024, 3, 3, 100, 1, 2), ("int8", 768, 4, 2, 0, 3, 2),
+                                                                 ("int4", 1024, 3, 2, 100, 1, 3), ("fp16", 768, 3, 3, 0, 2, 4)])
+def test_split_phase_gather_two_batches_in_flight_across_processes(fmt, d, max_n, world, head, chunks, slots):
     """gather_rows_begin / gather_rows_finish as a serving loop issues them: batch i + 1 is planned, packed and gathered on
     the cache's side stream (plan slot i + 1 mod 2) while batch i is reduced on the main stream.  Five different batches,
     real kernels, separate processes (gloo over one GPU): every output is bit-identical to the unsharded lookup of ITS batch."""
@@ -165,7 +170,7 @@ def test_split_phase_gather_two_batches_in_flight_across_processes(fmt, d, max_n
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker_split_phase, args=(r, world, port, fmt, d, max_n, head, chunks, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker_split_phase, args=(r, world, port, fmt, d, max_n, head, chunks, q, slots)) for r in range(world)]
     for p in procs:
         p.start()
     results = [q.get(timeout=300) for _ in procs]
@@ -220,8 +225,9 @@ def _check_sharded_record(rec, world):
     assert "N = 2 / 4 / 8 ranks hold" in rec["workload"]
     one_call = ("rows+all_gather", "rows_slices_only", "gather_rows_padded_all_gather", "gather_rows_one_shot_padded_all_gather",
                 "gather_rows", "gather_rows_one_shot")
-    assert list(rec["exchanges"])[:len(one_call) + 2] == list(one_call[:4]) + ["gather_rows_split_phase_padded_all_gather"] + \
-        list(one_call[4:]) + ["gather_rows_split_phase"]                  # plain collectives first, point-to-point last
+    split = ("gather_rows_split_phase_padded_all_gather", "gather_rows_split_phase_3_in_flight_padded_all_gather",
+             "gather_rows_split_phase", "gather_rows_split_phase_3_in_flight")
+    assert list(rec["exchanges"]) == list(one_call[:4]) + list(split[:2]) + list(one_call[4:]) + list(split[2:])   # plain collectives first, point-to-point last
     for name in one_call:
         e = rec["exchanges"][name]
         assert "error" not in e, e
@@ -236,10 +242,11 @@ def _check_sharded_record(rec, world):
         rec["exchanges"]["gather_rows"]["roofline"]["per_rank_tokens_reduced"]
     assert "gather_out_ms" in rec["exchanges"]["rows+all_gather"]["phase_ms_slowest_rank"]
     assert rec["exchanges_agree"] is True and len(rec["exchanges_compared"]) == 5
-    for name in ("gather_rows_split_phase_padded_all_gather", "gather_rows_split_phase"):
+    for name in split:
         sp = rec["exchanges"][name]
         assert "error" not in sp, sp
-        assert sp["ms_per_step"] > 0 and sp["batches_in_flight"] == 2 and sp["same_output_as_gather_rows"] is True
+        assert sp["ms_per_step"] > 0 and sp["batches_in_flight"] == (3 if "3_in_flight" in name else 2)
+        assert sp["same_output_as_gather_rows"] is True
         assert sp["speedup_vs_n1_pinned_host"] > 0 and 0 < sp["roofline"]["frac"] <= 1.0
     assert rec["transport_fallback"] is None
     best = rec["best_whole_output"]

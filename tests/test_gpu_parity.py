@@ -1011,8 +1011,12 @@ def test_native_table_file_round_trip_against_the_oracle(tmp_path, fmt, with_ind
     shard._dirty, shard.keep_host_copy = False, False
     ps = str(tmp_path / "shard")
     shard.save_native(ps, with_index=with_index)
-    zf = np.load(ps + ".npz")
-    assert zf["rows"].shape[0] == b - a and zf["scales"].shape[0] == b - a
+    import json
+    raw = np.load(ps + ".npy", mmap_mode="r")                         # a valid .npy of bytes; the json header says what is where
+    meta = json.loads(bytes(raw[8:8 + int(np.frombuffer(bytes(raw[:8]), dtype=np.uint64)[0])]).decode())
+    assert meta["sections"]["rows"]["shape"][0] == b - a and meta["sections"]["scales"]["shape"][0] == b - a
+    assert ("index_slots" in meta["sections"]) == with_index and all(o % 4096 == 0 for o in meta["section_offsets"].values())
+    del raw
     sh2 = EmbeddingCache.load_native(ps)
     assert (sh2.table.row_begin, sh2.table.row_end) == (a, b)
     partial, counts = sh2.table.embed_partial(torch.from_numpy(tok))
@@ -1022,6 +1026,67 @@ def test_native_table_file_round_trip_against_the_oracle(tmp_path, fmt, with_ind
     np.cumsum(np.bincount(seg[own], minlength=len(ro) - 1), out=off_own[1:])
     assert np.array_equal(partial.cpu().numpy(), R.embed_numpy(deq, off_own, ri[own], "sum"))
     assert np.array_equal(counts.cpu().numpy(), np.diff(ro))
+
+
+def _rss_anon_kb():
+    for ln in open("/proc/self/status"):
+        if ln.startswith("RssAnon:"):
+            return int(ln.split()[1])
+    return 0
+
+
+@pytest.mark.parametrize("with_index", [False, True])
+def test_native_table_file_streams_a_4gb_shard_with_bounded_host_memory(tmp_path, with_index):
+    """save_native / load_native at a shard's scale (round-2 VERDICT, weak #7): the LAST of 4 shards of a 33.6M-row INT4
+    d = 1024 table -- 8.4M rows = 4.4 GB of rows + scales (with the index: + 1 GB of slots and bitmap) -- goes to one
+    memory-mapped file and back in 256k-row chunks.  The process's ANONYMOUS memory (what is not the file's page cache)
+    grows by less than 1 GB on the way out and on the way in -- the round-2 code held the whole shard twice -- the vocabulary
+    has no key arrays (StructuredVocab: recorded by its parameters), and the loaded shard gives the oracle's partial sums."""
+    import shutil
+    from scone_amd import EmbeddingCache
+    from scone_amd import synthetic as S
+    from scone_amd.distributed import ShardedEmbeddingCache
+    N, W, d = 33_600_000, 4, 1024
+    if shutil.disk_usage(tmp_path).free < 8e9:
+        pytest.skip("needs 8 GB of scratch space")
+    vocab = S.StructuredVocab(N)
+    sh = ShardedEmbeddingCache.from_synthetic(vocab, d, table_format="int4", seed=7, base_scale=0.02 / 127, rank=W - 1, world=W,
+                                              n_rows=N)
+    a, b = sh.row_begin, sh.row_end
+    assert (b - a) * 528 > 4.3e9
+    shard = EmbeddingCache(vocab, d, table_format="int4", keep_host_copy=False)
+    shard._table, shard._dirty = sh.table, False
+    p = str(tmp_path / "shard")
+    torch.cuda.synchronize()
+    before = _rss_anon_kb()
+    shard.save_native(p, with_index=with_index)
+    grown_save = _rss_anon_kb() - before
+    assert os.path.getsize(p + ".npy") > (b - a) * 528
+    before = _rss_anon_kb()
+    again = EmbeddingCache.load_native(p)
+    grown_load = _rss_anon_kb() - before
+    assert grown_save < 1_000_000 and grown_load < 1_000_000, (grown_save, grown_load)       # kB
+    t2 = again.table
+    assert (t2.row_begin, t2.row_end, t2.n_rows) == (a, b, N) and isinstance(again.n_gram_extractor, S.StructuredVocab)
+    ids = np.array([a, a + 1, (a + b) // 2, a + (1 << 18) - 1, a + (1 << 18), b - 2, b - 1], dtype=np.int64)   # chunk edges too
+    assert np.array_equal(t2.gather_rows(torch.from_numpy(ids)).cpu().numpy(), R.dequantize_i4(*R.synth_rows_i4(7, ids, d, 0.02 / 127)))
+    # lookups: partial sums over the rows of this shard equal the oracle's on the recomputed rows
+    tok = S.stream_uniform_ids(vocab, None, 4, 512, 3)
+    off, mids = t2.match_csr(torch.from_numpy(tok))
+    ro, ri = off.cpu().numpy().astype(np.int64), mids.cpu().numpy().astype(np.int64)
+    off0, mids0 = sh.table.match_csr(torch.from_numpy(tok))        # the handle that was saved (index built by insertion)
+    assert torch.equal(off0, off) and torch.equal(mids0, mids)
+    pos = np.repeat(np.arange(len(ro) - 1), np.diff(ro))
+    own = (ri >= a) & (ri < b)
+    assert own.any()
+    uniq, inv = np.unique(ri[own], return_inverse=True)
+    rows = R.dequantize_i4(*R.synth_rows_i4(7, uniq, d, 0.02 / 127))
+    off_own = np.zeros(len(ro), dtype=np.int64)
+    np.cumsum(np.bincount(pos[own], minlength=len(ro) - 1), out=off_own[1:])
+    partial, counts = t2.embed_partial(torch.from_numpy(tok))
+    assert np.array_equal(partial.cpu().numpy(), R.embed_numpy(rows, off_own, inv, "sum"))
+    assert np.array_equal(counts.cpu().numpy(), np.diff(ro))
+    os.remove(p + ".npy")
 
 
 @pytest.mark.parametrize("fmt,d", [("int8", 768), ("int4", 1024), ("fp16", 1280)])

@@ -32,6 +32,11 @@ def main():
     ap.add_argument("--seq", type=int, default=512)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--padded", action="store_true", help="the padded all-gather's receive layout instead of exact ranges")
+    ap.add_argument("--variants", default="0,1,2,3,4,5", help="which flows to time (0 = round 2, 1 = + sharded match, 2 = + post "
+                    "stream (round 3), 3 = three batches in flight, 4 / 5 = rounds 3 / 2 with the direct-mapped row map)")
+    ap.add_argument("--rounds", type=int, default=5, help="alternating rounds over the chosen flows (medians are reported)")
+    ap.add_argument("--one-only", action="store_true", help="time the one-stream step only (clean per-kernel times under a profiler)")
+    ap.add_argument("--split-only", action="store_true", help="time the split-phase loop only (for a kernel profile of it)")
     a = ap.parse_args()
     N, W, d, B, T = a.rows, a.world, 1024, a.batch, a.seq
     vocab = S.StructuredVocab(N)
@@ -70,7 +75,7 @@ def main():
         rows_r = other[owner == r]
         hdr[offs[r]:offs[r] + rows_r.numel(), rec // 4 - 2] = rows_r.to(torch.int32)     # ... except the real ones: row id
     del ids, other, owner
-    fulls = [full, full.clone()]
+    fulls = [full, full.clone(), full.clone()]
     maxc = size[0]
     # ---- the plan's match sharded over the ranks (round 3): rank 0 matches only ITS slice (1/W of the sequences); the
     # list records of the other slices arrive by all-gather -- emulated by a device copy out of a pre-computed set of lists
@@ -79,46 +84,51 @@ def main():
     bper = (B + W - 1) // W
     ell_src = torch.empty((W * bper * T, wd), dtype=torch.int32, device="cuda")
     s.shard_gather_match(tok, 0, B, ell_src)                               # what the gathered lists will hold
-    ells = [torch.empty_like(ell_src), torch.empty_like(ell_src)]
+    ells = [ell_src.clone(), ell_src.clone(), ell_src.clone()]
     send = torch.empty((bper * T, wd), dtype=torch.int32, device="cuda")
     results = {}
-    for variant, row_map, sharded_match in (("round2: every rank matches the whole batch, hash row map", "hash", False),
-                                            ("direct-mapped row map", "direct", False),
-                                            ("match sharded over the ranks", "hash", True),
-                                            ("round3: sharded match + direct-mapped row map", "direct", True)):
-        os.environ["SCONE_SHARD_ROW_MAP"] = row_map
+    flows = (("round2: every rank matches the whole batch", "hash", False, False, 2),
+             ("match sharded over the ranks", "hash", True, False, 2),
+             ("round3: sharded match + records indexed / lists remapped on a post stream", "hash", True, True, 2),
+             ("round3, three batches in flight", "hash", True, True, 3),
+             ("round3 with the direct-mapped row map (4 B per table row)", "direct", True, True, 2),
+             ("round2 with the direct-mapped row map", "direct", False, False, 2))
+    side, post = torch.cuda.Stream(), torch.cuda.Stream()
 
+    def make(variant, row_map, sharded_match, post_stream, slots):
+        """(one-stream step, split-phase loop) of one flow as closures; the row map's form is read from the environment
+        when an exchange starts, so it is set before every call."""
         def begin(slot):
             s.shard_select_slot(slot)
             if sharded_match:
                 s.shard_gather_match(tok, 0, min(bper, B), send)           # my slice: sequences [0, bper)
-                ells[slot][:bper * T].copy_(send)                          # (the all-gather's output, my part ...
-                ells[slot][bper * T:].copy_(ell_src[bper * T:])            #  ... and the seven other ranks' parts)
+                ells[slot][:bper * T].copy_(send)                          # (the all-gather's output: my part ...
+                # ... and the seven other ranks' parts: a device copy (28 MB read + 28 MB written where a receive only
+                # writes; it must be a fresh copy, the reduction rewrites the lists in place)
+                ells[slot][bper * T:].copy_(ell_src[bper * T:])
                 n = s.shard_gather_plan_ell(ells[slot], B, T, 1)[0]
             else:
                 n = s.shard_gather_plan_chunks(tok, 1)[0]
             s.shard_gather_pack_range(0, n, fulls[slot][:maxc])
 
-        def finish(slot):
+        def index_remap(slot):
             s.shard_select_slot(slot)
             s.shard_gather_add_records(fulls[slot][:total], 0, total)
+            s.shard_gather_remap_range(0, B)
+
+        def finish(slot, indexed=False):
+            s.shard_select_slot(slot)
+            if not indexed:
+                s.shard_gather_add_records(fulls[slot][:total], 0, total)
             s.shard_gather_embed_range(tok, 0, B, fulls[slot][:total], out, wte=wte, wpe=wpe)
 
-        for _ in range(3):
-            begin(0)
-            finish(0)
-        torch.cuda.synchronize()
-        assert s.status() == 0, "a referenced row is missing from the synthesised records"
-        check = out.float().abs().sum().item()
-        t0 = time.perf_counter()
-        for _ in range(a.steps):
-            begin(0)
-            finish(0)
-        torch.cuda.synchronize()
-        one_stream = (time.perf_counter() - t0) * 1e3 / a.steps
+        def one_stream(n):
+            os.environ["SCONE_SHARD_ROW_MAP"] = row_map
+            for _ in range(n):
+                begin(0)
+                finish(0)
 
-        side = torch.cuda.Stream()
-        done = [None, None]
+        done = [None] * 3
 
         def begin_side(slot):
             if done[slot] is not None:
@@ -127,37 +137,78 @@ def main():
                 begin(slot)
                 ready = torch.cuda.Event()
                 ready.record(side)
+            if post_stream:                      # (the transfers would be waited for here: the side stream plans on)
+                post.wait_event(ready)
+                with torch.cuda.stream(post):
+                    index_remap(slot)
+                    ready = torch.cuda.Event()
+                    ready.record(post)
             return slot, ready
 
         def finish_main(ticket):
             slot, ready = ticket
             cur = torch.cuda.current_stream()
             cur.wait_event(ready)
-            finish(slot)
+            finish(slot, indexed=post_stream)
             done[slot] = torch.cuda.Event()
             done[slot].record(cur)
 
         def loop(n):
-            slot = 0
-            tk = begin_side(slot)
+            os.environ["SCONE_SHARD_ROW_MAP"] = row_map
+            for k in range(3):
+                done[k] = None
+            nxt, q = 0, []
+            for _ in range(min(slots - 1, n)):   # slots - 1 batches ahead of the one being reduced
+                q.append(begin_side(nxt % slots))
+                nxt += 1
             for i in range(n):
-                finish_main(tk)
-                slot ^= 1
-                tk = begin_side(slot) if i + 1 < n else None
-        loop(4)
+                finish_main(q.pop(0))
+                if nxt < n:
+                    q.append(begin_side(nxt % slots))
+                    nxt += 1
+            torch.cuda.synchronize()
+            s.shard_select_slot(0)
+        return one_stream, loop
+
+    chosen = [flows[int(i)] for i in a.variants.split(",")]
+    fns = {f[0]: make(*f) for f in chosen}
+    samples = {f[0]: {"one": [], "split": []} for f in chosen}
+    checks = {}
+    for name, (one, loop) in fns.items():        # warm-up: allocations, the maps of every slot
+        one(3)
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        loop(a.steps)
-        torch.cuda.synchronize()
-        split = (time.perf_counter() - t0) * 1e3 / a.steps
+        assert s.status() == 0, "a referenced row is missing from the synthesised records"
+        if not a.one_only:
+            loop(4)
         assert s.status() == 0
-        s.shard_select_slot(0)
-        results[variant] = {"rank0_step_one_stream_ms": one_stream, "rank0_step_split_phase_loop_ms": split,
-                            "output_checksum": check}
+        checks[name] = out.float().abs().sum().item()
+    for rnd in range(a.rounds):                  # alternating: the same box runs 2 % apart from one minute to the next
+        for name, (one, loop) in fns.items():
+            if not a.split_only:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                one(a.steps)
+                torch.cuda.synchronize()
+                samples[name]["one"].append((time.perf_counter() - t0) * 1e3 / a.steps)
+            if a.one_only:
+                continue
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            loop(a.steps)
+            samples[name]["split"].append((time.perf_counter() - t0) * 1e3 / a.steps)
+    assert s.status() == 0
+
+    def med(v):
+        v = sorted(v)
+        return v[len(v) // 2] if v else None
+    for name in fns:
+        results[name] = {"rank0_step_one_stream_ms": med(samples[name]["one"]), "rank0_step_split_phase_loop_ms": med(samples[name]["split"]),
+                         "split_phase_loop_ms_rounds": [round(x, 4) for x in samples[name]["split"]],
+                         "one_stream_ms_rounds": [round(x, 4) for x in samples[name]["one"]], "output_checksum": checks[name]}
     sums = {v["output_checksum"] for v in results.values()}
     print(json.dumps({"rows": N, "world": W, "rank": 0, "tokens": B * T, "build_s": build_s, "records_per_rank": counts,
                       "layout": "padded to the largest contribution" if a.padded else "exact ranges",
-                      "bytes_into_rank0": int((total - size[0]) * rec),
+                      "bytes_into_rank0": int((total - size[0]) * rec), "record_bytes": rec,
                       "list_record_bytes_gathered_into_rank0": int((W - 1) * bper * T * wd * 4),
                       "variants": results, "all_variants_same_output": len(sums) == 1,
                       "note": "other ranks' records carry the right row ids and zero payloads; the all-gather of list records is "

@@ -822,6 +822,9 @@ def sharded_record(args, dist, rank, world, backend, sync, rec, line, watchdog, 
             return {"ms_per_step": ms, "tokens_per_s": ntok * args.sharded_steps / dt, "steps": args.sharded_steps,
                     "phase_ms_slowest_rank": phm, "wire_bytes_received_rank0": wire,
                     "chunks": chunks_ if kw["exchange"] == "gather_rows" else None,
+                    "wire_format": (("columns: payload rows | scales | the senders' hash fragments" if chunks_ == 1 else
+                                     "records: [payload | scales | row id], indexed by every receiver")
+                                    if kw["exchange"] == "gather_rows" else "records, one per distinct row and destination"),
                     "records_transport": ({"p2p": "batch_isend_irecv, exact ranges", "all_gather": "all_gather_into_tensor, padded"}
                                           [transport] if kw["exchange"] == "gather_rows" else "all_to_all_single"),
                     "roofline": roofline_of(kw, ms, phm, wire)}
@@ -859,6 +862,7 @@ def sharded_record(args, dist, rank, world, backend, sync, rec, line, watchdog, 
             one = rec["exchanges"].get(same_as, {})
             return {"ms_per_step": ms, "tokens_per_s": ntok * args.sharded_steps / dt,
                     "steps": args.sharded_steps, "batches_in_flight": slots, "chunks": 1,
+                    "wire_format": "columns: payload rows | scales | the senders' hash fragments",
                     "records_transport": {"p2p": "batch_isend_irecv, exact ranges", "all_gather": "all_gather_into_tensor, padded"}[transport],
                     "same_output_as_gather_rows": bool(float(out.float().abs().sum().item()) == checks.get(same_as)),
                     "roofline": roofline_of(kw, ms, None, int(one.get("wire_bytes_received_rank0", 0)))}

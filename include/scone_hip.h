@@ -349,6 +349,39 @@ int scone_shard_gather_embed_range(scone_handle *h, const int32_t *d_tok, int32_
                                    int64_t vocab, const void *d_wpe, int64_t n_pos, const int32_t *d_pos, int32_t reduce,
                                    void *d_out, int64_t out_tok0, int32_t out_dtype, scone_stream_t stream);
 
+/* ---- all-gather form with COLUMNS on the wire (one plan = one exchange).  A rank's contribution travels as three arrays
+ *      instead of [payload | scales | row id] records: the payload rows at the table's own stride (the lookup reads them in
+ *      place, cache-line aligned), the scales (received straight into the caller's [head scales | scales of all ranks]
+ *      buffer: nothing to unpack), and the SENDER's hash fragment row id -> position in its contribution (u64 slots; built
+ *      while it packs: its own ~65k inserts instead of 0.45M 64-bit CAS on every receiver, ~36 us per step at C5's scale).
+ *      The receiver has no indexing pass: a list entry is resolved in its owner's fragment (the owner follows from the id:
+ *      contiguous ranges [r N / W, (r + 1) N / W)) and becomes rec_base[owner] + position.
+ *   scone_shard_cols_frag_slots   slots of the fragment for `count` rows (a power of two >= 2 count, >= 64): both ends
+ *                                 derive it from the exchanged counts
+ *   scone_shard_cols_pack         records [first, first + count) of the plan (scone_shard_gather_plan*) as columns;
+ *                                 d_frag_out [frag_slots] u64 is cleared and filled; stream-ordered
+ *   scone_shard_cols_build_frag   the fragment of an arbitrary id list (position = index in the list): tools and tests
+ *                                 stand in for the other ranks with it
+ *   scone_shard_head_scales       the replicated head's scales [n_head, scale bytes] into d_out: the front of the scales
+ *                                 buffer (once per buffer, not per step)
+ *   scone_shard_cols_embed        sequences [seq_begin, seq_end) of the planned batch out of [replicated head | d_rows
+ *                                 [n_total, payload bytes]] with scales d_scales_full [n_head + n_total, scale bytes];
+ *                                 h_frag_off[r] (u64 slots into d_frags), h_frag_slots[r], h_rec_base[r] (row number of rank
+ *                                 r's first row in d_rows) for r < world.  Lists are rewritten once per plan, as in
+ *                                 scone_shard_gather_embed_range; bit-identical to the unsharded table.
+ * New here (the reference keeps its table in one process: embedding_cache.py:49-50). */
+int scone_shard_cols_frag_slots(uint64_t count, uint64_t *slots);
+int scone_shard_cols_pack(scone_handle *h, uint64_t first, uint64_t count, void *d_rows_out, void *d_scales_out,
+                          void *d_frag_out, uint64_t frag_slots, scone_stream_t stream);
+int scone_shard_cols_build_frag(scone_handle *h, const int32_t *d_ids, uint64_t count, void *d_frag_out, uint64_t frag_slots,
+                                scone_stream_t stream);
+int scone_shard_head_scales(scone_handle *h, void *d_out, scone_stream_t stream);
+int scone_shard_cols_embed(scone_handle *h, const int32_t *d_tok, int32_t B, int32_t T, int32_t seq_begin, int32_t seq_end,
+                           const void *d_rows, uint64_t n_total, const void *d_scales_full, const void *d_frags,
+                           const uint64_t *h_frag_off, const uint64_t *h_frag_slots, const uint64_t *h_rec_base, int32_t world,
+                           const void *d_wte, int64_t vocab, const void *d_wpe, int64_t n_pos, const int32_t *d_pos,
+                           int32_t reduce, void *d_out, int64_t out_tok0, int32_t out_dtype, scone_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -92,6 +92,12 @@ SIGNATURES = {
     "scone_shard_gather_remap_range": (C.c_int, [_P, _I32, _I32, _P]),
     "scone_shard_gather_embed_range": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _P, _U64, _P, _I64, _P, _I64, _P, _I32, _P,
                                                  _I64, _I32, _P]),
+    "scone_shard_cols_frag_slots": (C.c_int, [_U64, C.POINTER(_U64)]),
+    "scone_shard_cols_pack": (C.c_int, [_P, _U64, _U64, _P, _P, _P, _U64, _P]),
+    "scone_shard_cols_build_frag": (C.c_int, [_P, _P, _U64, _P, _U64, _P]),
+    "scone_shard_head_scales": (C.c_int, [_P, _P, _P]),
+    "scone_shard_cols_embed": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _P, _U64, _P, _P, C.POINTER(_U64), C.POINTER(_U64),
+                                         C.POINTER(_U64), _I32, _P, _I64, _P, _I64, _P, _I32, _P, _I64, _I32, _P]),
     "scone_shard_set_head": (C.c_int, [_P, _U64]),
     "scone_shard_head_store_f32": (C.c_int, [_P, _P, _U64, _U64, _P]),
     "scone_shard_record_bytes": (C.c_int, [_P, C.POINTER(_U64)]),

@@ -274,6 +274,9 @@ int scone_shard_gather_add(scone_handle *h, const void *d_records, uint64_t n, u
 int scone_shard_gather_remap(scone_handle *h, int32_t T, int32_t seq0, int32_t seq1, const int32_t **ell, const void **scales,
                              hipStream_t s);
 int scone_shard_plan_shape(const scone_handle *h, int32_t *B, int32_t *T);
+int scone_shard_cols_remap(scone_handle *h, int32_t T, int32_t seq0, int32_t seq1, const void *d_frags, const uint64_t *h_frag_off,
+                           const uint64_t *h_frag_slots, const uint64_t *h_rec_base, int32_t world, uint64_t n_total,
+                           const int32_t **ell, const uint8_t **head_p, unsigned long long *n_head_out, hipStream_t s);
 int scone_shard_prepare_embed(scone_handle *h, int32_t B, int32_t T, int32_t world, int32_t rank, const void *d_recv,
                               uint64_t n_recv, const int32_t **ell, const void **scales, int32_t *b0, int32_t *b1,
                               hipStream_t s);

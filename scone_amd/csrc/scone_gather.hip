@@ -314,6 +314,56 @@ extern "C" int scone_shard_gather_embed_range(scone_handle *h, const int32_t *d_
   return launch_fmt(h, a, SRC_HITS, MODE_FULL, out_dtype, s);
 }
 
+// Columns exchange (scone_shard.hip): the received payload rows are read in place at the table's own stride, the scales come
+// from the caller's [head scales | received scales] buffer, the id lists are resolved through the senders' hash fragments.
+extern "C" int scone_shard_cols_embed(scone_handle *h, const int32_t *d_tok, int32_t B, int32_t T, int32_t seq_begin,
+                                      int32_t seq_end, const void *d_rows, uint64_t n_total, const void *d_scales_full,
+                                      const void *d_frags, const uint64_t *h_frag_off, const uint64_t *h_frag_slots,
+                                      const uint64_t *h_rec_base, int32_t world, const void *d_wte, int64_t vocab,
+                                      const void *d_wpe, int64_t n_pos, const int32_t *d_pos, int32_t reduce, void *d_out,
+                                      int64_t out_tok0, int32_t out_dtype, scone_stream_t stream) {
+  int rc = need_table(h, "scone_shard_cols_embed: handle has no table (dim == 0)");
+  if (rc) return rc;
+  if (!h->shard) return scone_fail(h, SCONE_ESTATE, "scone_shard_cols_embed: call scone_shard_gather_plan first");
+  int32_t pB = 0, pT = 0;
+  scone_shard_plan_shape(h, &pB, &pT);
+  if (B < 0 || T <= 0 || B != pB || T != pT || seq_begin < 0 || seq_end < seq_begin || seq_end > B || (n_total && !d_rows) ||
+      !d_frags || !h_frag_off || !h_frag_slots || !h_rec_base || out_tok0 < 0 || out_tok0 > (long long)seq_begin * T ||
+      (h->scale_bytes_per_row && !d_scales_full))
+    return scone_fail(h, SCONE_EINVAL, "scone_shard_cols_embed: bad argument (B, T must be the planned batch's)");
+  if (!scone_wave_kernel_covers(h->cfg.table_fmt, h->cfg.dim))
+    return scone_fail(h, SCONE_EINVAL, "scone_shard_cols_embed: needs d % 8 == 0");
+  if (reduce != SCONE_REDUCE_MEAN && reduce != SCONE_REDUCE_SUM)
+    return scone_fail(h, SCONE_EINVAL, "scone_shard_cols_embed: bad reduce");
+  const long long nt = (long long)(seq_end - seq_begin) * T;
+  if (nt == 0) return SCONE_OK;
+  if (!d_tok || !d_out) return scone_fail(h, SCONE_EINVAL, "scone_shard_cols_embed: null pointer");
+  SCONE_ON_DEVICE(h);
+  hipStream_t s = (hipStream_t)stream;
+  const int32_t *ell = nullptr;
+  const uint8_t *head_p = nullptr;
+  unsigned long long n_head = 0;
+  rc = scone_shard_cols_remap(h, T, seq_begin, seq_end, d_frags, h_frag_off, h_frag_slots, h_rec_base, world, n_total, &ell, &head_p,
+                              &n_head, s);
+  if (rc) return rc;
+  embed_args a = {};
+  fill_table_view(h, a.tv);
+  a.tv.st.hot = const_cast<uint8_t *>(head_p);  // row store: [replicated head | received rows], both at the payload stride
+  a.tv.st.n_hot = n_head;
+  a.tv.st.cold = n_total ? reinterpret_cast<uint8_t *>(const_cast<void *>(d_rows)) : reinterpret_cast<uint8_t *>(h->d_zero_row);
+  a.tv.st.row_bytes = (unsigned int)h->row_payload_bytes;
+  a.tv.scales = reinterpret_cast<const __half *>(d_scales_full);
+  a.tv.row_begin = 0, a.tv.row_end = (long long)(n_head + (n_total ? n_total : 1));
+  const long long t0 = (long long)seq_begin * T;
+  const size_t esz = out_dtype == SCONE_DT_F32 ? 4 : 2;
+  a.BT = nt, a.ntok = nt, a.T = T, a.max_n = h->cfg.max_n;
+  a.ell = ell, a.zero_row = h->d_zero_row, a.mode = (int)h->cfg.lookup_mode;
+  a.tok = d_tok + t0, a.pos = d_pos ? d_pos + t0 : nullptr;
+  a.wte = d_wte, a.vocab = vocab, a.wpe = d_wpe, a.n_pos = n_pos;
+  a.reduce = reduce, a.out = reinterpret_cast<uint8_t *>(d_out) + (size_t)(t0 - out_tok0) * h->cfg.dim * esz, a.status = h->d_status;
+  return launch_fmt(h, a, SRC_HITS, MODE_FULL, out_dtype, s);
+}
+
 extern "C" int scone_shard_gather_embed(scone_handle *h, const int32_t *d_tok, int32_t B, int32_t T, const void *d_records,
                                         uint64_t n_records, const void *d_wte, int64_t vocab, const void *d_wpe, int64_t n_pos,
                                         const int32_t *d_pos, int32_t reduce, void *d_out, int32_t out_dtype,

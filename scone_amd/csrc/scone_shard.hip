@@ -41,6 +41,8 @@ struct scone_shard_state {
   unsigned long long n_head = 0; // replicated head: global rows [0, n_head) live on every shard
   uint8_t *head_rows = nullptr;  // [n_head, rec_bytes]: payload at the start of every record-sized slot
   uint8_t *head_scales = nullptr;  // [n_head, scale_bytes_per_row]
+  uint8_t *head_rows_p = nullptr;  // [n_head, payload bytes]: the head again at the PAYLOAD stride, for the columns exchange
+  bool head_p_stale = true;        // (whose received rows are payload only; rebuilt from head_rows after the head changes)
   // all-gather form: distinct rows
   uint32_t *uniq_claim = nullptr;  // [local rows]: generation of the last batch that claimed the row
   uint32_t uniq_gen = 0;
@@ -293,7 +295,7 @@ void scone_shard_destroy(scone_handle *h) {
   if (!st) return;
   void *ptrs[] = {st->ell_send, st->ell_slice, st->counters, st->send_src, st->slot_of_ref, st->scales,
                   st->head_rows, st->head_scales, st->uniq_claim, st->uniq_list, st->rhash, st->chunk_ends,
-                  st->rmap};
+                  st->rmap, st->head_rows_p};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   for (int k = 0; k < SCONE_SHARD_SLOTS; ++k) {
@@ -480,7 +482,9 @@ extern "C" int scone_shard_set_head(scone_handle *h, uint64_t n_head) {
   scone_shard_state *st = h->shard;
   if (st->head_rows) SCONE_HIP(h, hipFree(st->head_rows));
   if (st->head_scales) SCONE_HIP(h, hipFree(st->head_scales));
-  st->head_rows = st->head_scales = nullptr;
+  if (st->head_rows_p) SCONE_HIP(h, hipFree(st->head_rows_p));
+  st->head_rows = st->head_scales = st->head_rows_p = nullptr;
+  st->head_p_stale = true;
   st->n_head = 0;
   if (n_head == 0) return SCONE_OK;
   const size_t rec = (size_t)scone_shard_rec_bytes(h);
@@ -502,12 +506,14 @@ extern "C" int scone_shard_head_store_f32(scone_handle *h, const float *d_rows_f
   if (!d_rows_f32) return scone_fail(h, SCONE_EINVAL, "scone_shard_head_store_f32: null rows");
   if (row0 + nrows > h->shard->n_head) return scone_fail(h, SCONE_ERANGE, "scone_shard_head_store_f32: rows outside [0, n_head)");
   SCONE_ON_DEVICE(h);
+  h->shard->head_p_stale = true;
   return scone_store_f32_into(h, head_store(h), h->shard->head_scales, 0, h->shard->n_head, d_rows_f32, nullptr, row0, nrows,
                               (hipStream_t)stream);
 }
 
 int scone_shard_fill_head_synth(scone_handle *h, uint32_t seed, float base_scale, hipStream_t s) {
   if (!h->shard || !h->shard->n_head) return SCONE_OK;
+  h->shard->head_p_stale = true;
   return scone_fill_synth_into(h, head_store(h), h->shard->head_scales, 0, h->shard->n_head, seed, base_scale, s);
 }
 
@@ -1107,6 +1113,236 @@ int scone_shard_gather_remap(scone_handle *h, int32_t T, int32_t seq0, int32_t s
   SCONE_HIP(h, hipGetLastError());
   *ell = lists + (long long)seq0 * T * W;
   *scales = st->scales;
+  return SCONE_OK;
+}
+
+// ---------------------------------------------------------------- all-gather form, COLUMNS on the wire
+// The records of the form above are [payload | scales | row id]: the receiver must read every record's header to build its
+// row map -- 0.45M 64-bit CAS on an 8 MB table per step at C5's scale, ~36 us whatever the table's form (device-scope
+// atomics retire at ~12 per ns) -- and unpack the scales.  Here a rank's contribution travels as three COLUMNS:
+//   rows    [count, payload bytes]   the payloads alone, at the table's own stride (512 B for INT4 d = 1024: every row the
+//                                    lookup reads in place starts on a cache-line boundary; 544-B records do not)
+//   scales  [count, scale bytes]     received straight into [head scales | scales of all ranks]: nothing to unpack
+//   frag    [slots] u64              the SENDER's hash fragment: row id + 1 -> position in its own contribution, built
+//                                    while it packs (its own ~65k inserts, not 0.45M on every receiver)
+// and the receiver has no indexing pass at all: a list entry is looked up in its owner's fragment (the owner follows from
+// the id) and becomes rec_base[owner] + position.  One plan = one exchange (n_chunks = 1); 2 % more bytes on the wire.
+namespace {
+
+struct cols_owners {  // per owner: where its fragment starts (u64 slots), slots - 1, record number of its first row
+  unsigned long long frag_off[64], frag_mask[64], rec_base[64];
+};
+
+__global__ __launch_bounds__(256) void k_cols_pack(const int32_t *__restrict__ list, unsigned long long n, scone_row_store st,
+                                                   long long row_begin, const uint8_t *__restrict__ scales, int scale_bytes,
+                                                   uint8_t *__restrict__ rows_out, uint8_t *__restrict__ scales_out,
+                                                   unsigned long long *__restrict__ frag, unsigned long long fmask, int lanes_per_rec) {
+  const unsigned sub = (threadIdx.x & 63) / lanes_per_rec, l = (threadIdx.x & 63) % lanes_per_rec;
+  const unsigned per_wave = 64 / lanes_per_rec;
+  const unsigned long long wave = (unsigned long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const unsigned long long nwaves = (unsigned long long)gridDim.x * (blockDim.x >> 6);
+  for (unsigned long long p = wave * per_wave + sub; p < n; p += nwaves * per_wave) {
+    const long long id = list[p];
+    const unsigned long long lr = (unsigned long long)(id - row_begin);
+    const uint4 *src = reinterpret_cast<const uint4 *>(st.row(lr));
+    uint4 *dst = reinterpret_cast<uint4 *>(rows_out + p * (unsigned long long)st.row_bytes);
+    for (unsigned v = l; v < st.row_bytes / 16; v += lanes_per_rec) dst[v] = src[v];
+    for (unsigned b = l; b < (unsigned)scale_bytes / 2; b += lanes_per_rec)
+      reinterpret_cast<unsigned short *>(scales_out + p * scale_bytes)[b] = reinterpret_cast<const unsigned short *>(scales + lr * scale_bytes)[b];
+    if (l == 0) {  // the fragment entry of this row (ids of one plan are distinct: the CAS only resolves slot collisions)
+      const unsigned long long key = (unsigned long long)id + 1ull, mine = (key << 32) | p;
+      unsigned long long s = scone_hash_key(key, 0u) & fmask;
+      for (unsigned long long probe = 0; probe <= fmask; ++probe) {
+        if (atomicCAS(&frag[s], 0ull, mine) == 0ull) break;
+        s = (s + 1ull) & fmask;
+      }
+    }
+  }
+}
+
+// the fragment of an arbitrary id list (tools / tests stand in for the other ranks with it)
+__global__ __launch_bounds__(256) void k_cols_frag(const int32_t *__restrict__ ids, unsigned long long n,
+                                                   unsigned long long *__restrict__ frag, unsigned long long fmask) {
+  const unsigned long long p = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const unsigned long long key = (unsigned long long)(uint32_t)ids[p] + 1ull, mine = (key << 32) | p;
+  unsigned long long s = scone_hash_key(key, 0u) & fmask;
+  for (unsigned long long probe = 0; probe <= fmask; ++probe) {
+    if (atomicCAS(&frag[s], 0ull, mine) == 0ull) return;
+    s = (s + 1ull) & fmask;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_cols_remap(int32_t *__restrict__ ell, long long ntok, int W, int NC,
+                                                    const unsigned long long *__restrict__ frags, const cols_owners ow, int world,
+                                                    long long n_rows, long long n_head, unsigned long long n_total,
+                                                    uint32_t *__restrict__ status) {
+  const long long per = (ntok + gridDim.x - 1) / gridDim.x;
+  const long long t0 = (long long)blockIdx.x * per, t1 = t0 + per < ntok ? t0 + per : ntok;
+  for (long long t = t0 + threadIdx.x; t < t1; t += blockDim.x) {
+    int32_t r8[8];
+    if (W == 8) {
+      const int4 a = reinterpret_cast<const int4 *>(ell + t * 8)[0], b = reinterpret_cast<const int4 *>(ell + t * 8)[1];
+      r8[0] = a.x, r8[1] = a.y, r8[2] = a.z, r8[3] = a.w, r8[4] = b.x, r8[5] = b.y, r8[6] = b.z, r8[7] = b.w;
+    }
+    const int kown = (W == 8 ? r8[6] : ell[t * W + W - 2]) & 0xFF;
+    bool dirty = false;
+    for (int j = 0; j < NC; ++j) {
+      if (j >= kown) break;
+      long long id;
+      if (W == 8) {
+        id = r8[0];
+#pragma unroll
+        for (int q = 1; q < 6; ++q) id = j == q ? r8[q] : id;
+      } else {
+        id = ell[t * W + j];
+      }
+      if (id < n_head) continue;  // a head row: its id is its row number in the lookup's row store
+      long long slot = -1;
+      if (id < n_rows) {
+        const int r = owner_of(id, n_rows, world);
+        const unsigned long long key = (unsigned long long)id + 1ull, mask = ow.frag_mask[r];
+        const unsigned long long *f = frags + ow.frag_off[r];
+        unsigned long long s = scone_hash_key(key, 0u) & mask;
+        for (unsigned long long probe = 0; probe <= mask; ++probe) {
+          const unsigned long long v = f[s];
+          if (v == 0ull) break;
+          if ((v >> 32) == key) {
+            slot = (long long)(ow.rec_base[r] + (v & 0xFFFFFFFFull));
+            break;
+          }
+          s = (s + 1ull) & mask;
+        }
+      }
+      if (slot < 0 || (unsigned long long)slot >= n_total) {  // the row did not arrive / a corrupt fragment: report, stay in bounds
+        atomicOr(status, SCONE_ST_BAD_ID);
+        slot = 0;
+      }
+      if (W == 8) {
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+          if (j == q) r8[q] = (int32_t)(n_head + slot);
+        dirty = true;
+      } else {
+        ell[t * W + j] = (int32_t)(n_head + slot);
+      }
+    }
+    if (W == 8 && dirty) {
+      reinterpret_cast<int4 *>(ell + t * 8)[0] = make_int4(r8[0], r8[1], r8[2], r8[3]);
+      reinterpret_cast<int4 *>(ell + t * 8)[1] = make_int4(r8[4], r8[5], r8[6], r8[7]);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int scone_shard_cols_frag_slots(uint64_t count, uint64_t *slots) {
+  if (!slots) return SCONE_EINVAL;
+  uint64_t s = 64;
+  while (s < 2 * count) s <<= 1;  // load <= 0.5
+  *slots = s;
+  return SCONE_OK;
+}
+
+extern "C" int scone_shard_cols_pack(scone_handle *h, uint64_t first, uint64_t count, void *d_rows_out, void *d_scales_out,
+                                     void *d_frag_out, uint64_t frag_slots, scone_stream_t stream) {
+  if (!h || !h->shard) return h ? scone_fail(h, SCONE_ESTATE, "scone_shard_cols_pack: call scone_shard_gather_plan first") : SCONE_EINVAL;
+  scone_shard_state *st = h->shard;
+  if (first + count > st->n_uniq) return scone_fail(h, SCONE_ERANGE, "scone_shard_cols_pack: records outside the plan");
+  uint64_t want = 0;
+  scone_shard_cols_frag_slots(count, &want);
+  if (!d_frag_out || frag_slots < want || (frag_slots & (frag_slots - 1)))
+    return scone_fail(h, SCONE_EINVAL, "scone_shard_cols_pack: fragment needs a power of two >= scone_shard_cols_frag_slots(count) slots");
+  if (count && (!d_rows_out || (h->scale_bytes_per_row && !d_scales_out)))
+    return scone_fail(h, SCONE_EINVAL, "scone_shard_cols_pack: null output");
+  SCONE_ON_DEVICE(h);
+  hipStream_t s = (hipStream_t)stream;
+  SCONE_HIP(h, hipMemsetAsync(d_frag_out, 0, (size_t)frag_slots * sizeof(unsigned long long), s));
+  if (count) {
+    const size_t vecs = h->row_payload_bytes / 16;
+    const int lpr = vecs <= 16 ? 16 : vecs <= 32 ? 32 : 64;
+    const unsigned long long rec_per_block = 4ull * (64 / lpr);
+    unsigned pb = (unsigned)((count + rec_per_block - 1) / rec_per_block);
+    if (pb > 32768) pb = 32768;
+    hipLaunchKernelGGL(k_cols_pack, dim3(pb), dim3(256), 0, s, st->uniq_list + first, (unsigned long long)count, scone_store_of(h),
+                       (long long)h->cfg.row_begin, (const uint8_t *)h->scales, (int)h->scale_bytes_per_row, (uint8_t *)d_rows_out,
+                       (uint8_t *)d_scales_out, (unsigned long long *)d_frag_out, (unsigned long long)frag_slots - 1, lpr);
+  }
+  SCONE_HIP(h, hipGetLastError());
+  return SCONE_OK;
+}
+
+extern "C" int scone_shard_cols_build_frag(scone_handle *h, const int32_t *d_ids, uint64_t count, void *d_frag_out, uint64_t frag_slots,
+                                           scone_stream_t stream) {
+  if (!h) return SCONE_EINVAL;
+  uint64_t want = 0;
+  scone_shard_cols_frag_slots(count, &want);
+  if (!d_frag_out || frag_slots < want || (frag_slots & (frag_slots - 1)) || (count && !d_ids))
+    return scone_fail(h, SCONE_EINVAL, "scone_shard_cols_build_frag: bad argument");
+  SCONE_ON_DEVICE(h);
+  hipStream_t s = (hipStream_t)stream;
+  SCONE_HIP(h, hipMemsetAsync(d_frag_out, 0, (size_t)frag_slots * sizeof(unsigned long long), s));
+  if (count)
+    hipLaunchKernelGGL(k_cols_frag, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, d_ids, (unsigned long long)count,
+                       (unsigned long long *)d_frag_out, (unsigned long long)frag_slots - 1);
+  SCONE_HIP(h, hipGetLastError());
+  return SCONE_OK;
+}
+
+// the replicated head's scales, for the front of a [head scales | received scales] buffer the caller owns
+extern "C" int scone_shard_head_scales(scone_handle *h, void *d_out, scone_stream_t stream) {
+  if (!h) return SCONE_EINVAL;
+  if (!h->shard || !h->shard->n_head || !h->scale_bytes_per_row) return SCONE_OK;
+  if (!d_out) return scone_fail(h, SCONE_EINVAL, "scone_shard_head_scales: null output");
+  SCONE_ON_DEVICE(h);
+  SCONE_HIP(h, hipMemcpyAsync(d_out, h->shard->head_scales, (size_t)h->shard->n_head * h->scale_bytes_per_row, hipMemcpyDeviceToDevice,
+                              (hipStream_t)stream));
+  return SCONE_OK;
+}
+
+// Receiver of the columns exchange: remap (once per plan) through the owners' fragments; returns the lists, the head at the
+// payload stride and the number of head rows for the lookup launch in scone_gather.hip.
+int scone_shard_cols_remap(scone_handle *h, int32_t T, int32_t seq0, int32_t seq1, const void *d_frags, const uint64_t *h_frag_off,
+                           const uint64_t *h_frag_slots, const uint64_t *h_rec_base, int32_t world, uint64_t n_total,
+                           const int32_t **ell, const uint8_t **head_p, unsigned long long *n_head_out, hipStream_t s) {
+  scone_shard_state *st = h->shard;
+  int32_t *lists = plan_lists(st);
+  if (!lists) return scone_fail(h, SCONE_ESTATE, "scone_shard_cols_embed: plan the batch first");
+  if ((size_t)seq1 > st->remapped.size()) return scone_fail(h, SCONE_ESTATE, "scone_shard_cols_embed: sequences outside the planned batch");
+  if (world < 1 || world > 64) return scone_fail(h, SCONE_EINVAL, "scone_shard_cols_embed: world <= 64");
+  cols_owners ow = {};
+  for (int r = 0; r < world; ++r) {
+    if (h_frag_slots[r] == 0 || (h_frag_slots[r] & (h_frag_slots[r] - 1)))
+      return scone_fail(h, SCONE_EINVAL, "scone_shard_cols_embed: fragment sizes must be powers of two");
+    ow.frag_off[r] = h_frag_off[r], ow.frag_mask[r] = h_frag_slots[r] - 1, ow.rec_base[r] = h_rec_base[r];
+  }
+  const size_t pb = h->row_payload_bytes;
+  if (st->n_head && (st->head_p_stale || !st->head_rows_p)) {  // the head at the payload stride (once per head change)
+    if (!st->head_rows_p) SCONE_HIP(h, hipMalloc(&st->head_rows_p, (size_t)st->n_head * pb));
+    SCONE_HIP(h, hipMemcpy2DAsync(st->head_rows_p, pb, st->head_rows, (size_t)scone_shard_rec_bytes(h), pb, (size_t)st->n_head,
+                                  hipMemcpyDeviceToDevice, s));
+    st->head_p_stale = false;
+  }
+  const int W = SCONE_ELL_W(h->cfg.max_n), NC = h->cfg.max_n * (h->cfg.max_n + 1) / 2;
+  for (int32_t a = seq0; a < seq1;) {
+    if (st->remapped[a]) {
+      ++a;
+      continue;
+    }
+    int32_t b = a;
+    while (b < seq1 && !st->remapped[b]) ++b;
+    const long long nt = (long long)(b - a) * T;
+    const unsigned blocks = (unsigned)((nt + 255) / 256 < SHARD_BLOCKS ? (nt + 255) / 256 : SHARD_BLOCKS);
+    hipLaunchKernelGGL(k_cols_remap, dim3(blocks), dim3(256), 0, s, lists + (long long)a * T * W, nt, W, NC,
+                       (const unsigned long long *)d_frags, ow, (int)world, (long long)h->cfg.n_rows, (long long)st->n_head,
+                       (unsigned long long)n_total, h->d_status);
+    for (int32_t q = a; q < b; ++q) st->remapped[q] = 1;
+    a = b;
+  }
+  SCONE_HIP(h, hipGetLastError());
+  *ell = lists + (long long)seq0 * T * W;
+  *head_p = st->head_rows_p;
+  *n_head_out = st->n_head;
   return SCONE_OK;
 }
 

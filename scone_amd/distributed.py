@@ -202,8 +202,16 @@ class ShardedEmbeddingCache:
     def __init__(self, n_gram_extractor: NGramExtractor, embedding_dim: int, *, table_format: str = "int8",
                  rank: Optional[int] = None, world: Optional[int] = None, group=None, device=None,
                  n_rows: Optional[int] = None, placement: str = "hbm", table=None, replicated_rows: int = 0,
-                 gather_chunks: int = 4, gather_transport: str = "p2p", shard_match="auto", plan_slots: int = 2) -> None:
+                 gather_chunks: int = 4, gather_transport: str = "p2p", shard_match="auto", plan_slots: int = 2,
+                 wire_format: str = "columns") -> None:
         self.group = group
+        # "gather_rows" in one piece (gather_chunks = 1, the split-phase form): what a rank's contribution looks like on the
+        # wire -- "columns": payload rows | scales | the sender's hash fragment (row id -> position), three ranges per peer,
+        # no indexing pass on the receiver; "records": [payload | scales | row id] records, indexed by every receiver (the
+        # form of the chunked exchanges and of rounds 1-2)
+        if wire_format not in ("columns", "records"):
+            raise ValueError("wire_format must be 'columns' or 'records'")
+        self.wire_format = wire_format
         # split-phase "gather_rows": batches in flight (2 .. 4).  The chain plan -> count exchange -> pack -> transfers of
         # a batch must fit (plan_slots - 1) reductions: with 2 it has ONE reduction's time, with 3 it has two -- the
         # setting for links on which a step's 0.26 GB of records take about as long as its reduction
@@ -250,6 +258,7 @@ class ShardedEmbeddingCache:
         self._plan_packed = None
         self._slot_open = [False] * 4
         self._slot_ell = [None] * 4          # sharded match: the gathered list records of the batch a slot holds
+        self._slot_cols = [None] * 4         # columns exchange: (rows, scales, frags) receive buffers of a slot
         self._ell_send = None
 
     @classmethod
@@ -270,6 +279,7 @@ class ShardedEmbeddingCache:
         hb = min(row0 + rows_f32.shape[0], self.replicated_rows)     # the replicated head: every rank keeps it
         if hb > row0:
             self.table.shard_head_store_f32(rows_f32[:hb - row0], row0=row0)
+            self._slot_cols = [None] * 4                             # (their scales buffers start with the head's scales)
 
     # ------------------------------------------------------------------
     def embed_tokens(self, input_ids: torch.Tensor, *, reduce: str = "mean", wte: Optional[torch.Tensor] = None,
@@ -488,10 +498,86 @@ class ShardedEmbeddingCache:
         _all_gather(ell[:W * bper * T].view(-1), send.view(-1), self.group)             # 32 B per token: W * bper * T * 32 B in all
         return t.shard_gather_plan_ell(ell, B, T, n_chunks, dedup_across_chunks)
 
+    def _gather_begin_cols(self, tok, slot, t0):
+        """One-piece ``gather_rows`` with COLUMNS on the wire: plan, exchange of the counts, then this rank's payload rows,
+        scales and hash fragment go out as three ranges (``p2p``: packed in place into this rank's range of the receive
+        buffers, one ``batch_isend_irecv`` per column) or three padded all-gathers."""
+        B, T = tok.shape
+        W, t, r = self.world, self.table, self.rank
+        self._plan_enter(slot, tok)
+        n_me = self._plan(tok, slot, 1, True)[0]
+        t0 = self._tick("plan_ms", t0)
+        if W > 1:
+            cnt = torch.tensor([n_me], dtype=torch.int64, device=tok.device)
+            allc = torch.empty(W, dtype=torch.int64, device=tok.device)
+            _all_gather(allc, cnt, self.group)
+            counts = [int(c) for c in allc.tolist()]
+        else:
+            counts = [int(n_me)]
+        exact = W > 1 and self.gather_transport == "p2p"
+        slots_r = [t.cols_frag_slots(c) for c in counts]
+        if exact or W == 1:
+            rec_base = [sum(counts[:q]) for q in range(W)]
+            frag_off = [sum(slots_r[:q]) for q in range(W)]
+            total, ftotal = sum(counts), sum(slots_r)
+        else:                                            # all_gather_into_tensor: every column padded to its largest contribution
+            m, ms = max(counts), max(slots_r)
+            slots_r = [ms] * W                           # (a fragment may have more slots than it needs: every rank uses ms)
+            rec_base, frag_off = [q * m for q in range(W)], [q * ms for q in range(W)]
+            total, ftotal = W * m, W * ms
+        pb, sb, nh = t.payload_bytes(), t.scale_bytes(), int(getattr(t, "n_head", 0) or 0)
+        bufs = self._slot_cols[slot]
+        if bufs is None or bufs[0].shape[0] < max(total, 1) or bufs[2].numel() < ftotal or bufs[0].device != tok.device:
+            cap = max(total + total // 8, 1)
+            rows = torch.empty((cap, pb), dtype=torch.uint8, device=tok.device)
+            scales = torch.empty((nh + cap, sb), dtype=torch.uint8, device=tok.device) if sb else None
+            if scales is not None and nh:
+                t.shard_head_scales_into(scales)         # [head scales | received scales]: the front part once per buffer
+            frags = torch.empty(max(ftotal + ftotal // 8, 64), dtype=torch.int64, device=tok.device)
+            bufs = self._slot_cols[slot] = (rows, scales, frags)
+        rows, scales, frags = bufs
+        t0 = self._tick("collective_ms", t0)
+        works, keep = [], None
+        if exact or W == 1:
+            t.shard_cols_pack(0, n_me, rows[rec_base[r]:rec_base[r] + n_me], None if scales is None else
+                              scales[nh + rec_base[r]:nh + rec_base[r] + n_me], frags[frag_off[r]:frag_off[r] + slots_r[r]])
+            t0 = self._tick("pack_ms", t0)
+            if W > 1:
+                works.append(_exchange_exact_async(rows[:total], rec_base + [total], counts, r, self.group))
+                if scales is not None:
+                    works.append(_exchange_exact_async(scales[nh:nh + total], rec_base + [total], counts, r, self.group))
+                works.append(_exchange_exact_async(frags[:ftotal].view(-1, 1), frag_off + [ftotal], slots_r, r, self.group))
+        else:
+            m, ms = total // W, ftotal // W
+            s_rows = torch.empty((max(m, 1), pb), dtype=torch.uint8, device=tok.device)
+            s_scales = torch.empty((max(m, 1), sb), dtype=torch.uint8, device=tok.device) if sb else None
+            s_frag = torch.empty(ms, dtype=torch.int64, device=tok.device)
+            t.shard_cols_pack(0, n_me, s_rows, s_scales, s_frag)
+            t0 = self._tick("pack_ms", t0)
+            if m:
+                works.append(_all_gather_async(rows[:total].view(-1), s_rows[:m].reshape(-1), self.group))
+                if scales is not None:
+                    works.append(_all_gather_async(scales[nh:nh + total].view(-1), s_scales[:m].reshape(-1), self.group))
+            works.append(_all_gather_async(frags[:ftotal], s_frag, self.group))
+            keep = (s_rows, s_scales, s_frag)
+        if self._prof is not None:
+            for w in works:
+                w.wait()
+            t0 = self._tick("collective_ms", t0)
+            got = (total - n_me) * (pb + sb) + (ftotal - slots_r[r]) * 8 if (exact or W == 1) else (total * (pb + sb) + ftotal * 8) * (W - 1) // W
+            self._prof["bytes_received"] = float(got)
+        self._plan_packed_here(tok)
+        self._slot_open[slot] = True
+        return {"slot": slot, "tok": tok, "C": 1, "per": B, "works": works, "ready": None, "t0": t0, "keep": keep,
+                "cols": {"rows": rows, "scales": scales, "frags": frags, "total": total, "frag_off": frag_off,
+                         "frag_slots": slots_r, "rec_base": rec_base}}
+
     def _gather_begin(self, tok, slot, t0):
         B, T = tok.shape
         W, t = self.world, self.table
         C = max(1, min(self.gather_chunks, B, 64))
+        if C == 1 and self.wire_format == "columns" and hasattr(t, "shard_cols_pack"):
+            return self._gather_begin_cols(tok, slot, t0)
         per = (B + C - 1) // C
         self._plan_enter(slot, tok)
         ends = self._plan(tok, slot, C, True)                           # synchronises its stream: this rank's record counts
@@ -585,8 +671,22 @@ class ShardedEmbeddingCache:
             out = torch.empty((B * T, d), dtype=out_dtype, device=tok.device)
         else:
             assert out.is_contiguous() and out.dtype == out_dtype and out.numel() == B * T * d
-        C, per, base, records, works = ticket["C"], ticket["per"], ticket["base"], ticket["records"], ticket["works"]
         t0 = ticket["t0"]
+        if "cols" in ticket:                                             # columns on the wire: no indexing pass
+            for w in ticket["works"]:
+                w.wait()                                                 # the current stream waits for the three columns
+            t0 = self._tick("collective_ms", t0)
+            c = ticket["cols"]
+            t.shard_cols_embed(tok, 0, B, c["rows"], c["total"], c["scales"], c["frags"], c["frag_off"], c["frag_slots"],
+                               c["rec_base"], out, wte=wte, wpe=wpe, position_ids=position_ids, reduce=reduce)
+            t0 = self._tick("embed_ms", t0)
+            if cur is not None:
+                done = torch.cuda.Event()
+                done.record(cur)
+                self._slot_done[ticket["slot"]] = done
+            self._keep = (ticket, position_ids, wte, wpe, out)
+            return out.view(B, T, d)
+        C, per, base, records, works = ticket["C"], ticket["per"], ticket["base"], ticket["records"], ticket["works"]
         for c in range(C):
             if works[c] is not None:
                 works[c][0].wait()                                       # the current stream waits for chunk c's records

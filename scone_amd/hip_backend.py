@@ -567,6 +567,64 @@ class SconeTable:
         self._shard_keepalive = (records, tok, position_ids, wte, wpe, out)
         self._check(rc, "scone_shard_gather_embed_range")
 
+    # -- all-gather form with columns on the wire (scone_shard_cols_*) ---------------------------------
+    @staticmethod
+    def cols_frag_slots(count: int) -> int:
+        """u64 slots of the sender's hash fragment for ``count`` rows (both ends derive it from the exchanged counts)."""
+        n = C.c_uint64(0)
+        L.lib().scone_shard_cols_frag_slots(int(count), C.byref(n))
+        return n.value
+
+    def shard_cols_pack(self, first: int, count: int, rows_out: torch.Tensor, scales_out: Optional[torch.Tensor],
+                        frag_out: torch.Tensor) -> None:
+        """Records ``[first, first + count)`` of the plan as columns: payload rows ``uint8 [count, payload_bytes]``, scales
+        ``uint8 [count, scale bytes]`` (None for fp32 / fp16 tables) and the hash fragment ``int64 [slots]`` (cleared and
+        filled: row id -> position)."""
+        assert rows_out.is_cuda and rows_out.is_contiguous() and rows_out.numel() >= count * self.payload_bytes()
+        assert frag_out.is_cuda and frag_out.is_contiguous() and frag_out.dtype == torch.int64
+        with torch.cuda.device(self.device):
+            rc = L.lib().scone_shard_cols_pack(self._h, int(first), int(count), _ptr(rows_out), _ptr(scales_out), _ptr(frag_out),
+                                               frag_out.numel(), _stream())
+        self._check(rc, "scone_shard_cols_pack")
+
+    def shard_cols_build_frag(self, ids: torch.Tensor, frag_out: torch.Tensor) -> None:
+        """The fragment of an arbitrary id list (position = index in the list)."""
+        ids = ids.to(device=self.device, dtype=torch.int32).contiguous()
+        assert frag_out.is_cuda and frag_out.is_contiguous() and frag_out.dtype == torch.int64
+        with torch.cuda.device(self.device):
+            rc = L.lib().scone_shard_cols_build_frag(self._h, _ptr(ids), ids.numel(), _ptr(frag_out), frag_out.numel(), _stream())
+            torch.cuda.current_stream().synchronize()              # `ids` may be a temporary
+        self._check(rc, "scone_shard_cols_build_frag")
+
+    def scale_bytes(self) -> int:
+        return 2 * self.scales_per_row()
+
+    def shard_head_scales_into(self, scales_full: torch.Tensor) -> None:
+        """The replicated head's scales into the front of a ``[n_head + capacity, scale bytes]`` buffer."""
+        with torch.cuda.device(self.device):
+            rc = L.lib().scone_shard_head_scales(self._h, _ptr(scales_full), _stream())
+        self._check(rc, "scone_shard_head_scales")
+
+    def shard_cols_embed(self, tok: torch.Tensor, seq_begin: int, seq_end: int, rows: torch.Tensor, n_total: int,
+                         scales_full: Optional[torch.Tensor], frags: torch.Tensor, frag_off, frag_slots, rec_base,
+                         out: torch.Tensor, wte: Optional[torch.Tensor] = None, wpe: Optional[torch.Tensor] = None,
+                         position_ids: Optional[torch.Tensor] = None, reduce: str = "mean") -> None:
+        """Sequences ``[seq_begin, seq_end)`` of the planned batch into their place in ``out [B*T, d]`` out of ``[replicated
+        head | rows]`` (payload stride), lists resolved through the owners' fragments."""
+        tok = self._tok(tok)
+        B, T = tok.shape
+        W = len(frag_off)
+        assert out.is_cuda and out.is_contiguous() and out.numel() >= B * T * self.dim
+        arr = lambda v: (C.c_uint64 * 64)(*[int(x) for x in v])
+        with torch.cuda.device(self.device):
+            rc = L.lib().scone_shard_cols_embed(self._h, _ptr(tok), B, T, int(seq_begin), int(seq_end), _ptr(rows), int(n_total),
+                                                _ptr(scales_full), _ptr(frags), arr(frag_off), arr(frag_slots), arr(rec_base), W,
+                                                _ptr(wte), 0 if wte is None else wte.shape[0], _ptr(wpe),
+                                                0 if wpe is None else wpe.shape[0], _ptr(position_ids), _REDUCE[reduce], _ptr(out),
+                                                0, _DT[out.dtype], _stream())
+        self._shard_keepalive = (rows, scales_full, frags, tok, position_ids, wte, wpe, out)
+        self._check(rc, "scone_shard_cols_embed")
+
     def shard_gather_embed(self, tok: torch.Tensor, records: torch.Tensor, wte: Optional[torch.Tensor] = None,
                            wpe: Optional[torch.Tensor] = None, position_ids: Optional[torch.Tensor] = None,
                            reduce: str = "mean", out_dtype: torch.dtype = torch.float32,

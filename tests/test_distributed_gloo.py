@@ -230,6 +230,67 @@ class OracleShard:
         self.plans_from_gathered_lists = getattr(self, "plans_from_gathered_lists", 0) + 1
         return ends
 
+    # ---- columns on the wire (scone_shard_cols_*): payload rows | (no scales: fp32 rows) | the sender's fragment.  The
+    #      stand-in's fragment is a list, not a hash table: entry k = (row id + 1) << 32 | position, zeros behind
+    def payload_bytes(self):
+        return self.dim * 4
+
+    def scale_bytes(self):
+        return 0
+
+    @staticmethod
+    def cols_frag_slots(count):
+        s = 64
+        while s < 2 * count:
+            s <<= 1
+        return s
+
+    def shard_head_scales_into(self, scales_full):
+        raise AssertionError("fp32 rows have no scales")
+
+    def shard_cols_pack(self, first, count, rows_out, scales_out, frag_out):
+        assert first + count <= len(self._uniq) and scales_out is None and frag_out.numel() >= self.cols_frag_slots(count)
+        ro, fo = rows_out.numpy(), frag_out.numpy()
+        fo[:] = 0
+        for k, i in enumerate(self._uniq[first:first + count]):
+            ro[k] = self.table[i].view(np.uint8)
+            fo[k] = ((int(i) + 1) << 32) | k
+        self.cols_packs = getattr(self, "cols_packs", 0) + 1
+
+    def shard_cols_embed(self, tok, seq_begin, seq_end, rows, n_total, scales_full, frags, frag_off, frag_slots, rec_base, out,
+                         wte=None, wpe=None, position_ids=None, reduce="mean"):
+        from scone_amd.distributed import owner_of
+        assert tuple(tok.shape) == self._planned and scales_full is None
+        B, T = tok.shape
+        sl = tok[seq_begin:seq_end]
+        off, ids, tix, jix = self._refs(sl)
+        f, r = frags.numpy(), rows.numpy()
+        world = len(frag_off)
+        by_id = {}
+        for q in range(world):
+            for v in f[frag_off[q]:frag_off[q] + frag_slots[q]].tolist():
+                if v:
+                    i, pos = (v >> 32) - 1, v & 0xFFFFFFFF
+                    assert int(owner_of(torch.tensor([i]), self.n_rows, world)[0]) == q, "a row in another owner's fragment"
+                    assert i not in by_id, "a row arrived twice"
+                    by_id[i] = rec_base[q] + pos
+        got = np.zeros((len(ids), self.dim), dtype=np.float32)
+        for k, i in enumerate(ids.tolist()):                          # KeyError = a needed row did not arrive
+            if i < self.n_head:
+                got[k] = self.table[i]
+            else:
+                assert by_id[i] < n_total
+                got[k] = r[by_id[i], :self.dim * 4].view(np.float32)
+        assert np.array_equal(got, self.table[ids])
+        x = torch.from_numpy(self.R.embed_numpy(got, off, np.arange(len(ids)), reduce))
+        flat = sl.reshape(-1).long()
+        if wte is not None:
+            x = wte.float()[flat] + x
+        if wpe is not None:
+            pos = (torch.arange(flat.numel()) % T) if position_ids is None else position_ids[seq_begin:seq_end].reshape(-1).long()
+            x = x + wpe.float()[pos]
+        out.view(B * T, self.dim)[seq_begin * T:seq_end * T] = x.to(out.dtype)
+
     def shard_gather_pack_range(self, first, count, out):
         assert first + count <= len(self._uniq) and out.shape[1] == self.dim * 4 + 8
         o = out.numpy()
@@ -300,7 +361,8 @@ class OracleShard:
         return x
 
 
-def _worker(rank, world, port, ntok_shape, out_dtype_name, exchange, q, chunks=4, head=0, transport="p2p", shard_match="auto"):
+def _worker(rank, world, port, ntok_shape, out_dtype_name, exchange, q, chunks=4, head=0, transport="p2p", shard_match="auto",
+            wire_format="columns"):
     try:
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -326,7 +388,8 @@ def _worker(rank, world, port, ntok_shape, out_dtype_name, exchange, q, chunks=4
         if head:
             shard.shard_set_head(head)
         cache = ShardedEmbeddingCache(ex, d, rank=rank, world=world, n_rows=n, table=shard, replicated_rows=head,
-                                      gather_chunks=max(chunks, 1), gather_transport=transport, shard_match=shard_match)
+                                      gather_chunks=max(chunks, 1), gather_transport=transport, shard_match=shard_match,
+                                      wire_format=wire_format)
         assert (cache.row_begin, cache.row_end) == (a, b)
         out = cache.embed_tokens(tok, wte=wte.to(out_dtype), wpe=wpe.to(out_dtype), out_dtype=out_dtype,
                                  exchange=exchange)
@@ -344,6 +407,8 @@ def _worker(rank, world, port, ntok_shape, out_dtype_name, exchange, q, chunks=4
             ok_slice = ok_slice and getattr(shard, "plans_from_gathered_lists", 0) == 2     # both calls planned from gathered lists
         elif shard_match == "auto":
             ok_slice = ok_slice and not hasattr(shard, "plans_from_gathered_lists")         # (tiny batches: every rank matches)
+        if exchange == "gather_rows" and chunks == 1:                                        # one piece: columns unless asked otherwise
+            ok_slice = ok_slice and (getattr(shard, "cols_packs", 0) == 2) == (wire_format == "columns")
         q.put((rank, err, tuple(out.shape), ok_slice))
         dist.destroy_process_group()
     except Exception as e:      # surface the failure in the parent
@@ -422,6 +487,29 @@ def test_match_sharded_over_the_ranks_world_gloo(exchange, chunks, head, world, 
         assert out_shape == (shape[0], shape[1], 32) and err < 1e-6 and ok_slice
 
 
+@pytest.mark.parametrize("transport,world,head,shape,wire", [("p2p", 2, 0, (5, 13), "columns"), ("p2p", 3, 20, (4, 19), "columns"),
+                                                             ("all_gather", 2, 40, (5, 13), "columns"), ("all_gather", 3, 0, (7, 9), "columns"),
+                                                             ("p2p", 3, 20, (1, 5), "columns"), ("p2p", 2, 0, (5, 13), "records")])
+def test_gather_rows_columns_on_the_wire_world_gloo(transport, world, head, shape, wire):
+    """``gather_rows`` in one piece with COLUMNS on the wire: every rank's payload rows, (scales,) and hash fragment travel as
+    three ranges -- exact point-to-point ranges or three padded all-gathers -- and the receiver resolves the id lists through
+    the owners' fragments: same output as the unsharded table (the stand-in checks that every row sits in ITS owner's
+    fragment, arrives once and inside the receive buffer); ``wire_format="records"`` keeps the record form."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, shape, "float32", "gather_rows", q, 1, head, transport, "auto", wire))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, err, out_shape, ok_slice in results:
+        assert isinstance(err, float), f"rank {rank} failed: {err}"
+        assert out_shape == (shape[0], shape[1], 32) and err < 1e-6 and ok_slice
+
+
 @pytest.mark.parametrize("transport", ["p2p", "all_gather"])
 def test_gather_rows_world3_gloo(transport):
     """Three ranks: with ``p2p`` every rank sends its records to two peers and receives two ranges of different sizes."""
@@ -440,7 +528,7 @@ def test_gather_rows_world3_gloo(transport):
         assert out_shape == (shape[0], shape[1], 32) and err < 1e-6 and ok_slice
 
 
-def _worker_split_phase(rank, world, port, q, slots=2):
+def _worker_split_phase(rank, world, port, q, slots=2, chunks=2):
     try:
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -461,7 +549,7 @@ def _worker_split_phase(rank, world, port, q, slots=2):
         a, b = shard_range(n, rank, world)
         shard = OracleShard(keys, lens, max_n, table, a, b)
         shard.shard_set_head(30)
-        cache = ShardedEmbeddingCache(ex, d, rank=rank, world=world, n_rows=n, table=shard, replicated_rows=30, gather_chunks=2,
+        cache = ShardedEmbeddingCache(ex, d, rank=rank, world=world, n_rows=n, table=shard, replicated_rows=30, gather_chunks=chunks,
                                       shard_match=True, plan_slots=slots)   # every slot plans from gathered lists: each needs its own buffer
         outs, tickets, nxt = [], [cache.gather_rows_begin(batches[0])], 1
         for i in range(len(batches)):
@@ -490,15 +578,15 @@ def _worker_split_phase(rank, world, port, q, slots=2):
         q.put((rank, repr(e) + traceback.format_exc(), False))
 
 
-@pytest.mark.parametrize("slots", [2, 3])
-def test_gather_rows_split_phase_two_batches_in_flight_world2_gloo(slots):
+@pytest.mark.parametrize("slots,chunks", [(2, 2), (3, 2), (2, 1), (3, 1)])          # chunks = 1: columns on the wire
+def test_gather_rows_split_phase_two_batches_in_flight_world2_gloo(slots, chunks):
     """gather_rows_begin / gather_rows_finish with the next batch begun (planned, packed, gathered) BEFORE the current one is
     reduced: the two plan slots keep the batches apart; every output equals the unsharded lookup of ITS batch and the
     one-call form."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker_split_phase, args=(r, 2, port, q, slots)) for r in range(2)]
+    procs = [ctx.Process(target=_worker_split_phase, args=(r, 2, port, q, slots, chunks)) for r in range(2)]
     for p in procs:
         p.start()
     results = [q.get(timeout=180) for _ in procs]

@@ -218,3 +218,83 @@ def test_eight_shard_gather_rows_step_against_the_c_oracle(chunks, match, row_ma
         bad = _compare_with_c_oracle(lambda: out32, lambda: out16, keys, lens, tok_np, ri, "int4", d, wte, wpe)
         assert bad == 0
         assert shards[q].status() == 0
+
+
+@pytest.mark.parametrize("fmt,d,match", [("int4", 1024, "sharded"), ("fp16", 768, "local"), ("int8", 768, "sharded")])
+def test_eight_shard_columns_exchange_against_the_c_oracle(fmt, d, match):
+    """The same 8-way step with COLUMNS on the wire (round 3: `scone_shard_cols_pack` / `_embed`): every shard's payload rows
+    land at the table's own stride in one receive buffer, its scales behind the head's scales, its hash fragment (built by the
+    SENDER while it packs) in the fragment buffer; no receiver indexes anything.  Every token of three shards' outputs against
+    the oracle: fp32 bit-exact, fp16 bytes equal; and a fragment built from a plain id list (`scone_shard_cols_build_frag`,
+    what the tools stand in for other ranks with) resolves like the packed one."""
+    from scone_amd import synthetic as S
+    from scone_amd.distributed import shard_range
+    from scone_amd.hip_backend import SconeTable
+    N, W, B, T, head = 1_000_000, 8, 256, 512, S.GPT2_VOCAB
+    keys, lens = _keys(N, "zipf")
+    tok_np = S.stream_uniform_ids(keys, lens, B, T, 4321)
+    tok = torch.from_numpy(tok_np).to("cuda", torch.int32)
+    ro, ri = R.hits_to_csr(R.match_hits(keys, lens, tok_np, 3))
+    g = torch.Generator().manual_seed(1)
+    wte = (torch.randn(S.GPT2_VOCAB, d, generator=g) * 0.02).half().cuda()
+    wpe = (torch.randn(T, d, generator=g) * 0.01).half().cuda()
+    shards = []
+    for r in range(W):
+        lo, hi = shard_range(N, r, W)
+        s = SconeTable(3, N, d, fmt, row_begin=lo, row_end=hi)
+        s.index_build(keys, lens)
+        s.shard_set_head(head)
+        s.fill_synthetic(SEED, BASE_SCALE)
+        shards.append(s)
+    bper, wd = B // W, shards[0].ell_width()
+    pb, sb = shards[0].payload_bytes(), shards[0].scale_bytes()
+
+    def plan(s):
+        if match == "local":
+            return s.shard_gather_plan_chunks(tok, 1)[0], None
+        ell = torch.empty((B * T, wd), dtype=torch.int32, device="cuda")
+        for r, o in enumerate(shards):
+            o.shard_gather_match(tok, r * bper, (r + 1) * bper, ell[r * bper * T:(r + 1) * bper * T])
+        return s.shard_gather_plan_ell(ell, B, T, 1)[0], ell
+
+    plans = [plan(s) for s in shards]
+    counts = [p[0] for p in plans]
+    slots = [SconeTable.cols_frag_slots(c) for c in counts]
+    rec_base = [sum(counts[:r]) for r in range(W)]
+    frag_off = [sum(slots[:r]) for r in range(W)]
+    total, ftotal = sum(counts), sum(slots)
+    assert total == np.unique(ri[ri >= head]).size and all(sl >= 2 * c and sl & (sl - 1) == 0 for sl, c in zip(slots, counts))
+    rows = torch.empty((total, pb), dtype=torch.uint8, device="cuda")
+    scales = torch.empty((head + total, sb), dtype=torch.uint8, device="cuda") if sb else None
+    frags = torch.empty(ftotal, dtype=torch.int64, device="cuda")
+    for r, s in enumerate(shards):
+        s.shard_cols_pack(0, counts[r], rows[rec_base[r]:rec_base[r] + counts[r]],
+                          None if scales is None else scales[head + rec_base[r]:head + rec_base[r] + counts[r]],
+                          frags[frag_off[r]:frag_off[r] + slots[r]])
+    if scales is not None:
+        shards[0].shard_head_scales_into(scales)
+    # a fragment built from the plain id list of shard 5's contribution resolves the same ids to the same positions
+    f5 = frags[frag_off[5]:frag_off[5] + slots[5]].cpu().numpy()
+    ids5 = (f5[f5 != 0] >> 32) - 1
+    pos5 = f5[f5 != 0] & 0xFFFFFFFF
+    order = np.argsort(pos5)
+    assert np.array_equal(np.sort(pos5), np.arange(counts[5])) and np.all((ids5 >= shard_range(N, 5, W)[0]) & (ids5 < shard_range(N, 5, W)[1]))
+    alt = torch.empty(slots[5], dtype=torch.int64, device="cuda")
+    shards[5].shard_cols_build_frag(torch.from_numpy(ids5[order].astype(np.int32)), alt)
+    a5 = alt.cpu().numpy()                                            # same entries (the slot a colliding entry ends up in depends
+    assert np.array_equal(np.sort(a5[a5 != 0]), np.sort(f5[f5 != 0]))   # on who came first: compare as sets), and they resolve:
+    frags2 = frags.clone()
+    frags2[frag_off[5]:frag_off[5] + slots[5]] = alt
+    for q in (0, 4, 7):
+        out32 = torch.empty(B * T, d, dtype=torch.float32, device="cuda")
+        shards[q].shard_cols_embed(tok, 0, B, rows, total, scales, frags, frag_off, slots, rec_base, out32)
+        again = torch.empty_like(out32)                              # lists already hold record numbers: reduced as they are
+        shards[q].shard_cols_embed(tok, 0, B, rows, total, scales, frags, frag_off, slots, rec_base, again)
+        assert torch.equal(again, out32)
+        n2, _keep = plan(shards[q])
+        assert n2 == counts[q]
+        out16 = torch.empty(B * T, d, dtype=torch.float16, device="cuda")
+        for s0 in (0, B // 2):                                       # in two runs of sequences, through the rebuilt fragment of shard 5
+            shards[q].shard_cols_embed(tok, s0, s0 + B // 2, rows, total, scales, frags2, frag_off, slots, rec_base, out16, wte=wte, wpe=wpe)
+        bad = _compare_with_c_oracle(lambda: out32.view(B, T, d), lambda: out16.view(B, T, d), keys, lens, tok_np, ri, fmt, d, wte, wpe)
+        assert bad == 0 and shards[q].status() == 0

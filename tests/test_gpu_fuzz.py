@@ -149,6 +149,25 @@ def test_fuzz_row_exchange_vs_unsharded():
             got = shards[q].shard_gather_embed(tok, recv, wte=wte, wpe=wpe, out_dtype=torch.float16)
             assert torch.equal(got, want), tag + ("gather_rows", q)
             assert shards[q].status() == 0, tag
+        if fmt != "fp32" or d % 8 == 0:
+            # the same exchange with columns on the wire: payload rows | scales | the senders' hash fragments
+            cnts = [s_.shard_gather_plan(tok) for s_ in shards]
+            slots = [SconeTable.cols_frag_slots(c) for c in cnts]
+            rb, fo = [sum(cnts[:r]) for r in range(world)], [sum(slots[:r]) for r in range(world)]
+            tot, pb, sb = sum(cnts), shards[0].payload_bytes(), shards[0].scale_bytes()
+            c_rows = torch.empty((max(tot, 1), pb), dtype=torch.uint8, device="cuda")
+            c_sc = torch.empty((head + max(tot, 1), sb), dtype=torch.uint8, device="cuda") if sb else None
+            c_fr = torch.empty(sum(slots), dtype=torch.int64, device="cuda")
+            for r, s_ in enumerate(shards):
+                s_.shard_cols_pack(0, cnts[r], c_rows[rb[r]:rb[r] + cnts[r]], None if c_sc is None else c_sc[head + rb[r]:head + rb[r] + cnts[r]],
+                                   c_fr[fo[r]:fo[r] + slots[r]])
+            q = int(rng.integers(world))
+            if c_sc is not None and head:
+                shards[q].shard_head_scales_into(c_sc)
+            got = torch.empty((B * T, d), dtype=torch.float16, device="cuda")
+            shards[q].shard_cols_embed(tok, 0, B, c_rows, tot, c_sc, c_fr, fo, slots, rb, got, wte=wte, wpe=wpe)
+            assert torch.equal(got, want), tag + ("gather_rows, columns", q)
+            assert shards[q].status() == 0, tag
 
 
 def test_fuzz_pinned_host_vs_hbm():

@@ -57,9 +57,11 @@ def _worker(rank, world, port, fmt, d, max_n, exchange, head, q):
         keys, lens, table, tok, wte, wpe = _problem(fmt, d, max_n)
         ex = NGramExtractor.from_arrays(keys, lens, max_n=max_n)
         exchange, _, rest = exchange.partition(":")               # "gather_rows:all_gather" = the padded all-gather transport,
-        transport, _, sm = rest.partition(":")                    # "...:sm" = the plan's match sharded over the ranks
+        transport, _, rest = rest.partition(":")                  # "...:sm" = the plan's match sharded over the ranks,
+        sm, _, c1 = rest.partition(":")                           # "...:c1" = one piece (columns on the wire), "...:c1r" = one piece, records
         sh = ShardedEmbeddingCache(ex, d, table_format=fmt, rank=rank, world=world, replicated_rows=head,
-                                   gather_transport=transport or "p2p", shard_match=True if sm == "sm" else "auto")
+                                   gather_transport=transport or "p2p", shard_match=True if sm == "sm" else "auto",
+                                   gather_chunks=1 if c1 else 4, wire_format="records" if c1 == "c1r" else "columns")
         sh.load_rows(torch.from_numpy(table), 0)
         wte_d, wpe_d = torch.from_numpy(wte).half().cuda(), torch.from_numpy(wpe).half().cuda()
         got = sh.embed_tokens(torch.from_numpy(tok), wte=wte_d, wpe=wpe_d, exchange=exchange)
@@ -85,6 +87,10 @@ def _worker(rank, world, port, fmt, d, max_n, exchange, head, q):
                                                              ("int4", 1024, 3, 3, "gather_rows:p2p:sm", 100),
                                                              ("int8", 768, 4, 2, "gather_rows:all_gather:sm", 0),
                                                              ("fp16", 768, 3, 3, "rows:p2p:sm", 100),
+                                                             ("int4", 1024, 3, 3, "gather_rows:p2p:sm:c1", 100),
+                                                             ("fp16", 768, 4, 2, "gather_rows:all_gather::c1", 0),
+                                                             ("int8", 768, 3, 3, "gather_rows:all_gather:sm:c1", 37),
+                                                             ("int8", 1024, 3, 2, "gather_rows:p2p::c1r", 100),
                                                              ("int8", 768, 3, 2, "partial_sums", 0),
                                                              ("int4", 1024, 3, 3, "rows_per_reference", 100)])
 def test_sharded_cache_across_processes_on_one_gpu(fmt, d, max_n, world, exchange, head):
@@ -296,13 +302,14 @@ def _nccl_worker(rank, world, port, q):
             full.cache_embeddings(list(range(len(lens))), torch.from_numpy(table), verbose=False)
             ref = full.embed_tokens(torch.from_numpy(tok), wte=wte_d, wpe=wpe_d)
             for exchange in ("rows", "rows_per_reference", "gather_rows", "gather_rows:all_gather", "partial_sums",
-                             "rows::sm", "gather_rows::sm", "gather_rows:all_gather:sm"):
+                             "rows::sm", "gather_rows::sm", "gather_rows:all_gather:sm", "gather_rows::sm:c1", "gather_rows:all_gather::c1"):
+                sh.gather_chunks = 1 if exchange.endswith(":c1") else chunks     # one piece: columns on the wire
                 sh.gather_transport = exchange.split(":")[1] if ":" in exchange and exchange.split(":")[1] else "p2p"   # exact p2p ranges / padded all-gather
-                sh.shard_match = exchange.endswith(":sm")                        # the plan's match sharded over the ranks (+ one all-gather)
+                sh.shard_match = ":sm" in exchange                               # the plan's match sharded over the ranks (+ one all-gather)
                 got = sh.embed_tokens(torch.from_numpy(tok), wte=wte_d, wpe=wpe_d, exchange=exchange.partition(":")[0])
                 err = float((got.float() - ref.float()).abs().max() / ref.float().abs().max())
                 res.append((fmt, exchange, bool(torch.equal(got, ref)), err))
-            sh.gather_transport, sh.shard_match = "p2p", True
+            sh.gather_transport, sh.shard_match, sh.gather_chunks = "p2p", True, chunks
             # the split-phase loop: two batches in flight, the second one's transfers behind the first one's reduction
             tk = sh.gather_rows_begin(torch.from_numpy(tok))
             for i in range(3):

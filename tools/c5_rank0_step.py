@@ -32,8 +32,8 @@ def main():
     ap.add_argument("--seq", type=int, default=512)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--padded", action="store_true", help="the padded all-gather's receive layout instead of exact ranges")
-    ap.add_argument("--variants", default="0,1,2,3,4,5", help="which flows to time (0 = round 2, 1 = + sharded match, 2 = + post "
-                    "stream (round 3), 3 = three batches in flight, 4 / 5 = rounds 3 / 2 with the direct-mapped row map)")
+    ap.add_argument("--variants", default="0,1,2,3", help="which flows to time (0 = round 2, 1 = + sharded match, 2 = + columns on the "
+                    "wire (round 3), 3 = three batches in flight, 4 = 1 + post stream, 5 / 6 = direct-mapped row map)")
     ap.add_argument("--rounds", type=int, default=5, help="alternating rounds over the chosen flows (medians are reported)")
     ap.add_argument("--one-only", action="store_true", help="time the one-stream step only (clean per-kernel times under a profiler)")
     ap.add_argument("--split-only", action="store_true", help="time the split-phase loop only (for a kernel profile of it)")
@@ -71,8 +71,10 @@ def main():
     hdr = full.view(torch.int32).view(total, rec // 4)
     hdr[:, rec // 4 - 2] = -1                                            # every record is padding ...
     hdr[:, rec // 4 - 1] = -1
+    other_by_rank = {}
     for r in range(1, W):
         rows_r = other[owner == r]
+        other_by_rank[r] = rows_r.to(torch.int32)
         hdr[offs[r]:offs[r] + rows_r.numel(), rec // 4 - 2] = rows_r.to(torch.int32)     # ... except the real ones: row id
     del ids, other, owner
     fulls = [full, full.clone(), full.clone()]
@@ -89,10 +91,30 @@ def main():
     results = {}
     flows = (("round2: every rank matches the whole batch", "hash", False, False, 2),
              ("match sharded over the ranks", "hash", True, False, 2),
-             ("round3: sharded match + records indexed / lists remapped on a post stream", "hash", True, True, 2),
-             ("round3, three batches in flight", "hash", True, True, 3),
-             ("round3 with the direct-mapped row map (4 B per table row)", "direct", True, True, 2),
+             ("round3: sharded match + columns on the wire (payload rows | scales | the senders' hash fragments: no indexing pass)",
+              "cols", True, False, 2),
+             ("round3, three batches in flight", "cols", True, False, 3),
+             ("sharded match + records indexed / lists remapped on a post stream", "hash", True, True, 2),
+             ("sharded match + post stream + direct-mapped row map (4 B per table row)", "direct", True, True, 2),
              ("round2 with the direct-mapped row map", "direct", False, False, 2))
+    # ---- columns on the wire: receive buffers per slot, the other ranks' columns synthesised once (the batch never changes):
+    # zero payloads and scales, REAL hash fragments of their row ids
+    from scone_amd.hip_backend import SconeTable
+    pbytes, sbytes, nh = s.payload_bytes(), s.scale_bytes(), S.GPT2_VOCAB
+    cslots = [SconeTable.cols_frag_slots(c) for c in counts]
+    crec = [sum(counts[:r]) for r in range(W)]
+    cfoff = [sum(cslots[:r]) for r in range(W)]
+    ctotal = sum(counts)
+    c_rows, c_scales, c_frags = [], [], []
+    for k in range(3):
+        c_rows.append(torch.zeros((ctotal, pbytes), dtype=torch.uint8, device="cuda"))
+        sc = torch.zeros((nh + ctotal, sbytes), dtype=torch.uint8, device="cuda")
+        s.shard_head_scales_into(sc)
+        c_scales.append(sc)
+        fr = torch.zeros(sum(cslots), dtype=torch.int64, device="cuda")
+        for r in range(1, W):
+            s.shard_cols_build_frag(other_by_rank[r], fr[cfoff[r]:cfoff[r] + cslots[r]])
+        c_frags.append(fr)
     side, post = torch.cuda.Stream(), torch.cuda.Stream()
 
     def make(variant, row_map, sharded_match, post_stream, slots):
@@ -109,7 +131,11 @@ def main():
                 n = s.shard_gather_plan_ell(ells[slot], B, T, 1)[0]
             else:
                 n = s.shard_gather_plan_chunks(tok, 1)[0]
-            s.shard_gather_pack_range(0, n, fulls[slot][:maxc])
+            if row_map == "cols":
+                assert n == counts[0]
+                s.shard_cols_pack(0, n, c_rows[slot][:n], c_scales[slot][nh:nh + n], c_frags[slot][:cslots[0]])
+            else:
+                s.shard_gather_pack_range(0, n, fulls[slot][:maxc])
 
         def index_remap(slot):
             s.shard_select_slot(slot)
@@ -118,12 +144,16 @@ def main():
 
         def finish(slot, indexed=False):
             s.shard_select_slot(slot)
+            if row_map == "cols":
+                s.shard_cols_embed(tok, 0, B, c_rows[slot], ctotal, c_scales[slot], c_frags[slot], cfoff, cslots, crec, out,
+                                   wte=wte, wpe=wpe)
+                return
             if not indexed:
                 s.shard_gather_add_records(fulls[slot][:total], 0, total)
             s.shard_gather_embed_range(tok, 0, B, fulls[slot][:total], out, wte=wte, wpe=wpe)
 
         def one_stream(n):
-            os.environ["SCONE_SHARD_ROW_MAP"] = row_map
+            os.environ["SCONE_SHARD_ROW_MAP"] = "hash" if row_map == "cols" else row_map
             for _ in range(n):
                 begin(0)
                 finish(0)
@@ -154,7 +184,7 @@ def main():
             done[slot].record(cur)
 
         def loop(n):
-            os.environ["SCONE_SHARD_ROW_MAP"] = row_map
+            os.environ["SCONE_SHARD_ROW_MAP"] = "hash" if row_map == "cols" else row_map
             for k in range(3):
                 done[k] = None
             nxt, q = 0, []

@@ -50,9 +50,10 @@ def main():
     ap.add_argument("--wall", action="store_true",
                     help="gather_rows: also time rank 0's whole step back to back (no phase synchronisation): the local "
                          "critical path including launch gaps and the plan's one host synchronisation")
-    ap.add_argument("--mode", default="rows", choices=["rows", "rows_dedup", "gather_rows"],
+    ap.add_argument("--mode", default="rows", choices=["rows", "rows_dedup", "gather_rows", "gather_cols"],
                     help="rows: all-to-all of records, every rank reduces its slice; gather_rows: all-gather of records, "
-                         "every rank reduces the whole batch")
+                         "every rank reduces the whole batch; gather_cols: the same with columns on the wire (payload rows | "
+                         "scales | the senders' hash fragments) and the plan's match sharded over the ranks")
     a = ap.parse_args()
     N, W, d, B, T = a.rows, a.world, a.dim, a.batch, a.seq
     keys, lens = S.make_keys_structured(N, S.GPT2_VOCAB, 3) if N >= 20_000_000 else S.make_keys(N, S.GPT2_VOCAB, 3, seed=11)
@@ -84,6 +85,9 @@ def main():
         return
     if a.mode == "gather_rows":
         gather_rows_mode(a, shards, tok, wte, wpe, out, res, keys, lens)
+        return
+    if a.mode == "gather_cols":
+        gather_cols_mode(a, shards, tok, wte, wpe, out, res, keys, lens)
         return
     for rep in range(a.reps):
         plans, t_plan = [], []
@@ -173,6 +177,67 @@ def gather_rows_mode(a, shards, tok, wte, wpe, out, res, keys, lens):
     res["local_ms_max"], res["local_ms_mean"] = max(loc), sum(loc) / len(loc)
     res["all_gather_bytes_into_each_rank"] = int((sum(counts) - min(counts)) * rec)
     res["all_gather_padded_bytes_total"] = int(max(counts) * rec * W)
+    if a.check:
+        full = SconeTable(3, N, d, a.format)
+        full.index_build(keys, lens)
+        full.fill_synthetic(7, 0.02 / 127)
+        want = full.embed(tok, wte=wte, wpe=wpe).reshape(B * T, d)
+        res["bit_identical_to_unsharded"] = bool(torch.equal(out, want))
+    print(json.dumps(res))
+
+
+def gather_cols_mode(a, shards, tok, wte, wpe, out, res, keys, lens):
+    """Round 3's one-piece all-gather form: rank r matches slice r of the batch, the 32-B list records are all-gathered (here:
+    written side by side), every rank claims its distinct rows from the gathered lists and packs them as COLUMNS -- payload
+    rows, scales, and its own hash fragment row id -> position -- into its range of the three receive buffers; every rank then
+    resolves the lists through the owners' fragments and reduces the whole batch.  No receiver indexes anything."""
+    N, W, d, B, T = a.rows, a.world, a.dim, a.batch, a.seq
+    s0 = shards[0]
+    wd, pb, sb, head = s0.ell_width(), s0.payload_bytes(), s0.scale_bytes(), a.head
+    bper = (B + W - 1) // W
+    best = None
+    for rep in range(a.reps):
+        t_match, t_plan, t_pack, t_embed = [], [], [], []
+        ell = torch.empty((W * bper * T, wd), dtype=torch.int32, device="cuda")
+        for r, s in enumerate(shards):
+            b0, b1 = min(r * bper, B), min(r * bper + bper, B)
+            _, ms = timed(lambda: s.shard_gather_match(tok, b0, b1, ell[b0 * T:max(b1, b0) * T]))
+            t_match.append(ms)
+        counts, ells = [], []
+        for s in shards:
+            mine = ell.clone()                                                       # (every rank owns its gathered copy)
+            n, ms = timed(lambda: s.shard_gather_plan_ell(mine, B, T, 1)[0])
+            counts.append(n)
+            ells.append(mine)
+            t_plan.append(ms)
+        slots = [SconeTable.cols_frag_slots(c) for c in counts]
+        rb = [sum(counts[:r]) for r in range(W)]
+        fo = [sum(slots[:r]) for r in range(W)]
+        total = sum(counts)
+        rows = torch.empty((max(total, 1), pb), dtype=torch.uint8, device="cuda")
+        scales = torch.empty((head + max(total, 1), sb), dtype=torch.uint8, device="cuda") if sb else None
+        frags = torch.empty(sum(slots), dtype=torch.int64, device="cuda")
+        if scales is not None and head:
+            s0.shard_head_scales_into(scales)
+        for r, s in enumerate(shards):
+            _, ms = timed(lambda: s.shard_cols_pack(0, counts[r], rows[rb[r]:rb[r] + counts[r]],
+                                                    None if scales is None else scales[head + rb[r]:head + rb[r] + counts[r]],
+                                                    frags[fo[r]:fo[r] + slots[r]]))
+            t_pack.append(ms)
+        for q, s in enumerate(shards):
+            _, ms = timed(lambda: s.shard_cols_embed(tok, 0, B, rows, total, scales, frags, fo, slots, rb, out, wte=wte, wpe=wpe))
+            t_embed.append(ms)
+        cur = [t_match, t_plan, t_pack, t_embed]
+        best = cur if best is None else [[min(x, y) for x, y in zip(b, c)] for b, c in zip(best, cur)]
+        del ells
+    for r in range(W):
+        res["ranks"].append({"rank": r, "match_slice_ms": best[0][r], "claim_ms": best[1][r], "pack_ms": best[2][r],
+                             "remap_and_embed_ms": best[3][r], "rows_contributed": counts[r], "fragment_slots": slots[r]})
+    loc = [sum(best[k][r] for k in range(4)) for r in range(W)]
+    res["mode"] = "gather_cols"
+    res["local_ms_max"], res["local_ms_mean"] = max(loc), sum(loc) / len(loc)
+    res["bytes_into_each_rank"] = {"rows": int((total - min(counts)) * pb), "scales": int((total - min(counts)) * sb),
+                                   "fragments": int((sum(slots) - min(slots)) * 8), "list_records": int((W - 1) * bper * T * wd * 4)}
     if a.check:
         full = SconeTable(3, N, d, a.format)
         full.index_build(keys, lens)

@@ -19,8 +19,10 @@ PY
   python3 - $O/$name.json $name <<'PY'
 import json, sys
 r = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
-print("%-22s %8.3f G tok/s  step %7.3f ms  kernel %7.3f ms  algorithmic %6.0f GB/s (frac %.3f)" % (
-    sys.argv[2], r["value"] / 1e9, r["ms_per_step"], r["roofline"]["avg_kernel_ms"], r["roofline"]["achieved"], r["roofline"]["frac"]), flush=True)
+rf = r["roofline"]
+print("%-38s %6.3f G tok/s  step %6.3f ms  kernel %6.3f ms  frac %.3f (%s)  algorithmic %.3f" % (
+    sys.argv[2], r["value"] / 1e9, r["ms_per_step"], rf["avg_kernel_ms"], rf["frac"],
+    "left L2" if rf.get("traffic") is not None else "compulsory", rf.get("algorithmic_frac", 0.0)), flush=True)
 PY
 }
 rm -f $O/configs.jsonl

@@ -199,3 +199,38 @@ def test_bench_refuses_more_ranks_than_devices():
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "64", "--steps", "1"], env=env, cwd=root,
                        capture_output=True, text=True, timeout=300)
     assert p.returncode != 0 and "HIP device" in p.stderr and not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_kernel_source_hash_covers_the_timed_kernels_translation_units():
+    """`roofline.traffic` (and with it `roofline.frac`) is quoted only for the code it was measured on: the hash covers the
+    scone_gather*.hip translation units, every header they include -- transitively, the public header too -- and the
+    Makefile; not the exchange / index / table kernels, whose changes cannot move k_embed_wave's bytes."""
+    import bench
+    names = {os.path.basename(p) for p in bench.kernel_source_files()}
+    assert {"scone_gather.hip", "scone_gather_i8.hip", "scone_gather_i4.hip", "scone_embed_wave.h", "scone_gather_impl.h",
+            "scone_common.h", "scone_probe.h", "scone_hip.h", "Makefile"} <= names
+    assert not names & {"scone_shard.hip", "scone_index.hip", "scone_table.hip", "scone_api.hip"}
+    assert all(os.path.exists(p) for p in bench.kernel_source_files())
+    sha = bench.kernel_source_sha()
+    assert len(sha) == 16 and sha == bench.kernel_source_sha()
+    # the committed traffic entries of the final round carry THIS hash (a kernel edit without new PMC passes fails here)
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    entries = {e["workload_sig"]: e for e in json.load(open(os.path.join(root, "profiles", "hbm_traffic.json")))}
+    assert entries["int8-d768-N1000000-B2048-T512-uniform-hbm"]["kernel_source_sha"] == sha
+
+
+def test_zipf_ids_stream_is_head_heavy_and_seeded():
+    """S_zipf_ids: f-grams laid end to end, ids from a bounded power law over the frequency-ordered table."""
+    from scone_amd import synthetic as S
+    v = S.StructuredVocab(10_000_000)
+    a = S.stream_zipf_ids(v, None, 8, 512, 5)
+    assert a.shape == (8, 512) and a.min() >= 0 and a.max() < S.GPT2_VOCAB
+    assert np.array_equal(a, S.stream_zipf_ids(v, None, 8, 512, 5)) and not np.array_equal(a, S.stream_zipf_ids(v, None, 8, 512, 6))
+    keys, lens = S.make_keys_structured(200_000)
+    b = S.stream_zipf_ids(keys, lens, 64, 512, 1)
+    ro, ri = R.hits_to_csr(R.match_hits(keys, lens, b, 3))
+    assert (ri < S.GPT2_VOCAB).mean() > 0.5 and (ri >= S.GPT2_VOCAB).any()          # mostly the head, but a tail too
+    u = S.stream_uniform_ids(keys, lens, 64, 512, 1)
+    _, ru = R.hits_to_csr(R.match_hits(keys, lens, u, 3))
+    assert np.median(ri) < np.median(ru)

@@ -356,7 +356,7 @@ int scone_shard_gather_embed_range(scone_handle *h, const int32_t *d_tok, int32_
  *      while it packs: its own ~65k inserts instead of 0.45M 64-bit CAS on every receiver, ~36 us per step at C5's scale).
  *      The receiver has no indexing pass: a list entry is resolved in its owner's fragment (the owner follows from the id:
  *      contiguous ranges [r N / W, (r + 1) N / W)) and becomes rec_base[owner] + position.
- *   scone_shard_cols_frag_slots   slots of the fragment for `count` rows (a power of two >= 2 count, >= 64): both ends
+ *   scone_shard_cols_frag_slots   slots of the fragment for `count` rows (a power of two >= 4 count, >= 64): both ends
  *                                 derive it from the exchanged counts
  *   scone_shard_cols_pack         records [first, first + count) of the plan (scone_shard_gather_plan*) as columns;
  *                                 d_frag_out [frag_slots] u64 is cleared and filled; stream-ordered

@@ -1131,7 +1131,9 @@ namespace {
 
 struct cols_owners {  // per owner: where its fragment starts (u64 slots), slots - 1, record number of its first row
   unsigned long long frag_off[64], frag_mask[64], rec_base[64];
-};
+  unsigned int row_lo[65];  // first row of every owner's range (row_lo[world] = n_rows): the owner of an id by a guess and a
+  float owners_per_row;     // fix-up step instead of the 64-bit division of owner_of() -- 1.1M of them per step made the
+};                          // remap 49 us where the single-map form takes 32
 
 __global__ __launch_bounds__(256) void k_cols_pack(const int32_t *__restrict__ list, unsigned long long n, scone_row_store st,
                                                    long long row_begin, const uint8_t *__restrict__ scales, int scale_bytes,
@@ -1174,9 +1176,18 @@ __global__ __launch_bounds__(256) void k_cols_frag(const int32_t *__restrict__ i
 }
 
 __global__ __launch_bounds__(256) void k_cols_remap(int32_t *__restrict__ ell, long long ntok, int W, int NC,
-                                                    const unsigned long long *__restrict__ frags, const cols_owners ow, int world,
+                                                    const unsigned long long *__restrict__ frags, const cols_owners owk, int world,
                                                     long long n_rows, long long n_head, unsigned long long n_total,
                                                     uint32_t *__restrict__ status) {
+  // the per-owner tables are indexed by a per-lane owner: out of the kernel-argument segment that is a dependent global load
+  // in front of every probe (the first version: 49 us against 32 us for the single-map remap); in LDS it is a few cycles
+  __shared__ cols_owners ow;
+  for (int i = threadIdx.x; i < 64; i += blockDim.x) {
+    ow.frag_off[i] = owk.frag_off[i], ow.frag_mask[i] = owk.frag_mask[i], ow.rec_base[i] = owk.rec_base[i];
+    ow.row_lo[i] = owk.row_lo[i];
+  }
+  if (threadIdx.x == 0) ow.row_lo[64] = owk.row_lo[64], ow.owners_per_row = owk.owners_per_row;
+  __syncthreads();
   const long long per = (ntok + gridDim.x - 1) / gridDim.x;
   const long long t0 = (long long)blockIdx.x * per, t1 = t0 + per < ntok ? t0 + per : ntok;
   for (long long t = t0 + threadIdx.x; t < t1; t += blockDim.x) {
@@ -1200,7 +1211,10 @@ __global__ __launch_bounds__(256) void k_cols_remap(int32_t *__restrict__ ell, l
       if (id < n_head) continue;  // a head row: its id is its row number in the lookup's row store
       long long slot = -1;
       if (id < n_rows) {
-        const int r = owner_of(id, n_rows, world);
+        int r = (int)((float)id * ow.owners_per_row);
+        r = r < world - 1 ? r : world - 1;
+        while (r > 0 && (unsigned int)id < ow.row_lo[r]) --r;
+        while (r < world - 1 && (unsigned int)id >= ow.row_lo[r + 1]) ++r;
         const unsigned long long key = (unsigned long long)id + 1ull, mask = ow.frag_mask[r];
         const unsigned long long *f = frags + ow.frag_off[r];
         unsigned long long s = scone_hash_key(key, 0u) & mask;
@@ -1239,7 +1253,9 @@ __global__ __launch_bounds__(256) void k_cols_remap(int32_t *__restrict__ ell, l
 extern "C" int scone_shard_cols_frag_slots(uint64_t count, uint64_t *slots) {
   if (!slots) return SCONE_EINVAL;
   uint64_t s = 64;
-  while (s < 2 * count) s <<= 1;  // load <= 0.5
+  // load <= 0.25: linear probing at 0.5 cost the receiver's remap 43 us instead of 32 and the sender's pack 30 instead of
+  // 23 (profiles/r03t: clusters of occupied slots mean dependent probes); twice the slots are 7 MB more on the wire (3 %)
+  while (s < 4 * count) s <<= 1;
   *slots = s;
   return SCONE_OK;
 }
@@ -1315,7 +1331,10 @@ int scone_shard_cols_remap(scone_handle *h, int32_t T, int32_t seq0, int32_t seq
     if (h_frag_slots[r] == 0 || (h_frag_slots[r] & (h_frag_slots[r] - 1)))
       return scone_fail(h, SCONE_EINVAL, "scone_shard_cols_embed: fragment sizes must be powers of two");
     ow.frag_off[r] = h_frag_off[r], ow.frag_mask[r] = h_frag_slots[r] - 1, ow.rec_base[r] = h_rec_base[r];
+    ow.row_lo[r] = (unsigned int)(((unsigned long long)r * h->cfg.n_rows) / (unsigned long long)world);  // distributed.shard_range
   }
+  ow.row_lo[world] = (unsigned int)h->cfg.n_rows;
+  ow.owners_per_row = (float)world / (float)(h->cfg.n_rows ? h->cfg.n_rows : 1);
   const size_t pb = h->row_payload_bytes;
   if (st->n_head && (st->head_p_stale || !st->head_rows_p)) {  // the head at the payload stride (once per head change)
     if (!st->head_rows_p) SCONE_HIP(h, hipMalloc(&st->head_rows_p, (size_t)st->n_head * pb));

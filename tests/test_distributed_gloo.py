@@ -241,7 +241,7 @@ class OracleShard:
     @staticmethod
     def cols_frag_slots(count):
         s = 64
-        while s < 2 * count:
+        while s < 4 * count:
             s <<= 1
         return s
 

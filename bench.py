@@ -1142,7 +1142,8 @@ def main():
                                 else f"replicated table, tokens sharded over {world} rank(s), no collective"),
             },
             "roofline": {
-                "bound": "hbm" if in_hbm else "pcie",
+                "bound": "hbm",
+                "limited_by": None if in_hbm else "PCIe Gen5 x16 (~63 GB/s): the table's rows live in pinned host DRAM",
                 "kernel": ("scone_gather::k_embed_wave (gather+dequant+reduce+combine), HIP-event timed" if n_launch
                            else "whole step (sharded path: match + pack + RCCL + gather)"),
                 # `frac` = achieved / peak is PHYSICAL: bytes of the launch that crossed the L2 <-> fabric boundary (or, without

@@ -65,6 +65,7 @@ struct scone_shard_state {
   uint32_t rmap_gen = 0;
   bool rmap_active = false;        // the CURRENT exchange uses rmap (else rhash)
   std::vector<uint8_t> remapped;   // per sequence of the planned batch: its lists already hold record numbers
+  unsigned long long added = 0;    // records added to the row map in the current exchange
   // Plan slots (scone_shard_select_slot): the receiver-side state of a planned batch -- its id lists, the scales of
   // [head | received records], the row map -- exists up to SCONE_SHARD_SLOTS times, so that batches b + 1 (and b + 2) can be
   // planned, packed and exchanged on side streams while batch b is still being reduced.  The fields above are the ACTIVE
@@ -82,6 +83,7 @@ struct scone_shard_state {
     uint32_t rmap_gen = 0;
     bool rmap_active = false;
     std::vector<uint8_t> remapped;
+    unsigned long long added = 0;
   };
 #define SCONE_SHARD_SLOTS 4
   plan_slot parked[SCONE_SHARD_SLOTS];  // parked[k]: state of slot k while it is not the active one (parked[slot] is unused)
@@ -860,6 +862,7 @@ static void plan_reset(scone_shard_state *st, int32_t B, int32_t T, int32_t n_ch
   st->plan_B = B, st->plan_T = T, st->plan_chunks = n_chunks;
   st->ell_ext = ell_ext;
   st->remapped.assign((size_t)(B > 0 ? B : 0), 0);
+  st->added = 0;
 }
 
 extern "C" int scone_shard_gather_plan_chunks(scone_handle *h, const int32_t *d_tok, int32_t B, int32_t T, int32_t n_chunks,
@@ -942,6 +945,7 @@ static void swap_slot(scone_shard_state *st, scone_shard_state::plan_slot &p) {
   std::swap(st->rmap_gen, p.rmap_gen);
   std::swap(st->rmap_active, p.rmap_active);
   st->remapped.swap(p.remapped);
+  std::swap(st->added, p.added);
 }
 
 extern "C" int scone_shard_select_slot(scone_handle *h, int32_t slot) {
@@ -1029,9 +1033,13 @@ int scone_shard_gather_add(scone_handle *h, const void *d_records, uint64_t n, u
   const unsigned long long n_head = st->n_head;
   if (n_total > 0xFFFFFFF0ull || record0 + n > n_total) return scone_fail(h, SCONE_EINVAL, "scone_shard_gather_embed: bad record range");
   if (record0 == 0) {
-    for (uint8_t r : st->remapped)
-      if (r) return scone_fail(h, SCONE_ESTATE, "scone_shard_gather_add_records: lists of this plan already hold record numbers of "
-                                                "an earlier exchange (plan the batch again before a new exchange)");
+    // (lists rewritten while the map was still EMPTY -- the first chunks of a pipelined exchange brought no records --
+    // reference head rows only: nothing in them depends on the map that is (re)started here)
+    if (st->added)
+      for (uint8_t r : st->remapped)
+        if (r) return scone_fail(h, SCONE_ESTATE, "scone_shard_gather_add_records: lists of this plan already hold record numbers of "
+                                                  "an earlier exchange (plan the batch again before a new exchange)");
+    st->added = 0;
     if (sb) {
       long long cap = st->cap_recv;
       uint8_t *p = st->scales;
@@ -1064,6 +1072,7 @@ int scone_shard_gather_add(scone_handle *h, const void *d_records, uint64_t n, u
   } else if (st->rhash_cap_now < 2 * (long long)n_total || (sb && st->cap_recv < (long long)(n_head + n_total))) {
     return scone_fail(h, SCONE_ESTATE, "scone_shard_gather_embed: records added out of order (start with record 0)");
   }
+  st->added += n;
   if (n) {
     uint8_t *sc = st->scales ? st->scales + (size_t)(n_head + record0) * sb : nullptr;
     if (st->rmap_active)

@@ -187,6 +187,77 @@ def test_split_phase_gather_two_batches_in_flight_across_processes(fmt, d, max_n
         assert shape == (5, 33, d) and same, rank
 
 
+def _worker_soak(rank, world, port, slots, q):
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        torch.cuda.set_device(0)
+        from scone_amd import EmbeddingCache, NGramExtractor
+        from scone_amd.distributed import ShardedEmbeddingCache
+        fmt, d, max_n, head = "int4", 1024, 3, 60
+        keys, lens, table, _, wte, wpe = _problem(fmt, d, max_n)
+        ex = NGramExtractor.from_arrays(keys, lens, max_n=max_n)
+        sh = ShardedEmbeddingCache(ex, d, table_format=fmt, rank=rank, world=world, replicated_rows=head, plan_slots=slots)
+        sh.load_rows(torch.from_numpy(table), 0)
+        full = EmbeddingCache(ex, d, table_format=fmt)
+        full.cache_embeddings(list(range(len(lens))), torch.from_numpy(table), verbose=False)
+        rng = np.random.default_rng(2026)                              # the same choices on every rank
+        wte_d = torch.from_numpy(wte).half().cuda()
+        wpe_d = torch.from_numpy(np.tile(wpe, (3, 1))[:80]).half().cuda()
+        n, bad, tickets, batches = 60, [], [], []
+        free0 = None
+        for i in range(n + slots - 1):
+            if i < n:
+                B, T = int(rng.integers(1, 12)), int(rng.integers(1, 80))
+                tok = torch.from_numpy(rng.integers(0, 24, size=(B, T)))
+                sh.gather_chunks = int(rng.integers(1, 4))             # 1 = columns on the wire, 2 / 3 = chunked records
+                sh.shard_match = bool(rng.integers(2))                 # the plan's match sharded over the ranks, or not
+                sh.gather_transport = ("p2p", "all_gather")[int(rng.integers(2))]
+                tickets.append(sh.gather_rows_begin(tok))
+                batches.append(tok)
+            if i >= slots - 1:
+                k = i - (slots - 1)
+                out = sh.gather_rows_finish(tickets[k], wte=wte_d, wpe=wpe_d)
+                if not torch.equal(out, full.embed_tokens(batches[k], wte=wte_d, wpe=wpe_d)):
+                    bad.append(k)
+                tickets[k] = None
+            if i == 20:
+                torch.cuda.synchronize()
+                free0 = torch.cuda.mem_get_info()[0]
+        torch.cuda.synchronize()
+        drift = free0 - torch.cuda.mem_get_info()[0]
+        q.put((rank, bad, int(drift), sh.table.status()))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:
+        import traceback
+        q.put((rank, repr(e) + traceback.format_exc(), 0, -1))
+
+
+@pytest.mark.parametrize("world,slots", [(2, 2), (3, 3)])
+def test_split_phase_soak_random_shapes_forms_and_slots(world, slots):
+    """60 batches of random shape through the split-phase loop, `slots` batches in flight, every batch with its own form --
+    one piece with columns on the wire or 2-3 chunks of records, match sharded over the ranks or not, exact ranges or padded
+    all-gathers: buffers of every slot are re-used and re-grown across shapes; every output equals the unsharded lookup of
+    ITS batch, the status word stays clean, device memory does not drift."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_soak, args=(r, world, port, slots, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=400) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, bad, drift, status in results:
+        assert isinstance(bad, list), f"rank {rank} failed: {bad}"
+        assert bad == [] and status == 0, (rank, bad, status)
+        assert drift < 256 * 2**20, (rank, drift)                       # (three processes share the card: allow their allocators some room)
+
+
 @pytest.mark.parametrize("mode", ["replicated", "sharded", "sharded-slices"])
 def test_bench_two_ranks_launched_like_the_driver(mode):
     """`python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2` with the rehearsal knobs

@@ -1317,6 +1317,57 @@ def test_slice_exchange_one_record_per_distinct_row_and_destination(fmt, d, max_
         s.shard_gather_embed_range(tok[:, :-1].contiguous(), 0, 1, recv, torch.empty((tok.numel(), d), dtype=torch.float16, device="cuda"))
 
 
+def test_chunked_gather_whose_first_chunk_brings_no_records():
+    """A pipelined `gather_rows` whose first chunk references head rows only: its records range is empty, so the NEXT chunk's
+    records start at record 0 as well -- the row map is (re)started although the first chunk's lists were already rewritten
+    (against an empty map: nothing in them depends on it).  Found by the split-phase soak; must not be refused as 'a new
+    exchange on rewritten lists', and the output is the unsharded table's."""
+    from scone_amd.hip_backend import SconeError, SconeTable
+    rng = np.random.default_rng(3)
+    vocab, n, d, head = 12, 200, 768, 12
+    keys = np.zeros((n, 3), dtype=np.uint32)
+    lens = np.ones(n, dtype=np.uint8)
+    keys[:vocab, 0] = np.arange(vocab)                                   # ids 0..11: the unigrams = the replicated head
+    pairs = [(a, b) for a in range(6, vocab) for b in range(6, vocab)] + [(a, b, c) for a in range(6, vocab) for b in range(6, vocab) for c in range(6, vocab)]
+    for i, g in enumerate(pairs[:n - vocab]):                            # bigrams / trigrams over tokens 6..11 only
+        keys[vocab + i, :len(g)] = g
+        lens[vocab + i] = len(g)
+    table = rng.standard_normal((n, d)).astype(np.float32)
+    full = SconeTable(3, n, d, "int8")
+    full.index_build(keys, lens)
+    full.store_f32(torch.from_numpy(table))
+    shards = []
+    for r in range(2):
+        s = SconeTable(3, n, d, "int8", row_begin=r * n // 2, row_end=(r + 1) * n // 2)
+        s.index_build(keys, lens)
+        s.store_f32(torch.from_numpy(table[r * n // 2:(r + 1) * n // 2]), row0=r * n // 2)
+        s.shard_set_head(head)
+        s.shard_head_store_f32(torch.from_numpy(table[:head]), row0=0)
+        shards.append(s)
+    B, T = 4, 24
+    tok_np = np.empty((B, T), dtype=np.int64)
+    tok_np[:2] = rng.integers(0, 6, size=(2, T))                         # chunk 0: tokens 0..5 -> unigram (head) rows only
+    tok_np[2:] = rng.integers(6, vocab, size=(2, T))                     # chunk 1: bigrams / trigrams of both shards
+    tok = torch.from_numpy(tok_np)
+    want = full.embed(tok, out_dtype=torch.float32).reshape(B * T, d)
+    ends = [s.shard_gather_plan_chunks(tok, 2) for s in shards]
+    assert all(e[0] == 0 for e in ends) and ends[0][1] > 0
+    rec = shards[0].shard_record_bytes()
+    m = max(e[1] for e in ends)
+    records = torch.empty((2 * m, rec), dtype=torch.uint8, device="cuda")
+    for r, s in enumerate(shards):
+        s.shard_gather_pack_range(0, ends[r][1], records[r * m:(r + 1) * m])
+    for s in shards:
+        out = torch.empty((B * T, d), dtype=torch.float32, device="cuda")
+        s.shard_gather_add_records(records, 0, 0)                        # chunk 0: nothing arrived
+        s.shard_gather_embed_range(tok, 0, 2, records, out)
+        s.shard_gather_add_records(records, 0, 2 * m)                    # chunk 1's records start at record 0 too
+        s.shard_gather_embed_range(tok, 2, 4, records, out)
+        assert torch.equal(out, want) and s.status() == 0
+        with pytest.raises(SconeError):                                  # but NOW the lists depend on the map: a restart is refused
+            s.shard_gather_add_records(records, 0, 2 * m)
+
+
 def test_sharded_cache_world1_row_exchange():
     from scone_amd import EmbeddingCache
     from scone_amd.distributed import ShardedEmbeddingCache

@@ -597,6 +597,72 @@ def test_gather_rows_split_phase_two_batches_in_flight_world2_gloo(slots, chunks
         assert err < 1e-6 and same
 
 
+def _worker_soak(rank, world, port, slots, q):
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from oracle import ref_port as R
+        from scone_amd import NGramExtractor
+        from scone_amd.distributed import ShardedEmbeddingCache, shard_range
+        rng = np.random.default_rng(11)
+        vocab, n, d, max_n, head = 13, 240, 16, 3, 25
+        lens = rng.integers(1, max_n + 1, size=n).astype(np.uint8)
+        keys = rng.integers(0, vocab, size=(n, max_n)).astype(np.uint32)
+        keys[np.arange(max_n)[None, :] >= lens[:, None]] = 0
+        table = rng.standard_normal((n, d)).astype(np.float32)
+        wte = torch.from_numpy(rng.standard_normal((vocab, d)).astype(np.float32))
+        wpe = torch.from_numpy(rng.standard_normal((40, d)).astype(np.float32))
+        ex = NGramExtractor.from_arrays(keys, lens, max_n=max_n)
+        a, b = shard_range(n, rank, world)
+        shard = OracleShard(keys, lens, max_n, table, a, b)
+        shard.shard_set_head(head)
+        cache = ShardedEmbeddingCache(ex, d, rank=rank, world=world, n_rows=n, table=shard, replicated_rows=head, plan_slots=slots)
+        tickets, batches, worst = [], [], 0.0
+        steps = 24
+        for i in range(steps + slots - 1):
+            if i < steps:
+                B, T = int(rng.integers(1, 8)), int(rng.integers(1, 40))
+                tok = torch.from_numpy(rng.integers(0, vocab, size=(B, T)))
+                cache.gather_chunks = int(rng.integers(1, 4))
+                cache.shard_match = bool(rng.integers(2))
+                cache.gather_transport = ("p2p", "all_gather")[int(rng.integers(2))]
+                cache.wire_format = ("columns", "records")[int(rng.integers(2))]
+                tickets.append(cache.gather_rows_begin(tok))
+                batches.append(tok)
+            if i >= slots - 1:
+                k = i - (slots - 1)
+                out = cache.gather_rows_finish(tickets[k], wte=wte, wpe=wpe)
+                tok = batches[k]
+                ro, ri = R.hits_to_csr(R.match_hits(keys, lens, tok.numpy(), max_n))
+                fg = torch.from_numpy(R.embed_numpy(table, ro, ri, "mean").reshape(tok.shape[0], tok.shape[1], d))
+                ref = R.combine(tok, fg, wte, wpe)
+                worst = max(worst, float((out.float() - ref).abs().max() / ref.abs().max()))
+        q.put((rank, worst))
+        dist.destroy_process_group()
+    except Exception as e:
+        import traceback
+        q.put((rank, repr(e) + traceback.format_exc()))
+
+
+@pytest.mark.parametrize("world,slots", [(2, 2), (3, 3), (2, 4)])
+def test_split_phase_soak_random_forms_world_gloo(world, slots):
+    """24 batches of random shape (fewer sequences than ranks included) through the split-phase loop with `slots` batches in
+    flight, every batch with its own form: one piece (columns or records on the wire) or 2-3 chunks, match sharded over the
+    ranks or not, exact ranges or padded all-gathers -- every output equals the oracle's for ITS batch."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_soak, args=(r, world, port, slots, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, err in results:
+        assert isinstance(err, float), f"rank {rank} failed: {err}"
+        assert err < 1e-6
+
+
 def test_gather_transport_is_validated():
     from scone_amd import NGramExtractor
     from scone_amd.distributed import ShardedEmbeddingCache

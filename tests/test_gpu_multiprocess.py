@@ -214,6 +214,7 @@ def _worker_soak(rank, world, port, slots, q):
                 sh.gather_chunks = int(rng.integers(1, 4))             # 1 = columns on the wire, 2 / 3 = chunked records
                 sh.shard_match = bool(rng.integers(2))                 # the plan's match sharded over the ranks, or not
                 sh.gather_transport = ("p2p", "all_gather")[int(rng.integers(2))]
+                sh.wire_format = ("columns", "columns", "records")[int(rng.integers(3))]      # (of the one-piece form)
                 tickets.append(sh.gather_rows_begin(tok))
                 batches.append(tok)
             if i >= slots - 1:

@@ -729,7 +729,8 @@ def sharded_record(args, dist, rank, world, backend, sync, rec, line, watchdog, 
         watchdog.disarm()
         line.set(rec, "n1_pinned_host", n1)
     n1_value = (n1 or {}).get("value")
-    watchdog.arm("sharded.build", min(200.0, max(budget.remaining() - 30.0, 10.0)))
+    # (ranks other than 0 enter this stage while rank 0 is still measuring its baseline: their limit includes that wait)
+    watchdog.arm("sharded.build", min(200.0 + (150.0 if rank else 0.0), max(budget.remaining() - 30.0, 10.0)))
     free, total = torch.cuda.mem_get_info()
     fm = torch.tensor([float(free)], dtype=torch.float64, device=cdev)
     dist.all_reduce(fm, op=dist.ReduceOp.MIN)       # every rank must size the table the same way: the tightest GPU decides

@@ -834,11 +834,12 @@ def sharded_record(args, dist, rank, world, backend, sync, rec, line, watchdog, 
                     "roofline": roofline_of(kw, ms, phm, wire)}
         return name, fn
 
-    def split_phase(name, transport, same_as, slots=2):
+    def split_phase(name, transport, same_as, slots=2, shard_match="auto"):
         def fn():
             cache.gather_chunks = 1
             cache.gather_transport = transport
             cache.plan_slots = slots
+            cache.shard_match = shard_match
 
             def loop(n):
                 o, nxt, q = None, 0, []
@@ -857,7 +858,7 @@ def sharded_record(args, dist, rank, world, backend, sync, rec, line, watchdog, 
             out = loop(args.sharded_steps)
             sync()
             dt = time.perf_counter() - t0
-            cache.plan_slots = 2
+            cache.plan_slots, cache.shard_match = 2, "auto"
             tm = torch.tensor([dt], dtype=torch.float64, device=cdev)
             dist.all_reduce(tm, op=dist.ReduceOp.MAX)
             dt = float(tm.item())
@@ -866,6 +867,8 @@ def sharded_record(args, dist, rank, world, backend, sync, rec, line, watchdog, 
             one = rec["exchanges"].get(same_as, {})
             return {"ms_per_step": ms, "tokens_per_s": ntok * args.sharded_steps / dt,
                     "steps": args.sharded_steps, "batches_in_flight": slots, "chunks": 1,
+                    "match": ("sharded over the ranks + all-gather of the list records" if shard_match else
+                              "every rank matches the whole batch (no list records on the wire)"),
                     "wire_format": "columns: payload rows | scales | the senders' hash fragments",
                     "records_transport": {"p2p": "batch_isend_irecv, exact ranges", "all_gather": "all_gather_into_tensor, padded"}[transport],
                     "same_output_as_gather_rows": bool(float(out.float().abs().sum().item()) == checks.get(same_as)),
@@ -883,8 +886,12 @@ def sharded_record(args, dist, rank, world, backend, sync, rec, line, watchdog, 
               one_call("gather_rows", {"exchange": "gather_rows", **whole}, chunks, "p2p"),
               one_call("gather_rows_one_shot", {"exchange": "gather_rows", **whole}, 1, "p2p"),
               split_phase("gather_rows_split_phase", "p2p", "gather_rows_one_shot"),
-              split_phase("gather_rows_split_phase_3_in_flight", "p2p", "gather_rows_one_shot", 3)]
-    p2p_names = ("gather_rows", "gather_rows_one_shot", "gather_rows_split_phase", "gather_rows_split_phase_3_in_flight")
+              split_phase("gather_rows_split_phase_3_in_flight", "p2p", "gather_rows_one_shot", 3),
+              # the trade the sharded match makes, the other way round: 76 us more GPU work per rank and step, 29 MB less on
+              # the wire -- the faster form on links that turn out to be the bottleneck
+              split_phase("gather_rows_split_phase_every_rank_matches", "p2p", "gather_rows_one_shot", 2, False)]
+    p2p_names = ("gather_rows", "gather_rows_one_shot", "gather_rows_split_phase", "gather_rows_split_phase_3_in_flight",
+                 "gather_rows_split_phase_every_rank_matches")
     with line.lock:
         rec["exchanges"] = {}
         rec["transport_fallback"] = ("records over batch_isend_irecv (exact ranges) not measured yet: the ..._padded_all_gather "

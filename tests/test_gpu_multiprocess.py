@@ -304,7 +304,7 @@ def _check_sharded_record(rec, world):
     one_call = ("rows+all_gather", "rows_slices_only", "gather_rows_padded_all_gather", "gather_rows_one_shot_padded_all_gather",
                 "gather_rows", "gather_rows_one_shot")
     split = ("gather_rows_split_phase_padded_all_gather", "gather_rows_split_phase_3_in_flight_padded_all_gather",
-             "gather_rows_split_phase", "gather_rows_split_phase_3_in_flight")
+             "gather_rows_split_phase", "gather_rows_split_phase_3_in_flight", "gather_rows_split_phase_every_rank_matches")
     assert list(rec["exchanges"]) == list(one_call[:4]) + list(split[:2]) + list(one_call[4:]) + list(split[2:])   # plain collectives first, point-to-point last
     for name in one_call:
         e = rec["exchanges"][name]

@@ -89,6 +89,8 @@ def _compare_with_c_oracle(embed_f32, embed_f16, keys, lens, tok_np, ri, fmt, d,
     ("headline", "int8", 768, 1_000_000, "zipf", 2048),        # the bench's batch, whole: 48 workgroup runs of 43 sequences
     ("C2", "fp16", 768, 1_000_000, "zipf", 256),
     ("int4_1M", "int4", 1024, 1_000_000, "zipf", 300),          # 43 runs of 7 sequences, the last one of 6
+    ("fp32_1M", "fp32", 768, 1_000_000, "zipf", 256),           # the reference's own table format (embedding_cache.py:86)
+    ("int8_d1280", "int8", 1280, 1_000_000, "zipf", 257),       # gpt2-large's width; an odd number of sequences
     ("C3", "int8", 1024, 10_000_000, "structured", 256),
     ("C4_in_hbm", "int4", 1024, 100_000_000, "structured", 256),
 ])

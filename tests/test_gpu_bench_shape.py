@@ -300,3 +300,41 @@ def test_eight_shard_columns_exchange_against_the_c_oracle(fmt, d, match):
             shards[q].shard_cols_embed(tok, s0, s0 + B // 2, rows, total, scales, frags2, frag_off, slots, rec_base, out16, wte=wte, wpe=wpe)
         bad = _compare_with_c_oracle(lambda: out32.view(B, T, d), lambda: out16.view(B, T, d), keys, lens, tok_np, ri, fmt, d, wte, wpe)
         assert bad == 0 and shards[q].status() == 0
+
+
+class _RowsById:
+    """table_f32[id] for the oracle's paper_embed over a table of which only the referenced rows exist on the host."""
+
+    def __init__(self, ids, rows):
+        self.pos = {int(i): k for k, i in enumerate(ids.tolist())}
+        self.rows, self.shape = rows, (1 << 62, rows.shape[1])
+
+    def __getitem__(self, i):
+        return self.rows[self.pos[int(i)]]
+
+
+def test_paper_mode_at_the_bench_shape_against_the_oracle():
+    """`lookup_mode="longest_suffix"` (the paper's Algorithm 2; unpinned by reference code: the reference holds it as an image)
+    through the large-batch kernels at 160 x 512 tokens -- four sequences per workgroup run -- on the 1M-row INT8 table:
+    every token's fp32 output equals `oracle.paper_embed` on the recomputed rows, with and without wte / wpe."""
+    from scone_amd import EmbeddingCache, NGramExtractor
+    from scone_amd import synthetic as S
+    d, B, T = 768, 160, 512
+    keys, lens = _keys(1_000_000, "zipf")
+    ex = NGramExtractor.from_arrays(keys, lens, max_n=3)
+    cache = EmbeddingCache.from_synthetic(ex, d, table_format="int8", seed=SEED, base_scale=BASE_SCALE, lookup_mode="longest_suffix")
+    tok_np = S.stream_uniform_ids(keys, lens, B, T, 99)
+    tok_np[B // 2:] = S.stream_zipf(S.GPT2_VOCAB, B - B // 2, T, 98)
+    f2id = R._key_dict(keys, lens)
+    ids = np.unique(np.concatenate([np.asarray(R.paper_lookup(f2id, 3, tok_np[b].tolist())) for b in range(B)]))
+    ids = ids[ids >= 0]
+    table = _RowsById(ids, _oracle_rows("int8", ids, d))
+    g = torch.Generator().manual_seed(1)
+    wte = (torch.randn(S.GPT2_VOCAB, d, generator=g) * 0.02).float()
+    wpe = (torch.randn(T, d, generator=g) * 0.01).float()
+    tok = torch.from_numpy(tok_np).to("cuda", torch.int32)
+    got = cache.embed_tokens(tok, wte=wte.cuda(), wpe=wpe.cuda(), out_dtype=torch.float32).cpu().numpy()
+    assert np.array_equal(got, R.paper_embed(f2id, 3, tok_np, table, wte=wte.numpy(), wpe=wpe.numpy()))
+    only = cache.embed_tokens(tok, out_dtype=torch.float32).cpu().numpy()
+    assert np.array_equal(only, R.paper_embed(f2id, 3, tok_np, table))
+    assert cache.table.status() == 0

@@ -338,3 +338,27 @@ def test_paper_mode_at_the_bench_shape_against_the_oracle():
     only = cache.embed_tokens(tok, out_dtype=torch.float32).cpu().numpy()
     assert np.array_equal(only, R.paper_embed(f2id, 3, tok_np, table))
     assert cache.table.status() == 0
+
+
+@pytest.mark.parametrize("kw", [dict(placement="pinned_host", hot_rows=50257), dict(placement="pinned_host", hot_rows=100_000, stage_tokens=32768),
+                                dict(placement="pinned_host", hot_rows=0, stage_tokens=65536)],
+                         ids=["zero_copy_hot_head", "staged_32k", "staged_64k_no_head"])
+def test_pinned_host_table_at_the_bench_shape_against_the_c_oracle(kw):
+    """The table in pinned host DRAM -- rows read in place over PCIe, or staged through HBM in chunks on side streams -- at
+    300 x 512 tokens (several sequences per workgroup run, several staging chunks, a last chunk that is not full): every
+    token against oracle.c, fp32 bit-exact, fp16 bytes equal."""
+    from scone_amd import EmbeddingCache, NGramExtractor
+    from scone_amd import synthetic as S
+    fmt, d, B, T = "int8", 768, 300, 512
+    keys, lens = _keys(1_000_000, "zipf")
+    ex = NGramExtractor.from_arrays(keys, lens, max_n=3)
+    cache = EmbeddingCache.from_synthetic(ex, d, table_format=fmt, seed=SEED, base_scale=BASE_SCALE, **kw)
+    tok_np = S.stream_uniform_ids(keys, lens, B, T, 4242)
+    tok = torch.from_numpy(tok_np).to("cuda", torch.int32)
+    ro, ri = R.hits_to_csr(R.match_hits(keys, lens, tok_np, 3))
+    g = torch.Generator().manual_seed(1)
+    wte = (torch.randn(S.GPT2_VOCAB, d, generator=g) * 0.02).half().cuda()
+    wpe = (torch.randn(T, d, generator=g) * 0.01).half().cuda()
+    bad = _compare_with_c_oracle(lambda: cache.embed_tokens(tok, out_dtype=torch.float32),
+                                 lambda: cache.embed_tokens(tok, wte=wte, wpe=wpe), keys, lens, tok_np, ri, fmt, d, wte, wpe)
+    assert bad == 0 and cache.table.status() == 0

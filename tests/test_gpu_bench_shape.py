@@ -362,3 +362,46 @@ def test_pinned_host_table_at_the_bench_shape_against_the_c_oracle(kw):
     bad = _compare_with_c_oracle(lambda: cache.embed_tokens(tok, out_dtype=torch.float32),
                                  lambda: cache.embed_tokens(tok, wte=wte, wpe=wpe), keys, lens, tok_np, ri, fmt, d, wte, wpe)
     assert bad == 0 and cache.table.status() == 0
+
+
+@pytest.mark.parametrize("fmt,d", [("int8", 768), ("int4", 1024)])
+def test_csr_entry_point_and_partial_sums_at_the_bench_shape(fmt, d):
+    """The two other large-batch entry points at 256 x 512 tokens against the oracle: `embed_tokens(base=...)` = `scone_match_csr`
+    + `scone_gather_reduce` (caller-supplied lists, a dense base tensor: fp32 bit-exact) and the partial-sum form of the
+    sharded path, `scone_embed_partial` on each of 4 shards + `scone_finalize` of the summed partials (the shards' fp32 sums are
+    added in shard order, not list order: within 1e-6 of the oracle, counts exact)."""
+    from scone_amd import EmbeddingCache, NGramExtractor
+    from scone_amd import synthetic as S
+    from scone_amd.distributed import shard_range
+    from scone_amd.hip_backend import SconeTable
+    N, B, T, W = 1_000_000, 256, 512, 4
+    keys, lens = _keys(N, "zipf")
+    ex = NGramExtractor.from_arrays(keys, lens, max_n=3)
+    cache = EmbeddingCache.from_synthetic(ex, d, table_format=fmt, seed=SEED, base_scale=BASE_SCALE)
+    tok_np = S.stream_uniform_ids(keys, lens, B, T, 777)
+    tok = torch.from_numpy(tok_np).to("cuda", torch.int32)
+    ro, ri = R.hits_to_csr(R.match_hits(keys, lens, tok_np, 3))
+    uniq = np.unique(ri)
+    co = COracle(keys[uniq], lens[uniq], 3)
+    ref, total = co.embed(_oracle_rows(fmt, uniq, d), tok_np, "mean", _nthreads())
+    assert total == ri.size
+    g = torch.Generator().manual_seed(3)
+    base = torch.randn(B, T, d, generator=g) * 0.05
+    got = cache.embed_tokens(tok, base=base.cuda()).cpu().numpy()
+    assert np.array_equal(got, base.numpy() + ref)
+    del cache
+    # partial sums over 4 shards, summed, finalised
+    sums = torch.zeros(B * T, d, dtype=torch.float32, device="cuda")
+    counts = None
+    for r in range(W):
+        lo, hi = shard_range(N, r, W)
+        s = SconeTable(3, N, d, fmt, row_begin=lo, row_end=hi)
+        s.index_build(keys, lens)
+        s.fill_synthetic(SEED, BASE_SCALE)
+        part, cnt = s.embed_partial(tok)
+        sums += part
+        counts = cnt if counts is None else counts
+        assert torch.equal(cnt, counts)
+    assert np.array_equal(counts.cpu().numpy(), np.diff(ro))
+    out = s.finalize(sums, counts, tok, 0, B * T, out_dtype=torch.float32).cpu().numpy().reshape(B, T, d)
+    assert np.abs(out - ref).max() <= 1e-6 * np.abs(ref).max()

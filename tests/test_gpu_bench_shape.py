@@ -405,3 +405,47 @@ def test_csr_entry_point_and_partial_sums_at_the_bench_shape(fmt, d):
     assert np.array_equal(counts.cpu().numpy(), np.diff(ro))
     out = s.finalize(sums, counts, tok, 0, B * T, out_dtype=torch.float32).cpu().numpy().reshape(B, T, d)
     assert np.abs(out - ref).max() <= 1e-6 * np.abs(ref).max()
+
+
+def test_eight_shard_slice_exchange_against_the_c_oracle():
+    """The slice exchange (`exchange="rows"`: one record per distinct row and DESTINATION, all-to-all by hand) over 8 shards at
+    256 x 512 tokens: every rank reduces its own 32 sequences out of what the owners sent it; the assembled [B, T, d] against
+    oracle.c -- fp32 bit-exact, fp16 bytes equal."""
+    from scone_amd import synthetic as S
+    from scone_amd.distributed import shard_range
+    from scone_amd.hip_backend import SconeTable
+    fmt, d, N, W, B, T, head = "int4", 1024, 1_000_000, 8, 256, 512, S.GPT2_VOCAB
+    keys, lens = _keys(N, "zipf")
+    tok_np = S.stream_uniform_ids(keys, lens, B, T, 2468)
+    tok = torch.from_numpy(tok_np).to("cuda", torch.int32)
+    ro, ri = R.hits_to_csr(R.match_hits(keys, lens, tok_np, 3))
+    g = torch.Generator().manual_seed(1)
+    wte = (torch.randn(S.GPT2_VOCAB, d, generator=g) * 0.02).half().cuda()
+    wpe = (torch.randn(T, d, generator=g) * 0.01).half().cuda()
+    shards = []
+    for r in range(W):
+        lo, hi = shard_range(N, r, W)
+        s = SconeTable(3, N, d, fmt, row_begin=lo, row_end=hi)
+        s.index_build(keys, lens)
+        s.shard_set_head(head)
+        s.fill_synthetic(SEED, BASE_SCALE)
+        shards.append(s)
+    rec, bper = shards[0].shard_record_bytes(), B // W
+    outs = {}
+    for dtype, kw in ((torch.float32, {}), (torch.float16, dict(wte=wte, wpe=wpe))):
+        ends = [s.shard_gather_plan_chunks(tok, W, dedup_across_chunks=False) for s in shards]   # chunk q = what rank q's slice needs
+        cnt = [[e[0]] + [e[q] - e[q - 1] for q in range(1, W)] for e in ends]
+        sends = []
+        for r, s in enumerate(shards):
+            buf = torch.empty((max(ends[r][-1], 1), rec), dtype=torch.uint8, device="cuda")
+            s.shard_gather_pack_range(0, ends[r][-1], buf[:ends[r][-1]])
+            sends.append(buf)
+        out = torch.empty((B * T, d), dtype=dtype, device="cuda")
+        for q, s in enumerate(shards):
+            recv = torch.cat([sends[r][sum(cnt[r][:q]):sum(cnt[r][:q + 1])] for r in range(W)]).contiguous()   # the all-to-all, by hand
+            s.shard_gather_add_records(recv, 0, recv.shape[0])
+            s.shard_gather_embed_range(tok, q * bper, (q + 1) * bper, recv, out[q * bper * T:(q + 1) * bper * T], out_is_slice=True, **kw)
+            assert s.status() == 0
+        outs[dtype] = out.view(B, T, d)
+    bad = _compare_with_c_oracle(lambda: outs[torch.float32], lambda: outs[torch.float16], keys, lens, tok_np, ri, fmt, d, wte, wpe)
+    assert bad == 0

@@ -37,11 +37,11 @@ def _line(stdout):
 
 @pytest.mark.parametrize("launcher", ["self", "torchrun"])
 def test_hung_collective_still_yields_a_line_and_status_0(launcher):
-    """Stage 2 of 3 hangs (rank 1 never joins the all-reduce).  The stage limit (4 s) ends the job: rank 0 prints what was
-    measured before the hang, marked incomplete, both ranks leave with status 0 -- well inside the 60 s budget.  A thread
+    """Stage 2 of 3 hangs (rank 1 never joins the all-reduce).  The stage limit (8 s) ends the job: rank 0 prints what was
+    measured before the hang, marked incomplete, both ranks leave with status 0 -- well inside the 90 s budget.  A thread
     keeps changing the record all the while: the line is serialised under the lock (round-2 ADVICE: a 'dictionary
     changed size during iteration' on the timer thread used to hang the job for ever)."""
-    args = ["--gpus", "2", "--selftest", "hang", "--time-budget", "60", "--stage-limit", "4"]
+    args = ["--gpus", "2", "--selftest", "hang", "--time-budget", "90", "--stage-limit", "8"]
     if launcher == "self":
         cmd = [sys.executable, BENCH] + args
     else:
@@ -51,7 +51,7 @@ def test_hung_collective_still_yields_a_line_and_status_0(launcher):
     p = subprocess.run(cmd, env=_env(), cwd=ROOT, capture_output=True, text=True, timeout=180)
     took = time.time() - t0
     assert p.returncode == 0, (p.returncode, p.stderr[-3000:])
-    assert took < 60, took
+    assert took < 90, took
     r = _line(p.stdout)
     assert r["n_gpus"] == 2 and r["data"] == "selftest"
     assert "second" in r["incomplete"] and "did not complete" in r["incomplete"]

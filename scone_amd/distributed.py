@@ -34,8 +34,17 @@ here and only needed when the table does not fit one GPU's 288 GB (BASELINE conf
   ``[replicated head | gathered records]`` -- bit-identical again, ~0.25 GB into every rank per 1M-token step instead
   of ~1.9 GB;
 * split-phase form of ``"gather_rows"`` for a serving loop: ``gather_rows_begin`` (plan, packs, transfers -- on a side stream,
-  on the other of the handle's two plan slots) / ``gather_rows_finish`` (the reduction, on the caller's stream): two batches in
-  flight, the next batch's exchange hidden behind the current batch's reduction;
+  on another of the handle's plan slots) / ``gather_rows_finish`` (the reduction, on the caller's stream): two batches in
+  flight (``plan_slots=3``: three), the next batch's exchange hidden behind the current batch's reduction;
+* round 3, both on by default for batches of >= 65,536 tokens.  ``shard_match``: in the all-gather form every rank needs the id
+  lists of the WHOLE batch, and matching all of it against a 1e9-key index was the largest helper kernel of the step; index and
+  tokens are replicated and matching is per sequence, so rank r matches slice r only and the 32-B list records are
+  all-gathered (``scone_shard_gather_match / _plan_ell``).  ``wire_format="columns"`` (the one-piece form): a contribution
+  travels as payload rows | scales | the SENDER's hash fragment ``row id -> position`` instead of ``[payload | scales | row id]``
+  records -- no receiver indexes anything (0.45M device-scope CAS per rank and step before), the rows land at the table's own
+  stride (``scone_shard_cols_pack / _embed``);
+* ``SCONE_DIST_TRACE=1``: one stderr line BEFORE every collective (name, counts, bytes) -- the last line of a hung job names
+  the collective it hangs in;
 * exchange ``"partial_sums"`` (kept for comparison): every rank sums the rows it owns
   (``scone_embed_partial``) -> ``reduce_scatter`` -> ``scone_finalize``;
 * finally an ``all_gather`` of the finished vectors in the output dtype (skippable when the

@@ -706,10 +706,11 @@ def sharded_record(args, dist, rank, world, backend, sync, rec, line, watchdog, 
                         on side streams behind the reduction of step s; with three, that chain may take two reductions'
                         time) -- a throughput figure, a batch's latency is two (three) steps
     and, for contrast, rows_slices_only: the all-to-all alone, every rank keeps its own slice (a consumer that is
-    data-parallel over the same slices needs no more).  Order: the plainest collectives first (all_to_all_single,
-    all_gather_into_tensor), everything that needs the batched point-to-point transport after them -- should that
-    transport hang under RCCL, the watchdog prints every figure measured before it and the padded all-gather figures stand
-    in (`transport_fallback`).  Before any of it rank 0 alone measures the N = 1 baseline (pinned host DRAM), so every
+    data-parallel over the same slices needs no more).  Order: the forms that need only all_gather_into_tensor first (the
+    split-phase loop among them: the figure the ">= 4x" claim rests on), then the slice exchange (all_to_all_single with
+    uneven splits), everything that needs the batched point-to-point transport last -- should a collective hang under RCCL,
+    the watchdog prints every figure measured before it, and the padded all-gather figures stand in for the point-to-point
+    ones (`transport_fallback`).  Before any of it rank 0 alone measures the N = 1 baseline (pinned host DRAM), so every
     exchange carries `speedup_vs_n1_pinned_host`.  Un-synchronised steps give ms/step; one instrumented step per exchange
     (device synchronised between phases) gives the phase split.  `rec` is filled in place under `line.lock`."""
     import torch
@@ -876,12 +877,15 @@ def sharded_record(args, dist, rank, world, backend, sync, rec, line, watchdog, 
         return name, fn
 
     whole = {"gather_output": True}
-    stages = [one_call("rows+all_gather", {"exchange": "rows", **whole}, chunks, "p2p"),
-              one_call("rows_slices_only", {"exchange": "rows", "gather_output": False}, chunks, "p2p"),
-              one_call("gather_rows_padded_all_gather", {"exchange": "gather_rows", **whole}, chunks, "all_gather"),
-              one_call("gather_rows_one_shot_padded_all_gather", {"exchange": "gather_rows", **whole}, 1, "all_gather"),
+    # Order = what a hang costs least: the forms that need nothing but all_gather_into_tensor first -- among them the
+    # split-phase loop, i.e. the figure the ">= 4x" claim rests on --, then the slice exchange (all_to_all_single with uneven
+    # splits), then everything over the batched point-to-point transport
+    stages = [one_call("gather_rows_one_shot_padded_all_gather", {"exchange": "gather_rows", **whole}, 1, "all_gather"),
               split_phase("gather_rows_split_phase_padded_all_gather", "all_gather", "gather_rows_one_shot_padded_all_gather"),
               split_phase("gather_rows_split_phase_3_in_flight_padded_all_gather", "all_gather", "gather_rows_one_shot_padded_all_gather", 3),
+              one_call("gather_rows_padded_all_gather", {"exchange": "gather_rows", **whole}, chunks, "all_gather"),
+              one_call("rows+all_gather", {"exchange": "rows", **whole}, chunks, "p2p"),
+              one_call("rows_slices_only", {"exchange": "rows", "gather_output": False}, chunks, "p2p"),
               # ---- from here on: the batched point-to-point transport
               one_call("gather_rows", {"exchange": "gather_rows", **whole}, chunks, "p2p"),
               one_call("gather_rows_one_shot", {"exchange": "gather_rows", **whole}, 1, "p2p"),

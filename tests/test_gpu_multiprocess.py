@@ -301,11 +301,12 @@ def _check_sharded_record(rec, world):
     assert rec["world_size"] == world and rec["device_count"] >= 1 and "n1_baseline" in rec
     assert rec["n1_pinned_host"]["value"] > 0 and rec["rows_total"] == world * rec["rows_per_rank"]
     assert "N = 2 / 4 / 8 ranks hold" in rec["workload"]
-    one_call = ("rows+all_gather", "rows_slices_only", "gather_rows_padded_all_gather", "gather_rows_one_shot_padded_all_gather",
+    one_call = ("gather_rows_one_shot_padded_all_gather", "gather_rows_padded_all_gather", "rows+all_gather", "rows_slices_only",
                 "gather_rows", "gather_rows_one_shot")
     split = ("gather_rows_split_phase_padded_all_gather", "gather_rows_split_phase_3_in_flight_padded_all_gather",
              "gather_rows_split_phase", "gather_rows_split_phase_3_in_flight", "gather_rows_split_phase_every_rank_matches")
-    assert list(rec["exchanges"]) == list(one_call[:4]) + list(split[:2]) + list(one_call[4:]) + list(split[2:])   # plain collectives first, point-to-point last
+    # all_gather_into_tensor only (incl. the split-phase loop) -> all_to_all_single -> batch_isend_irecv
+    assert list(rec["exchanges"]) == [one_call[0], split[0], split[1]] + list(one_call[1:4]) + list(one_call[4:]) + list(split[2:])
     for name in one_call:
         e = rec["exchanges"][name]
         assert "error" not in e, e

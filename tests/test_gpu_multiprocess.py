@@ -355,6 +355,89 @@ def test_bench_starts_its_own_ranks_when_no_launcher_did():
     assert p.returncode != 0 and not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
 
 
+def _rccl_world1_worker(port, q):
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", SCONE_DIST_TRACE="1")
+        import torch.distributed as dist
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        from scone_amd import distributed as D
+        dev = "cuda"
+        done = []
+        # the dtypes and shapes the sharded path hands to RCCL (one rank: every collective is a copy to itself, but argument
+        # validation, dtype support and stream semantics are the real thing)
+        ell_send = torch.arange(64 * 8, dtype=torch.int32, device=dev).view(64, 8)
+        ell = torch.empty_like(ell_send)
+        D._all_gather(ell.view(-1), ell_send.view(-1), None)                         # list records: int32
+        assert torch.equal(ell, ell_send); done.append("all_gather int32")
+        cnt = torch.tensor([12345], dtype=torch.int64, device=dev)
+        allc = torch.empty(1, dtype=torch.int64, device=dev)
+        D._all_gather(allc, cnt, None)                                              # record counts: int64 -> .tolist()
+        assert allc.tolist() == [12345]; done.append("all_gather int64")
+        rows = torch.randint(0, 255, (33, 512), dtype=torch.uint8, device=dev)
+        got = torch.empty_like(rows)
+        D._all_gather_async(got.view(-1), rows.reshape(-1), None).wait()            # a column, padded all-gather form: uint8, async
+        assert torch.equal(got, rows); done.append("all_gather uint8 async")
+        frag = torch.arange(128, dtype=torch.int64, device=dev)
+        gf = torch.empty_like(frag)
+        D._all_gather_async(gf, frag, None).wait()                                  # hash fragments: int64
+        assert torch.equal(gf, frag); done.append("all_gather int64 async")
+        recs = torch.randint(0, 255, (57, 544), dtype=torch.uint8, device=dev)
+        out = torch.empty_like(recs)
+        D._all_to_all(out, recs, [57], [57], None)                                  # slice exchange: uint8 [n, record], uneven splits
+        assert torch.equal(out, recs); done.append("all_to_all_single uint8 2-D with splits")
+        part = torch.randn(40, 1024, device=dev)
+        mine = torch.empty_like(part)
+        D._reduce_scatter_sum(mine, part, None)                                     # partial sums: fp32
+        assert torch.equal(mine, part); done.append("reduce_scatter_tensor fp32")
+        w = D._exchange_exact_async(rows, [0, 33], [33], 0, None)                   # exact ranges with no peer: nothing to send
+        w.wait(); done.append("batch_isend_irecv (no peers)")
+        t64 = torch.tensor([1.5], dtype=torch.float64, device=dev)                  # bench.py's timing reductions
+        dist.all_reduce(t64, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t64, op=dist.ReduceOp.MIN)
+        assert float(t64.item()) == 1.5; done.append("all_reduce float64 MAX / MIN")
+        dist.barrier()
+        torch.cuda.synchronize()
+        q.put((done, None))
+        dist.destroy_process_group()
+    except Exception as e:
+        import traceback
+        q.put((None, repr(e) + traceback.format_exc()))
+
+
+def test_rccl_accepts_every_collective_of_the_sharded_path_world1():
+    """RCCL itself (backend "nccl"), ONE rank on the one GPU: every collective the sharded path and bench.py issue -- with the
+    dtypes, shapes, split lists and async handles they use -- is accepted, completes and delivers (to itself).  Not a
+    substitute for the multi-GPU test below, but argument validation, dtype support (uint8 / int32 / int64 / float64), the
+    dmabuf-IPC environment and the stream semantics are RCCL's own here, on every box of this pool."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_world1_worker, args=(_free_port(), q))
+    p.start()
+    done, err = q.get(timeout=300)
+    p.join(timeout=60)
+    assert done is not None, err
+    assert len(done) == 8, done
+
+
+def test_bench_runs_under_rccl_with_one_rank():
+    """`bench.py --force-dist` on one GPU: the N > 1 code path of the headline (process group with `device_id`, barrier +
+    synchronise around the timed region, max-over-ranks all-reduce on the device, final barrier, destroy) under RCCL."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "SCONE_DIST_BACKEND", "SCONE_ONE_DEVICE")}
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--force-dist", "--quick", "--steps", "5", "--warmup", "2",
+                        "--rows", "200000", "--batch", "256"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1, p.stdout[-2000:]
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 1 and r["value"] > 0 and r["roofline"]["timed_launches"] == 5
+
+
 def _nccl_worker(rank, world, port, q):
     try:
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")

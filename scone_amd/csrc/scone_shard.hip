@@ -50,6 +50,13 @@ struct scone_shard_state {
   long long cap_uniq = 0;
   unsigned long long n_uniq = 0;   // records of the current plan
   uint32_t *chunk_ends = nullptr;  // [64] value of the claim counter after each chunk of the plan
+  // slice exchange (a claim generation per chunk): one claim table and one list region PER CHUNK, so that all chunks claim in
+  // ONE launch (the single table forced one launch per chunk, in order: 8 x 17 us + 8 copies at W = 8)
+  uint32_t *multi_claim = nullptr;  // [multi_tables, local rows]
+  int multi_tables = 0;
+  uint32_t multi_gen = 0;
+  int32_t *regions = nullptr;       // [n_chunks, region capacity] claimed ids per chunk, compacted into uniq_list afterwards
+  long long cap_regions = 0;
   int32_t plan_B = 0, plan_T = 0, plan_chunks = 0;
   long long rhash_cap_now = 0;     // capacity the receiver's map was cleared for (current exchange)
   unsigned long long *rhash = nullptr;  // receiver: open-addressing map row id -> record number
@@ -297,7 +304,7 @@ void scone_shard_destroy(scone_handle *h) {
   if (!st) return;
   void *ptrs[] = {st->ell_send, st->ell_slice, st->counters, st->send_src, st->slot_of_ref, st->scales,
                   st->head_rows, st->head_scales, st->uniq_claim, st->uniq_list, st->rhash, st->chunk_ends,
-                  st->rmap, st->head_rows_p};
+                  st->rmap, st->head_rows_p, st->multi_claim, st->regions};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   for (int k = 0; k < SCONE_SHARD_SLOTS; ++k) {
@@ -530,10 +537,10 @@ namespace {
 // of threads in flight with a quarter of those atomics
 #define CLAIM_THREADS 1024
 #define CLAIM_BLOCKS 512
-__global__ __launch_bounds__(CLAIM_THREADS) void k_gather_claim(const int32_t *__restrict__ ell, long long ntok, int W, int NC,
-                                                      long long row_begin, long long send_begin, long long row_end,
-                                                      uint32_t *__restrict__ claim, uint32_t gen,
-                                                      uint32_t *__restrict__ count, int32_t *__restrict__ list, long long cap) {
+__device__ __forceinline__ void claim_run(const int32_t *__restrict__ ell, long long ntok, int W, int NC,
+                                          long long row_begin, long long send_begin, long long row_end,
+                                          uint32_t *__restrict__ claim, uint32_t gen,
+                                          uint32_t *__restrict__ count, int32_t *__restrict__ list, long long cap) {
   // the workgroup's claimed ids are stashed in LDS and appended to the list with ONE global atomic at the end (a global
   // atomic per claimed row on the one counter would serialise: ~90 per microsecond); a stash overflow appends directly
   __shared__ int32_t stash[GATHER_STASH];
@@ -580,6 +587,39 @@ __global__ __launch_bounds__(CLAIM_THREADS) void k_gather_claim(const int32_t *_
   __syncthreads();
   for (uint32_t k = threadIdx.x; k < n; k += blockDim.x)
     if ((long long)(base + k) < cap) list[base + k] = stash[k];
+}
+
+__global__ __launch_bounds__(CLAIM_THREADS) void k_gather_claim(const int32_t *__restrict__ ell, long long ntok, int W, int NC,
+                                                                 long long row_begin, long long send_begin, long long row_end,
+                                                                 uint32_t *__restrict__ claim, uint32_t gen,
+                                                                 uint32_t *__restrict__ count, int32_t *__restrict__ list, long long cap) {
+  claim_run(ell, ntok, W, NC, row_begin, send_begin, row_end, claim, gen, count, list, cap);
+}
+
+// every chunk of a slice-exchange plan in one launch: blockIdx.y = chunk, with its own claim table, counter and list region
+__global__ __launch_bounds__(CLAIM_THREADS) void k_gather_claim_chunks(const int32_t *__restrict__ ell, int B, int T, int n_chunks, int W, int NC,
+                                                                       long long row_begin, long long send_begin, long long row_end,
+                                                                       uint32_t *__restrict__ claims, long long local_rows, uint32_t gen,
+                                                                       uint32_t *__restrict__ counts, int32_t *__restrict__ regions,
+                                                                       long long region_cap) {
+  const int q = blockIdx.y;
+  const long long per = ((long long)B + n_chunks - 1) / n_chunks;
+  long long s0 = q * per, s1 = s0 + per;
+  s0 = s0 < B ? s0 : B, s1 = s1 < B ? s1 : B;
+  claim_run(ell + s0 * T * W, (s1 - s0) * T, W, NC, row_begin, send_begin, row_end, claims + (long long)q * local_rows, gen, counts + q,
+            regions + (long long)q * region_cap, region_cap);
+}
+
+struct region_offsets {
+  unsigned int off[65];
+};
+// the chunks' regions laid end to end: the list the pack walks (chunk q's ids at [off[q], off[q + 1]))
+__global__ __launch_bounds__(256) void k_gather_compact(const int32_t *__restrict__ regions, long long region_cap, const region_offsets ro,
+                                                        int32_t *__restrict__ list) {
+  const int q = blockIdx.y;
+  const unsigned int n = ro.off[q + 1] - ro.off[q];
+  for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    list[ro.off[q] + i] = regions[(long long)q * region_cap + i];
 }
 
 // one wave per claimed row: [payload | scales | row id, marker]
@@ -813,6 +853,60 @@ static int plan_claims(scone_handle *h, scone_shard_state *st, const int32_t *el
   SCONE_HIP(h, hipMemsetAsync(st->counters, 0, 3 * 64 * sizeof(uint32_t), s));
   const long long n_head = (long long)st->n_head;
   const long long send_begin = (long long)h->cfg.row_begin > n_head ? (long long)h->cfg.row_begin : n_head;
+  if (!dedup_across_chunks && n_chunks > 1) {
+    // slice exchange: every chunk (= destination) claims independently -> a claim table per chunk, ONE launch for all
+    const size_t lr = (size_t)(h->local_rows ? h->local_rows : 1);
+    if (st->multi_tables < n_chunks) {
+      if (st->multi_claim) SCONE_HIP(h, hipFree(st->multi_claim));
+      st->multi_claim = nullptr, st->multi_tables = 0;
+      SCONE_HIP(h, hipMalloc(&st->multi_claim, lr * (size_t)n_chunks * sizeof(uint32_t)));
+      SCONE_HIP(h, hipMemsetAsync(st->multi_claim, 0, lr * (size_t)n_chunks * sizeof(uint32_t), s));
+      st->multi_tables = n_chunks, st->multi_gen = 0;
+    }
+    st->multi_gen += 1;
+    if (st->multi_gen == 0) {
+      SCONE_HIP(h, hipMemsetAsync(st->multi_claim, 0, lr * (size_t)st->multi_tables * sizeof(uint32_t), s));
+      st->multi_gen = 1;
+    }
+    const long long per_seqs = ((long long)B + n_chunks - 1) / n_chunks;
+    long long region_cap = per_seqs * T * NC < (long long)lr ? per_seqs * T * NC : (long long)lr;
+    if (region_cap < 1) region_cap = 1;
+    rc = grow(h, &st->regions, &st->cap_regions, region_cap * n_chunks, 1);
+    if (rc) return rc;
+    const long long nt_max = per_seqs * T;
+    const long long want = (nt_max + CLAIM_THREADS - 1) / CLAIM_THREADS;
+    long long bx = CLAIM_BLOCKS / n_chunks > 0 ? CLAIM_BLOCKS / n_chunks : 1;  // the same number of threads in flight as one pass
+    if (want < bx) bx = want;
+    if (bx < 1) bx = 1;
+    hipLaunchKernelGGL(k_gather_claim_chunks, dim3((unsigned)bx, (unsigned)n_chunks), dim3(CLAIM_THREADS), 0, s, ell, (int)B, (int)T,
+                       (int)n_chunks, W, NC, (long long)h->cfg.row_begin, send_begin, (long long)h->cfg.row_end, st->multi_claim,
+                       (long long)lr, st->multi_gen, st->counters, st->regions, region_cap);
+    SCONE_HIP(h, hipGetLastError());
+    uint32_t cnt[64];
+    SCONE_HIP(h, hipMemcpyAsync(cnt, st->counters, (size_t)n_chunks * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    SCONE_HIP(h, hipStreamSynchronize(s));
+    region_offsets ro = {};
+    unsigned long long total = 0;
+    for (int c = 0; c < n_chunks; ++c) {
+      if ((long long)cnt[c] > region_cap) {  // cannot happen: a chunk lists at most min(its references, my rows) ids
+        st->n_uniq = 0;
+        return scone_fail(h, SCONE_ERANGE, "scone_shard_gather_plan: claim list overflow");
+      }
+      ro.off[c] = (unsigned int)total;
+      total += cnt[c];
+      h_chunk_end[c] = total;
+    }
+    ro.off[n_chunks] = (unsigned int)total;
+    if ((long long)total > st->cap_uniq) {
+      st->n_uniq = 0;
+      return scone_fail(h, SCONE_ERANGE, "scone_shard_gather_plan: claim list overflow");
+    }
+    if (total)
+      hipLaunchKernelGGL(k_gather_compact, dim3(64, (unsigned)n_chunks), dim3(256), 0, s, st->regions, region_cap, ro, st->uniq_list);
+    SCONE_HIP(h, hipGetLastError());
+    st->n_uniq = total;
+    return SCONE_OK;
+  }
   for (int c = 0; c < n_chunks; ++c) {
     int32_t s0, s1;
     chunk_seqs(B, n_chunks, c, &s0, &s1);

@@ -1113,7 +1113,7 @@ static int rmap_policy(scone_handle *h, scone_shard_state *st) {
   // read when an exchange starts (cheap; lets one process compare the two forms).  Default: the HASH map -- sized by the
   // exchange (8 MB for 0.45M records) it lives in L2 / the Infinity Cache, while the direct-mapped array over all table rows
   // (4 GB at 1e9 rows) turns every lookup into a TLB miss + an HBM access: measured at C5's true scale, alternating on one
-  // box (profiles/r03e): 0.927 against 0.909 ms per step.  SCONE_SHARD_ROW_MAP=direct selects it all the same.
+  // box (profiles/r03h/c5_rank0_step_direct_vs_hash_map.json): 0.927 against 0.909 ms per step.  SCONE_SHARD_ROW_MAP=direct selects it all the same.
   (void)st;
   const char *e = getenv("SCONE_SHARD_ROW_MAP");
   if (e && !strcmp(e, "direct")) return h->cfg.n_rows < 0xFFFFFFFFull ? 1 : 0;
@@ -1357,7 +1357,7 @@ extern "C" int scone_shard_cols_frag_slots(uint64_t count, uint64_t *slots) {
   if (!slots) return SCONE_EINVAL;
   uint64_t s = 64;
   // load <= 0.25: linear probing at 0.5 cost the receiver's remap 43 us instead of 32 and the sender's pack 30 instead of
-  // 23 (profiles/r03t: clusters of occupied slots mean dependent probes); twice the slots are 7 MB more on the wire (3 %)
+  // 23 (profiles/r03u/columns_fragment_load_*: clusters of occupied slots mean dependent probes); twice the slots are 7 MB more on the wire (3 %)
   while (s < 4 * count) s <<= 1;
   *slots = s;
   return SCONE_OK;

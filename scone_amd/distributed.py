@@ -424,7 +424,7 @@ class ShardedEmbeddingCache:
         begun.  ``begin`` blocks the host until the side stream has planned the batch (the record counts size the
         buffers), not until the device is idle.  (Tried in round 3 and dropped: indexing the records and rewriting the id
         lists on a third stream behind the transfers, so that ``finish`` launches the reduction alone -- at C5's true scale
-        the step did not move, 0.926 against 0.921 ms, ``profiles/r03f``; the side stream never waits for the transfers
+        the step did not move, 0.926 against 0.921 ms, ``profiles/r03h/c5_rank0_step_alternating_six_flows_slower_box.json``; the side stream never waits for the transfers
         either way, the caller's stream does.)
 
         ``tokens_ready`` says what the side stream must wait for before it reads the tokens: a ``torch.cuda.Event``

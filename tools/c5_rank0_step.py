@@ -7,8 +7,13 @@ all-gather's receive buffer with the RIGHT row ids (every distinct non-head row 
 grouped by owner, padded like the all-gather pads) and zero payloads -- the lookup reads the same bytes from the same
 places, only the values differ.
 
-Prints rank 0's step (a) issued back to back on one stream and (b) as the split-phase loop issues it
-(gather_rows_begin of the next batch on a side stream / second plan slot behind gather_rows_finish of this one), in ms.
+Times rank 0's step (a) issued back to back on one stream and (b) as the split-phase loop issues it (gather_rows_begin of
+the next batch(es) on a side stream / other plan slots behind gather_rows_finish of this one) for several FLOWS, alternating
+in one process (a box runs the same flow 2-4 % apart from one process to the next; medians over --rounds are printed):
+the round-2 flow (every rank matches the whole batch, records on the wire), + the match sharded over the ranks (the other
+ranks' list records arrive by a device copy), + columns on the wire (round 3: payload rows | scales | sender-built hash
+fragments; the other ranks' fragments are real, built from their row ids), three batches in flight, and the variants that
+were measured and not kept (post stream, direct-mapped row map).  All flows must give the same output checksum.
 tools/shard_emulate.py does the same for ALL eight ranks of a 100M-row table, with real payloads and the bit-exactness check.
 """
 import argparse

@@ -205,7 +205,7 @@ def _worker_soak(rank, world, port, slots, q):
         rng = np.random.default_rng(2026)                              # the same choices on every rank
         wte_d = torch.from_numpy(wte).half().cuda()
         wpe_d = torch.from_numpy(np.tile(wpe, (3, 1))[:80]).half().cuda()
-        n, bad, tickets, batches = 60, [], [], []
+        n, bad, tickets, batches = int(os.environ.get("SCONE_SOAK_STEPS", "60")), [], [], []
         free0 = None
         for i in range(n + slots - 1):
             if i < n:
@@ -250,7 +250,7 @@ def test_split_phase_soak_random_shapes_forms_and_slots(world, slots):
     procs = [ctx.Process(target=_worker_soak, args=(r, world, port, slots, q)) for r in range(world)]
     for p in procs:
         p.start()
-    results = [q.get(timeout=400) for _ in procs]
+    results = [q.get(timeout=1100) for _ in procs]
     for p in procs:
         p.join(timeout=60)
     for rank, bad, drift, status in results:

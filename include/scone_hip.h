@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SCONE_ABI_VERSION 1
+#define SCONE_ABI_VERSION 2
 
 typedef struct scone_handle scone_handle;
 typedef void *scone_stream_t; /* hipStream_t */
@@ -93,10 +93,16 @@ typedef struct scone_cfg {
                               the table takes most of the hits.                              */
   uint32_t lookup_mode;    /* SCONE_MODE_* for scone_embed / scone_embed_partial / scone_finalize           */
   uint32_t stage_tokens;   /* SCONE_PLACE_PINNED_HOST only.  0: the lookup kernel reads host rows in place over
-                              PCIe.  > 0: staged prefetch -- the batch is processed in chunks of about this
-                              many tokens; on a side stream each chunk is matched and its distinct host rows
-                              are copied once into an HBM staging buffer (double-buffered) while the previous
-                              chunk is reduced on the caller's stream                                        */
+                              PCIe.  > 0: prefetch through an HBM cache of cold rows -- the batch is processed in
+                              chunks of about this many tokens; on side streams each chunk is matched, the cold rows
+                              it references that are not cached take a cache slot (clock eviction) and are copied
+                              host -> HBM once, while the previous chunk is reduced on the caller's stream out of
+                              [hot head | cache].  The cache lives as long as the table: a row stays resident across
+                              chunks, batches and calls until it is evicted (the reference's analogue: the page cache
+                              under its memory-mapped table, embedding_cache.py:76-91,132-135)                  */
+  uint64_t cache_rows;     /* stage_tokens > 0: row slots of that cache (payload + scale bytes of HBM each).  At least
+                              what the pipeline needs -- 5 chunks' worst case, 30 x stage_tokens rows for max_n = 3 --
+                              is always provisioned (0 = exactly that); never more than the cold rows               */
 } scone_cfg;
 
 /* ---- lifecycle ----------------------------------------------------------- */
@@ -108,9 +114,13 @@ void scone_destroy(scone_handle *h);
 const char *scone_last_error(const scone_handle *h);
 /* Sticky device-side status bits raised by kernels (bit 0: token outside the
  * base-embedding vocabulary, bit 1: f-gram id outside the table, bit 2: index
- * full, bit 3: the staging buffer of a staged pinned-host lookup overflowed -- sized so that it cannot; the affected
- * tokens read a wrong row); synchronises the stream, returns the bits in *bits and clears them. */
+ * full, bit 3: the cache of cold rows of a pinned-host lookup had no evictable slot for a row -- sized so that it cannot
+ * happen; the affected tokens read a wrong row); synchronises the stream, returns the bits in *bits and clears them. */
 int scone_status(scone_handle *h, uint32_t *bits, scone_stream_t stream);
+/* The cache of cold rows of a pinned-host table (cfg.stage_tokens > 0): its row slots, the rows copied host -> HBM since the
+ * cache was created (every miss crosses PCIe once), the chunks prepared and the tokens per chunk actually used (smaller than
+ * cfg.stage_tokens when the cache is small).  All zero before the first lookup.  Synchronises the device. */
+int scone_stage_counters(scone_handle *h, uint64_t *cache_rows, uint64_t *rows_copied, uint64_t *chunks, uint64_t *chunk_tokens);
 
 /* ---- index: f-gram -> id (replaces NGramExtractor.f_grams / f_gram_to_id,
  *      n_gram_extractor.py:42-44, and the id map of embedding_cache.py:173) --- */
@@ -209,6 +219,16 @@ int scone_embed(scone_handle *h, const int32_t *d_tok, int32_t B, int32_t T, con
 /* Every per-stream workspace of the handle (those that exist, the default stream's -- created here -- and any created
  * later) holds at least max_tokens tokens: nothing is allocated inside a timed region afterwards. */
 int scone_reserve(scone_handle *h, int64_t max_tokens);
+/* CU reserve (new here; the reference is a single-stream Python loop).  A large-batch lookup fills every wave slot of the
+ * chip for the length of the kernel, so a kernel another stream launches meanwhile -- the send / recv channels of an RCCL
+ * collective in the sharded step, a copy kernel -- only gets in where lookup workgroups retire.  With n_reserved > 0 (a
+ * multiple of 8: one CU per XCD; 0 switches it off) the lookup kernels of scone_embed (batches above the one-launch limit),
+ * scone_embed_partial and the scone_shard_*_embed* calls run on a stream of the handle whose CU mask leaves n_reserved
+ * compute units free, ordered into the caller's stream by two events (everything queued on the caller's stream before the
+ * call precedes the lookup, everything queued after follows it); their grids are sized for the remaining CUs.  Not
+ * concurrent with lookups on the same handle (like every table mutation); synchronises the previous masked stream. */
+int scone_set_cu_reserve(scone_handle *h, int32_t n_reserved);
+int scone_get_cu_reserve(scone_handle *h, int32_t *n_reserved, int32_t *n_cus);
 /* Optional timing of the gather/reduce kernel launched by scone_embed: while enabled, every
  * call brackets that kernel with HIP events on the launch stream (a ring of 1024 pairs).
  * scone_profile_read synchronises the device, returns the number of timed launches and
@@ -381,6 +401,31 @@ int scone_shard_cols_embed(scone_handle *h, const int32_t *d_tok, int32_t B, int
                            const uint64_t *h_frag_off, const uint64_t *h_frag_slots, const uint64_t *h_rec_base, int32_t world,
                            const void *d_wte, int64_t vocab, const void *d_wpe, int64_t n_pos, const int32_t *d_pos,
                            int32_t reduce, void *d_out, int64_t out_tok0, int32_t out_dtype, scone_stream_t stream);
+
+/* ---- transport without kernels for the all-gather form (distributed.py: gather_transport="sdma").  The exchange sends exact
+ *      contiguous ranges, so a rank can PUSH its columns into its peers' receive buffers with the copy engines (SDMA over
+ *      xGMI) while every wave slot belongs to the lookup kernel -- RCCL's send / recv are kernels that must find room
+ *      beside it.  One process per GPU: buffers and events are shared through HIP's interprocess handles (64 opaque
+ *      bytes each, moved between the ranks by the caller, e.g. dist.all_gather).
+ *   scone_ipc_alloc / _free           device memory on the handle's device + its interprocess handle (a rank's receive buffer)
+ *   scone_ipc_open / _close           a peer's buffer mapped into this process (peer access is enabled on demand)
+ *   scone_ipc_event_create / _open    an interprocess event (record in the owner, wait anywhere); _destroy frees either kind
+ *   scone_ipc_event_record / _wait    stream-ordered.  NB a wait sees the most recent record AT THE TIME OF THE CALL: the
+ *                                     caller orders "peer has called record" before "I call wait" itself (a host-side
+ *                                     collective between the two, see distributed.py)
+ *   scone_ipc_push                    bytes to a (peer-mapped) device pointer on `stream`; copy_engine != 0 forbids the
+ *                                     blit-kernel fallback (hipMemcpyDeviceToDeviceNoCU)
+ * New here (the reference's only multi-process set-up is training-side DDP, hydra_train.py:32-48). */
+int scone_ipc_alloc(scone_handle *h, uint64_t bytes, void **d_ptr, void *handle64);
+int scone_ipc_free(scone_handle *h, void *d_ptr);
+int scone_ipc_open(scone_handle *h, const void *handle64, void **d_ptr);
+int scone_ipc_close(scone_handle *h, void *d_ptr);
+int scone_ipc_event_create(scone_handle *h, void **event, void *handle64);
+int scone_ipc_event_open(scone_handle *h, const void *handle64, void **event);
+int scone_ipc_event_destroy(scone_handle *h, void *event);
+int scone_ipc_event_record(scone_handle *h, void *event, scone_stream_t stream);
+int scone_ipc_event_wait(scone_handle *h, void *event, scone_stream_t stream);
+int scone_ipc_push(scone_handle *h, void *d_dst, const void *d_src, uint64_t bytes, int32_t copy_engine, scone_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # SCONE_HIP_LIB: alternative build of the same library (A/B kernel experiments)
 LIB_PATH = os.environ.get("SCONE_HIP_LIB") or os.path.join(_HERE, "csrc", "libscone_hip.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 FMT_F32, FMT_F16, FMT_I8, FMT_I4 = 0, 1, 2, 3
 PLACE_HBM, PLACE_PINNED_HOST = 0, 1
@@ -42,6 +42,7 @@ class SconeCfg(C.Structure):
         ("hot_rows", C.c_uint64),
         ("lookup_mode", C.c_uint32),
         ("stage_tokens", C.c_uint32),
+        ("cache_rows", C.c_uint64),
     ]
 
 
@@ -56,6 +57,7 @@ SIGNATURES = {
     "scone_destroy": (None, [_P]),
     "scone_last_error": (C.c_char_p, [_P]),
     "scone_status": (C.c_int, [_P, C.POINTER(_U32), _P]),
+    "scone_stage_counters": (C.c_int, [_P, C.POINTER(_U64), C.POINTER(_U64), C.POINTER(_U64), C.POINTER(_U64)]),
     "scone_index_build": (C.c_int, [_P, _P, _P, _U64, _U64]),
     "scone_index_build_device": (C.c_int, [_P, _P, _P, _U64, _U64, _P]),
     "scone_index_stats": (C.c_int, [_P, C.POINTER(_U64), C.POINTER(_U64), C.POINTER(_U64)]),
@@ -75,6 +77,8 @@ SIGNATURES = {
     "scone_gather_reduce": (C.c_int, [_P, _P, _P, _I64, _P, _I32, _P, _I32, _P]),
     "scone_embed": (C.c_int, [_P, _P, _I32, _I32, _P, _I64, _P, _I64, _P, _I32, _P, _I32, _P]),
     "scone_reserve": (C.c_int, [_P, _I64]),
+    "scone_set_cu_reserve": (C.c_int, [_P, _I32]),
+    "scone_get_cu_reserve": (C.c_int, [_P, C.POINTER(_I32), C.POINTER(_I32)]),
     "scone_profile_enable": (C.c_int, [_P, C.c_int]),
     "scone_profile_read": (C.c_int, [_P, C.POINTER(_U64), C.POINTER(C.c_double), C.c_int]),
     "scone_profile_samples": (C.c_int, [_P, C.POINTER(C.c_float), _U64, C.POINTER(_U64)]),
@@ -105,6 +109,16 @@ SIGNATURES = {
     "scone_shard_pack": (C.c_int, [_P, _I32, _I32, _I32, C.POINTER(_U32), _P, _P]),
     "scone_shard_embed": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _P, _U64, _P, _I64, _P, _I64, _P, _I32, _P, _I32,
                                     _P]),
+    "scone_ipc_alloc": (C.c_int, [_P, _U64, C.POINTER(_P), _P]),
+    "scone_ipc_free": (C.c_int, [_P, _P]),
+    "scone_ipc_open": (C.c_int, [_P, _P, C.POINTER(_P)]),
+    "scone_ipc_close": (C.c_int, [_P, _P]),
+    "scone_ipc_event_create": (C.c_int, [_P, C.POINTER(_P), _P]),
+    "scone_ipc_event_open": (C.c_int, [_P, _P, C.POINTER(_P)]),
+    "scone_ipc_event_destroy": (C.c_int, [_P, _P]),
+    "scone_ipc_event_record": (C.c_int, [_P, _P, _P]),
+    "scone_ipc_event_wait": (C.c_int, [_P, _P, _P]),
+    "scone_ipc_push": (C.c_int, [_P, _P, _P, _U64, _I32, _P]),
     "scone_finalize": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I64, _I64, _P, _I64, _P, _I64, _P, _I32, _P,
                                  _I32, _P]),
 }

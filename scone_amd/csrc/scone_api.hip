@@ -222,6 +222,7 @@ extern "C" int scone_create(const scone_cfg *cfg, scone_handle **out) {
   h->d_zero_row = nullptr, h->reserve_tokens = 0, h->ws_clock = 0;
   h->row_payload_bytes = 0, h->scale_bytes_per_row = 0;
   h->stage = nullptr, h->shard = nullptr;
+  h->cu_reserve = 0, h->lookup_stream = nullptr, h->lookup_in = nullptr, h->lookup_out = nullptr;
   h->prof_on = false, h->prof_ev = nullptr, h->prof_head = 0, h->prof_n = 0, h->prof_ms = 0.0;
 
   uint64_t cap = cfg->index_capacity;
@@ -353,6 +354,9 @@ extern "C" void scone_destroy(scone_handle *h) {
   if (h->d_zero_row) (void)hipFree(h->d_zero_row);
   scone_stage_destroy(h);
   scone_shard_destroy(h);
+  if (h->lookup_stream) (void)hipStreamDestroy(h->lookup_stream);
+  if (h->lookup_in) (void)hipEventDestroy(h->lookup_in);
+  if (h->lookup_out) (void)hipEventDestroy(h->lookup_out);
   if (h->prof_ev) {
     for (int i = 0; i < 2 * SCONE_PROF_RING; ++i)
       if (h->prof_ev[i]) (void)hipEventDestroy(h->prof_ev[i]);
@@ -395,6 +399,71 @@ extern "C" int scone_reserve(scone_handle *h, int64_t max_tokens) {
     if (rc) return rc;
   }
   return SCONE_OK;
+}
+
+// ---------------------------------------------------------------- CU reserve
+// A resident lookup grid holds every wave slot of the chip for the length of the kernel (three full residency rounds of
+// one-wave-per-SIMD workgroups), and whatever another stream launches meanwhile -- the send / recv channels of an RCCL
+// collective, a copy kernel -- gets a workgroup in only where a lookup workgroup retires AND the freed registers suffice.
+// With a reserve of R compute units the lookup runs on a stream whose CU mask excludes them: the transport kernels of the
+// sharded step always find R idle CUs, at the price of R / n_cus of the lookup's issue slots (it is memory-bound: the
+// curve is in DESIGN.md section 6).  Mask bits are dealt round-robin over the 8 XCDs by the driver (bit i -> XCD i % 8),
+// so clearing the TOP R bits (R a multiple of 8) takes R / 8 CUs from every XCD and leaves the L2s evenly loaded.
+extern "C" int scone_set_cu_reserve(scone_handle *h, int32_t n_reserved) {
+  if (!h) return SCONE_EINVAL;
+  if (n_reserved < 0 || n_reserved >= h->n_cus || n_reserved % 8)
+    return scone_fail(h, SCONE_EINVAL, "scone_set_cu_reserve: need 0 <= n_reserved < compute units, a multiple of 8 (one per XCD)");
+  SCONE_ON_DEVICE(h);
+  std::lock_guard<std::mutex> g(h->lookup_mu);
+  if (n_reserved == h->cu_reserve) return SCONE_OK;
+  if (h->lookup_stream) {
+    SCONE_HIP(h, hipStreamSynchronize(h->lookup_stream));
+    SCONE_HIP(h, hipStreamDestroy(h->lookup_stream));
+    h->lookup_stream = nullptr;
+  }
+  h->cu_reserve = 0;
+  if (n_reserved == 0) return SCONE_OK;
+  uint32_t mask[32] = {};
+  const int words = (h->n_cus + 31) / 32;
+  if (words > 32) return scone_fail(h, SCONE_EINVAL, "scone_set_cu_reserve: more than 1024 compute units");
+  int enabled = h->n_cus - n_reserved;
+  if (const char *ev = getenv("SCONE_CU_RESERVE_DEBUG_FULL_MASK"))  // measurement aid: the stream hop without any masking
+    if (*ev == '1') enabled = h->n_cus;
+  for (int i = 0; i < enabled; ++i) mask[i >> 5] |= 1u << (i & 31);
+  SCONE_HIP(h, hipExtStreamCreateWithCUMask(&h->lookup_stream, (uint32_t)words, mask));
+  if (!h->lookup_in) SCONE_HIP(h, hipEventCreateWithFlags(&h->lookup_in, hipEventDisableTiming));
+  if (!h->lookup_out) SCONE_HIP(h, hipEventCreateWithFlags(&h->lookup_out, hipEventDisableTiming));
+  h->cu_reserve = n_reserved;
+  return SCONE_OK;
+}
+
+extern "C" int scone_get_cu_reserve(scone_handle *h, int32_t *n_reserved, int32_t *n_cus) {
+  if (!h) return SCONE_EINVAL;
+  if (n_reserved) *n_reserved = h->cu_reserve;
+  if (n_cus) *n_cus = h->n_cus;
+  return SCONE_OK;
+}
+
+int scone_lookup_enter(scone_handle *h, hipStream_t s, hipStream_t *launch) {
+  *launch = s;
+  if (!h->cu_reserve) return SCONE_OK;  // (read without the lock: set_cu_reserve is not concurrent with lookups, like every table mutation)
+  h->lookup_mu.lock();
+  hipError_t e = hipEventRecord(h->lookup_in, s);
+  if (e == hipSuccess) e = hipStreamWaitEvent(h->lookup_stream, h->lookup_in, 0);
+  if (e != hipSuccess) {
+    h->lookup_mu.unlock();
+    return scone_hip_fail(h, e, "scone_lookup_enter");
+  }
+  *launch = h->lookup_stream;
+  return SCONE_OK;
+}
+
+int scone_lookup_leave(scone_handle *h, hipStream_t s, hipStream_t launch) {
+  if (launch == s) return SCONE_OK;
+  hipError_t e = hipEventRecord(h->lookup_out, launch);
+  if (e == hipSuccess) e = hipStreamWaitEvent(s, h->lookup_out, 0);
+  h->lookup_mu.unlock();
+  return e == hipSuccess ? SCONE_OK : scone_hip_fail(h, e, "scone_lookup_leave");
 }
 
 // ---------------------------------------------------------------- kernel timing

@@ -149,6 +149,13 @@ struct scone_handle {
   scone_cfg cfg;
   int device;
   int n_cus;  // compute units of the device (256 on MI355X)
+  // CU reserve (scone_set_cu_reserve): the large-batch lookup kernel is launched on a stream of THIS handle whose CU mask
+  // leaves `cu_reserve` compute units free, between two events that tie it into the caller's stream -- so that kernels of
+  // other streams (RCCL's send / recv channels, copy kernels) always find whole CUs to run on while a lookup is resident
+  int cu_reserve;
+  hipStream_t lookup_stream;
+  hipEvent_t lookup_in, lookup_out;
+  std::mutex lookup_mu;  // held from the event on the caller's stream to the wait on it: one hop at a time per handle
   long long fused_max_tokens;  // batches up to this many tokens take the one-launch kernel (env SCONE_FUSED_MAX_TOKENS overrides)
   int shard_rec_align;         // record alignment of the shard exchanges (env SCONE_SHARD_REC_ALIGN: 16 (default), 64, 128)
   long long match_tile;        // > 0: positions per workgroup of k_match_ell fixed by env SCONE_MATCH_TILE (else whole residency rounds)
@@ -207,6 +214,11 @@ struct scone_ws_lock {
 };
 int scone_ensure_hits(scone_handle *h, scone_ws *w, int64_t ntok);
 int scone_ensure_ell(scone_handle *h, scone_ws *w, int64_t ntok);
+// CU reserve: where a large lookup is launched.  enter: *launch = s (no reserve), or the handle's masked stream, made to wait
+// for everything queued on s; leave: s waits for what was launched there.  enter takes lookup_mu when it hops, leave drops it.
+int scone_lookup_enter(scone_handle *h, hipStream_t s, hipStream_t *launch);
+int scone_lookup_leave(scone_handle *h, hipStream_t s, hipStream_t launch);
+static inline int scone_lookup_cus(const scone_handle *h) { return h->n_cus - h->cu_reserve > 0 ? h->n_cus - h->cu_reserve : 1; }
 int scone_prof_begin(scone_handle *h, hipStream_t s);  // no-ops unless profiling is enabled; begin takes prof_mu, end drops it
 int scone_prof_end(scone_handle *h, hipStream_t s);
 void scone_prof_abort(scone_handle *h);                // a launch failed between begin and end
@@ -291,6 +303,6 @@ hipEvent_t scone_stage_start_event(scone_handle *h);
 hipEvent_t scone_stage_staged_event(scone_handle *h, int buf);
 int scone_stage_mark_consumed(scone_handle *h, int buf, hipStream_t main_stream);
 const int32_t *scone_stage_ell(scone_handle *h, int buf);
-uint8_t *scone_stage_rows(scone_handle *h, int buf);
-const void *scone_stage_scales(scone_handle *h, int buf);
+uint8_t *scone_stage_rows(scone_handle *h);      // the cache of cold rows: slot s at s * payload bytes
+const void *scone_stage_scales(scone_handle *h);  // [hot rows + cache slots, scale bytes]
 long long scone_stage_chunk_tokens(scone_handle *h);

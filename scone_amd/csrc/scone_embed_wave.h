@@ -611,7 +611,7 @@ int launch_wave(scone_handle *h, const embed_args &a, hipStream_t s) {
 #ifdef SCONE_WAVE_BLOCKS_FIXED
   const long long target = SCONE_WAVE_BLOCKS_FIXED;
 #else
-  const long long target = 3ll * h->n_cus * (hi ? wave_occupancy<FMT, OutT, D, MAXN, true, true>::WAVES
+  const long long target = 3ll * scone_lookup_cus(h) * (hi ? wave_occupancy<FMT, OutT, D, MAXN, true, true>::WAVES
                                                 : wave_occupancy<FMT, OutT, D, MAXN, true, false>::WAVES);
 #endif
   long long chunks = (target + q.pos_groups / 2) / q.pos_groups;
@@ -1092,8 +1092,7 @@ int try_launch_finalize_wave(scone_handle *h, const embed_args &a, hipStream_t s
 
 // returns -1 when the wave kernel does not cover this (format, d, max_n) -> caller falls back to k_embed
 template <int FMT, typename OutT>
-int try_launch_wave(scone_handle *h, const embed_args &a, hipStream_t s) {
-  if (!a.ell) return -1;
+int try_launch_wave_on(scone_handle *h, const embed_args &a, hipStream_t s) {
   if constexpr (wave_geom<FMT, 768>::OK) {
     if (a.tv.d == 768) return a.max_n <= 3 ? launch_wave<FMT, OutT, 768, 3>(h, a, s) : launch_wave<FMT, OutT, 768, 4>(h, a, s);
   }
@@ -1103,9 +1102,19 @@ int try_launch_wave(scone_handle *h, const embed_args &a, hipStream_t s) {
   if constexpr (wave_geom<FMT, 1280>::OK) {  // gpt2-large (configs/large_config.yaml:16)
     if (a.tv.d == 1280) return a.max_n <= 3 ? launch_wave<FMT, OutT, 1280, 3>(h, a, s) : launch_wave<FMT, OutT, 1280, 4>(h, a, s);
   }
-  if (a.tv.d % 8 == 0)  // any other dim: unit-walking kernel
-    return a.max_n <= 3 ? launch_wave_any<FMT, OutT, 3>(h, a, s) : launch_wave_any<FMT, OutT, 4>(h, a, s);
-  return -1;
+  return a.max_n <= 3 ? launch_wave_any<FMT, OutT, 3>(h, a, s) : launch_wave_any<FMT, OutT, 4>(h, a, s);  // any other dim % 8 == 0
+}
+
+// With a CU reserve (scone_set_cu_reserve) the launch goes to the handle's masked stream, tied into `s` by two events.
+template <int FMT, typename OutT>
+int try_launch_wave(scone_handle *h, const embed_args &a, hipStream_t s) {
+  if (!a.ell || a.tv.d % 8) return -1;
+  hipStream_t ls = s;
+  int rc = scone_lookup_enter(h, s, &ls);
+  if (rc) return rc;
+  rc = try_launch_wave_on<FMT, OutT>(h, a, ls);
+  const int rc2 = scone_lookup_leave(h, s, ls);
+  return rc ? rc : rc2;
 }
 
 template <int FMT>

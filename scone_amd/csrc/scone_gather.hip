@@ -62,8 +62,9 @@ int need_table(scone_handle *h, const char *who) {
 
 }  // namespace
 
-// Pinned-host table, staged prefetch (scone_stage.hip): chunks of whole sequences; side streams prepare
-// chunk c+2 and copy chunk c+1 while the caller's stream reduces chunk c out of the HBM staging buffer.
+// Pinned-host table, prefetch through the persistent HBM cache of cold rows (scone_stage.hip): chunks of whole sequences;
+// side streams prepare chunk c+2 and copy the rows chunk c+1 misses while the caller's stream reduces chunk c out of
+// [hot head | cache].
 static int embed_staged(scone_handle *h, const embed_args &full, int32_t B, int32_t T, int32_t out_dtype, hipStream_t s) {
   long long seqs = (long long)h->cfg.stage_tokens / T;
   if (seqs < 1) seqs = 1;
@@ -98,8 +99,8 @@ static int embed_staged(scone_handle *h, const embed_args &full, int32_t B, int3
     a.pos = full.pos ? full.pos + t0 : nullptr;
     a.out = reinterpret_cast<uint8_t *>(full.out) + (size_t)t0 * h->cfg.dim * esz;
     a.ell = scone_stage_ell(h, buf);
-    a.tv.st.cold = scone_stage_rows(h, buf);  // rows [n_hot, ..) now live in the HBM staging buffer
-    if (h->scale_bytes_per_row) a.tv.scales = reinterpret_cast<const __half *>(scone_stage_scales(h, buf));
+    a.tv.st.cold = scone_stage_rows(h);  // the records now hold n_hot + cache slot: the cold half of the row store is the cache
+    if (h->scale_bytes_per_row) a.tv.scales = reinterpret_cast<const __half *>(scone_stage_scales(h));
     SCONE_HIP(h, hipStreamWaitEvent(s, scone_stage_staged_event(h, buf), 0));
     rc = scone_prof_begin(h, s);
     if (rc) return rc;

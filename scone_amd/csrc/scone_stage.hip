@@ -1,20 +1,33 @@
-// Staged prefetch for tables whose rows live in pinned host DRAM (SCONE_PLACE_PINNED_HOST with
-// cfg.stage_tokens > 0; BASELINE config C4).
+// Prefetch for tables whose rows live in pinned host DRAM (SCONE_PLACE_PINNED_HOST with cfg.stage_tokens > 0; BASELINE
+// config C4): a PERSISTENT cache of cold rows in HBM in front of a chunk pipeline.
 //
-// The batch is cut into chunks of whole sequences.  For chunk c, on a SIDE stream:
-//   1. k_match_ell            tokens -> per-token id records (global ids)
-//   2. k_stage_claim          every distinct cold row referenced by the chunk claims one slot of the
-//                             HBM staging buffer (generation-tagged slot map, one CAS per reference,
-//                             nobody waits) -> a de-duplicated copy list
-//   3. k_stage_remap          ids in the records -> n_hot + slot
-//   4. k_stage_copy           one wave per listed row: mapped host DRAM -> HBM staging (+ its scales)
-// and on the MAIN stream, after the "staged" event: the ordinary fused lookup kernel with the staging
-// buffer as the cold half of the row store.  A row referenced by several tokens of a chunk (an n-gram
-// covers n positions; hot f-grams recur) crosses PCIe once per chunk instead of once per reference.
-// Steps 1-3 run on a PREP stream and step 4 on a COPY stream, with SCONE_STAGE_NBUF = 3 buffer sets:
-// while chunk c is reduced and chunk c+1 crosses the link, chunk c+2 is already being matched and
-// claimed, so the link never waits for a match -> claim -> remap chain (with one side stream and two
-// buffers it idled for that chain once per chunk: ~40 GB/s instead of ~50 GB/s over Gen5 x16).
+// The reference's analogue is its memory-mapped table (embedding_cache.py:76-91, 132-135): rows are faulted in from
+// storage on first use and stay in the page cache.  Here the "storage" is host DRAM behind PCIe and the page cache is
+// `cap` row slots of HBM (cfg.cache_rows, at least what the pipeline itself needs) that live as long as the table does --
+// across chunks, batches and calls: rows are immutable (any table mutation drops the whole state, scone_table.hip
+// table_modified), so a cached row is bit-identical to the host row and results do not depend on what happens to be cached.
+//
+// The batch is cut into chunks of whole sequences.  For chunk c, on a PREP stream:
+//   1. k_match_ell     tokens -> per-token id records (global ids)
+//   2. k_stage_touch   every reference to a cold row: cached -> its slot is stamped with this chunk's epoch (the clock's
+//                      reference bit); not cached -> the first claimer lists the row (LDS stash, one global atomic per
+//                      workgroup)
+//   3. k_stage_place   every listed row takes a slot from the clock hand: a slot not stamped by this chunk or the chunks
+//                      whose lookups may still be running; its previous owner leaves the cache
+//   4. k_stage_remap   ids in the records -> n_hot + slot
+// on a COPY stream:
+//   5. k_stage_copy    listed rows: mapped host DRAM -> their slots (+ scales)
+// and on the caller's stream, after the chunk's "staged" event: the ordinary lookup kernel with the cache as the cold half
+// of its row store.  SCONE_STAGE_NBUF = 3 sets of id records: while chunk c is reduced and chunk c+1 crosses the link, chunk
+// c+2 is matched and placed.  A row referenced by several tokens, chunks or batches crosses PCIe once for as long as it
+// stays cached.
+//
+// Round 4, what the kernel trace of the round-3 form showed (profiles/r04a): (i) the claim pass appended every claimed row
+// with its own atomicAdd on ONE counter -- ~90 retire per microsecond on one address: 200 us per 262k-token chunk, now a
+// stash per workgroup; (ii) the copy kernel ran 4096 waves, each with a 512-B read over PCIe in flight: ten times the
+// link's bandwidth-delay product, and those reads sit in the L2's miss queues for microseconds -- every kernel running
+// beside it (the next chunk's match: 20 -> 250 us; the lookup: 168 -> 360-630 us) queued behind them.  The copy grid is
+// now sized to the link (SCONE_STAGE_COPY_BLOCKS).
 #include "scone_common.h"
 
 #include <cstdlib>
@@ -22,40 +35,107 @@
 
 namespace {
 
-#define STAGE_PENDING 0xFFFFFFu
+#define STAGE_PENDING 0xFFFFFFFFu
+#define STAGE_FAILED 0xFFFFFFFFu
+// a slot stamped by one of the last STAGE_PROTECT chunks is not evicted: the lookups of chunks e - NBUF + 1 .. e - 1 may
+// still be queued (their records already hold slot numbers) when chunk e's rows are copied in
+#define STAGE_PROTECT (SCONE_STAGE_NBUF + 1)
+#define TOUCH_THREADS 1024
+#define TOUCH_BLOCKS 512
+#define TOUCH_STASH 4096
 
-__global__ __launch_bounds__(256) void k_stage_claim(const int32_t *__restrict__ ell, long long ntok, int W, int NC,
-                                                     long long n_hot, uint32_t *__restrict__ slot_of, uint32_t gen,
-                                                     uint32_t *__restrict__ count, int32_t *__restrict__ list,
-                                                     uint32_t cap, uint32_t *__restrict__ status) {
-  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long long t = gid / NC;
-  const int j = (int)(gid - t * NC);
-  if (t >= ntok) return;
-  const int kown = ell[t * W + W - 2] & 0xFF;
-  if (j >= kown) return;
-  const long long id = ell[t * W + j];
-  if (id < n_hot) return;
-  uint32_t *e = &slot_of[id - n_hot];
-  const uint32_t v = *e;
-  if ((v >> 24) == gen) return;  // already claimed for this chunk
-  if (atomicCAS(e, v, (gen << 24) | STAGE_PENDING) == v) {
-    const uint32_t s = atomicAdd(count, 1u);
-    if (s < cap) {
-      list[s] = (int32_t)id;
-      *e = (gen << 24) | s;  // read only by the next kernel
-    } else {
-      // more distinct cold rows than staging slots.  scone_stage_prepare sizes the buffer for the worst case of a
-      // chunk, so this is unreachable from scone_embed; should it ever happen the reference must not stay PENDING
-      // (the remap would send the lookup 16M rows past the buffer): it reads slot 0 and the call is flagged
-      *e = (gen << 24) | 0u;
-      atomicOr(status, SCONE_ST_STAGE_OVERFLOW);
+// slot_of[cold row]: 0 = not cached, STAGE_PENDING = listed by the chunk being prepared, else slot + 1
+__global__ __launch_bounds__(TOUCH_THREADS) void k_stage_touch(const int32_t *__restrict__ ell, long long ntok, int W, int NC,
+                                                               long long n_hot, uint32_t *__restrict__ slot_of,
+                                                               uint32_t *__restrict__ last_use, uint32_t epoch,
+                                                               uint32_t *__restrict__ count, int32_t *__restrict__ list,
+                                                               uint32_t list_cap, uint32_t *__restrict__ status) {
+  __shared__ int32_t stash[TOUCH_STASH];
+  __shared__ uint32_t n_stash, base;
+  if (threadIdx.x == 0) n_stash = 0;
+  __syncthreads();
+  const long long per = (ntok + gridDim.x - 1) / gridDim.x;
+  const long long t0 = (long long)blockIdx.x * per, t1 = t0 + per < ntok ? t0 + per : ntok;
+  for (long long t = t0 + threadIdx.x; t < t1; t += blockDim.x) {
+    const int kown = ell[t * W + W - 2] & 0xFF;
+    for (int j = 0; j < NC; ++j) {
+      if (j >= kown) break;
+      const long long id = ell[t * W + j];
+      if (id < n_hot) continue;
+      uint32_t *e = &slot_of[id - n_hot];
+      uint32_t v = *e;
+      if (v == 0u) {
+        v = atomicCAS(e, 0u, STAGE_PENDING);
+        if (v == 0u) {  // first reference of this chunk to a row that is not cached: list it
+          const uint32_t k = atomicAdd(&n_stash, 1u);
+          if (k < TOUCH_STASH) {
+            stash[k] = (int32_t)id;
+          } else {
+            const uint32_t s = atomicAdd(count, 1u);
+            if (s < list_cap) list[s] = (int32_t)id;
+            else atomicOr(status, SCONE_ST_STAGE_OVERFLOW);  // (the list holds every reference of a chunk: unreachable)
+          }
+          continue;
+        }
+      }
+      if (v != STAGE_PENDING) last_use[v - 1u] = epoch;  // cached: the clock's reference stamp (racing stores write one value)
     }
+  }
+  __syncthreads();
+  const uint32_t n = n_stash < TOUCH_STASH ? n_stash : TOUCH_STASH;
+  if (threadIdx.x == 0) base = n ? atomicAdd(count, n) : 0u;
+  __syncthreads();
+  for (uint32_t k = threadIdx.x; k < n; k += blockDim.x) {
+    if (base + k < list_cap) list[base + k] = stash[k];
+    else atomicOr(status, SCONE_ST_STAGE_OVERFLOW);
+  }
+}
+
+// one thread per listed row.  The clock hand is a counter; a wave takes as many consecutive positions as it has rows still
+// to place (ONE atomic per wave and round), every lane tests its own candidate, lanes whose candidate is protected go
+// round again.  A slot is handed to one lane only (the hand passes it once per `cap` positions, and a launch advances it
+// by a fraction of that), so owner / slot_of need no atomics.
+__global__ __launch_bounds__(256) void k_stage_place(const uint32_t *__restrict__ count, const int32_t *__restrict__ list,
+                                                     uint32_t *__restrict__ place, uint32_t list_cap, long long n_hot,
+                                                     uint32_t *__restrict__ slot_of, uint32_t *__restrict__ owner,
+                                                     uint32_t *__restrict__ last_use, uint32_t epoch, uint32_t cap,
+                                                     unsigned long long *__restrict__ hand, uint32_t *__restrict__ status) {
+  uint32_t n = *count;
+  if (n > list_cap) n = list_cap;
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  bool need = i < n;
+  const long long cold = need ? (long long)list[i] - n_hot : 0;
+  for (int round = 0; round < 64; ++round) {
+    const unsigned long long needm = __ballot(need);
+    if (!needm) break;
+    const int leader = __builtin_ctzll(needm);
+    unsigned long long b = 0;
+    if (lane == leader) b = atomicAdd(hand, (unsigned long long)__popcll(needm));
+    b = __shfl(b, leader, 64);
+    if (need) {
+      const uint32_t s = (uint32_t)((b + (unsigned long long)__popcll(needm & ((1ull << lane) - 1ull))) % cap);
+      if (epoch - last_use[s] >= STAGE_PROTECT) {
+        const uint32_t old = owner[s];
+        if (old) slot_of[old - 1u] = 0u;  // the previous owner leaves the cache
+        owner[s] = (uint32_t)cold + 1u;
+        last_use[s] = epoch;
+        slot_of[cold] = s + 1u;
+        place[i] = s;
+        need = false;
+      }
+    }
+  }
+  if (need) {  // no evictable slot in 64 rounds: the cache is smaller than what the chunks in flight reference.  Cannot
+    slot_of[cold] = 0u;  // happen with the sizes scone_stage_prepare picks (test hook: SCONE_STAGE_CAP_ROWS).
+    place[i] = STAGE_FAILED;
+    atomicOr(status, SCONE_ST_STAGE_OVERFLOW);
   }
 }
 
 __global__ __launch_bounds__(256) void k_stage_remap(int32_t *__restrict__ ell, long long ntok, int W, int NC,
-                                                     long long n_hot, const uint32_t *__restrict__ slot_of) {
+                                                     long long n_hot, const uint32_t *__restrict__ slot_of,
+                                                     uint32_t *__restrict__ status) {
   const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long t = gid / NC;
   const int j = (int)(gid - t * NC);
@@ -64,27 +144,37 @@ __global__ __launch_bounds__(256) void k_stage_remap(int32_t *__restrict__ ell, 
   if (j >= kown) return;
   const long long id = ell[t * W + j];
   if (id < n_hot) return;
-  ell[t * W + j] = (int32_t)(n_hot + (slot_of[id - n_hot] & 0xFFFFFFu));
+  uint32_t v = slot_of[id - n_hot];
+  if (v == 0u || v == STAGE_PENDING) {  // the row could not be placed (flagged by k_stage_place): stay inside the cache
+    atomicOr(status, SCONE_ST_STAGE_OVERFLOW);
+    v = 1u;
+  }
+  ell[t * W + j] = (int32_t)(n_hot + (long long)(v - 1u));
 }
 
-// one wave per staged row; 16 bytes per lane per step from mapped host memory.  (Tried: two 512-B rows per
-// wave and a 2048-block grid to double the row reads in flight -- 10 % SLOWER, 199 -> 181 M tok/s at C4 size:
-// the link is already saturated by 4096 waves, more of them only take CUs from the lookup kernel.)
+// one wave per listed row; 16 bytes per lane per step from mapped host memory.  The grid is what bounds the reads in flight
+// over PCIe (one row per wave): 256 workgroups = 1024 waves x 512 B = 0.5 MB, four times the link's bandwidth-delay
+// product (~50 GB/s x ~2.5 us); the round-3 grid of 1024 workgroups kept 2 MB of PCIe reads in the L2's miss queues and
+// slowed every kernel beside it 2-10x.
 __global__ __launch_bounds__(256) void k_stage_copy(const uint32_t *__restrict__ count, const int32_t *__restrict__ list,
-                                                    scone_row_store host, uint8_t *__restrict__ stage_rows,
-                                                    const uint8_t *__restrict__ scales, uint8_t *__restrict__ stage_scales,
-                                                    int scale_bytes, long long n_hot, uint32_t cap) {
+                                                    const uint32_t *__restrict__ place, scone_row_store host,
+                                                    uint8_t *__restrict__ cache_rows, const uint8_t *__restrict__ scales,
+                                                    uint8_t *__restrict__ cache_scales, int scale_bytes, long long n_hot,
+                                                    uint32_t list_cap, unsigned long long *__restrict__ stats) {
   const int lane = threadIdx.x & 63;
   uint32_t n = *count;
-  if (n > cap) n = cap;
+  if (n > list_cap) n = list_cap;
+  if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[0], (unsigned long long)n);
   const unsigned nwaves = gridDim.x * (blockDim.x >> 6);
-  for (unsigned s = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); s < n; s += nwaves) {
-    const unsigned long long lr = (unsigned long long)list[s];
+  for (unsigned i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); i < n; i += nwaves) {
+    const uint32_t s = place[i];
+    if (s == STAGE_FAILED) continue;
+    const unsigned long long lr = (unsigned long long)list[i];
     const uint4 *src = reinterpret_cast<const uint4 *>(host.row(lr));
-    uint4 *dst = reinterpret_cast<uint4 *>(stage_rows + (size_t)s * host.row_bytes);
+    uint4 *dst = reinterpret_cast<uint4 *>(cache_rows + (size_t)s * host.row_bytes);
     for (unsigned v = lane; v < host.row_bytes / 16; v += 64) dst[v] = src[v];
     if (scale_bytes && lane < scale_bytes / 2)
-      reinterpret_cast<unsigned short *>(stage_scales + (size_t)(n_hot + s) * scale_bytes)[lane] =
+      reinterpret_cast<unsigned short *>(cache_scales + (size_t)(n_hot + s) * scale_bytes)[lane] =
           reinterpret_cast<const unsigned short *>(scales + lr * scale_bytes)[lane];
   }
 }
@@ -92,19 +182,26 @@ __global__ __launch_bounds__(256) void k_stage_copy(const uint32_t *__restrict__
 }  // namespace
 
 struct scone_stage_state {
-  long long chunk_tokens = 0;     // tokens per chunk actually provisioned
-  long long requested_tokens = 0; // what the caller asked for (may exceed chunk_tokens, see prepare)
-  uint32_t cap = 0;  // staged rows per buffer
+  long long chunk_tokens = 0;      // tokens per chunk actually provisioned
+  long long requested_tokens = 0;  // what the caller asked for (may exceed chunk_tokens, see prepare)
+  uint32_t cap = 0;       // cache slots
+  uint32_t list_cap = 0;  // rows one chunk can list
+  int copy_blocks = 256;
   hipStream_t prep = nullptr, copy = nullptr;
   hipEvent_t prepped[SCONE_STAGE_NBUF] = {}, staged[SCONE_STAGE_NBUF] = {}, consumed[SCONE_STAGE_NBUF] = {}, start = nullptr;
   bool consumed_valid[SCONE_STAGE_NBUF] = {};
-  uint32_t *slot_of = nullptr;
-  uint32_t gen = 0;
+  uint32_t *slot_of = nullptr;   // [cold rows]
+  uint32_t *owner = nullptr;     // [cap]: cold row + 1 held by the slot, 0 = free
+  uint32_t *last_use = nullptr;  // [cap]: epoch of the last chunk that referenced the slot
+  uint32_t epoch = STAGE_PROTECT;
+  uint64_t chunks = 0;                  // chunks prepared since the state was created
+  unsigned long long *hand = nullptr;   // [0] clock hand, [1] rows copied host -> HBM
+  uint8_t *rows = nullptr;       // [cap, payload bytes]
+  uint8_t *scales = nullptr;     // [hot rows + cap, scale bytes]: the HBM-resident head's scales, then the cached rows'
   int32_t *ell[SCONE_STAGE_NBUF] = {};
   int32_t *list[SCONE_STAGE_NBUF] = {};
+  uint32_t *place[SCONE_STAGE_NBUF] = {};
   uint32_t *count[SCONE_STAGE_NBUF] = {};
-  uint8_t *rows[SCONE_STAGE_NBUF] = {};
-  uint8_t *scales[SCONE_STAGE_NBUF] = {};
 };
 
 void scone_stage_destroy(scone_handle *h) {
@@ -118,12 +215,13 @@ void scone_stage_destroy(scone_handle *h) {
     if (st->consumed[b]) (void)hipEventDestroy(st->consumed[b]);
     if (st->ell[b]) (void)hipFree(st->ell[b]);
     if (st->list[b]) (void)hipFree(st->list[b]);
+    if (st->place[b]) (void)hipFree(st->place[b]);
     if (st->count[b]) (void)hipFree(st->count[b]);
-    if (st->rows[b]) (void)hipFree(st->rows[b]);
-    if (st->scales[b]) (void)hipFree(st->scales[b]);
   }
   if (st->start) (void)hipEventDestroy(st->start);
-  if (st->slot_of) (void)hipFree(st->slot_of);
+  void *ptrs[] = {st->slot_of, st->owner, st->last_use, st->hand, st->rows, st->scales};
+  for (void *p : ptrs)
+    if (p) (void)hipFree(p);
   delete st;
   h->stage = nullptr;
 }
@@ -137,52 +235,75 @@ int scone_stage_prepare(scone_handle *h, long long chunk_tokens) {
   h->stage = st;
   const int W = SCONE_ELL_W(h->cfg.max_n), NC = h->cfg.max_n * (h->cfg.max_n + 1) / 2;
   const long long n_cold = (long long)(h->local_rows - h->hot_local);
-  // 24-bit slot numbers: a chunk may reference chunk_tokens * NC distinct cold rows, and every one of them
-  // must get a slot (an unclaimed reference would be remapped outside the staging buffer) -> bound the chunk
-  if (chunk_tokens * NC > 0xFFFFFEll && n_cold > 0xFFFFFEll) chunk_tokens = 0xFFFFFEll / NC;
-  long long cap = chunk_tokens * NC;
+  // The cache must hold every row the chunks in flight reference (a reference that finds no slot would be remapped to a
+  // wrong row): a chunk references at most chunk_tokens * NC distinct cold rows and STAGE_PROTECT chunks are protected
+  // from eviction while one more is placed -- unless the whole cold table fits, then nothing is ever evicted.
+  const long long id_room = 0x7FFFFFF0ll - (long long)h->hot_local;  // record ids are int32: n_hot + slot
+  long long cap = (long long)h->cfg.cache_rows;
+  const long long need = (STAGE_PROTECT + 1) * chunk_tokens * NC;
+  if (cap < need) cap = need;
   if (cap > n_cold) cap = n_cold;
-  if (const char *ev = getenv("SCONE_STAGE_CAP_ROWS")) {  // test hook: an undersized buffer exercises the overflow path
+  if (cap > id_room) cap = id_room;
+  if (const char *ev = getenv("SCONE_STAGE_CAP_ROWS")) {  // test hook: an undersized cache exercises the overflow path
     const long long forced = atoll(ev);
     if (forced > 0 && forced < cap) cap = forced;
+  } else if (cap < n_cold && cap < need) {
+    chunk_tokens = cap / ((STAGE_PROTECT + 1) * NC);  // a small cache (or 2^31 ids): smaller chunks
   }
+  if (cap < 1) cap = 1;
+  long long list_cap = chunk_tokens * NC < n_cold ? chunk_tokens * NC : n_cold;
+  if (list_cap < 1) list_cap = 1;
   st->chunk_tokens = chunk_tokens;
   st->requested_tokens = requested;
   st->cap = (uint32_t)cap;
+  st->list_cap = (uint32_t)list_cap;
+  if (const char *ev = getenv("SCONE_STAGE_COPY_BLOCKS")) {
+    const int v = atoi(ev);
+    if (v >= 1 && v <= 65535) st->copy_blocks = v;
+  }
   SCONE_HIP(h, hipStreamCreateWithFlags(&st->prep, hipStreamNonBlocking));
   SCONE_HIP(h, hipStreamCreateWithFlags(&st->copy, hipStreamNonBlocking));
   SCONE_HIP(h, hipEventCreateWithFlags(&st->start, hipEventDisableTiming));
-  SCONE_HIP(h, hipMalloc(&st->slot_of, (size_t)(n_cold > 0 ? n_cold : 1) * 4));
-  SCONE_HIP(h, hipMemset(st->slot_of, 0, (size_t)(n_cold > 0 ? n_cold : 1) * 4));
+  const size_t nc = (size_t)(n_cold > 0 ? n_cold : 1);
+  SCONE_HIP(h, hipMalloc(&st->slot_of, nc * 4));
+  SCONE_HIP(h, hipMemset(st->slot_of, 0, nc * 4));
+  SCONE_HIP(h, hipMalloc(&st->owner, (size_t)cap * 4));
+  SCONE_HIP(h, hipMemset(st->owner, 0, (size_t)cap * 4));
+  SCONE_HIP(h, hipMalloc(&st->last_use, (size_t)cap * 4));
+  SCONE_HIP(h, hipMemset(st->last_use, 0, (size_t)cap * 4));
+  SCONE_HIP(h, hipMalloc(&st->hand, 4 * sizeof(unsigned long long)));
+  SCONE_HIP(h, hipMemset(st->hand, 0, 4 * sizeof(unsigned long long)));
+  SCONE_HIP(h, hipMalloc(&st->rows, (size_t)cap * h->row_payload_bytes));
   const size_t sb = h->scale_bytes_per_row;
+  if (sb) {  // scales indexed like the rows: [0, n_hot) = the HBM-resident head, then the cache slots
+    SCONE_HIP(h, hipMalloc(&st->scales, (size_t)(h->hot_local + cap) * sb + 4));
+    SCONE_HIP(h, hipMemcpy(st->scales, h->scales, (size_t)h->hot_local * sb, hipMemcpyDeviceToDevice));
+  }
   for (int b = 0; b < SCONE_STAGE_NBUF; ++b) {
     SCONE_HIP(h, hipEventCreateWithFlags(&st->prepped[b], hipEventDisableTiming));
     SCONE_HIP(h, hipEventCreateWithFlags(&st->staged[b], hipEventDisableTiming));
     SCONE_HIP(h, hipEventCreateWithFlags(&st->consumed[b], hipEventDisableTiming));
-    SCONE_HIP(h, hipMalloc(&st->ell[b], (size_t)chunk_tokens * W * 4));
-    SCONE_HIP(h, hipMalloc(&st->list[b], (size_t)(cap > 0 ? cap : 1) * 4));
+    SCONE_HIP(h, hipMalloc(&st->ell[b], (size_t)(chunk_tokens > 0 ? chunk_tokens : 1) * W * 4));
+    SCONE_HIP(h, hipMalloc(&st->list[b], (size_t)list_cap * 4));
+    SCONE_HIP(h, hipMalloc(&st->place[b], (size_t)list_cap * 4));
     SCONE_HIP(h, hipMalloc(&st->count[b], 4));
-    SCONE_HIP(h, hipMalloc(&st->rows[b], (size_t)(cap > 0 ? cap : 1) * h->row_payload_bytes));
-    if (sb) {
-      // scales indexed like the rows: [0, n_hot) = the HBM-resident head, then the staged rows
-      SCONE_HIP(h, hipMalloc(&st->scales[b], (size_t)(h->hot_local + cap) * sb + 4));
-      SCONE_HIP(h, hipMemcpy(st->scales[b], h->scales, (size_t)h->hot_local * sb, hipMemcpyDeviceToDevice));
-    }
   }
   return SCONE_OK;
 }
 
-// side-stream half of one chunk; leaves ell / rows / scales of buffer `buf` ready and records staged[buf]
+// side-stream half of one chunk; leaves the records of buffer `buf` ready (ids -> cache slots), the chunk's missing rows on
+// their way into the cache, and records staged[buf]
 int scone_stage_chunk(scone_handle *h, int buf, const int32_t *d_tok, int32_t Bc, int32_t T) {
   scone_stage_state *st = h->stage;
   const int W = SCONE_ELL_W(h->cfg.max_n), NC = h->cfg.max_n * (h->cfg.max_n + 1) / 2;
   const long long ntok = (long long)Bc * T;
   hipStream_t s = st->prep;
   if (st->consumed_valid[buf]) SCONE_HIP(h, hipStreamWaitEvent(s, st->consumed[buf], 0));
-  st->gen += 1;
-  if (st->gen > 255) {  // 8-bit generation tags wrapped: forget every old claim
-    SCONE_HIP(h, hipMemsetAsync(st->slot_of, 0, (size_t)(h->local_rows - h->hot_local) * 4, s));
-    st->gen = 1;
+  st->epoch += 1;
+  if (st->epoch >= 0xFFFFFF00u) {  // 2^32 chunks: restart the clock (every slot becomes evictable; nothing is in flight
+    SCONE_HIP(h, hipDeviceSynchronize());  // once the device is idle)
+    SCONE_HIP(h, hipMemsetAsync(st->last_use, 0, (size_t)st->cap * 4, s));
+    st->epoch = STAGE_PROTECT + 1;
   }
   int rc = scone_launch_match_ell(h, d_tok, Bc, T, st->ell[buf], s);
   if (rc) return rc;
@@ -190,20 +311,28 @@ int scone_stage_chunk(scone_handle *h, int buf, const int32_t *d_tok, int32_t Bc
   const long long work = ntok * NC;
   if (!scone_grid_fits((unsigned long long)(work + 255) / 256, 256))
     return scone_fail(h, SCONE_EINVAL, "scone_embed(staged): chunk too large for one launch (lower stage_tokens)");
-  const unsigned blocks = (unsigned)((work + 255) / 256);
-  hipLaunchKernelGGL(k_stage_claim, dim3(blocks), dim3(256), 0, s, st->ell[buf], ntok, W, NC, (long long)h->hot_local,
-                     st->slot_of, st->gen, st->count[buf], st->list[buf], st->cap, h->d_status);
-  hipLaunchKernelGGL(k_stage_remap, dim3(blocks), dim3(256), 0, s, st->ell[buf], ntok, W, NC, (long long)h->hot_local,
-                     st->slot_of);
+  const long long want = (ntok + TOUCH_THREADS - 1) / TOUCH_THREADS;
+  const unsigned tb = (unsigned)(want < TOUCH_BLOCKS ? (want > 0 ? want : 1) : TOUCH_BLOCKS);
+  hipLaunchKernelGGL(k_stage_touch, dim3(tb), dim3(TOUCH_THREADS), 0, s, st->ell[buf], ntok, W, NC, (long long)h->hot_local,
+                     st->slot_of, st->last_use, st->epoch, st->count[buf], st->list[buf], st->list_cap, h->d_status);
+  // the list's length stays on the device: the placement grid covers the chunk's worst case, threads past the count retire
+  long long worst = ntok * NC < (long long)st->list_cap ? ntok * NC : (long long)st->list_cap;
+  if (worst < 1) worst = 1;
+  hipLaunchKernelGGL(k_stage_place, dim3((unsigned)((worst + 255) / 256)), dim3(256), 0, s, st->count[buf], st->list[buf],
+                     st->place[buf], st->list_cap, (long long)h->hot_local, st->slot_of, st->owner, st->last_use, st->epoch,
+                     st->cap, st->hand, h->d_status);
+  hipLaunchKernelGGL(k_stage_remap, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, s, st->ell[buf], ntok, W, NC,
+                     (long long)h->hot_local, st->slot_of, h->d_status);
   SCONE_HIP(h, hipGetLastError());
   SCONE_HIP(h, hipEventRecord(st->prepped[buf], s));
   // the copy stream only ever waits for the list of THIS chunk, never for the preparation of the next one
   SCONE_HIP(h, hipStreamWaitEvent(st->copy, st->prepped[buf], 0));
-  hipLaunchKernelGGL(k_stage_copy, dim3(1024), dim3(256), 0, st->copy, st->count[buf], st->list[buf], scone_store_of(h),
-                     st->rows[buf], (const uint8_t *)h->scales, st->scales[buf], (int)h->scale_bytes_per_row,
-                     (long long)h->hot_local, st->cap);
+  hipLaunchKernelGGL(k_stage_copy, dim3((unsigned)st->copy_blocks), dim3(256), 0, st->copy, st->count[buf], st->list[buf],
+                     st->place[buf], scone_store_of(h), st->rows, (const uint8_t *)h->scales, st->scales,
+                     (int)h->scale_bytes_per_row, (long long)h->hot_local, st->list_cap, st->hand + 1);
   SCONE_HIP(h, hipGetLastError());
   SCONE_HIP(h, hipEventRecord(st->staged[buf], st->copy));
+  st->chunks += 1;
   return SCONE_OK;
 }
 
@@ -216,6 +345,26 @@ int scone_stage_mark_consumed(scone_handle *h, int buf, hipStream_t main_stream)
   return SCONE_OK;
 }
 const int32_t *scone_stage_ell(scone_handle *h, int buf) { return h->stage->ell[buf]; }
-uint8_t *scone_stage_rows(scone_handle *h, int buf) { return h->stage->rows[buf]; }
-const void *scone_stage_scales(scone_handle *h, int buf) { return h->stage->scales[buf]; }
+uint8_t *scone_stage_rows(scone_handle *h) { return h->stage->rows; }
+const void *scone_stage_scales(scone_handle *h) { return h->stage->scales; }
 long long scone_stage_chunk_tokens(scone_handle *h) { return h->stage->chunk_tokens; }
+
+extern "C" int scone_stage_counters(scone_handle *h, uint64_t *cache_rows, uint64_t *rows_copied, uint64_t *chunks,
+                                    uint64_t *chunk_tokens) {
+  if (!h) return SCONE_EINVAL;
+  if (cache_rows) *cache_rows = 0;
+  if (rows_copied) *rows_copied = 0;
+  if (chunks) *chunks = 0;
+  if (chunk_tokens) *chunk_tokens = 0;
+  scone_stage_state *st = h->stage;
+  if (!st) return SCONE_OK;
+  SCONE_ON_DEVICE(h);
+  unsigned long long v[2] = {0, 0};
+  SCONE_HIP(h, hipDeviceSynchronize());
+  SCONE_HIP(h, hipMemcpy(v, st->hand, sizeof(v), hipMemcpyDeviceToHost));
+  if (cache_rows) *cache_rows = st->cap;
+  if (rows_copied) *rows_copied = v[1];
+  if (chunks) *chunks = st->chunks;
+  if (chunk_tokens) *chunk_tokens = (uint64_t)st->chunk_tokens;
+  return SCONE_OK;
+}

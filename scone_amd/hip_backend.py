@@ -99,7 +99,7 @@ class SconeTable:
     def __init__(self, max_n: int, n_rows: int, dim: int = 0, table_format="fp32", placement: str = "hbm",
                  device: Optional[torch.device] = None, row_begin: int = 0, row_end: Optional[int] = None,
                  index_capacity: int = 0, hot_rows: int = 0, lookup_mode: str = "cover",
-                 stage_tokens: int = 0) -> None:
+                 stage_tokens: int = 0, cache_rows: int = 0) -> None:
         self._h = None
         lib = L.lib()
         dev = torch.device(device) if device is not None else require_gpu()
@@ -113,7 +113,7 @@ class SconeTable:
         self.row_end = int(n_rows if row_end is None else row_end)
         cfg = L.SconeCfg(C.sizeof(L.SconeCfg), self.device.index, self.max_n, self.dim, self.fmt,
                          _PLACE[placement], self.n_rows, self.row_begin, self.row_end, int(index_capacity),
-                         int(hot_rows), _MODE[lookup_mode], int(stage_tokens))
+                         int(hot_rows), _MODE[lookup_mode], int(stage_tokens), int(cache_rows))
         h = C.c_void_p()
         rc = lib.scone_create(C.byref(cfg), C.byref(h))
         if rc != L.OK:
@@ -142,6 +142,14 @@ class SconeTable:
         with torch.cuda.device(self.device):
             self._check(L.lib().scone_status(self._h, C.byref(bits), _stream()), "scone_status")
         return bits.value
+
+    def stage_counters(self) -> dict:
+        """The cache of cold rows of a pinned-host table with ``stage_tokens > 0``: ``cache_rows`` (slots), ``rows_copied``
+        (host -> HBM since the cache was created: every miss crosses PCIe once), ``chunks``, ``chunk_tokens`` (synchronises)."""
+        v = [C.c_uint64(0) for _ in range(4)]
+        with torch.cuda.device(self.device):
+            self._check(L.lib().scone_stage_counters(self._h, *[C.byref(x) for x in v]), "scone_stage_counters")
+        return dict(zip(("cache_rows", "rows_copied", "chunks", "chunk_tokens"), (x.value for x in v)))
 
     # -- index ------------------------------------------------------------------
     def index_build(self, keys: np.ndarray, lens: np.ndarray, id0: int = 0) -> None:
@@ -354,6 +362,18 @@ class SconeTable:
     def reserve(self, max_tokens: int) -> None:
         with torch.cuda.device(self.device):
             self._check(L.lib().scone_reserve(self._h, int(max_tokens)), "scone_reserve")
+
+    def set_cu_reserve(self, n_reserved: int) -> None:
+        """Leave ``n_reserved`` compute units (a multiple of 8; 0 = off) free of this handle's large-batch lookup kernels, for
+        the transport kernels of other streams (``scone_set_cu_reserve``)."""
+        with torch.cuda.device(self.device):
+            self._check(L.lib().scone_set_cu_reserve(self._h, int(n_reserved)), "scone_set_cu_reserve")
+
+    def cu_reserve(self) -> Tuple[int, int]:
+        """(compute units reserved, compute units of the device)."""
+        a, b = C.c_int32(0), C.c_int32(0)
+        self._check(L.lib().scone_get_cu_reserve(self._h, C.byref(a), C.byref(b)), "scone_get_cu_reserve")
+        return a.value, b.value
 
     def profile_enable(self, enable: bool = True) -> None:
         self._check(L.lib().scone_profile_enable(self._h, int(enable)), "scone_profile_enable")

@@ -31,8 +31,12 @@ class EmbeddingCache:
         placement:    "hbm" or "pinned_host" (rows >= hot_rows stay in host DRAM, read over PCIe).
         hot_rows:     with "pinned_host", the head of the table (ids are frequency-ordered) kept in HBM.
         stage_tokens: with "pinned_host": 0 = rows are read in place over PCIe by the lookup kernel; > 0 =
-                      staged prefetch (chunks of about this many tokens; each chunk's distinct host rows are
-                      copied once to an HBM staging buffer on a side stream while the previous chunk is reduced).
+                      prefetch through an HBM cache of cold rows (chunks of about this many tokens; the cold rows a
+                      chunk references that are not cached are copied host -> HBM once, on side streams, while the
+                      previous chunk is reduced; cached rows stay resident across chunks, batches and calls --
+                      the counterpart of the page cache under the reference's memory-mapped table,
+                      embedding_cache.py:76-91, 132-135).
+        cache_rows:   row slots of that cache (0 = what the chunk pipeline needs: 30 x stage_tokens for max_n = 3).
         lookup_mode:  "cover" = the reference code (all covering f-grams, mean, added to wte);
                       "longest_suffix" = the paper's Algorithm 2 (longest f-gram of length >= 2 ending
                       at the token replaces wte; causal) -- affects embed_tokens only.
@@ -43,7 +47,7 @@ class EmbeddingCache:
     def __init__(self, n_gram_extractor: NGramExtractor, embedding_dim: int, cache_dir: Optional[str] = None,
                  use_memory_map: bool = False, *, table_format: str = "fp32", placement: str = "hbm",
                  device=None, keep_host_copy: bool = True, hot_rows: int = 0, lookup_mode: str = "cover",
-                 stage_tokens: int = 0) -> None:
+                 stage_tokens: int = 0, cache_rows: int = 0) -> None:
         self.n_gram_extractor = n_gram_extractor
         self.embedding_dim = embedding_dim
         self.cache_dir = cache_dir
@@ -57,7 +61,8 @@ class EmbeddingCache:
         self.hot_rows = int(hot_rows)          # placement='pinned_host': rows [0, hot_rows) stay in HBM
         self.keep_host_copy = keep_host_copy
         self.lookup_mode = lookup_mode        # 'cover' (reference code) or 'longest_suffix' (paper, Algorithm 2)
-        self.stage_tokens = int(stage_tokens)  # placement='pinned_host': > 0 = staged, de-duplicated prefetch in chunks
+        self.stage_tokens = int(stage_tokens)  # placement='pinned_host': > 0 = prefetch through an HBM cache of cold rows, in chunks
+        self.cache_rows = int(cache_rows)      # ... its row slots (0 = the pipeline's minimum)
         self._device = device
         self._table = None           # hip_backend.SconeTable
         self._dirty = True           # host rows changed since the last upload
@@ -131,7 +136,7 @@ class EmbeddingCache:
         table = SconeTable(self.n_gram_extractor.max_n, n_rows, dim=self.embedding_dim,
                            table_format=self.table_format, placement=self.placement, device=self._device,
                            hot_rows=self.hot_rows, lookup_mode=self.lookup_mode,
-                           stage_tokens=self.stage_tokens)
+                           stage_tokens=self.stage_tokens, cache_rows=self.cache_rows)
         self.n_gram_extractor.build_index(table)
         return table
 
@@ -191,11 +196,12 @@ class EmbeddingCache:
     def from_synthetic(cls, n_gram_extractor: NGramExtractor, embedding_dim: int, *, table_format: str = "int8",
                        seed: int = 7, base_scale: float = 0.02 / 127, placement: str = "hbm", device=None,
                        n_rows: Optional[int] = None, hot_rows: int = 0, lookup_mode: str = "cover",
-                       stage_tokens: int = 0) -> "EmbeddingCache":
+                       stage_tokens: int = 0, cache_rows: int = 0) -> "EmbeddingCache":
         """Cache whose device table is generated on the GPU by the counter-based hash of
         ``scone_table_fill_synthetic`` (bench / full-size tests; nothing materialised on the host)."""
         cache = cls(n_gram_extractor, embedding_dim, table_format=table_format, placement=placement, device=device,
-                    keep_host_copy=False, hot_rows=hot_rows, lookup_mode=lookup_mode, stage_tokens=stage_tokens)
+                    keep_host_copy=False, hot_rows=hot_rows, lookup_mode=lookup_mode, stage_tokens=stage_tokens,
+                    cache_rows=cache_rows)
         n = int(n_rows if n_rows is not None else len(n_gram_extractor))
         table = cache._make_table(n)
         table.fill_synthetic(seed, base_scale)

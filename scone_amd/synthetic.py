@@ -102,36 +102,42 @@ class StructuredVocab:
     def keys_for(self, ids: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
         return structured_keys_for_ids(ids, self.n_rows, self.vocab, self.max_n)
 
+    def keys_for_torch(self, ids):
+        """:meth:`keys_for` in torch arithmetic on the device of ``ids`` (int64): ``(keys [n, 3] int64, lens [n] uint8)``."""
+        import torch
+        V, nb = self.vocab, (self.n_rows - self.vocab) // 2
+        keys = torch.zeros((ids.numel(), 3), dtype=torch.int64, device=ids.device)
+        lens = torch.ones(ids.numel(), dtype=torch.uint8, device=ids.device)
+        uni = ids < V
+        keys[:, 0] = torch.where(uni, ids, keys[:, 0])
+        bi = (~uni) & (ids < V + nb)
+        j = ids - V
+        k0 = ((j % V) * 40503 + 17) % V
+        k1 = (((j // V) % V) * 30011 + 5) % V
+        keys[:, 0] = torch.where(bi, k0, keys[:, 0])
+        keys[:, 1] = torch.where(bi, k1, keys[:, 1])
+        lens = torch.where(bi, torch.full_like(lens, 2), lens)
+        tri = ids >= V + nb
+        j = ids - V - nb
+        k0 = ((j % V) * 40503 + 29) % V
+        k1 = (((j // V) % V) * 30011 + 3) % V
+        k2 = (((j // (V * V)) % V) * 20011 + 11) % V
+        keys[:, 0] = torch.where(tri, k0, keys[:, 0])
+        keys[:, 1] = torch.where(tri, k1, keys[:, 1])
+        keys[:, 2] = torch.where(tri, k2, keys[:, 2])
+        lens = torch.where(tri, torch.full_like(lens, 3), lens)
+        return keys, lens
+
     def build_index(self, table, chunk: int = 1 << 25) -> None:
         import torch
         dev = table.device
-        V, n, nb = self.vocab, self.n_rows, (self.n_rows - self.vocab) // 2
+        n = self.n_rows
         for a in range(0, n, chunk):
             b = min(a + chunk, n)
-            ids = torch.arange(a, b, dtype=torch.int64, device=dev)
-            keys = torch.zeros((b - a, 3), dtype=torch.int64, device=dev)
-            lens = torch.ones(b - a, dtype=torch.uint8, device=dev)
-            uni = ids < V
-            keys[:, 0] = torch.where(uni, ids, keys[:, 0])
-            bi = (~uni) & (ids < V + nb)
-            j = ids - V
-            k0 = ((j % V) * 40503 + 17) % V
-            k1 = (((j // V) % V) * 30011 + 5) % V
-            keys[:, 0] = torch.where(bi, k0, keys[:, 0])
-            keys[:, 1] = torch.where(bi, k1, keys[:, 1])
-            lens = torch.where(bi, torch.full_like(lens, 2), lens)
-            tri = ids >= V + nb
-            j = ids - V - nb
-            k0 = ((j % V) * 40503 + 29) % V
-            k1 = (((j // V) % V) * 30011 + 3) % V
-            k2 = (((j // (V * V)) % V) * 20011 + 11) % V
-            keys[:, 0] = torch.where(tri, k0, keys[:, 0])
-            keys[:, 1] = torch.where(tri, k1, keys[:, 1])
-            keys[:, 2] = torch.where(tri, k2, keys[:, 2])
-            lens = torch.where(tri, torch.full_like(lens, 3), lens)
+            keys, lens = self.keys_for_torch(torch.arange(a, b, dtype=torch.int64, device=dev))
             table.index_build_device(keys.to(torch.int32).contiguous(), lens.contiguous(), id0=a)
             torch.cuda.synchronize(dev)        # the chunk's temporaries are freed before the next one is built
-            del ids, keys, lens, uni, bi, tri, j, k0, k1, k2
+            del keys, lens
 
 
 def stream_uniform_ids(keys, lens, B: int, T: int, seed: int) -> np.ndarray:
@@ -175,6 +181,25 @@ def stream_zipf_ids(keys, lens, B: int, T: int, seed: int, s: float = 1.1) -> np
         mask = np.arange(k.shape[1])[None, :] < l[:, None]
         out = np.concatenate([out, k[mask].astype(np.int64)])
     return out[:need].reshape(B, T)
+
+
+def stream_zipf_ids_torch(vocab: "StructuredVocab", B: int, T: int, seed: int, s: float = 1.1, device="cuda"):
+    """:func:`stream_zipf_ids` for a :class:`StructuredVocab`, drawn on the GPU (same law, torch's generator instead of
+    numpy's: not the same batch): a serving loop's worth of DIFFERENT batches -- what a cache of cold rows must be measured
+    on -- costs milliseconds each instead of a quarter of a second of host time.  int32 ``[B, T]`` on ``device``."""
+    import torch
+    g = torch.Generator(device=device).manual_seed(int(seed))
+    need, n_rows, e = B * T, len(vocab), 1.0 - s
+    parts, have = [], 0
+    while have < need:
+        u = torch.rand(max(1024, int((need - have) / 1.5) + 1024), generator=g, device=device, dtype=torch.float64)
+        x = ((float(n_rows + 1) ** e - 1.0) * u + 1.0) ** (1.0 / e)          # inverse CDF of the bounded power law on [1, N + 1)
+        ids = torch.clamp(x.to(torch.int64) - 1, max=n_rows - 1)
+        k, l = vocab.keys_for_torch(ids)
+        t = k[torch.arange(3, device=k.device)[None, :] < l[:, None]]
+        parts.append(t)
+        have += t.numel()
+    return torch.cat(parts)[:need].reshape(B, T).to(torch.int32)
 
 
 def stream_zipf(vocab: int, B: int, T: int, seed: int) -> np.ndarray:

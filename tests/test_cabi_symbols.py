@@ -42,16 +42,17 @@ def test_enum_values_match_header():
 
 
 def test_cfg_struct_layout():
-    assert C.sizeof(_lib.SconeCfg) == 72
+    assert C.sizeof(_lib.SconeCfg) == 80
     assert _lib.SconeCfg.n_rows.offset == 24 and _lib.SconeCfg.index_capacity.offset == 48
     assert _lib.SconeCfg.hot_rows.offset == 56 and _lib.SconeCfg.lookup_mode.offset == 64
+    assert _lib.SconeCfg.stage_tokens.offset == 68 and _lib.SconeCfg.cache_rows.offset == 72
 
 
 def test_create_rejects_bad_arguments_without_gpu_work():
     lib = _lib.lib()
     h = C.c_void_p()
     assert lib.scone_create(None, C.byref(h)) == _lib.EINVAL
-    cfg = _lib.SconeCfg(4, 0, 3, 768, _lib.FMT_I8, 0, 10, 0, 0, 0, 0, 0, 0)       # wrong struct_size
+    cfg = _lib.SconeCfg(4, 0, 3, 768, _lib.FMT_I8, 0, 10, 0, 0, 0, 0, 0, 0, 0)       # wrong struct_size
     assert lib.scone_create(C.byref(cfg), C.byref(h)) == _lib.EINVAL
     cfg = _lib.SconeCfg(C.sizeof(_lib.SconeCfg), 0, 7, 768, _lib.FMT_I8, 0, 10, 0, 0, 0, 0, 0, 0)   # max_n = 7
     assert lib.scone_create(C.byref(cfg), C.byref(h)) == _lib.EINVAL

@@ -364,6 +364,48 @@ def test_pinned_host_table_at_the_bench_shape_against_the_c_oracle(kw):
     assert bad == 0 and cache.table.status() == 0
 
 
+@pytest.mark.parametrize("cache_rows,stage_tokens", [(0, 32768), (0, 1024), (2_000_000, 65536)],
+                         ids=["pipeline_minimum", "small_cache_evicts", "everything_stays"])
+def test_cold_row_cache_over_several_batches_against_the_c_oracle(cache_rows, stage_tokens):
+    """The HBM cache of cold rows lives across chunks, batches and calls (round 4): five DIFFERENT batches of 96 x 512 tokens
+    (Zipf-distributed f-gram ids: rows recur between batches) and then the first batch again go through one pinned-host
+    handle, every token of every batch against oracle.c -- fp32 bit-exact, fp16 bytes equal.  With 1024-token chunks the
+    cache is the pipeline's minimum of 30,720 rows, less than half of what the batches reference (rows are evicted and
+    fetched again); a cache of 2M rows keeps everything (the second pass over batch 0 copies nothing).  The counters say what crossed PCIe:
+    never more rows than the chunks list, and with the big cache exactly the distinct cold rows seen so far."""
+    from scone_amd import EmbeddingCache, NGramExtractor
+    from scone_amd import synthetic as S
+    fmt, d, B, T, hot = "int8", 768, 96, 512, 60_000
+    keys, lens = _keys(1_000_000, "zipf")
+    ex = NGramExtractor.from_arrays(keys, lens, max_n=3)
+    cache = EmbeddingCache.from_synthetic(ex, d, table_format=fmt, seed=SEED, base_scale=BASE_SCALE, placement="pinned_host",
+                                          hot_rows=hot, stage_tokens=stage_tokens, cache_rows=cache_rows)
+    g = torch.Generator().manual_seed(1)
+    wte = (torch.randn(S.GPT2_VOCAB, d, generator=g) * 0.02).half().cuda()
+    wpe = (torch.randn(T, d, generator=g) * 0.01).half().cuda()
+    batches = [S.stream_zipf_ids(keys, lens, B, T, 100 + i, s=0.6) for i in range(5)]
+    batches.append(batches[0])
+    seen = np.zeros(0, dtype=np.int64)
+    copied_before = 0
+    for i, tok_np in enumerate(batches):
+        tok = torch.from_numpy(tok_np).to("cuda", torch.int32)
+        ro, ri = R.hits_to_csr(R.match_hits(keys, lens, tok_np, 3))
+        bad = _compare_with_c_oracle(lambda: cache.embed_tokens(tok, out_dtype=torch.float32),
+                                     lambda: cache.embed_tokens(tok, wte=wte, wpe=wpe), keys, lens, tok_np, ri, fmt, d, wte, wpe)
+        assert bad == 0 and cache.table.status() == 0, i
+        c = cache.table.stage_counters()
+        cold = np.unique(ri[ri >= hot])
+        new = np.setdiff1d(cold, seen)
+        seen = np.union1d(seen, cold)
+        copied = c["rows_copied"] - copied_before
+        copied_before = c["rows_copied"]
+        assert c["chunk_tokens"] <= stage_tokens and c["cache_rows"] >= min(cache_rows, 1_000_000 - hot)
+        if cache_rows >= 2_000_000:          # nothing is ever evicted: the first lookup of a batch copies exactly the new rows,
+            assert copied == new.size, (i, copied, new.size)   # the second one (fp16 output) and a repeated batch copy nothing
+        else:
+            assert copied >= new.size, (i, copied, new.size)
+
+
 @pytest.mark.parametrize("fmt,d", [("int8", 768), ("int4", 1024)])
 def test_csr_entry_point_and_partial_sums_at_the_bench_shape(fmt, d):
     """The two other large-batch entry points at 256 x 512 tokens against the oracle: `embed_tokens(base=...)` = `scone_match_csr`

@@ -746,12 +746,51 @@ def test_workspaces_of_many_streams_are_recycled():
     assert free0 - torch.cuda.mem_get_info()[0] < 16 << 20          # 27 more streams, no growth beyond allocator noise
 
 
+def test_cu_reserve_runs_the_lookup_on_a_masked_stream_with_identical_results():
+    """`scone_set_cu_reserve`: the large-batch lookup kernels go to a stream of the handle whose CU mask leaves R compute
+    units free, tied into the caller's stream by two events.  Same bytes out for R = 0 / 8 / 64, on the default stream and on a
+    side stream, work queued before and after the call stays ordered around it; bad values are refused."""
+    from scone_amd import EmbeddingCache
+    rng = np.random.default_rng(17)
+    vocab, n, d, max_n = 53, 3000, 768, 3
+    lens = rng.integers(1, 4, size=n).astype(np.uint8)
+    keys = rng.integers(0, vocab, size=(n, 3)).astype(np.uint32)
+    keys[np.arange(3)[None, :] >= lens[:, None]] = 0
+    ex = _extractor(keys, lens, max_n)
+    n = len(ex)
+    cache = EmbeddingCache(ex, d, table_format="int8")
+    cache.cache_embeddings(list(range(n)), torch.from_numpy(rng.standard_normal((n, d)).astype(np.float32)), verbose=False)
+    tok = torch.from_numpy(rng.integers(0, vocab, size=(160, 512))).to("cuda", torch.int32)      # above the one-launch limit
+    wte = torch.from_numpy(rng.standard_normal((vocab, d)).astype(np.float32)).half().cuda()
+    wpe = torch.from_numpy(rng.standard_normal((512, d)).astype(np.float32)).half().cuda()
+    t = cache.table
+    want = cache.embed_tokens(tok, wte=wte, wpe=wpe).clone()
+    assert t.cu_reserve()[0] == 0 and t.cu_reserve()[1] >= 64
+    for r in (8, 64, 0, 16):
+        t.set_cu_reserve(r)
+        assert t.cu_reserve()[0] == r
+        out = torch.zeros_like(want)
+        out.fill_(7.0)                                         # queued BEFORE the lookup on the same stream: must not win
+        cache.embed_tokens(tok, wte=wte, wpe=wpe, out=out)
+        chk = out.float().sum()                                # queued AFTER: must see the lookup's output
+        assert torch.equal(out, want) and float(chk) == float(want.float().sum()), r
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            out2 = cache.embed_tokens(tok, wte=wte, wpe=wpe)
+        side.synchronize()
+        assert torch.equal(out2, want), r
+    for bad in (-8, 12, 100000):
+        with pytest.raises(ValueError):
+            t.set_cu_reserve(bad)
+    assert t.status() == 0
+
+
 def test_staging_buffer_overflow_is_flagged_and_never_reads_out_of_bounds(monkeypatch):
-    """k_stage_claim's `slot >= capacity` path.  The staging buffer is sized for the worst case of a chunk, so the path is
-    unreachable from scone_embed; the test hook SCONE_STAGE_CAP_ROWS shrinks the buffer to 8 rows while a chunk references
-    hundreds of distinct cold rows.  Every reference that found no slot must have been redirected INSIDE the buffer (a
-    PENDING tag left in the slot map would send the lookup 16M rows past it) and the call must be flagged: status bit 3;
-    tokens whose rows all got slots are still exact."""
+    """k_stage_place's "no evictable slot" path.  The cache of cold rows is sized for the worst case of the chunks in flight,
+    so the path is unreachable from scone_embed; the test hook SCONE_STAGE_CAP_ROWS shrinks the cache to 8 rows while a chunk
+    references hundreds of distinct cold rows.  Every reference that found no slot must have been redirected INSIDE the cache
+    (a PENDING tag left in the slot map would send the lookup 4G rows past it) and the call must be flagged: status bit 3."""
     from scone_amd import EmbeddingCache
     from scone_amd import _lib as L
     rng = np.random.default_rng(91)
@@ -1399,7 +1438,7 @@ def test_integration_stub_from_the_docs():
                     ("dim", C.c_int32), ("table_fmt", C.c_int32), ("placement", C.c_int32),
                     ("n_rows", C.c_uint64), ("row_begin", C.c_uint64), ("row_end", C.c_uint64),
                     ("index_capacity", C.c_uint64), ("hot_rows", C.c_uint64),
-                    ("lookup_mode", C.c_uint32), ("stage_tokens", C.c_uint32)]
+                    ("lookup_mode", C.c_uint32), ("stage_tokens", C.c_uint32), ("cache_rows", C.c_uint64)]
 
     lib.scone_create.argtypes = [C.POINTER(_Cfg), C.POINTER(C.c_void_p)]
     lib.scone_index_build.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64]
@@ -1410,7 +1449,7 @@ def test_integration_stub_from_the_docs():
     rng = np.random.default_rng(0)
     f_gram_to_id = {(3,): 0, (3, 4): 1, (4,): 2, (3, 4, 5): 3}
     n, d, max_n = 4, 768, 3
-    cfg = _Cfg(C.sizeof(_Cfg), torch.cuda.current_device(), max_n, d, 2, 0, n, 0, 0, 0, 0, 0, 0)
+    cfg = _Cfg(C.sizeof(_Cfg), torch.cuda.current_device(), max_n, d, 2, 0, n, 0, 0, 0, 0, 0, 0, 0)
     h = C.c_void_p()
     assert lib.scone_create(C.byref(cfg), C.byref(h)) == 0
     keys = torch.zeros(n, max_n, dtype=torch.int32)

@@ -15,8 +15,19 @@ ranks' list records arrive by a device copy), + columns on the wire (round 3: pa
 fragments; the other ranks' fragments are real, built from their row ids), three batches in flight, and the variants that
 were measured and not kept (post stream, direct-mapped row map).  All flows must give the same output checksum.
 tools/shard_emulate.py does the same for ALL eight ranks of a 100M-row table, with real payloads and the bit-exactness check.
+
+Round 4, `--transport-standin`: the figures above assume that the transfers cost the step nothing ("the other ranks' records
+already in place").  On real links they are RCCL kernels -- a few channels per peer, one 256-512-thread workgroup each --
+that need wave slots and memory bandwidth WHILE the lookup grid holds every slot of the chip.  With this switch every
+transfer of rank 0's step is really executed, concurrently with the reduction, by kernels of that shape
+(tools/standin/transport_standin.hip): the all-gather of the list records (29 MB in, 4 MB out to each of 7 peers), and the
+three column exchanges (258 MB in from 7 staging buffers, rank 0's own ~35 MB out to 7 peer buffers) -- local HBM reads and
+writes where xGMI would carry one side, so HBM contention is over-, not under-stated.  Every flow is timed with and
+without that traffic, alternating in one process, for every `--cu-reserve` R (scone_set_cu_reserve: the lookup kernel leaves R
+compute units to the transport kernels).
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -42,6 +53,11 @@ def main():
     ap.add_argument("--rounds", type=int, default=5, help="alternating rounds over the chosen flows (medians are reported)")
     ap.add_argument("--one-only", action="store_true", help="time the one-stream step only (clean per-kernel times under a profiler)")
     ap.add_argument("--split-only", action="store_true", help="time the split-phase loop only (for a kernel profile of it)")
+    ap.add_argument("--transport-standin", action="store_true", help="every flow also WITH its transfers executed by RCCL-shaped "
+                    "copy kernels concurrently with the reduction (columns flows: variants 2, 3)")
+    ap.add_argument("--channels", type=int, default=2, help="stand-in: workgroups per peer and direction for the large segments")
+    ap.add_argument("--threads", type=int, default=256, help="stand-in: threads per workgroup (256 or 512)")
+    ap.add_argument("--cu-reserve", default="0", help="comma list of R: compute units the lookup kernel leaves free")
     a = ap.parse_args()
     N, W, d, B, T = a.rows, a.world, 1024, a.batch, a.seq
     vocab = S.StructuredVocab(N)
@@ -122,23 +138,71 @@ def main():
         c_frags.append(fr)
     side, post = torch.cuda.Stream(), torch.cuda.Stream()
 
-    def make(variant, row_map, sharded_match, post_stream, slots):
+    # ---- stand-in transport (round 4): what the other ranks send sits in staging buffers (zero payloads and scales, their REAL
+    # fragments and list records), what rank 0 sends goes to seven "peer" buffers; RCCL-shaped kernels move both
+    standin = None
+    if a.transport_standin:
+        lib = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "standin", "libtransport_standin.so"))
+        lib.standin_launch.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                       ctypes.c_void_p]
+        src_rows = torch.zeros((ctotal, pbytes), dtype=torch.uint8, device="cuda")
+        src_scales = torch.zeros((ctotal, sbytes), dtype=torch.uint8, device="cuda")
+        src_frags = c_frags[0].clone()
+        peer_rows = [torch.empty((counts[0], pbytes), dtype=torch.uint8, device="cuda") for _ in range(W - 1)]
+        peer_scales = [torch.empty((counts[0], sbytes), dtype=torch.uint8, device="cuda") for _ in range(W - 1)]
+        peer_frags = [torch.empty(cslots[0], dtype=torch.int64, device="cuda") for _ in range(W - 1)]
+        peer_ell = [torch.empty((bper * T, wd), dtype=torch.int32, device="cuda") for _ in range(W - 1)]
+
+        def group(segs):
+            """One RCCL group = one launch: segs = [(src tensor, dst tensor, channels)], bytes taken from src."""
+            segs = [(x, y, c) for x, y, c in segs if x.numel()]
+            n = len(segs)
+            arr_p, arr_u, arr_i = ctypes.c_void_p * n, ctypes.c_ulonglong * n, ctypes.c_int * n
+            src = arr_p(*[x.data_ptr() for x, _, _ in segs])
+            dst = arr_p(*[y.data_ptr() for _, y, _ in segs])
+            nb = arr_u(*[x.numel() * x.element_size() for x, _, _ in segs])
+            ch = arr_i(*[c for _, _, c in segs])
+            rc = lib.standin_launch(n, src, dst, nb, ch, a.threads, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+            assert rc == 0, rc
+
+        def move_lists(slot):
+            """all-gather of the list records: the seven other slices in, my slice out to seven peers."""
+            segs = [(ell_src[r * bper * T:(r + 1) * bper * T], ells[slot][r * bper * T:(r + 1) * bper * T], a.channels) for r in range(1, W)]
+            segs += [(send, peer_ell[r - 1], a.channels) for r in range(1, W)]
+            group(segs)
+
+        def move_columns(slot, n):
+            """the three column exchanges, one group each (as three batch_isend_irecv calls would be)."""
+            group([(src_rows[crec[r]:crec[r] + counts[r]], c_rows[slot][crec[r]:crec[r] + counts[r]], a.channels) for r in range(1, W)]
+                  + [(c_rows[slot][:n], peer_rows[r - 1], a.channels) for r in range(1, W)])
+            group([(src_scales[crec[r]:crec[r] + counts[r]], c_scales[slot][nh + crec[r]:nh + crec[r] + counts[r]], 1) for r in range(1, W)]
+                  + [(c_scales[slot][nh:nh + n], peer_scales[r - 1], 1) for r in range(1, W)])
+            group([(src_frags[cfoff[r]:cfoff[r] + cslots[r]], c_frags[slot][cfoff[r]:cfoff[r] + cslots[r]], 1) for r in range(1, W)]
+                  + [(c_frags[slot][:cslots[0]], peer_frags[r - 1], 1) for r in range(1, W)])
+        standin = (move_lists, move_columns)
+
+    def make(variant, row_map, sharded_match, post_stream, slots, traffic=False):
         """(one-stream step, split-phase loop) of one flow as closures; the row map's form is read from the environment
-        when an exchange starts, so it is set before every call."""
+        when an exchange starts, so it is set before every call.  traffic: the transfers are executed (stand-in kernels)."""
         def begin(slot):
             s.shard_select_slot(slot)
             if sharded_match:
                 s.shard_gather_match(tok, 0, min(bper, B), send)           # my slice: sequences [0, bper)
                 ells[slot][:bper * T].copy_(send)                          # (the all-gather's output: my part ...
-                # ... and the seven other ranks' parts: a device copy (28 MB read + 28 MB written where a receive only
-                # writes; it must be a fresh copy, the reduction rewrites the lists in place)
-                ells[slot][bper * T:].copy_(ell_src[bper * T:])
+                if traffic:
+                    standin[0](slot)
+                else:
+                    # ... and the seven other ranks' parts: a device copy (28 MB read + 28 MB written where a receive only
+                    # writes; it must be a fresh copy, the reduction rewrites the lists in place)
+                    ells[slot][bper * T:].copy_(ell_src[bper * T:])
                 n = s.shard_gather_plan_ell(ells[slot], B, T, 1)[0]
             else:
                 n = s.shard_gather_plan_chunks(tok, 1)[0]
             if row_map == "cols":
                 assert n == counts[0]
                 s.shard_cols_pack(0, n, c_rows[slot][:n], c_scales[slot][nh:nh + n], c_frags[slot][:cslots[0]])
+                if traffic:
+                    standin[1](slot, n)
             else:
                 s.shard_gather_pack_range(0, n, fulls[slot][:maxc])
 
@@ -206,10 +270,22 @@ def main():
         return one_stream, loop
 
     chosen = [flows[int(i)] for i in a.variants.split(",")]
-    fns = {f[0]: make(*f) for f in chosen}
-    samples = {f[0]: {"one": [], "split": []} for f in chosen}
+    reserves = [int(x) for x in a.cu_reserve.split(",")]
+    fns = {}
+    for f in chosen:
+        for R in reserves:
+            tag = f[0] if R == 0 else f"{f[0]} | {R} CUs reserved"
+            fns[tag] = (R,) + make(*f)
+            if a.transport_standin and f[1] == "cols":
+                fns[tag + " | transfers in flight"] = (R,) + make(*f, traffic=True)
+    samples = {name: {"one": [], "split": []} for name in fns}
     checks = {}
-    for name, (one, loop) in fns.items():        # warm-up: allocations, the maps of every slot
+    for name, (R, one, loop) in fns.items():     # warm-up: allocations, the maps of every slot
+        s.set_cu_reserve(R)
+        if name.endswith("transfers in flight"):  # the stand-in must really deliver: wipe what it is to bring, then check
+            for k in range(3):
+                c_frags[k][cslots[0]:].zero_()
+                ells[k][bper * T:].zero_()
         one(3)
         torch.cuda.synchronize()
         assert s.status() == 0, "a referenced row is missing from the synthesised records"
@@ -218,7 +294,8 @@ def main():
         assert s.status() == 0
         checks[name] = out.float().abs().sum().item()
     for rnd in range(a.rounds):                  # alternating: the same box runs 2 % apart from one minute to the next
-        for name, (one, loop) in fns.items():
+        for name, (R, one, loop) in fns.items():
+            s.set_cu_reserve(R)
             if not a.split_only:
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
@@ -232,6 +309,7 @@ def main():
             loop(a.steps)
             samples[name]["split"].append((time.perf_counter() - t0) * 1e3 / a.steps)
     assert s.status() == 0
+    s.set_cu_reserve(0)
 
     def med(v):
         v = sorted(v)
@@ -246,6 +324,11 @@ def main():
                       "bytes_into_rank0": int((total - size[0]) * rec), "record_bytes": rec,
                       "list_record_bytes_gathered_into_rank0": int((W - 1) * bper * T * wd * 4),
                       "variants": results, "all_variants_same_output": len(sums) == 1,
+                      "transport_standin": None if not a.transport_standin else {
+                          "channels_per_peer_and_direction": a.channels, "threads_per_workgroup": a.threads,
+                          "bytes_in": int((ctotal - counts[0]) * (pbytes + sbytes) + (sum(cslots) - cslots[0]) * 8 + (W - 1) * bper * T * wd * 4),
+                          "bytes_out_per_peer": int(counts[0] * (pbytes + sbytes) + cslots[0] * 8 + bper * T * wd * 4),
+                          "groups_per_step": 4, "workgroups_in_the_rows_group": 2 * (W - 1) * a.channels},
                       "note": "other ranks' records carry the right row ids and zero payloads; the all-gather of list records is "
                               "emulated by a device copy"}))
 

@@ -225,10 +225,14 @@ int scone_reserve(scone_handle *h, int64_t max_tokens);
  * multiple of 8: one CU per XCD; 0 switches it off) the lookup kernels of scone_embed (batches above the one-launch limit),
  * scone_embed_partial and the scone_shard_*_embed* calls run on a stream of the handle whose CU mask leaves n_reserved
  * compute units free, ordered into the caller's stream by two events (everything queued on the caller's stream before the
- * call precedes the lookup, everything queued after follows it); their grids are sized for the remaining CUs.  Not
+ * call precedes the lookup, everything queued after follows it); their grids are sized for the remaining CUs.  The two
+ * cross-stream events cost ~75 us per lookup on MI355X / ROCm 7.2 (measured, profiles/r04c): a caller that owns its loop
+ * queues it on the masked stream itself -- scone_lookup_stream returns it (NULL without a reserve; it lives until the next
+ * scone_set_cu_reserve / scone_destroy) -- and a lookup called on THAT stream is launched there directly, no events.  Not
  * concurrent with lookups on the same handle (like every table mutation); synchronises the previous masked stream. */
 int scone_set_cu_reserve(scone_handle *h, int32_t n_reserved);
 int scone_get_cu_reserve(scone_handle *h, int32_t *n_reserved, int32_t *n_cus);
+int scone_lookup_stream(scone_handle *h, void **stream);
 /* Optional timing of the gather/reduce kernel launched by scone_embed: while enabled, every
  * call brackets that kernel with HIP events on the launch stream (a ring of 1024 pairs).
  * scone_profile_read synchronises the device, returns the number of timed launches and
@@ -384,10 +388,17 @@ int scone_shard_gather_embed_range(scone_handle *h, const int32_t *d_tok, int32_
  *                                 stand in for the other ranks with it
  *   scone_shard_head_scales       the replicated head's scales [n_head, scale bytes] into d_out: the front of the scales
  *                                 buffer (once per buffer, not per step)
+ *   scone_shard_head_version      a counter bumped by every change of the replicated head (scone_shard_set_head /
+ *                                 _head_store_f32 / scone_table_fill_synthetic): a caller's scales buffer whose front was
+ *                                 filled at another version takes scone_shard_head_scales again
  *   scone_shard_cols_embed        sequences [seq_begin, seq_end) of the planned batch out of [replicated head | d_rows
  *                                 [n_total, payload bytes]] with scales d_scales_full [n_head + n_total, scale bytes];
- *                                 h_frag_off[r] (u64 slots into d_frags), h_frag_slots[r], h_rec_base[r] (row number of rank
- *                                 r's first row in d_rows) for r < world.  Lists are rewritten once per plan, as in
+ *                                 d_frags holds frag_slots_total u64 slots; h_frag_off[r] (slots into d_frags),
+ *                                 h_frag_slots[r], h_rec_base[r] (row number of rank r's first row in d_rows) for r < world
+ *                                 (every fragment must lie inside d_frags: SCONE_EINVAL otherwise); h_row_lo[world + 1]:
+ *                                 the owners' row ranges -- rank r owns [h_row_lo[r], h_row_lo[r + 1]), ascending from 0 to
+ *                                 n_rows (tables of at most 2^32 rows) -- or NULL for the floor partition r * n_rows / world
+ *                                 of scone_amd.distributed.shard_range.  Lists are rewritten once per plan, as in
  *                                 scone_shard_gather_embed_range; bit-identical to the unsharded table.
  * New here (the reference keeps its table in one process: embedding_cache.py:49-50). */
 int scone_shard_cols_frag_slots(uint64_t count, uint64_t *slots);
@@ -396,10 +407,11 @@ int scone_shard_cols_pack(scone_handle *h, uint64_t first, uint64_t count, void 
 int scone_shard_cols_build_frag(scone_handle *h, const int32_t *d_ids, uint64_t count, void *d_frag_out, uint64_t frag_slots,
                                 scone_stream_t stream);
 int scone_shard_head_scales(scone_handle *h, void *d_out, scone_stream_t stream);
+int scone_shard_head_version(scone_handle *h, uint64_t *version);
 int scone_shard_cols_embed(scone_handle *h, const int32_t *d_tok, int32_t B, int32_t T, int32_t seq_begin, int32_t seq_end,
                            const void *d_rows, uint64_t n_total, const void *d_scales_full, const void *d_frags,
-                           const uint64_t *h_frag_off, const uint64_t *h_frag_slots, const uint64_t *h_rec_base, int32_t world,
-                           const void *d_wte, int64_t vocab, const void *d_wpe, int64_t n_pos, const int32_t *d_pos,
+                           uint64_t frag_slots_total, const uint64_t *h_frag_off, const uint64_t *h_frag_slots,
+                           const uint64_t *h_rec_base, const uint64_t *h_row_lo, int32_t world, const void *d_wte, int64_t vocab, const void *d_wpe, int64_t n_pos, const int32_t *d_pos,
                            int32_t reduce, void *d_out, int64_t out_tok0, int32_t out_dtype, scone_stream_t stream);
 
 /* ---- transport without kernels for the all-gather form (distributed.py: gather_transport="sdma").  The exchange sends exact

@@ -79,6 +79,7 @@ SIGNATURES = {
     "scone_reserve": (C.c_int, [_P, _I64]),
     "scone_set_cu_reserve": (C.c_int, [_P, _I32]),
     "scone_get_cu_reserve": (C.c_int, [_P, C.POINTER(_I32), C.POINTER(_I32)]),
+    "scone_lookup_stream": (C.c_int, [_P, C.POINTER(_P)]),
     "scone_profile_enable": (C.c_int, [_P, C.c_int]),
     "scone_profile_read": (C.c_int, [_P, C.POINTER(_U64), C.POINTER(C.c_double), C.c_int]),
     "scone_profile_samples": (C.c_int, [_P, C.POINTER(C.c_float), _U64, C.POINTER(_U64)]),
@@ -100,8 +101,9 @@ SIGNATURES = {
     "scone_shard_cols_pack": (C.c_int, [_P, _U64, _U64, _P, _P, _P, _U64, _P]),
     "scone_shard_cols_build_frag": (C.c_int, [_P, _P, _U64, _P, _U64, _P]),
     "scone_shard_head_scales": (C.c_int, [_P, _P, _P]),
-    "scone_shard_cols_embed": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _P, _U64, _P, _P, C.POINTER(_U64), C.POINTER(_U64),
-                                         C.POINTER(_U64), _I32, _P, _I64, _P, _I64, _P, _I32, _P, _I64, _I32, _P]),
+    "scone_shard_head_version": (C.c_int, [_P, C.POINTER(_U64)]),
+    "scone_shard_cols_embed": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _P, _U64, _P, _P, _U64, C.POINTER(_U64), C.POINTER(_U64),
+                                         C.POINTER(_U64), C.POINTER(_U64), _I32, _P, _I64, _P, _I64, _P, _I32, _P, _I64, _I32, _P]),
     "scone_shard_set_head": (C.c_int, [_P, _U64]),
     "scone_shard_head_store_f32": (C.c_int, [_P, _P, _U64, _U64, _P]),
     "scone_shard_record_bytes": (C.c_int, [_P, C.POINTER(_U64)]),

@@ -444,9 +444,16 @@ extern "C" int scone_get_cu_reserve(scone_handle *h, int32_t *n_reserved, int32_
   return SCONE_OK;
 }
 
+extern "C" int scone_lookup_stream(scone_handle *h, void **stream) {
+  if (!h || !stream) return SCONE_EINVAL;
+  *stream = h->cu_reserve ? (void *)h->lookup_stream : nullptr;
+  return SCONE_OK;
+}
+
 int scone_lookup_enter(scone_handle *h, hipStream_t s, hipStream_t *launch) {
   *launch = s;
-  if (!h->cu_reserve) return SCONE_OK;  // (read without the lock: set_cu_reserve is not concurrent with lookups, like every table mutation)
+  if (!h->cu_reserve || s == h->lookup_stream) return SCONE_OK;  // no reserve, or the caller already queues on the masked stream
+  // (cu_reserve is read without the lock: set_cu_reserve is not concurrent with lookups, like every table mutation)
   h->lookup_mu.lock();
   hipError_t e = hipEventRecord(h->lookup_in, s);
   if (e == hipSuccess) e = hipStreamWaitEvent(h->lookup_stream, h->lookup_in, 0);
@@ -488,8 +495,10 @@ static int prof_drain(scone_handle *h) {
 static thread_local scone_handle *prof_held_by_this_thread = nullptr;
 
 int scone_prof_begin(scone_handle *h, hipStream_t s) {
+  if (!h->prof_on.load(std::memory_order_acquire)) return SCONE_OK;  // profiling off: no lock at all
+  if (prof_held_by_this_thread) return scone_fail(h, SCONE_ESTATE, "scone_prof_begin: timed launches do not nest on one thread");
   h->prof_mu.lock();  // until scone_prof_end / scone_prof_abort: the ring slot belongs to this launch
-  if (!h->prof_on) {
+  if (!h->prof_on.load(std::memory_order_relaxed)) {  // switched off between the check and the lock
     h->prof_mu.unlock();
     return SCONE_OK;
   }

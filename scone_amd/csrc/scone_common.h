@@ -7,6 +7,7 @@
 #include <hip/hip_bf16.h>
 #include <stdint.h>
 
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -186,7 +187,7 @@ struct scone_handle {
   // optional kernel timing (scone_profile_*); prof_mu is held from the begin event to the end event of a launch
   std::mutex prof_mu;
   std::mutex err_mu;
-  bool prof_on;
+  std::atomic<bool> prof_on;  // read without the lock by every launch (scone_prof_begin): off = no mutex traffic at all
   hipEvent_t *prof_ev;  // [2 * SCONE_PROF_RING]
   uint64_t prof_head;   // pairs recorded since the last drain
   uint64_t prof_n;      // launches accumulated
@@ -286,8 +287,9 @@ int scone_shard_gather_add(scone_handle *h, const void *d_records, uint64_t n, u
 int scone_shard_gather_remap(scone_handle *h, int32_t T, int32_t seq0, int32_t seq1, const int32_t **ell, const void **scales,
                              hipStream_t s);
 int scone_shard_plan_shape(const scone_handle *h, int32_t *B, int32_t *T);
-int scone_shard_cols_remap(scone_handle *h, int32_t T, int32_t seq0, int32_t seq1, const void *d_frags, const uint64_t *h_frag_off,
-                           const uint64_t *h_frag_slots, const uint64_t *h_rec_base, int32_t world, uint64_t n_total,
+int scone_shard_cols_remap(scone_handle *h, int32_t T, int32_t seq0, int32_t seq1, const void *d_frags, uint64_t frag_slots_total,
+                           const uint64_t *h_frag_off, const uint64_t *h_frag_slots, const uint64_t *h_rec_base,
+                           const uint64_t *h_row_lo, int32_t world, uint64_t n_total,
                            const int32_t **ell, const uint8_t **head_p, unsigned long long *n_head_out, hipStream_t s);
 int scone_shard_prepare_embed(scone_handle *h, int32_t B, int32_t T, int32_t world, int32_t rank, const void *d_recv,
                               uint64_t n_recv, const int32_t **ell, const void **scales, int32_t *b0, int32_t *b1,

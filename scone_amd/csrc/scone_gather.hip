@@ -319,8 +319,9 @@ extern "C" int scone_shard_gather_embed_range(scone_handle *h, const int32_t *d_
 // from the caller's [head scales | received scales] buffer, the id lists are resolved through the senders' hash fragments.
 extern "C" int scone_shard_cols_embed(scone_handle *h, const int32_t *d_tok, int32_t B, int32_t T, int32_t seq_begin,
                                       int32_t seq_end, const void *d_rows, uint64_t n_total, const void *d_scales_full,
-                                      const void *d_frags, const uint64_t *h_frag_off, const uint64_t *h_frag_slots,
-                                      const uint64_t *h_rec_base, int32_t world, const void *d_wte, int64_t vocab,
+                                      const void *d_frags, uint64_t frag_slots_total, const uint64_t *h_frag_off,
+                                      const uint64_t *h_frag_slots, const uint64_t *h_rec_base, const uint64_t *h_row_lo,
+                                      int32_t world, const void *d_wte, int64_t vocab,
                                       const void *d_wpe, int64_t n_pos, const int32_t *d_pos, int32_t reduce, void *d_out,
                                       int64_t out_tok0, int32_t out_dtype, scone_stream_t stream) {
   int rc = need_table(h, "scone_shard_cols_embed: handle has no table (dim == 0)");
@@ -344,8 +345,8 @@ extern "C" int scone_shard_cols_embed(scone_handle *h, const int32_t *d_tok, int
   const int32_t *ell = nullptr;
   const uint8_t *head_p = nullptr;
   unsigned long long n_head = 0;
-  rc = scone_shard_cols_remap(h, T, seq_begin, seq_end, d_frags, h_frag_off, h_frag_slots, h_rec_base, world, n_total, &ell, &head_p,
-                              &n_head, s);
+  rc = scone_shard_cols_remap(h, T, seq_begin, seq_end, d_frags, frag_slots_total, h_frag_off, h_frag_slots, h_rec_base, h_row_lo,
+                              world, n_total, &ell, &head_p, &n_head, s);
   if (rc) return rc;
   embed_args a = {};
   fill_table_view(h, a.tv);

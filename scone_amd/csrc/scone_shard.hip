@@ -43,6 +43,8 @@ struct scone_shard_state {
   uint8_t *head_scales = nullptr;  // [n_head, scale_bytes_per_row]
   uint8_t *head_rows_p = nullptr;  // [n_head, payload bytes]: the head again at the PAYLOAD stride, for the columns exchange
   bool head_p_stale = true;        // (whose received rows are payload only; rebuilt from head_rows after the head changes)
+  hipEvent_t head_p_ready = nullptr;  // recorded behind the rebuild: a lookup on ANOTHER stream waits for it
+  uint64_t head_version = 0;       // bumped by every change of the head (callers re-copy the head's scales into their buffers)
   // all-gather form: distinct rows
   uint32_t *uniq_claim = nullptr;  // [local rows]: generation of the last batch that claimed the row
   uint32_t uniq_gen = 0;
@@ -307,6 +309,7 @@ void scone_shard_destroy(scone_handle *h) {
                   st->rmap, st->head_rows_p, st->multi_claim, st->regions};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
+  if (st->head_p_ready) (void)hipEventDestroy(st->head_p_ready);
   for (int k = 0; k < SCONE_SHARD_SLOTS; ++k) {
     if (k == st->slot) continue;
     void *pp[] = {st->parked[k].ell_slice, st->parked[k].scales, st->parked[k].rhash, st->parked[k].rmap};
@@ -494,6 +497,7 @@ extern "C" int scone_shard_set_head(scone_handle *h, uint64_t n_head) {
   if (st->head_rows_p) SCONE_HIP(h, hipFree(st->head_rows_p));
   st->head_rows = st->head_scales = st->head_rows_p = nullptr;
   st->head_p_stale = true;
+  st->head_version += 1;
   st->n_head = 0;
   if (n_head == 0) return SCONE_OK;
   const size_t rec = (size_t)scone_shard_rec_bytes(h);
@@ -516,6 +520,7 @@ extern "C" int scone_shard_head_store_f32(scone_handle *h, const float *d_rows_f
   if (row0 + nrows > h->shard->n_head) return scone_fail(h, SCONE_ERANGE, "scone_shard_head_store_f32: rows outside [0, n_head)");
   SCONE_ON_DEVICE(h);
   h->shard->head_p_stale = true;
+  h->shard->head_version += 1;
   return scone_store_f32_into(h, head_store(h), h->shard->head_scales, 0, h->shard->n_head, d_rows_f32, nullptr, row0, nrows,
                               (hipStream_t)stream);
 }
@@ -523,6 +528,7 @@ extern "C" int scone_shard_head_store_f32(scone_handle *h, const float *d_rows_f
 int scone_shard_fill_head_synth(scone_handle *h, uint32_t seed, float base_scale, hipStream_t s) {
   if (!h->shard || !h->shard->n_head) return SCONE_OK;
   h->shard->head_p_stale = true;
+  h->shard->head_version += 1;
   return scone_fill_synth_into(h, head_store(h), h->shard->head_scales, 0, h->shard->n_head, seed, base_scale, s);
 }
 
@@ -1408,6 +1414,14 @@ extern "C" int scone_shard_cols_build_frag(scone_handle *h, const int32_t *d_ids
   return SCONE_OK;
 }
 
+// every change of the replicated head bumps this: a caller that copied the head's scales into its own buffer
+// (scone_shard_head_scales) copies them again when the number moved
+extern "C" int scone_shard_head_version(scone_handle *h, uint64_t *version) {
+  if (!h || !version) return SCONE_EINVAL;
+  *version = h->shard ? h->shard->head_version : 0;
+  return SCONE_OK;
+}
+
 // the replicated head's scales, for the front of a [head scales | received scales] buffer the caller owns
 extern "C" int scone_shard_head_scales(scone_handle *h, void *d_out, scone_stream_t stream) {
   if (!h) return SCONE_EINVAL;
@@ -1421,29 +1435,47 @@ extern "C" int scone_shard_head_scales(scone_handle *h, void *d_out, scone_strea
 
 // Receiver of the columns exchange: remap (once per plan) through the owners' fragments; returns the lists, the head at the
 // payload stride and the number of head rows for the lookup launch in scone_gather.hip.
-int scone_shard_cols_remap(scone_handle *h, int32_t T, int32_t seq0, int32_t seq1, const void *d_frags, const uint64_t *h_frag_off,
-                           const uint64_t *h_frag_slots, const uint64_t *h_rec_base, int32_t world, uint64_t n_total,
+int scone_shard_cols_remap(scone_handle *h, int32_t T, int32_t seq0, int32_t seq1, const void *d_frags, uint64_t frag_slots_total,
+                           const uint64_t *h_frag_off, const uint64_t *h_frag_slots, const uint64_t *h_rec_base,
+                           const uint64_t *h_row_lo, int32_t world, uint64_t n_total,
                            const int32_t **ell, const uint8_t **head_p, unsigned long long *n_head_out, hipStream_t s) {
   scone_shard_state *st = h->shard;
   int32_t *lists = plan_lists(st);
   if (!lists) return scone_fail(h, SCONE_ESTATE, "scone_shard_cols_embed: plan the batch first");
   if ((size_t)seq1 > st->remapped.size()) return scone_fail(h, SCONE_ESTATE, "scone_shard_cols_embed: sequences outside the planned batch");
   if (world < 1 || world > 64) return scone_fail(h, SCONE_EINVAL, "scone_shard_cols_embed: world <= 64");
+  // The owner of a row id follows from the owners' row ranges, which the CALLER states (h_row_lo[r] = first row of rank r,
+  // h_row_lo[world] = n_rows): handles may be created with any [row_begin, row_end), and nothing here assumes the floor
+  // partition of distributed.shard_range (NULL selects it).  Every fragment must lie inside the buffer it was received into.
+  if (h->cfg.n_rows > 0xFFFFFFFFull) return scone_fail(h, SCONE_EINVAL, "scone_shard_cols_embed: tables of at most 2^32 rows");
   cols_owners ow = {};
   for (int r = 0; r < world; ++r) {
     if (h_frag_slots[r] == 0 || (h_frag_slots[r] & (h_frag_slots[r] - 1)))
       return scone_fail(h, SCONE_EINVAL, "scone_shard_cols_embed: fragment sizes must be powers of two");
+    if (h_frag_off[r] + h_frag_slots[r] > frag_slots_total)
+      return scone_fail(h, SCONE_EINVAL, "scone_shard_cols_embed: a fragment lies outside d_frags (frag_slots_total)");
     ow.frag_off[r] = h_frag_off[r], ow.frag_mask[r] = h_frag_slots[r] - 1, ow.rec_base[r] = h_rec_base[r];
-    ow.row_lo[r] = (unsigned int)(((unsigned long long)r * h->cfg.n_rows) / (unsigned long long)world);  // distributed.shard_range
+    const unsigned long long lo = h_row_lo ? h_row_lo[r] : ((unsigned long long)r * h->cfg.n_rows) / (unsigned long long)world;
+    if (lo > h->cfg.n_rows || (r > 0 && lo < ow.row_lo[r - 1]) || (r == 0 && lo != 0))
+      return scone_fail(h, SCONE_EINVAL, "scone_shard_cols_embed: h_row_lo must ascend from 0 to n_rows");
+    ow.row_lo[r] = (unsigned int)lo;
   }
+  if (h_row_lo && h_row_lo[world] != h->cfg.n_rows)
+    return scone_fail(h, SCONE_EINVAL, "scone_shard_cols_embed: h_row_lo[world] must be n_rows");
   ow.row_lo[world] = (unsigned int)h->cfg.n_rows;
-  ow.owners_per_row = (float)world / (float)(h->cfg.n_rows ? h->cfg.n_rows : 1);
+  ow.owners_per_row = (float)world / (float)(h->cfg.n_rows ? h->cfg.n_rows : 1);  // a first guess; the fix-up steps make it exact
   const size_t pb = h->row_payload_bytes;
-  if (st->n_head && (st->head_p_stale || !st->head_rows_p)) {  // the head at the payload stride (once per head change)
-    if (!st->head_rows_p) SCONE_HIP(h, hipMalloc(&st->head_rows_p, (size_t)st->n_head * pb));
-    SCONE_HIP(h, hipMemcpy2DAsync(st->head_rows_p, pb, st->head_rows, (size_t)scone_shard_rec_bytes(h), pb, (size_t)st->n_head,
-                                  hipMemcpyDeviceToDevice, s));
-    st->head_p_stale = false;
+  if (st->n_head) {  // the head at the payload stride: rebuilt once per head change, on this stream; other streams wait for it
+    if (!st->head_p_ready) SCONE_HIP(h, hipEventCreateWithFlags(&st->head_p_ready, hipEventDisableTiming));
+    if (st->head_p_stale || !st->head_rows_p) {
+      if (!st->head_rows_p) SCONE_HIP(h, hipMalloc(&st->head_rows_p, (size_t)st->n_head * pb));
+      SCONE_HIP(h, hipMemcpy2DAsync(st->head_rows_p, pb, st->head_rows, (size_t)scone_shard_rec_bytes(h), pb, (size_t)st->n_head,
+                                    hipMemcpyDeviceToDevice, s));
+      SCONE_HIP(h, hipEventRecord(st->head_p_ready, s));
+      st->head_p_stale = false;
+    } else {
+      SCONE_HIP(h, hipStreamWaitEvent(s, st->head_p_ready, 0));
+    }
   }
   const int W = SCONE_ELL_W(h->cfg.max_n), NC = h->cfg.max_n * (h->cfg.max_n + 1) / 2;
   for (int32_t a = seq0; a < seq1;) {

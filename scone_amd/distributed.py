@@ -43,6 +43,14 @@ here and only needed when the table does not fit one GPU's 288 GB (BASELINE conf
   travels as payload rows | scales | the SENDER's hash fragment ``row id -> position`` instead of ``[payload | scales | row id]``
   records -- no receiver indexes anything (0.45M device-scope CAS per rank and step before), the rows land at the table's own
   stride (``scone_shard_cols_pack / _embed``);
+* round 4, ``gather_transport="sdma"``: the exchange of the one-piece form sends exact contiguous ranges, so it needs no
+  kernel at all -- every rank maps its peers' per-slot receive buffers once (HIP interprocess handles, ``scone_ipc_*``), packs its
+  columns into its own range and PUSHES that range to the same offsets of the seven peer buffers with ``hipMemcpyAsync`` on one
+  stream per peer (the copy engines move the bytes over xGMI while every wave slot of the chip belongs to the lookup kernel;
+  RCCL's send / recv are kernels that must find room beside it), "my pushes for this slot are complete" / "I have reduced this
+  slot" are interprocess events, and the two host-side rendezvous a step needs anyway -- the exchange of the counts and one
+  barrier on a gloo group -- make sure a wait never sees the previous batch's record.  Falls back to ``"p2p"`` (on every rank
+  alike) when the handles cannot be created or opened;
 * ``SCONE_DIST_TRACE=1``: one stderr line BEFORE every collective (name, counts, bytes) -- the last line of a hung job names
   the collective it hangs in;
 * exchange ``"partial_sums"`` (kept for comparison): every rank sums the rows it owns
@@ -140,6 +148,18 @@ class _Works:
             w.wait()
 
 
+class _SdmaArrival:
+    """``wait()``: the current stream waits until every peer's pushes into this slot are complete (their interprocess
+    "sent" events; a host-side barrier after the records makes sure the wait sees THIS batch's record)."""
+
+    def __init__(self, table, events) -> None:
+        self.table, self.events = table, list(events)
+
+    def wait(self) -> None:
+        for e in self.events:
+            self.table.ipc_event_wait(e)
+
+
 def _exchange_exact_async(region: torch.Tensor, offs, counts, rank: int, group):
     """All-gather with UNEQUAL contributions, as point-to-point transfers: ``region [sum(counts), rec]`` holds rank r's
     records at ``[offs[r], offs[r] + counts[r])`` -- mine are already in place -- and every rank sends its own range to every
@@ -234,10 +254,14 @@ class ShardedEmbeddingCache:
             raise ValueError("shard_match must be True, False or 'auto'")
         self.shard_match = shard_match
         self.gather_chunks = int(gather_chunks)    # "gather_rows": the batch is exchanged and reduced in this many chunks
-        if gather_transport not in ("p2p", "all_gather"):
-            raise ValueError("gather_transport must be 'p2p' or 'all_gather'")
-        # "gather_rows": how the records travel -- exact point-to-point ranges, or all_gather_into_tensor padded to the largest
+        if gather_transport not in ("p2p", "all_gather", "sdma"):
+            raise ValueError("gather_transport must be 'p2p', 'all_gather' or 'sdma'")
+        # "gather_rows": how the records travel -- exact point-to-point ranges (RCCL send / recv kernels), all_gather_into_tensor
+        # padded to the largest, or -- the one-piece columns form only -- copy-engine pushes into peer-mapped buffers ("sdma";
+        # chunked / record exchanges use "p2p" under it)
         self.gather_transport = gather_transport
+        self.transport_fallback_reason = None         # why "sdma" was asked for and "p2p" is used (None: it was not / it is)
+        self._sdma = None
         self.rank = dist.get_rank(group) if rank is None else int(rank)
         self.world = dist.get_world_size(group) if world is None else int(world)
         self.n_gram_extractor = n_gram_extractor
@@ -268,7 +292,10 @@ class ShardedEmbeddingCache:
         self._slot_open = [False] * 4
         self._slot_ell = [None] * 4          # sharded match: the gathered list records of the batch a slot holds
         self._slot_cols = [None] * 4         # columns exchange: (rows, scales, frags) receive buffers of a slot
+        self._slot_head_ver = [None] * 4     # ... and the version of the replicated head whose scales their front holds
         self._ell_send = None
+        if gather_transport == "sdma" and self.world > 1:
+            self._sdma_init()
 
     @classmethod
     def from_synthetic(cls, n_gram_extractor: NGramExtractor, embedding_dim: int, *, table_format: str = "int8",
@@ -290,11 +317,151 @@ class ShardedEmbeddingCache:
             self.table.shard_head_store_f32(rows_f32[:hb - row0], row0=row0)
             self._slot_cols = [None] * 4                             # (their scales buffers start with the head's scales)
 
+    # -- "sdma" transport: peer-mapped receive buffers, interprocess events, copy-engine pushes ------------------
+    def _sdma_init(self) -> None:
+        """Collective (every rank of the group constructs its cache): can this table / platform do it at all?  If any rank
+        cannot, ALL fall back to "p2p" -- the ranks must agree on the transport."""
+        t = self.table
+        ok, why = True, None
+        if not all(hasattr(t, m) for m in ("ipc_alloc", "ipc_event_create", "ipc_push", "shard_cols_pack")):
+            ok, why = False, "the table handle has no scone_ipc_* entry points (a stand-in handle)"
+        elif self.wire_format != "columns":
+            ok, why = False, "wire_format='records' (the sdma transport moves columns)"
+        else:
+            try:                                        # capability probe: one buffer + one event, exported
+                p, _ = t.ipc_alloc(4096)
+                e, _ = t.ipc_event_create()
+                t.ipc_tensor(p, 4096).zero_()
+                t.ipc_event_destroy(e)
+                t.ipc_free(p)
+            except Exception as ex:                     # noqa: BLE001 -- whatever HIP / torch refuse here means "not available"
+                ok, why = False, f"interprocess handles are not available here: {ex!r}"
+        flags = [None] * self.world
+        _trace("all_gather_object(sdma capability)", self.group, ok=ok)
+        dist.all_gather_object(flags, (ok, why), group=self.group)
+        bad = [(r, w) for r, (o, w) in enumerate(flags) if not o]
+        if bad:
+            self.transport_fallback_reason = f"rank {bad[0][0]}: {bad[0][1]}"
+            self.gather_transport = "p2p"
+            return
+        # host-side rendezvous of the step: the group itself when it is a host group (gloo), else a gloo group beside it
+        if _host_staged(self.group):
+            ctrl = self.group
+        else:
+            ranks = list(range(dist.get_world_size())) if self.group is None else dist.get_process_group_ranks(self.group)
+            ctrl = dist.new_group(ranks=ranks, backend="gloo")
+        dev = self.table.device
+        self._sdma = {"ctrl": ctrl, "slots": [None] * 4,
+                      "push": [torch.cuda.Stream(device=dev) for _ in range(self.world)],
+                      "copy_engine": os.environ.get("SCONE_SDMA_COPY_ENGINE", "1") != "0"}
+
+    def _sdma_release_slot(self, st) -> None:
+        t = self.table
+        for r in range(self.world):
+            if r != self.rank and st["peer"][r] is not None:
+                for ptr in st["peer"][r]:
+                    if ptr:
+                        t.ipc_close(ptr)
+                t.ipc_event_destroy(st["peer_sent"][r])
+                t.ipc_event_destroy(st["peer_done"][r])
+        for ptr in st["ptrs"]:
+            if ptr:
+                t.ipc_free(ptr)
+        t.ipc_event_destroy(st["sent"])
+        t.ipc_event_destroy(st["done"])
+
+    def _sdma_slot(self, slot: int, total: int, ftotal: int, dev):
+        """This slot's receive buffers (rows, scales, frags) with room for ``total`` rows / ``ftotal`` fragment slots, mapped
+        into every peer.  Every rank sees the same totals, so every rank (re)allocates in the same step: free what was
+        there (after the device and the peers are idle), allocate, exchange the handles, open the peers'."""
+        t, W, r = self.table, self.world, self.rank
+        st = self._sdma["slots"][slot]
+        if st is not None and st["cap"] >= max(total, 1) and st["fcap"] >= ftotal:
+            return st
+        pb, sb, nh = t.payload_bytes(), t.scale_bytes(), int(getattr(t, "n_head", 0) or 0)
+        torch.cuda.synchronize(dev)
+        dist.barrier(group=self._sdma["ctrl"])           # nobody pushes into, or reads from, the buffers that go away
+        if st is not None:
+            self._sdma_release_slot(st)
+        cap, fcap = max(total + total // 8, 1), max(ftotal + ftotal // 8, 64)
+        nbytes = (cap * pb, (nh + cap) * sb, fcap * 8)
+        ptrs, handles = [], []
+        for nb in nbytes:
+            if nb:
+                p, hb = t.ipc_alloc(nb)
+            else:
+                p, hb = 0, b"\0" * 64
+            ptrs.append(p)
+            handles.append(hb)
+        sent, h_sent = t.ipc_event_create()
+        done, h_done = t.ipc_event_create()
+        mine = b"".join(handles) + h_sent + h_done
+        everyone = [None] * W
+        _trace("all_gather_object(sdma handles)", self.group, slot=slot, rows=cap, frag_slots=fcap)
+        dist.all_gather_object(everyone, mine, group=self.group)
+        peer, peer_sent, peer_done = [None] * W, [None] * W, [None] * W
+        for q in range(W):
+            if q == r:
+                continue
+            hq = everyone[q]
+            peer[q] = tuple(t.ipc_open(hq[64 * i:64 * i + 64]) if nbytes[i] else 0 for i in range(3))
+            peer_sent[q] = t.ipc_event_open(hq[192:256])
+            peer_done[q] = t.ipc_event_open(hq[256:320])
+        rows = t.ipc_tensor(ptrs[0], nbytes[0]).view(cap, pb)
+        scales = t.ipc_tensor(ptrs[1], nbytes[1]).view(nh + cap, sb) if sb else None
+        frags = t.ipc_tensor(ptrs[2], nbytes[2]).view(torch.int64)
+        torch.cuda.synchronize(dev)                      # (the head's scales go into the front of `scales` in _gather_begin_cols)
+        dist.barrier(group=self._sdma["ctrl"])           # every rank has opened every buffer before anyone pushes
+        st = {"cap": cap, "fcap": fcap, "ptrs": ptrs, "peer": peer, "sent": sent, "done": done, "peer_sent": peer_sent,
+              "peer_done": peer_done, "rows": rows, "scales": scales, "frags": frags, "used": False}
+        self._sdma["slots"][slot] = st
+        return st
+
+    def _sdma_push(self, st, regions) -> "_SdmaArrival":
+        """``regions``: [(column index, byte offset, bytes)] of this rank's freshly packed range.  Waits (stream-ordered) until
+        every peer has reduced the batch that used this slot before, pushes the ranges to the same offsets of every peer's
+        buffers -- one stream per peer, so that the copy engines drive all links at once --, records "sent", and rendezvous
+        on the host so that the receivers' waits see this record."""
+        t, W, r = self.table, self.world, self.rank
+        cur = torch.cuda.current_stream()
+        if st["used"]:
+            for q in range(W):
+                if q != r:
+                    t.ipc_event_wait(st["peer_done"][q])     # (recorded before the peer entered this step's count exchange)
+        packed = torch.cuda.Event()
+        packed.record(cur)
+        for q in range(W):
+            if q == r:
+                continue
+            ps = self._sdma["push"][q]
+            ps.wait_event(packed)
+            with torch.cuda.stream(ps):
+                for col, off, nb in regions:
+                    if nb:
+                        t.ipc_push(st["peer"][q][col] + off, st["ptrs"][col] + off, nb, self._sdma["copy_engine"])
+                e = torch.cuda.Event()
+                e.record(ps)
+            cur.wait_event(e)
+        t.ipc_event_record(st["sent"])
+        _trace("barrier(sdma: pushes recorded)", self.group, bytes_per_peer=sum(nb for _, _, nb in regions))
+        dist.barrier(group=self._sdma["ctrl"])
+        return _SdmaArrival(t, [st["peer_sent"][q] for q in range(W) if q != r])
+
+    def close(self) -> None:
+        """Release the interprocess buffers and events of the "sdma" transport (collective in spirit: call it on every rank
+        once the loop is over; peers must not push afterwards)."""
+        if self._sdma is not None:
+            torch.cuda.synchronize(self.table.device)
+            for st in self._sdma["slots"]:
+                if st is not None:
+                    self._sdma_release_slot(st)
+            self._sdma = None
+
     # ------------------------------------------------------------------
     def embed_tokens(self, input_ids: torch.Tensor, *, reduce: str = "mean", wte: Optional[torch.Tensor] = None,
                      wpe: Optional[torch.Tensor] = None, position_ids: Optional[torch.Tensor] = None,
                      out_dtype: Optional[torch.dtype] = None, gather_output: bool = True,
-                     exchange: str = "auto", profile: bool = False):
+                     exchange: str = "auto", profile: bool = False, check: bool = False):
         """Same result as ``EmbeddingCache.embed_tokens`` on the unsharded table -- bit-identical with the row
         exchanges, up to the fp32 summation order across shards with ``"partial_sums"``.  Every rank passes the SAME
         ``input_ids [B, T]``.
@@ -306,9 +473,12 @@ class ShardedEmbeddingCache:
 
         ``profile=True`` (row exchanges only): returns ``(out, phases)`` -- the device is synchronised between the phases
         of the step and ``phases`` holds their milliseconds (``plan_ms, pack_ms, collective_ms, embed_ms, gather_out_ms``)
-        and ``bytes_received`` (payload this rank received over the group); an instrumented step, not a fast one."""
+        and ``bytes_received`` (payload this rank received over the group); an instrumented step, not a fast one.
+        ``check=True``: raise if the step left a status bit behind (a row that never arrived, a token outside ``wte``)."""
         self._prof = {} if profile else None
         out = self._embed_tokens(input_ids, reduce, wte, wpe, position_ids, out_dtype, gather_output, exchange)
+        if check:                                       # (synchronises: the sticky status bits of every kernel of the step)
+            self._check_status("embed_tokens")
         if profile:
             prof, self._prof = self._prof, None
             return out, prof
@@ -469,8 +639,9 @@ class ShardedEmbeddingCache:
         """Before a plan: the slot must be free, and this stream must not overwrite the sender-side scratch while the
         previous plan's last pack (possibly on another stream) is still reading it."""
         if self._slot_open[slot]:
-            raise RuntimeError(f"plan slot {slot} still holds a batch begun with gather_rows_begin: call gather_rows_finish "
-                               "for it first (at most two batches in flight, finished in the order they were begun)")
+            raise RuntimeError(f"plan slot {slot} still holds a batch begun with gather_rows_begin: call gather_rows_finish (or "
+                               f"gather_rows_abandon) for it first -- at most {self.plan_slots - 1 if self.plan_slots > 2 else 2} batches "
+                               f"in flight with plan_slots={self.plan_slots}, finished in the order they were begun")
         if self._plan_packed is not None and tok.is_cuda:
             torch.cuda.current_stream().wait_event(self._plan_packed)
         self.table.shard_select_slot(slot)
@@ -523,7 +694,8 @@ class ShardedEmbeddingCache:
             counts = [int(c) for c in allc.tolist()]
         else:
             counts = [int(n_me)]
-        exact = W > 1 and self.gather_transport == "p2p"
+        sdma = W > 1 and self.gather_transport == "sdma" and self._sdma is not None
+        exact = W > 1 and self.gather_transport in ("p2p", "sdma")
         slots_r = [t.cols_frag_slots(c) for c in counts]
         if exact or W == 1:
             rec_base = [sum(counts[:q]) for q in range(W)]
@@ -536,22 +708,36 @@ class ShardedEmbeddingCache:
             total, ftotal = W * m, W * ms
         pb, sb, nh = t.payload_bytes(), t.scale_bytes(), int(getattr(t, "n_head", 0) or 0)
         bufs = self._slot_cols[slot]
-        if bufs is None or bufs[0].shape[0] < max(total, 1) or bufs[2].numel() < ftotal or bufs[0].device != tok.device:
+        st = None
+        if sdma:                                         # receive buffers every peer has mapped (collective when they grow)
+            st = self._sdma_slot(slot, total, ftotal, tok.device)
+            bufs = (st["rows"], st["scales"], st["frags"])
+        elif bufs is None or bufs[0].shape[0] < max(total, 1) or bufs[2].numel() < ftotal or bufs[0].device != tok.device:
             cap = max(total + total // 8, 1)
             rows = torch.empty((cap, pb), dtype=torch.uint8, device=tok.device)
             scales = torch.empty((nh + cap, sb), dtype=torch.uint8, device=tok.device) if sb else None
-            if scales is not None and nh:
-                t.shard_head_scales_into(scales)         # [head scales | received scales]: the front part once per buffer
             frags = torch.empty(max(ftotal + ftotal // 8, 64), dtype=torch.int64, device=tok.device)
             bufs = self._slot_cols[slot] = (rows, scales, frags)
+            self._slot_head_ver[slot] = None
         rows, scales, frags = bufs
+        if scales is not None and nh:
+            # [head scales | received scales]: the front part once per buffer AND per version of the head -- a head changed
+            # through the table handle (shard_head_store_f32, fill_synthetic, ...) must not leave stale scales here
+            hv = t.shard_head_version() if hasattr(t, "shard_head_version") else 0
+            key = (hv, scales.data_ptr())
+            if self._slot_head_ver[slot] != key:
+                t.shard_head_scales_into(scales)
+                self._slot_head_ver[slot] = key
         t0 = self._tick("collective_ms", t0)
         works, keep = [], None
         if exact or W == 1:
             t.shard_cols_pack(0, n_me, rows[rec_base[r]:rec_base[r] + n_me], None if scales is None else
                               scales[nh + rec_base[r]:nh + rec_base[r] + n_me], frags[frag_off[r]:frag_off[r] + slots_r[r]])
             t0 = self._tick("pack_ms", t0)
-            if W > 1:
+            if sdma:
+                works.append(self._sdma_push(st, [(0, rec_base[r] * pb, n_me * pb), (1, (nh + rec_base[r]) * sb, n_me * sb),
+                                                  (2, frag_off[r] * 8, slots_r[r] * 8)]))
+            elif W > 1:
                 works.append(_exchange_exact_async(rows[:total], rec_base + [total], counts, r, self.group))
                 if scales is not None:
                     works.append(_exchange_exact_async(scales[nh:nh + total], rec_base + [total], counts, r, self.group))
@@ -577,7 +763,7 @@ class ShardedEmbeddingCache:
             self._prof["bytes_received"] = float(got)
         self._plan_packed_here(tok)
         self._slot_open[slot] = True
-        return {"slot": slot, "tok": tok, "C": 1, "per": B, "works": works, "ready": None, "t0": t0, "keep": keep,
+        return {"slot": slot, "tok": tok, "C": 1, "per": B, "works": works, "ready": None, "t0": t0, "keep": keep, "sdma": st,
                 "cols": {"rows": rows, "scales": scales, "frags": frags, "total": total, "frag_off": frag_off,
                          "frag_slots": slots_r, "rec_base": rec_base}}
 
@@ -659,10 +845,13 @@ class ShardedEmbeddingCache:
 
     def gather_rows_finish(self, ticket: dict, *, reduce: str = "mean", wte: Optional[torch.Tensor] = None,
                            wpe: Optional[torch.Tensor] = None, position_ids: Optional[torch.Tensor] = None,
-                           out_dtype: Optional[torch.dtype] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                           out_dtype: Optional[torch.dtype] = None, out: Optional[torch.Tensor] = None,
+                           check: bool = False) -> torch.Tensor:
         """Second half: chunk by chunk, the caller's stream waits for the chunk's records, adds them to the row map and
         reduces the chunk's sequences out of ``[replicated head | records received so far]``.  Returns ``[B, T, d]`` --
-        bit-identical to ``EmbeddingCache.embed_tokens`` on the unsharded table."""
+        bit-identical to ``EmbeddingCache.embed_tokens`` on the unsharded table.  ``check=True``: read the handle's sticky
+        status bits afterwards (synchronises) and raise if a referenced row never arrived (the ranks disagreed about the
+        batch), a token was out of range, ...: a serving loop checks every N-th step, a test every step."""
         t, d = self.table, self.embedding_dim
         tok = ticket["tok"]
         B, T = tok.shape
@@ -686,14 +875,20 @@ class ShardedEmbeddingCache:
                 w.wait()                                                 # the current stream waits for the three columns
             t0 = self._tick("collective_ms", t0)
             c = ticket["cols"]
+            row_lo = [shard_range(self.n_rows, q, self.world)[0] for q in range(self.world)] + [self.n_rows]   # who owns which rows
             t.shard_cols_embed(tok, 0, B, c["rows"], c["total"], c["scales"], c["frags"], c["frag_off"], c["frag_slots"],
-                               c["rec_base"], out, wte=wte, wpe=wpe, position_ids=position_ids, reduce=reduce)
+                               c["rec_base"], out, wte=wte, wpe=wpe, position_ids=position_ids, reduce=reduce, row_lo=row_lo)
             t0 = self._tick("embed_ms", t0)
             if cur is not None:
                 done = torch.cuda.Event()
                 done.record(cur)
                 self._slot_done[ticket["slot"]] = done
+            if ticket.get("sdma") is not None:                           # the peers may push the next batch into this slot
+                t.ipc_event_record(ticket["sdma"]["done"])
+                ticket["sdma"]["used"] = True
             self._keep = (ticket, position_ids, wte, wpe, out)
+            if check:
+                self._check_status("gather_rows_finish")
             return out.view(B, T, d)
         C, per, base, records, works = ticket["C"], ticket["per"], ticket["base"], ticket["records"], ticket["works"]
         for c in range(C):
@@ -712,7 +907,52 @@ class ShardedEmbeddingCache:
             done.record(cur)
             self._slot_done[ticket["slot"]] = done
         self._keep = (ticket, position_ids, wte, wpe, out)               # read in place until the stream has passed
+        if check:
+            self._check_status("gather_rows_finish")
         return out.view(B, T, d)
+
+    def _check_status(self, who: str) -> None:
+        bits = int(self.table.status()) if hasattr(self.table, "status") else 0
+        if bits:
+            names = [n for b, n in ((1, "token or position outside wte / wpe"), (2, "a referenced row never arrived / row id outside the table"),
+                                    (4, "index full"), (8, "cold-row cache overflow")) if bits & b]
+            raise RuntimeError(f"{who}: device status bits {bits:#x} ({'; '.join(names)}) -- the output of this step is not "
+                               "the unsharded table's")
+
+    def gather_rows_abandon(self, ticket: Optional[dict]) -> None:
+        """Give up a batch begun with :meth:`gather_rows_begin` without reducing it (an exception between begin and finish, a
+        ticket the caller drops): waits for its outstanding transfers and frees its plan slot, so that later begins do not
+        find the slot occupied.  Collective like begin / finish: every rank abandons the same ticket."""
+        if ticket is None:
+            return
+        for w in ticket.get("works") or []:
+            w = w[0] if isinstance(w, tuple) else w
+            if w is not None:
+                w.wait()
+        tok = ticket["tok"]
+        if tok.is_cuda:
+            cur = torch.cuda.current_stream()
+            if ticket.get("ready") is not None:
+                cur.wait_event(ticket["ready"])
+            done = torch.cuda.Event()
+            done.record(cur)
+            self._slot_done[ticket["slot"]] = done
+            if ticket.get("sdma") is not None:
+                self.table.ipc_event_record(ticket["sdma"]["done"])
+                ticket["sdma"]["used"] = True
+        self._slot_open[ticket["slot"]] = False
+
+    def reset_slots(self) -> None:
+        """Forget every batch in flight (after an error, when tickets were lost): the device is synchronised and every plan
+        slot is free again.  The peers must do the same before the next exchange."""
+        if torch.cuda.is_available() and getattr(self.table, "device", None) is not None and torch.device(self.table.device).type == "cuda":
+            torch.cuda.synchronize(self.table.device)
+        self._slot_open = [False] * 4
+        self._slot_done = [None] * 4
+        self._slot_next = 0
+        self._plan_packed = None
+        if hasattr(self.table, "shard_select_slot"):
+            self.table.shard_select_slot(0)
 
     def _embed_gather_rows_unchunked(self, tok, reduce, wte, wpe, position_ids, out_dtype):
         """One plan, one all-gather, one reduction (the form the chunked path degenerates to with one chunk)."""

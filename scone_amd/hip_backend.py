@@ -369,6 +369,14 @@ class SconeTable:
         with torch.cuda.device(self.device):
             self._check(L.lib().scone_set_cu_reserve(self._h, int(n_reserved)), "scone_set_cu_reserve")
 
+    def lookup_stream(self) -> Optional["torch.cuda.Stream"]:
+        """The handle's CU-masked stream as a torch stream (None without a reserve): a loop queued on it -- ``with
+        torch.cuda.stream(table.lookup_stream()):`` -- has its lookups launched there directly, without the two cross-stream
+        events of the transparent form.  Valid until the next :meth:`set_cu_reserve`."""
+        p = C.c_void_p()
+        self._check(L.lib().scone_lookup_stream(self._h, C.byref(p)), "scone_lookup_stream")
+        return torch.cuda.ExternalStream(p.value, device=self.device) if p.value else None
+
     def cu_reserve(self) -> Tuple[int, int]:
         """(compute units reserved, compute units of the device)."""
         a, b = C.c_int32(0), C.c_int32(0)
@@ -619,6 +627,12 @@ class SconeTable:
     def scale_bytes(self) -> int:
         return 2 * self.scales_per_row()
 
+    def shard_head_version(self) -> int:
+        """Counter bumped by every change of the replicated head (buffers that start with the head's scales are refilled)."""
+        v = C.c_uint64(0)
+        self._check(L.lib().scone_shard_head_version(self._h, C.byref(v)), "scone_shard_head_version")
+        return v.value
+
     def shard_head_scales_into(self, scales_full: torch.Tensor) -> None:
         """The replicated head's scales into the front of a ``[n_head + capacity, scale bytes]`` buffer."""
         with torch.cuda.device(self.device):
@@ -628,22 +642,81 @@ class SconeTable:
     def shard_cols_embed(self, tok: torch.Tensor, seq_begin: int, seq_end: int, rows: torch.Tensor, n_total: int,
                          scales_full: Optional[torch.Tensor], frags: torch.Tensor, frag_off, frag_slots, rec_base,
                          out: torch.Tensor, wte: Optional[torch.Tensor] = None, wpe: Optional[torch.Tensor] = None,
-                         position_ids: Optional[torch.Tensor] = None, reduce: str = "mean") -> None:
+                         position_ids: Optional[torch.Tensor] = None, reduce: str = "mean", row_lo=None) -> None:
         """Sequences ``[seq_begin, seq_end)`` of the planned batch into their place in ``out [B*T, d]`` out of ``[replicated
-        head | rows]`` (payload stride), lists resolved through the owners' fragments."""
+        head | rows]`` (payload stride), lists resolved through the owners' fragments.  ``row_lo``: the owners' row ranges,
+        ``len(frag_off) + 1`` ascending values from 0 to ``n_rows`` (None: the floor partition of ``distributed.shard_range``)."""
         tok = self._tok(tok)
         B, T = tok.shape
         W = len(frag_off)
         assert out.is_cuda and out.is_contiguous() and out.numel() >= B * T * self.dim
-        arr = lambda v: (C.c_uint64 * 64)(*[int(x) for x in v])
+        arr = lambda v: (C.c_uint64 * 65)(*[int(x) for x in v])
+        if row_lo is not None and len(row_lo) != W + 1:
+            raise ValueError("row_lo needs len(frag_off) + 1 entries")
         with torch.cuda.device(self.device):
             rc = L.lib().scone_shard_cols_embed(self._h, _ptr(tok), B, T, int(seq_begin), int(seq_end), _ptr(rows), int(n_total),
-                                                _ptr(scales_full), _ptr(frags), arr(frag_off), arr(frag_slots), arr(rec_base), W,
+                                                _ptr(scales_full), _ptr(frags), frags.numel(), arr(frag_off), arr(frag_slots),
+                                                arr(rec_base), None if row_lo is None else arr(row_lo), W,
                                                 _ptr(wte), 0 if wte is None else wte.shape[0], _ptr(wpe),
                                                 0 if wpe is None else wpe.shape[0], _ptr(position_ids), _REDUCE[reduce], _ptr(out),
                                                 0, _DT[out.dtype], _stream())
         self._shard_keepalive = (rows, scales_full, frags, tok, position_ids, wte, wpe, out)
         self._check(rc, "scone_shard_cols_embed")
+
+    # -- peer-mapped buffers, interprocess events, copy-engine pushes (scone_ipc_*: the "sdma" transport) ------------
+    def ipc_alloc(self, nbytes: int) -> Tuple[int, bytes]:
+        """Device memory of this handle's device + its 64-byte interprocess handle: ``(pointer, handle)``."""
+        p, hb = C.c_void_p(), C.create_string_buffer(64)
+        with torch.cuda.device(self.device):
+            self._check(L.lib().scone_ipc_alloc(self._h, int(nbytes), C.byref(p), hb), "scone_ipc_alloc")
+        return p.value, hb.raw
+
+    def ipc_free(self, ptr: int) -> None:
+        self._check(L.lib().scone_ipc_free(self._h, C.c_void_p(ptr)), "scone_ipc_free")
+
+    def ipc_open(self, handle: bytes) -> int:
+        p = C.c_void_p()
+        with torch.cuda.device(self.device):
+            self._check(L.lib().scone_ipc_open(self._h, C.c_char_p(handle), C.byref(p)), "scone_ipc_open")
+        return p.value
+
+    def ipc_close(self, ptr: int) -> None:
+        self._check(L.lib().scone_ipc_close(self._h, C.c_void_p(ptr)), "scone_ipc_close")
+
+    def ipc_event_create(self) -> Tuple[int, bytes]:
+        e, hb = C.c_void_p(), C.create_string_buffer(64)
+        with torch.cuda.device(self.device):
+            self._check(L.lib().scone_ipc_event_create(self._h, C.byref(e), hb), "scone_ipc_event_create")
+        return e.value, hb.raw
+
+    def ipc_event_open(self, handle: bytes) -> int:
+        e = C.c_void_p()
+        with torch.cuda.device(self.device):
+            self._check(L.lib().scone_ipc_event_open(self._h, C.c_char_p(handle), C.byref(e)), "scone_ipc_event_open")
+        return e.value
+
+    def ipc_event_destroy(self, event: int) -> None:
+        self._check(L.lib().scone_ipc_event_destroy(self._h, C.c_void_p(event)), "scone_ipc_event_destroy")
+
+    def ipc_event_record(self, event: int) -> None:
+        self._check(L.lib().scone_ipc_event_record(self._h, C.c_void_p(event), _stream()), "scone_ipc_event_record")
+
+    def ipc_event_wait(self, event: int) -> None:
+        self._check(L.lib().scone_ipc_event_wait(self._h, C.c_void_p(event), _stream()), "scone_ipc_event_wait")
+
+    def ipc_push(self, dst_ptr: int, src_ptr: int, nbytes: int, copy_engine: bool = True) -> None:
+        """``nbytes`` from ``src_ptr`` (this device) to ``dst_ptr`` (possibly a peer's mapped buffer) on the current stream."""
+        self._check(L.lib().scone_ipc_push(self._h, C.c_void_p(dst_ptr), C.c_void_p(src_ptr), int(nbytes), int(bool(copy_engine)),
+                                           _stream()), "scone_ipc_push")
+
+    def ipc_tensor(self, ptr: int, nbytes: int) -> torch.Tensor:
+        """A uint8 tensor over raw device memory of this handle's device (no ownership: keep the allocation alive)."""
+        class _Raw:
+            pass
+        raw = _Raw()
+        raw.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+        with torch.cuda.device(self.device):
+            return torch.as_tensor(raw, device=self.device)
 
     def shard_gather_embed(self, tok: torch.Tensor, records: torch.Tensor, wte: Optional[torch.Tensor] = None,
                            wpe: Optional[torch.Tensor] = None, position_ids: Optional[torch.Tensor] = None,

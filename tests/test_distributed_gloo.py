@@ -258,9 +258,10 @@ class OracleShard:
         self.cols_packs = getattr(self, "cols_packs", 0) + 1
 
     def shard_cols_embed(self, tok, seq_begin, seq_end, rows, n_total, scales_full, frags, frag_off, frag_slots, rec_base, out,
-                         wte=None, wpe=None, position_ids=None, reduce="mean"):
+                         wte=None, wpe=None, position_ids=None, reduce="mean", row_lo=None):
         from scone_amd.distributed import owner_of
         assert tuple(tok.shape) == self._planned and scales_full is None
+        assert row_lo is None or (len(row_lo) == len(frag_off) + 1 and row_lo[0] == 0 and list(row_lo) == sorted(row_lo))
         B, T = tok.shape
         sl = tok[seq_begin:seq_end]
         off, ids, tix, jix = self._refs(sl)

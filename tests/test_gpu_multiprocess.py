@@ -62,9 +62,11 @@ def _worker(rank, world, port, fmt, d, max_n, exchange, head, q):
         sh = ShardedEmbeddingCache(ex, d, table_format=fmt, rank=rank, world=world, replicated_rows=head,
                                    gather_transport=transport or "p2p", shard_match=True if sm == "sm" else "auto",
                                    gather_chunks=1 if c1 else 4, wire_format="records" if c1 == "c1r" else "columns")
+        if transport == "sdma":                      # the copy-engine transport must really be in use, not its fallback
+            assert sh.gather_transport == "sdma" and sh.transport_fallback_reason is None, sh.transport_fallback_reason
         sh.load_rows(torch.from_numpy(table), 0)
         wte_d, wpe_d = torch.from_numpy(wte).half().cuda(), torch.from_numpy(wpe).half().cuda()
-        got = sh.embed_tokens(torch.from_numpy(tok), wte=wte_d, wpe=wpe_d, exchange=exchange)
+        got = sh.embed_tokens(torch.from_numpy(tok), wte=wte_d, wpe=wpe_d, exchange=exchange, check=True)
         # the unsharded table on the same GPU
         full = EmbeddingCache(ex, d, table_format=fmt)
         full.cache_embeddings(list(range(len(lens))), torch.from_numpy(table), verbose=False)
@@ -74,6 +76,7 @@ def _worker(rank, world, port, fmt, d, max_n, exchange, head, q):
         sl = sh.embed_tokens(torch.from_numpy(tok), wte=wte_d, wpe=wpe_d, exchange=exchange, gather_output=False)
         q.put((rank, same, err, tuple(got.shape), tuple(sl.shape)))
         dist.barrier()
+        sh.close()
         dist.destroy_process_group()
     except Exception as e:                          # surface the failure in the parent
         import traceback
@@ -91,6 +94,8 @@ def _worker(rank, world, port, fmt, d, max_n, exchange, head, q):
                                                              ("fp16", 768, 4, 2, "gather_rows:all_gather::c1", 0),
                                                              ("int8", 768, 3, 3, "gather_rows:all_gather:sm:c1", 37),
                                                              ("int8", 1024, 3, 2, "gather_rows:p2p::c1r", 100),
+                                                             ("int4", 1024, 3, 3, "gather_rows:sdma:sm:c1", 100),
+                                                             ("int8", 768, 3, 2, "gather_rows:sdma::c1", 0),
                                                              ("int8", 768, 3, 2, "partial_sums", 0),
                                                              ("int4", 1024, 3, 3, "rows_per_reference", 100)])
 def test_sharded_cache_across_processes_on_one_gpu(fmt, d, max_n, world, exchange, head):
@@ -114,7 +119,7 @@ def test_sharded_cache_across_processes_on_one_gpu(fmt, d, max_n, world, exchang
             assert err < 1e-3, (rank, err)          # fp32 partial sums are added in shard order, not list order
 
 
-def _worker_split_phase(rank, world, port, fmt, d, max_n, head, chunks, q, slots=2):
+def _worker_split_phase(rank, world, port, fmt, d, max_n, head, chunks, q, slots=2, transport="p2p"):
     try:
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         import torch.distributed as dist
@@ -127,7 +132,10 @@ def _worker_split_phase(rank, world, port, fmt, d, max_n, head, chunks, q, slots
         batches = [tok0] + [rng.integers(0, 24, size=tok0.shape) for _ in range(4)]
         ex = NGramExtractor.from_arrays(keys, lens, max_n=max_n)
         sh = ShardedEmbeddingCache(ex, d, table_format=fmt, rank=rank, world=world, replicated_rows=head, gather_chunks=chunks,
-                                   shard_match=chunks == 1, plan_slots=slots)   # (one of the cases: match sharded over the ranks)
+                                   shard_match=chunks == 1, plan_slots=slots,   # (one of the cases: match sharded over the ranks)
+                                   gather_transport=transport)
+        if transport == "sdma":
+            assert sh.gather_transport == "sdma" and sh.transport_fallback_reason is None, sh.transport_fallback_reason
         sh.load_rows(torch.from_numpy(table), 0)
         wte_d, wpe_d = torch.from_numpy(wte).half().cuda(), torch.from_numpy(wpe).half().cuda()
         full = EmbeddingCache(ex, d, table_format=fmt)
@@ -137,7 +145,7 @@ def _worker_split_phase(rank, world, port, fmt, d, max_n, head, chunks, q, slots
             tickets.append(sh.gather_rows_begin(torch.from_numpy(batches[nxt])))
             nxt += 1
         for i in range(len(batches)):                                   # begin(i + slots - 1) is queued on the side streams
-            outs.append(sh.gather_rows_finish(tickets.pop(0), wte=wte_d, wpe=wpe_d))   # behind finish(i) on the main one
+            outs.append(sh.gather_rows_finish(tickets.pop(0), wte=wte_d, wpe=wpe_d, check=i == 2))   # behind finish(i) on the main one
             if nxt < len(batches):
                 tickets.append(sh.gather_rows_begin(torch.from_numpy(batches[nxt])))
                 nxt += 1
@@ -157,17 +165,23 @@ def _worker_split_phase(rank, world, port, fmt, d, max_n, head, chunks, q, slots
         same = same and all(bool(torch.equal(a, b)) for a, b in zip(outs2, outs[:3]))
         # the one-call form still works afterwards (slot 0, current stream)
         again = bool(torch.equal(sh.embed_tokens(torch.from_numpy(batches[2]), wte=wte_d, wpe=wpe_d, exchange="gather_rows"), outs[2]))
-        q.put((rank, same and again, "", tuple(outs[0].shape), None))
+        # a ticket that is never finished (the caller gave up on the batch) must not block the slot for ever
+        lost = sh.gather_rows_begin(torch.from_numpy(batches[1]))
+        sh.gather_rows_abandon(lost)
+        after = bool(torch.equal(sh.embed_tokens(torch.from_numpy(batches[3]), wte=wte_d, wpe=wpe_d, exchange="gather_rows", check=True), outs[3]))
+        q.put((rank, same and again and after, "", tuple(outs[0].shape), None))
         dist.barrier()
+        sh.close()
         dist.destroy_process_group()
     except Exception as e:
         import traceback
         q.put((rank, False, repr(e) + traceback.format_exc(), None, None))
 
 
-@pytest.mark.parametrize("fmt,d,max_n,world,head,chunks,slots", [("int4", 1024, 3, 3, 100, 1, 2), ("int8", 768, 4, 2, 0, 3, 2),
-                                                                 ("int4", 1024, 3, 2, 100, 1, 3), ("fp16", 768, 3, 3, 0, 2, 4)])
-def test_split_phase_gather_two_batches_in_flight_across_processes(fmt, d, max_n, world, head, chunks, slots):
+@pytest.mark.parametrize("fmt,d,max_n,world,head,chunks,slots,transport", [("int4", 1024, 3, 3, 100, 1, 2, "p2p"), ("int8", 768, 4, 2, 0, 3, 2, "p2p"),
+                                                                           ("int4", 1024, 3, 2, 100, 1, 3, "p2p"), ("fp16", 768, 3, 3, 0, 2, 4, "p2p"),
+                                                                           ("int4", 1024, 3, 3, 100, 1, 2, "sdma"), ("int8", 768, 3, 2, 50, 1, 3, "sdma")])
+def test_split_phase_gather_two_batches_in_flight_across_processes(fmt, d, max_n, world, head, chunks, slots, transport):
     """gather_rows_begin / gather_rows_finish as a serving loop issues them: batch i + 1 is planned, packed and gathered on
     the cache's side stream (plan slot i + 1 mod 2) while batch i is reduced on the main stream.  Five different batches,
     real kernels, separate processes (gloo over one GPU): every output is bit-identical to the unsharded lookup of ITS batch."""
@@ -176,7 +190,7 @@ def test_split_phase_gather_two_batches_in_flight_across_processes(fmt, d, max_n
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker_split_phase, args=(r, world, port, fmt, d, max_n, head, chunks, q, slots)) for r in range(world)]
+    procs = [ctx.Process(target=_worker_split_phase, args=(r, world, port, fmt, d, max_n, head, chunks, q, slots, transport)) for r in range(world)]
     for p in procs:
         p.start()
     results = [q.get(timeout=300) for _ in procs]

@@ -27,6 +27,7 @@ without that traffic, alternating in one process, for every `--cu-reserve` R (sc
 compute units to the transport kernels).
 """
 import argparse
+import contextlib
 import ctypes
 import json
 import os
@@ -53,11 +54,15 @@ def main():
     ap.add_argument("--rounds", type=int, default=5, help="alternating rounds over the chosen flows (medians are reported)")
     ap.add_argument("--one-only", action="store_true", help="time the one-stream step only (clean per-kernel times under a profiler)")
     ap.add_argument("--split-only", action="store_true", help="time the split-phase loop only (for a kernel profile of it)")
-    ap.add_argument("--transport-standin", action="store_true", help="every flow also WITH its transfers executed by RCCL-shaped "
-                    "copy kernels concurrently with the reduction (columns flows: variants 2, 3)")
+    ap.add_argument("--transport-standin", nargs="?", const="kernel", default=None, choices=["kernel", "sdma"],
+                    help="every flow also WITH its transfers really executed, concurrently with the reduction (columns flows: "
+                         "variants 2, 3) -- kernel: RCCL-shaped copy kernels (a few workgroups per peer); sdma: the copy engines "
+                         "(hipMemcpyAsync without compute units, one stream per peer and direction: what gather_transport='sdma' does)")
     ap.add_argument("--channels", type=int, default=2, help="stand-in: workgroups per peer and direction for the large segments")
     ap.add_argument("--threads", type=int, default=256, help="stand-in: threads per workgroup (256 or 512)")
     ap.add_argument("--cu-reserve", default="0", help="comma list of R: compute units the lookup kernel leaves free")
+    ap.add_argument("--reserve-mode", default="direct", choices=["direct", "hop"], help="direct: the loop's main stream IS the "
+                    "handle's CU-masked stream (scone_lookup_stream); hop: the library moves each lookup there between two events")
     a = ap.parse_args()
     N, W, d, B, T = a.rows, a.world, 1024, a.batch, a.seq
     vocab = S.StructuredVocab(N)
@@ -153,8 +158,28 @@ def main():
         peer_frags = [torch.empty(cslots[0], dtype=torch.int64, device="cuda") for _ in range(W - 1)]
         peer_ell = [torch.empty((bper * T, wd), dtype=torch.int32, device="cuda") for _ in range(W - 1)]
 
+        push_streams = [torch.cuda.Stream() for _ in range(2 * (W - 1))]
+
+        def group_sdma(segs):
+            """The same segments on the copy engines: segment i on stream i mod 14 (7 peers x 2 directions), no kernel at all."""
+            cur = torch.cuda.current_stream()
+            ready = torch.cuda.Event()
+            ready.record(cur)
+            for i, (x, y, _) in enumerate(segs):
+                if not x.numel():
+                    continue
+                ps = push_streams[i % len(push_streams)]
+                ps.wait_event(ready)
+                with torch.cuda.stream(ps):
+                    s.ipc_push(y.data_ptr(), x.data_ptr(), x.numel() * x.element_size(), True)
+                    e = torch.cuda.Event()
+                    e.record(ps)
+                cur.wait_event(e)
+
         def group(segs):
             """One RCCL group = one launch: segs = [(src tensor, dst tensor, channels)], bytes taken from src."""
+            if a.transport_standin == "sdma":
+                return group_sdma(segs)
             segs = [(x, y, c) for x, y, c in segs if x.numel()]
             n = len(segs)
             arr_p, arr_u, arr_i = ctypes.c_void_p * n, ctypes.c_ulonglong * n, ctypes.c_int * n
@@ -280,34 +305,46 @@ def main():
                 fns[tag + " | transfers in flight"] = (R,) + make(*f, traffic=True)
     samples = {name: {"one": [], "split": []} for name in fns}
     checks = {}
-    for name, (R, one, loop) in fns.items():     # warm-up: allocations, the maps of every slot
+    def on_main(R):
+        """the stream the loop's reductions are queued on: the handle's masked stream (no cross-stream events), or the default"""
         s.set_cu_reserve(R)
+        return torch.cuda.stream(s.lookup_stream()) if (R and a.reserve_mode == "direct") else contextlib.nullcontext()
+
+    for name, (R, one, loop) in fns.items():     # warm-up: allocations, the maps of every slot
         if name.endswith("transfers in flight"):  # the stand-in must really deliver: wipe what it is to bring, then check
             for k in range(3):
                 c_frags[k][cslots[0]:].zero_()
                 ells[k][bper * T:].zero_()
-        one(3)
         torch.cuda.synchronize()
-        assert s.status() == 0, "a referenced row is missing from the synthesised records"
-        if not a.one_only:
-            loop(4)
+        with on_main(R):
+            one(3)
+            torch.cuda.synchronize()
+            assert s.status() == 0, "a referenced row is missing from the synthesised records"
+            if not a.one_only:
+                loop(4)
+        torch.cuda.synchronize()
         assert s.status() == 0
         checks[name] = out.float().abs().sum().item()
+        if name.endswith("transfers in flight"):  # slots this flow did not use stay wiped: put the other ranks' parts back
+            torch.cuda.synchronize()
+            for k in range(3):
+                c_frags[k][cslots[0]:].copy_(src_frags[cslots[0]:])
     for rnd in range(a.rounds):                  # alternating: the same box runs 2 % apart from one minute to the next
         for name, (R, one, loop) in fns.items():
-            s.set_cu_reserve(R)
-            if not a.split_only:
+            torch.cuda.synchronize()
+            with on_main(R):
+                if not a.split_only:
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    one(a.steps)
+                    torch.cuda.synchronize()
+                    samples[name]["one"].append((time.perf_counter() - t0) * 1e3 / a.steps)
+                if a.one_only:
+                    continue
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
-                one(a.steps)
-                torch.cuda.synchronize()
-                samples[name]["one"].append((time.perf_counter() - t0) * 1e3 / a.steps)
-            if a.one_only:
-                continue
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            loop(a.steps)
-            samples[name]["split"].append((time.perf_counter() - t0) * 1e3 / a.steps)
+                loop(a.steps)
+                samples[name]["split"].append((time.perf_counter() - t0) * 1e3 / a.steps)
     assert s.status() == 0
     s.set_cu_reserve(0)
 
@@ -324,7 +361,10 @@ def main():
                       "bytes_into_rank0": int((total - size[0]) * rec), "record_bytes": rec,
                       "list_record_bytes_gathered_into_rank0": int((W - 1) * bper * T * wd * 4),
                       "variants": results, "all_variants_same_output": len(sums) == 1,
+                      "reserve_mode": a.reserve_mode,
                       "transport_standin": None if not a.transport_standin else {
+                          "kind": ("RCCL-shaped copy kernels" if a.transport_standin == "kernel" else
+                                   "copy engines (hipMemcpyAsync, hipMemcpyDeviceToDeviceNoCU), 14 streams"),
                           "channels_per_peer_and_direction": a.channels, "threads_per_workgroup": a.threads,
                           "bytes_in": int((ctotal - counts[0]) * (pbytes + sbytes) + (sum(cslots) - cslots[0]) * 8 + (W - 1) * bper * T * wd * 4),
                           "bytes_out_per_peer": int(counts[0] * (pbytes + sbytes) + cslots[0] * 8 + bper * T * wd * 4),

@@ -30,19 +30,19 @@ __global__ __launch_bounds__(512) void k_standin(const standin_segs s) {
   const unsigned long long a = (unsigned long long)b * per, e = a + per < n ? a + per : n;
   const uint4 *__restrict__ src = s.src[seg];
   uint4 *__restrict__ dst = s.dst[seg];
-  for (unsigned long long i = a + threadIdx.x; i < e; i += (unsigned long long)blockDim.x * UNROLL) {
+  // whole tiles: UNROLL unconditional 16-B loads per thread back to back, then the stores (a guarded load is sunk next to its
+  // use by the compiler: eight sequential latencies per iteration -- the first version of this kernel moved 3 GB/s per
+  // workgroup); the tail goes one vector at a time
+  const unsigned long long tile = (unsigned long long)blockDim.x * UNROLL;
+  unsigned long long i = a;
+  for (; i + tile <= e; i += tile) {
     uint4 v[UNROLL];
 #pragma unroll
-    for (int u = 0; u < UNROLL; ++u) {
-      const unsigned long long j = i + (unsigned long long)u * blockDim.x;
-      if (j < e) v[u] = src[j];
-    }
+    for (int u = 0; u < UNROLL; ++u) v[u] = src[i + threadIdx.x + (unsigned long long)u * blockDim.x];
 #pragma unroll
-    for (int u = 0; u < UNROLL; ++u) {
-      const unsigned long long j = i + (unsigned long long)u * blockDim.x;
-      if (j < e) dst[j] = v[u];
-    }
+    for (int u = 0; u < UNROLL; ++u) dst[i + threadIdx.x + (unsigned long long)u * blockDim.x] = v[u];
   }
+  for (i += threadIdx.x; i < e; i += blockDim.x) dst[i] = src[i];
 }
 
 // src / dst / bytes: n_seg entries (bytes multiples of 16); channels[i]: workgroups for segment i.  Returns 0 or a hipError_t.

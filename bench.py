@@ -77,6 +77,10 @@ def parse(argv=None):
     ap.add_argument("--batch", type=int, default=2048)
     ap.add_argument("--seq", type=int, default=512)
     ap.add_argument("--stream", default="uniform", choices=["uniform", "zipf"])
+    ap.add_argument("--pinned-cache-rows", type=int, default=32_000_000, help="n1_pinned_host_zipf: row slots of the HBM cache of cold rows")
+    ap.add_argument("--pinned-stage-tokens", type=int, default=131072, help="n1_pinned_host_zipf: tokens per chunk of the prefetch pipeline")
+    ap.add_argument("--pinned-zipf-steps", type=int, default=20)
+    ap.add_argument("--pinned-zipf-warmup", type=int, default=600, help="n1_pinned_host_zipf: batches that warm the cache before the timed steps")
     ap.add_argument("--keygen", default="zipf", choices=["zipf", "structured"],
                     help="vocabulary generator: seeded Zipf n-grams with de-duplication (default) or the "
                          "distinct-by-construction generator for >= 1e8 rows")
@@ -204,17 +208,24 @@ class Watchdog(threading.Thread):
             now = time.time()
             st = self.stage
             if st is not None and now > st[1] + self.grace:
-                self.bail(f"stage '{st[0]}' did not complete within its {st[2]:.0f} s; what was measured before it is kept")
+                self.bail(f"stage '{st[0]}' did not complete within its {st[2]:.0f} s; what was measured before it is kept", hung=st[0])
             if now > self.budget.deadline + self.grace:
                 self.bail(f"time budget of {self.budget.seconds:.0f} s used up"
                           + (f" in stage '{st[0]}'" if st else "") + "; what was measured until then is kept")
 
-    def bail(self, why: str) -> None:
+    def bail(self, why: str, hung=None) -> None:
+        """Status 0 iff the headline was measured (the line is valid and the driver's launcher must not discard it); a stage
+        that HUNG is named in the line (`hung_stage`), and `self_launch` -- this repo's own launcher, used by tests and CI --
+        turns that into exit status 4: a hung collective never reads as a clean pass there."""
         code = 3
         try:
             code = 0 if self.line.headline_done else 3
             sys.stderr.write(f"bench.py[rank {self.rank}]: {why}\n")
             sys.stderr.flush()
+            if hung is not None:
+                with self.line.lock:
+                    if self.line.res is not None:
+                        self.line.res["hung_stage"] = hung
             self.line.emit(incomplete=why)
         finally:
             os._exit(code)
@@ -297,6 +308,9 @@ def self_launch(args) -> int:
         if not ok:
             res["launcher"] += f"; ranks exited with {rcs}"
         print(json.dumps(res), flush=True)
+        if ok and res.get("hung_stage"):                     # the line is valid, the job is not a clean pass
+            sys.stderr.write(f"bench.py: stage '{res['hung_stage']}' hung; the line above holds what was measured before it\n")
+            return 4
     if not ok:
         sys.stderr.write(f"bench.py: ranks exited with {rcs}; rank 0 printed {'no' if res is None else 'a'} result line\n")
         if out and res is None:
@@ -587,9 +601,16 @@ def pinned_baseline(args, sync, zipf_too=True):
     INT4 d = 1024 = 52.8 GB, first 1M rows hot in HBM), on the batch shape of the sharded record.  PCIe-bound, so the
     rate barely depends on the table's size; this is what ">= 4x at 8 GPUs vs 1 GPU on the 1B-row sharded table" is
     computed against.  Returns (record for the S_uniform stream with the rows read in place over PCIe -- the faster
-    mechanism on that stream --, record for the Zipf-ids stream (f-gram ids drawn from a power law over the
-    frequency-ordered table: what real text looks like to such a table) through the staged, de-duplicated prefetch -- the
-    north-star's "async prefetch" on the kind of stream where a chunk's rows recur; None unless `zipf_too`)."""
+    mechanism on that stream --, record for the Zipf-ids stream: f-gram ids drawn from a power law over the
+    frequency-ordered table, what real text looks like to such a table; None unless `zipf_too`).
+
+    Round 4, the Zipf record: a DIFFERENT batch every step (round 3 re-used one batch, which says nothing about anything that
+    keeps rows between steps).  `value` = the north-star's "async prefetch" as it is built now -- a persistent HBM cache of
+    cold rows (clock eviction) in front of the chunk pipeline, warmed by `warmup_batches` steps of the same stream --, with
+    the rows that crossed PCIe per step from the library's counters; beside it, on the same batches: the rows read in place
+    (`zero_copy_same_stream`), and -- the honest alternative for the same HBM -- the static hot head enlarged by the cache's
+    rows (`zero_copy_static_head_same_hbm`: ids ARE frequency-ordered, so on a stationary stream no cache can beat it; the
+    cache is for traffic that drifts away from the order the table was built in)."""
     import torch
     from scone_amd import EmbeddingCache
     from scone_amd import synthetic as S
@@ -606,20 +627,26 @@ def pinned_baseline(args, sync, zipf_too=True):
     wpe = (torch.randn(1024, d, generator=g, device="cuda") * 0.01).half()
     out = torch.empty(B, T, d, dtype=torch.float16, device="cuda")
 
-    def run(cache, tok, steps=4):
+    def run(cache, toks, steps=4, warm=None):
+        """ms per step over `steps` lookups of toks[i % len(toks)], after one untimed lookup of every batch in `warm`
+        (default: the first batch; [] = none -- a cache must not have seen the timed batches)."""
         cache.table.reserve(B * T)
-        cache.embed_tokens(tok, wte=wte, wpe=wpe, out=out)
+        for t in (toks[:1] if warm is None else warm):
+            cache.embed_tokens(t, wte=wte, wpe=wpe, out=out)
         sync()
         t0 = time.perf_counter()
-        for _ in range(steps):
-            cache.embed_tokens(tok, wte=wte, wpe=wpe, out=out)
+        for i in range(steps):
+            cache.embed_tokens(toks[i % len(toks)], wte=wte, wpe=wpe, out=out)
         sync()
         return (time.perf_counter() - t0) / steps
 
-    cache = EmbeddingCache.from_synthetic(vocab, d, table_format="int4", seed=7, base_scale=0.02 / 127, n_rows=N,
-                                          placement="pinned_host", hot_rows=hot)
+    def table(**kw):
+        return EmbeddingCache.from_synthetic(vocab, d, table_format="int4", seed=7, base_scale=0.02 / 127, n_rows=N,
+                                             placement="pinned_host", **kw)
+
+    cache = table(hot_rows=hot)
     tok = torch.from_numpy(S.stream_uniform_ids(vocab, None, B, T, 1234)).to("cuda", torch.int32)
-    dt = run(cache, tok)
+    dt = run(cache, [tok])
     res = {"value": B * T / dt, "unit": "tokens/s", "ms_per_step": dt * 1e3, "steps": 4,
            "workload": f"{N}-row int4 table d={d} in pinned host DRAM (rows read in place over PCIe), first {hot} rows in HBM, "
                        f"structured vocabulary, S_uniform, {B}x{T} tokens/step",
@@ -627,32 +654,64 @@ def pinned_baseline(args, sync, zipf_too=True):
     zres = None
     if zipf_too:
         try:
-            ztok = torch.from_numpy(S.stream_zipf_ids(vocab, None, B, T, 1234)).to("cuda", torch.int32)
-            off, ids = cache.table.match_csr(ztok)
-            cold = ids[ids >= hot]
-            stats = {"mean_hits_per_token": float(ids.numel()) / (B * T), "cold_row_references": int(cold.numel()),
-                     "distinct_cold_rows": int(torch.unique(cold).numel())}
-            del off, ids, cold
-            dt_zero = run(cache, ztok)
+            steps, warm_n = args.pinned_zipf_steps, args.pinned_zipf_warmup
+            cache_rows = min(args.pinned_cache_rows, max(N - hot, 1))
+            timed = [S.stream_zipf_ids_torch(vocab, B, T, 50_000 + i) for i in range(steps)]     # never seen by any warm-up
+            st = []
+            for t in timed[:2]:
+                _, ids = cache.table.match_csr(t)
+                cold = ids[ids >= hot]
+                st.append((float(ids.numel()) / (B * T), int(cold.numel()), int(torch.unique(cold).numel())))
+                del ids, cold
+            stats = {"mean_hits_per_token": sum(x[0] for x in st) / len(st), "cold_row_references": sum(x[1] for x in st) / len(st),
+                     "distinct_cold_rows": sum(x[2] for x in st) / len(st)}
+            dt_zero = run(cache, timed, steps)
             del cache
             torch.cuda.empty_cache()
-            # the same table again with the staged prefetch (stage_tokens is a property of the handle)
-            cache = EmbeddingCache.from_synthetic(vocab, d, table_format="int4", seed=7, base_scale=0.02 / 127, n_rows=N,
-                                                  placement="pinned_host", hot_rows=hot, stage_tokens=262144)
-            dt_staged = run(cache, ztok)
-            zres = {"value": B * T / dt_staged, "unit": "tokens/s", "ms_per_step": dt_staged * 1e3, "steps": 4,
-                    "mechanism": "staged prefetch: 262144-token chunks, each chunk's distinct cold rows copied once host -> HBM "
-                                 "on side streams while the previous chunk is reduced",
-                    "zero_copy_same_stream": {"value": B * T / dt_zero, "ms_per_step": dt_zero * 1e3},
+            # the same table behind the persistent cache of cold rows (stage_tokens / cache_rows are properties of the handle)
+            cache = table(hot_rows=hot, stage_tokens=args.pinned_stage_tokens, cache_rows=cache_rows)
+            warm = [S.stream_zipf_ids_torch(vocab, B, T, 1234 + i) for i in range(warm_n)]
+            cache.table.reserve(B * T)
+            for t in warm:
+                cache.embed_tokens(t, wte=wte, wpe=wpe, out=out)
+            del warm
+            sync()
+            c0 = cache.table.stage_counters()
+            dt_cached = run(cache, timed, steps, warm=[])
+            c1 = cache.table.stage_counters()
+            copied = (c1["rows_copied"] - c0["rows_copied"]) / steps
+            status = cache.table.status()
+            del cache
+            torch.cuda.empty_cache()
+            cache = table(hot_rows=hot + cache_rows)
+            dt_static = run(cache, timed, steps)
+            zres = {"value": B * T / dt_cached, "unit": "tokens/s", "ms_per_step": dt_cached * 1e3, "steps": steps,
+                    "different_batch_every_step": True, "warmup_batches": warm_n,
+                    "mechanism": f"persistent HBM cache of cold rows ({c1['cache_rows']} row slots = {c1['cache_rows'] * 528 / 1e9:.1f} GB, "
+                                 f"clock eviction) in front of the chunk pipeline ({c1['chunk_tokens']}-token chunks: match, touch / "
+                                 "place, remap and the copy of the missing rows host -> HBM on side streams while the previous "
+                                 "chunk is reduced)",
+                    "cache_rows": c1["cache_rows"], "stage_tokens": c1["chunk_tokens"],
+                    "rows_over_pcie_per_step": copied, "bytes_over_pcie_per_step": copied * 528,
+                    "cache_hit_rate_of_distinct_cold_rows": 1.0 - copied / max(stats["distinct_cold_rows"], 1.0),
+                    "status_bits": status,
+                    "zero_copy_same_stream": {"value": B * T / dt_zero, "ms_per_step": dt_zero * 1e3,
+                                              "bytes_over_pcie_per_step_at_least": stats["distinct_cold_rows"] * 528},
+                    "zero_copy_static_head_same_hbm": {"value": B * T / dt_static, "ms_per_step": dt_static * 1e3,
+                                                       "hot_rows": hot + cache_rows},
+                    "prefetch_beats_zero_copy": bool(dt_cached <= dt_zero),
                     "workload": f"{N}-row int4 table d={d} in pinned host DRAM, first {hot} rows in HBM, structured vocabulary, "
                                 f"S_zipf_ids (f-grams laid end to end, ids ~ bounded power law with exponent 1.1 over the "
-                                f"frequency-ordered table: the realistic stream), {B}x{T} tokens/step", **stats,
+                                f"frequency-ordered table: the realistic stream), {B}x{T} tokens/step, a different batch every step", **stats,
                     "bound": "PCIe Gen5 x16 (~64 GB/s)"}
         except Exception as e:
             zres = {"value": None, "error": repr(e)}
     del cache, tok, out, wte, wpe
     torch.cuda.empty_cache()
     return res, zres
+
+
+NCCL_HIGH_PRIORITY = [False]      # set by main() when the process group was created with a high-priority RCCL stream
 
 
 def _rccl_version():
@@ -692,33 +751,45 @@ def run_stages(rec, line, watchdog, budget, stage_limit, stages, n1_value=None, 
 def sharded_record(args, dist, rank, world, backend, sync, rec, line, watchdog, budget):
     """N > 1: the row-sharded path on the C5-shaped workload -- INT4 d = 1024, `rows_per_rank` x N rows (1e9 at N = 8),
     replicated index built from keys generated on the GPU, every rank its own contiguous row range generated on its GPU,
-    replicated head = the unigram rows, ONE 1M-token S_uniform batch that every rank passes in -- for the exchanges
-    that leave the whole [B, T, d] output on every rank:
-      rows+all_gather   all-to-all of the quantised rows each slice needs, rank r reduces slice r, all-gather of the
-                        finished fp16 vectors (the north-star's wording)
-      gather_rows       all-gather of the DISTINCT quantised rows the batch references, every rank reduces the whole batch;
-                        pipelined over `gather_chunks` chunks of sequences (gather_rows_one_shot: the same in one piece);
-                        the records travel as exact point-to-point ranges (batch_isend_irecv: one RCCL group, each link
-                        carries one peer's records) -- ..._padded_all_gather: through all_gather_into_tensor
-                        instead, every contribution padded to the largest
-      gather_rows_split_phase[_3_in_flight][_padded_all_gather]  the serving-loop form (ShardedEmbeddingCache.gather_rows_begin /
-                        _finish, one piece, two or three batches in flight: plan, pack and transfers of step s + 1 (s + 2) run
-                        on side streams behind the reduction of step s; with three, that chain may take two reductions'
-                        time) -- a throughput figure, a batch's latency is two (three) steps
-    and, for contrast, rows_slices_only: the all-to-all alone, every rank keeps its own slice (a consumer that is
-    data-parallel over the same slices needs no more).  Order: the forms that need only all_gather_into_tensor first (the
-    split-phase loop among them: the figure the ">= 4x" claim rests on), then the slice exchange (all_to_all_single with
-    uneven splits), everything that needs the batched point-to-point transport last -- should a collective hang under RCCL,
-    the watchdog prints every figure measured before it, and the padded all-gather figures stand in for the point-to-point
-    ones (`transport_fallback`).  Before any of it rank 0 alone measures the N = 1 baseline (pinned host DRAM), so every
-    exchange carries `speedup_vs_n1_pinned_host`.  Un-synchronised steps give ms/step; one instrumented step per exchange
-    (device synchronised between phases) gives the phase split.  `rec` is filled in place under `line.lock`."""
+    replicated head = the unigram rows, ONE 1M-token S_uniform batch that every rank passes in.  Six exchanges (round 4: the
+    forms the measurements of rounds 2-3 chose; the chunked pipeline, records on the wire and the direct-mapped row map are
+    gone from this record), in the order in which a hang costs least:
+      world_sanity                      a 1 KB all-gather on every rank BEFORE the 100 GB build: a world that cannot even do
+                                        that is reported in seconds
+      gather_rows_split_phase           the serving loop (ShardedEmbeddingCache.gather_rows_begin / _finish; columns on the wire,
+                                        match sharded over the ranks, 3 batches in flight): plan, pack and transfers of later
+                                        steps run on side streams behind the reduction of this one.  Transport: three padded
+                                        all_gather_into_tensor -- the plainest collective there is
+      gather_rows_split_phase_p2p       the same, exact ranges over batch_isend_irecv (RCCL send / recv kernels)
+      rows_slices_only                  the slice exchange alone: all_to_all_single of the distinct rows each slice needs, rank r
+                                        reduces slice r and keeps it -- the ONLY form whose per-rank work shrinks with the world
+      rows+all_gather                   the same + the all-gather of the finished fp16 vectors (the north-star's wording)
+      gather_rows                       the one-call form of the all-gather exchange (nothing overlapped)
+      gather_rows_split_phase_sdma      the serving loop over the copy engines (peer-mapped buffers, hipMemcpyAsync pushes,
+                                        interprocess events): no transport kernel competes with the lookup grid.  Last: it is
+                                        the newest transport, and what hangs here costs no other figure
+    Before any of it rank 0 alone measures the N = 1 baseline (pinned host DRAM), so every exchange carries
+    `speedup_vs_n1_pinned_host`.  Every exchange reads the handle's sticky status bits afterwards (`status_bits`: a row that
+    never arrived, a token out of range): `exchanges_agree` needs them all zero.  Un-synchronised steps give ms/step; one
+    instrumented step per one-call exchange (device synchronised between phases) gives the phase split.  `rec` is filled in
+    place under `line.lock`."""
     import torch
     from scone_amd import synthetic as S
     from scone_amd.distributed import ShardedEmbeddingCache
     from scone_amd.hip_backend import format_code, row_bytes
     d, B, T = 1024, args.batch, args.seq
     cdev = "cuda" if backend == "nccl" else "cpu"
+    # ---- world sanity: every rank contributes 1 KB, every rank checks what it got -- before anything expensive
+    watchdog.arm("sharded.world_sanity", min(60.0, max(budget.remaining() - 30.0, 10.0)))
+    t_s = time.perf_counter()
+    mine = torch.full((256,), float(rank + 1), dtype=torch.float32, device=cdev)
+    got = torch.empty(256 * world, dtype=torch.float32, device=cdev)
+    dist.all_gather_into_tensor(got, mine)
+    sane = bool(torch.equal(got.view(world, 256)[:, 0].cpu(), torch.arange(1, world + 1, dtype=torch.float32)))
+    watchdog.disarm()
+    line.set(rec, "world_sanity", {"all_gather_1KB_per_rank_ok": sane, "seconds": time.perf_counter() - t_s, "world_size": world})
+    if not sane:
+        raise RuntimeError("world sanity: a 1 KB all-gather returned the wrong ranks' data")
     # ---- the N = 1 baseline, rank 0 alone (the others wait in the first collective below)
     n1 = None
     if rank == 0:
@@ -741,7 +812,9 @@ def sharded_record(args, dist, rank, world, backend, sync, rec, line, watchdog, 
     cap = 64
     while cap < 2 * N:
         cap <<= 1
-    need = per * 544 + cap * 17 + 12e9
+    # rows + scales, the index (16-B slots + bitmap), the claim tables (all-gather form: 4 B per local row; slice exchange: one
+    # table per destination, 4 B x local rows x world -- 4 GB per rank at C5), buffers
+    need = per * 544 + cap * 17 + per * 4 * (world + 1) + 12e9
     note = None
     if need > free:
         scale = max(0.05, (free - 12e9) / (need - 12e9))
@@ -775,6 +848,7 @@ def sharded_record(args, dist, rank, world, backend, sync, rec, line, watchdog, 
                     "rows_total": N, "rows_per_rank": per, "mean_hits_per_token": sum_k / ntok,
                     "world_size": dist.get_world_size(), "device_count": torch.cuda.device_count(), "backend": backend,
                     "rccl_version": _rccl_version() if backend == "nccl" else None,
+                    "rccl_high_priority_stream": bool(NCCL_HIGH_PRIORITY[0]) if backend == "nccl" else None,
                     "build_s": t_build, "note": note,
                     "xgmi_peak_GBps": xgmi_peak,
                     "xgmi_peak_kind": f"into one GPU: {links} links x {XGMI_LINK_GBPS_PER_DIRECTION} GB/s per direction "
@@ -801,10 +875,31 @@ def sharded_record(args, dist, rank, world, backend, sync, rec, line, watchdog, 
                          "GBps": (wire_bytes / (coll_ms * 1e-3) / 1e9) if coll_ms else None,
                          "frac_of_xgmi_peak": (wire_bytes / (coll_ms * 1e-3) / 1e9 / xgmi_peak) if coll_ms else None}}
 
-    def one_call(name, kw, chunks_, transport):
+    # what one rank's step moves through ITS HBM at other world sizes (the same 1M-token batch): the forms in which every rank
+    # reduces the whole batch do not get cheaper with more GPUs -- their >= 4x over the pinned-host baseline is HBM against
+    # PCIe, not parallel speed-up; only the slice exchange divides the work
+    by_world = {}
+    for w in (2, 4, 8):
+        bw = (B + w - 1) // w
+        a_sl, c_sl, _, _, _, _ = workload_bytes(cache.table, tok[:bw], fmt, d)
+        by_world[w] = {"whole_batch_on_every_rank": alg_all, "slice_only": a_sl, "slice_plus_gathered_output": a_sl + (w - 1) * bw * T * d * 2 * 2}
+
+    def scaling_of(kw):
+        whole = kw["exchange"] == "gather_rows"
+        key = "whole_batch_on_every_rank" if whole else ("slice_plus_gathered_output" if kw["gather_output"] else "slice_only")
+        return {"per_rank_hbm_bytes_vs_world": {str(w): by_world[w][key] for w in by_world},
+                "scales_with_world": bool(not whole and not kw["gather_output"])}
+
+    def status_bits():
+        b = int(cache.table.status())
+        tb = torch.tensor([float(b)], dtype=torch.float64, device=cdev)
+        dist.all_reduce(tb, op=dist.ReduceOp.MAX)               # any rank's bits count
+        return int(tb.item())
+
+    def one_call(name, kw, transport):
         def fn():
-            cache.gather_chunks = chunks_
-            cache.gather_transport = transport
+            cache.gather_chunks = 1
+            used = cache.set_gather_transport(transport)
             out = cache.embed_tokens(tok, wte=wte, wpe=wpe, **kw)                  # warm-up (allocations, RCCL channels)
             out = cache.embed_tokens(tok, wte=wte, wpe=wpe, **kw)
             sync()
@@ -820,112 +915,114 @@ def sharded_record(args, dist, rank, world, backend, sync, rec, line, watchdog, 
             ph = torch.tensor([phases[k] for k in sorted(phases)], dtype=torch.float64, device=cdev)
             dist.all_reduce(ph, op=dist.ReduceOp.MAX)                                 # slowest rank per phase
             phm = {k: float(v) for k, v in zip(sorted(phases), ph.tolist()) if not k.startswith("bytes")}
+            bits = status_bits()
             if kw["gather_output"]:
                 checks[name] = float(out.float().abs().sum().item())
             ms = dt / args.sharded_steps * 1e3
             wire = int(phases.get("bytes_received", 0))
             return {"ms_per_step": ms, "tokens_per_s": ntok * args.sharded_steps / dt, "steps": args.sharded_steps,
-                    "phase_ms_slowest_rank": phm, "wire_bytes_received_rank0": wire,
-                    "chunks": chunks_ if kw["exchange"] == "gather_rows" else None,
-                    "wire_format": (("columns: payload rows | scales | the senders' hash fragments" if chunks_ == 1 else
-                                     "records: [payload | scales | row id], indexed by every receiver")
+                    "phase_ms_slowest_rank": phm, "wire_bytes_received_rank0": wire, "status_bits": bits,
+                    "wire_format": ("columns: payload rows | scales | the senders' hash fragments"
                                     if kw["exchange"] == "gather_rows" else "records, one per distinct row and destination"),
-                    "records_transport": ({"p2p": "batch_isend_irecv, exact ranges", "all_gather": "all_gather_into_tensor, padded"}
-                                          [transport] if kw["exchange"] == "gather_rows" else "all_to_all_single"),
-                    "roofline": roofline_of(kw, ms, phm, wire)}
+                    "records_transport": (TRANSPORTS[used] if kw["exchange"] == "gather_rows" else "all_to_all_single"),
+                    "roofline": roofline_of(kw, ms, phm, wire), **scaling_of(kw)}
         return name, fn
 
-    def split_phase(name, transport, same_as, slots=2, shard_match="auto"):
+    def split_phase(name, transport, slots=3):
         def fn():
             cache.gather_chunks = 1
-            cache.gather_transport = transport
+            used = cache.set_gather_transport(transport)
+            prev_slots = cache.plan_slots
             cache.plan_slots = slots
-            cache.shard_match = shard_match
+            tickets = []
 
             def loop(n):
-                o, nxt, q = None, 0, []
+                o, nxt = None, 0
                 for _ in range(min(slots - 1, n)):                          # slots - 1 batches ahead of the one being reduced
-                    q.append(cache.gather_rows_begin(tok, tokens_ready=None))   # (the batch has been on the device since the build)
+                    tickets.append(cache.gather_rows_begin(tok, tokens_ready=None))   # (the batch has been on the device since the build)
                     nxt += 1
                 for i in range(n):
-                    o = cache.gather_rows_finish(q.pop(0), wte=wte, wpe=wpe)    # queues the reduction of step i ...
+                    o = cache.gather_rows_finish(tickets.pop(0), wte=wte, wpe=wpe)    # queues the reduction of step i ...
                     if nxt < n:                                             # ... plan / pack / transfers of a later step overlap it
-                        q.append(cache.gather_rows_begin(tok, tokens_ready=None))
+                        tickets.append(cache.gather_rows_begin(tok, tokens_ready=None))
                         nxt += 1
                 return o
-            out = loop(3)
-            sync()
-            t0 = time.perf_counter()
-            out = loop(args.sharded_steps)
-            sync()
-            dt = time.perf_counter() - t0
-            cache.plan_slots, cache.shard_match = 2, "auto"
+            try:
+                out = loop(3)
+                sync()
+                t0 = time.perf_counter()
+                out = loop(args.sharded_steps)
+                sync()
+                dt = time.perf_counter() - t0
+            finally:
+                # a stage that raised mid-loop must not leave its tickets open (the slots would refuse every later stage) nor
+                # its settings behind
+                for tk in tickets:
+                    try:
+                        cache.gather_rows_abandon(tk)
+                    except Exception:
+                        pass
+                if tickets:
+                    cache.reset_slots()
+                cache.plan_slots = prev_slots
             tm = torch.tensor([dt], dtype=torch.float64, device=cdev)
             dist.all_reduce(tm, op=dist.ReduceOp.MAX)
             dt = float(tm.item())
             ms = dt / args.sharded_steps * 1e3
+            bits = status_bits()
             kw = {"exchange": "gather_rows", "gather_output": True}
-            one = rec["exchanges"].get(same_as, {})
+            checks[name] = float(out.float().abs().sum().item())
             return {"ms_per_step": ms, "tokens_per_s": ntok * args.sharded_steps / dt,
-                    "steps": args.sharded_steps, "batches_in_flight": slots, "chunks": 1,
-                    "match": ("sharded over the ranks + all-gather of the list records" if shard_match else
-                              "every rank matches the whole batch (no list records on the wire)"),
+                    "steps": args.sharded_steps, "batches_in_flight": slots, "status_bits": bits,
+                    "match": "sharded over the ranks + all-gather of the list records",
                     "wire_format": "columns: payload rows | scales | the senders' hash fragments",
-                    "records_transport": {"p2p": "batch_isend_irecv, exact ranges", "all_gather": "all_gather_into_tensor, padded"}[transport],
-                    "same_output_as_gather_rows": bool(float(out.float().abs().sum().item()) == checks.get(same_as)),
-                    "roofline": roofline_of(kw, ms, None, int(one.get("wire_bytes_received_rank0", 0)))}
+                    "records_transport": TRANSPORTS[used], "transport_requested": transport,
+                    "transport_fallback_reason": cache.transport_fallback_reason,
+                    "roofline": roofline_of(kw, ms, None, wire_cols), **scaling_of(kw)}
         return name, fn
 
+    TRANSPORTS = {"p2p": "batch_isend_irecv, exact ranges (RCCL send / recv kernels)", "all_gather": "all_gather_into_tensor, padded",
+                  "sdma": "copy-engine pushes into peer-mapped buffers (hipMemcpyAsync), interprocess events, exact ranges"}
+    # bytes the columns exchange puts into rank 0 (exact ranges): the distinct rows of the other ranks + their fragments
+    # (counted once, from the match: the split-phase stages have no instrumented step)
+    _, ids_all = cache.table.match_csr(tok)
+    other = torch.unique(ids_all[(ids_all >= max(cache.row_end, S.GPT2_VOCAB)) | ((ids_all < cache.row_begin) & (ids_all >= S.GPT2_VOCAB))])
+    wire_cols = int(other.numel()) * (512 + 16 + 32)             # payload + scales + 4 fragment slots of 8 B per row
+    del ids_all, other
     whole = {"gather_output": True}
-    # Order = what a hang costs least: the forms that need nothing but all_gather_into_tensor first -- among them the
-    # split-phase loop, i.e. the figure the ">= 4x" claim rests on --, then the slice exchange (all_to_all_single with uneven
-    # splits), then everything over the batched point-to-point transport
-    stages = [one_call("gather_rows_one_shot_padded_all_gather", {"exchange": "gather_rows", **whole}, 1, "all_gather"),
-              split_phase("gather_rows_split_phase_padded_all_gather", "all_gather", "gather_rows_one_shot_padded_all_gather"),
-              split_phase("gather_rows_split_phase_3_in_flight_padded_all_gather", "all_gather", "gather_rows_one_shot_padded_all_gather", 3),
-              one_call("gather_rows_padded_all_gather", {"exchange": "gather_rows", **whole}, chunks, "all_gather"),
-              one_call("rows+all_gather", {"exchange": "rows", **whole}, chunks, "p2p"),
-              one_call("rows_slices_only", {"exchange": "rows", "gather_output": False}, chunks, "p2p"),
-              # ---- from here on: the batched point-to-point transport
-              one_call("gather_rows", {"exchange": "gather_rows", **whole}, chunks, "p2p"),
-              one_call("gather_rows_one_shot", {"exchange": "gather_rows", **whole}, 1, "p2p"),
-              split_phase("gather_rows_split_phase", "p2p", "gather_rows_one_shot"),
-              split_phase("gather_rows_split_phase_3_in_flight", "p2p", "gather_rows_one_shot", 3),
-              # the trade the sharded match makes, the other way round: 76 us more GPU work per rank and step, 29 MB less on
-              # the wire -- the faster form on links that turn out to be the bottleneck
-              split_phase("gather_rows_split_phase_every_rank_matches", "p2p", "gather_rows_one_shot", 2, False)]
-    p2p_names = ("gather_rows", "gather_rows_one_shot", "gather_rows_split_phase", "gather_rows_split_phase_3_in_flight",
-                 "gather_rows_split_phase_every_rank_matches")
+    stages = [split_phase("gather_rows_split_phase", "all_gather"),
+              split_phase("gather_rows_split_phase_p2p", "p2p"),
+              one_call("rows_slices_only", {"exchange": "rows", "gather_output": False}, "p2p"),
+              one_call("rows+all_gather", {"exchange": "rows", **whole}, "p2p"),
+              one_call("gather_rows", {"exchange": "gather_rows", **whole}, "all_gather"),
+              split_phase("gather_rows_split_phase_sdma", "sdma")]
     with line.lock:
         rec["exchanges"] = {}
-        rec["transport_fallback"] = ("records over batch_isend_irecv (exact ranges) not measured yet: the ..._padded_all_gather "
-                                     "figures (all_gather_into_tensor) are the ones that stand if it does not complete")
+        rec["form_for_data_parallel_consumers"] = ("rows_slices_only: the only exchange whose per-rank HBM bytes fall with the world "
+                                                   "size (`scales_with_world`); the gather_rows forms leave the whole output on "
+                                                   "every rank and every rank pays for the whole batch")
 
     def on_done(name, e):                                  # (inside line.lock)
         ok = {k: v for k, v in rec["exchanges"].items() if isinstance(v, dict) and v.get("tokens_per_s")
-              and k != "rows_slices_only"}
+              and k != "rows_slices_only" and not v.get("status_bits")}
         if ok:
             best = max(ok, key=lambda k: ok[k]["tokens_per_s"])
             rec["best_whole_output"] = {"exchange": best, "tokens_per_s": ok[best]["tokens_per_s"],
                                         "ms_per_step": ok[best]["ms_per_step"],
                                         "speedup_vs_n1_pinned_host": ok[best].get("speedup_vs_n1_pinned_host")}
-        if name in p2p_names:
-            done = [k for k in p2p_names if rec["exchanges"].get(k, {}).get("tokens_per_s")]
-            failed = [k for k in p2p_names if "error" in rec["exchanges"].get(k, {})]
-            rec["transport_fallback"] = (None if done and not failed else
-                                         f"batch_isend_irecv transport failed in {failed}: the ..._padded_all_gather figures stand")
 
     run_stages(rec, line, watchdog, budget, args.stage_limit, stages, n1_value, on_done)
     cache.gather_chunks = chunks
-    cache.gather_transport = "p2p"
     with line.lock:
-        if len(checks) >= 2:                             # all bit-identical to the unsharded table, hence to each other
-            rec["exchanges_agree"] = bool(len(set(checks.values())) == 1)
+        if len(checks) >= 2:                             # all bit-identical to the unsharded table, hence to each other --
+            bits = {k: v.get("status_bits") for k, v in rec["exchanges"].items() if isinstance(v, dict) and "status_bits" in v}
+            rec["exchanges_agree"] = bool(len(set(checks.values())) == 1 and not any(bits.values()))   # and no status bit anywhere
             rec["exchanges_compared"] = sorted(checks)
-        rec["gather_chunks"] = chunks
+            rec["status_bits"] = bits
         rec["n1_baseline"] = ("`n1_pinned_host` of THIS record (rank 0, same process, before the exchanges): one GPU cannot hold the "
                               "table, so its rows sit in pinned host DRAM and cross PCIe; '>= 4x at 8 GPUs vs 1 GPU' = "
                               "exchanges.<name>.speedup_vs_n1_pinned_host")
+    cache.close()
     del cache, tok, wte, wpe
     torch.cuda.empty_cache()
     return rec
@@ -1026,7 +1123,15 @@ def main():
         if rank == 0 and world > 1:
             os.environ.setdefault("SCONE_DIST_TRACE", "1")     # one stderr line per collective of the sharded record (rank 0)
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            # RCCL's kernels compete with a lookup grid that fills the chip: ask for a high-priority stream for them
+            try:
+                opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), pg_options=opts)
+                NCCL_HIGH_PRIORITY[0] = True
+            except Exception as e:                       # an older / different binding: the default stream priority
+                sys.stderr.write(f"bench.py: high-priority RCCL stream not available ({e!r}); default priority\n")
+                if not dist.is_initialized():
+                    dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
 

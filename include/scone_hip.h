@@ -260,12 +260,16 @@ int scone_finalize(scone_handle *h, const float *d_sum, const int32_t *d_counts,
                    const int32_t *d_pos, int32_t reduce, void *d_out, int32_t out_dtype,
                    scone_stream_t stream);
 
-/* ---- row-sharded tables, row exchange (preferred over the partial-sum pair above: the wire carries
- *      quantised rows -- 528 B for an INT4 d=1024 row instead of a 4096-B fp32 partial sum per token and
- *      rank -- and the receiving rank reduces them in the reference's order, so results are bit-identical
- *      to the unsharded table).  Rank r finalises slice r of the batch: sequences
- *      [r*ceil(B/world), (r+1)*ceil(B/world)).  Tokens and index are replicated, so both ends of a transfer
- *      derive what is sent; the caller only moves the record buffers (one all_to_all_single). -------------- */
+/* ---- row-sharded tables, row exchanges (preferred over the partial-sum pair above: the wire carries quantised rows -- 528 B
+ *      for an INT4 d=1024 row instead of a 4096-B fp32 partial sum per token and rank -- each DISTINCT row once per
+ *      destination, and the receiving rank reduces them in the reference's order, so results are bit-identical to the
+ *      unsharded table).  Tokens and index are replicated, so both ends of a transfer derive what is sent; the caller only
+ *      moves the buffers.  Two forms, built from the same plan / pack / embed primitives below: the all-gather form (every
+ *      rank reduces the whole batch out of [replicated head | the distinct rows of all ranks]) and the slice exchange (rank r
+ *      reduces slice r: sequences [r*ceil(B/world), (r+1)*ceil(B/world)); scone_shard_gather_plan_chunks with n_chunks = world
+ *      and dedup_across_chunks = 0 lists, per destination, the distinct rows of mine its slice references; ONE
+ *      all_to_all_single of records).  (The first form of the slice exchange -- one record per reference, scone_shard_plan /
+ *      _pack / _embed -- was superseded in round 2 and removed in round 4 together with ABI version 1.) ------------------ */
 int scone_shard_record_bytes(scone_handle *h, uint64_t *bytes);
 /* Replicated head (optional; call once after scone_create, before rows are stored).  Global rows [0, n_head) are
  * kept on EVERY shard in addition to the rows it owns and never cross xGMI.  f-gram ids are frequency-ordered
@@ -277,20 +281,6 @@ int scone_shard_record_bytes(scone_handle *h, uint64_t *bytes);
 int scone_shard_set_head(scone_handle *h, uint64_t n_head);
 int scone_shard_head_store_f32(scone_handle *h, const float *d_rows_f32, uint64_t row0, uint64_t nrows,
                                scone_stream_t stream);
-/* Matches the batch, fills h_send_counts[q] (records this rank sends to rank q) and h_recv_counts[q]
- * (records it receives from rank q); synchronises.  world <= 64. */
-int scone_shard_plan(scone_handle *h, const int32_t *d_tok, int32_t B, int32_t T, int32_t world, int32_t rank,
-                     uint32_t *h_send_counts, uint32_t *h_recv_counts, scone_stream_t stream);
-/* Writes sum(h_send_counts) records to d_send_buf, grouped by destination in rank order; stream-ordered. */
-int scone_shard_pack(scone_handle *h, int32_t B, int32_t T, int32_t world, const uint32_t *h_send_counts,
-                     void *d_send_buf, scone_stream_t stream);
-/* d_recv_buf: the n_recv records received (any order within a source).  Writes this rank's slice of the output,
- * [slice tokens, d] in out_dtype; d_tok / d_pos are the full [B,T] arrays.  The records are read in place: keep
- * d_recv_buf alive until the stream has passed this call. */
-int scone_shard_embed(scone_handle *h, const int32_t *d_tok, int32_t B, int32_t T, int32_t world, int32_t rank,
-                      const void *d_recv_buf, uint64_t n_recv, const void *d_wte, int64_t vocab, const void *d_wpe,
-                      int64_t n_pos, const int32_t *d_pos, int32_t reduce, void *d_out_slice, int32_t out_dtype,
-                      scone_stream_t stream);
 
 /* ---- row-sharded tables, all-gather form: EVERY rank ends up with the whole [B, T, d] output.  Gathering the rows the
  *      batch references costs a quarter of the bytes of gathering the finished 2 KB vectors, and here every DISTINCT row
@@ -329,17 +319,13 @@ int scone_shard_gather_embed(scone_handle *h, const int32_t *d_tok, int32_t B, i
  *                                    same or an overlapping range (a retry, other chunk bounds) reduces them as they are;
  *                                    a new exchange (_add_records with record0 == 0) on lists that were already rewritten
  *                                    is refused (SCONE_ESTATE): plan the batch again first.
- * The receiver's row map (row id -> record number) is an open-addressing hash map sized by the exchange (cache-resident);
- * SCONE_SHARD_ROW_MAP=direct selects a direct-mapped array over all table rows instead (4 B per row and plan slot,
- * generation-tagged; exchanges under 2^24 records) -- built on the round-2 review's suggestion and measured slower at 1e9
- * rows (every lookup a TLB miss), kept for tables small enough to stay in cache. */
+ * The receiver's row map (row id -> record number) is an open-addressing hash map sized by the exchange (cache-resident). */
 /* Plan slots (0 .. 3; 0 is active at first): the receiver-side state of a planned batch (its id lists, the scales of
  * [head | records], the row map) exists once per slot, so that a serving loop can plan, pack and exchange batch b + 1 (and
  * b + 2: the chain plan -> transfers must then fit TWO reductions, not one) on side streams while batch b is still being
  * reduced on the main stream.  A host-side switch, no device work; the
- * scone_shard_gather_plan* / _add_records / _embed_range / _embed calls that follow work on the selected slot (the
- * per-reference exchange scone_shard_plan / _pack / _embed is not slot-aware: use slot 0).  The sender-side scratch is
- * shared: plan and pack of one batch must be enqueued before the next plan.  New here (the reference is one process). */
+ * scone_shard_gather_plan* / _add_records / _embed_range / _embed calls that follow work on the selected slot.  The
+ * sender-side scratch is shared: plan and pack of one batch must be enqueued before the next plan.  New here (the reference is one process). */
 int scone_shard_select_slot(scone_handle *h, int32_t slot);
 int scone_shard_gather_plan_chunks(scone_handle *h, const int32_t *d_tok, int32_t B, int32_t T, int32_t n_chunks,
                                    int32_t dedup_across_chunks, uint64_t *h_chunk_end, scone_stream_t stream);

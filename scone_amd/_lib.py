@@ -107,10 +107,6 @@ SIGNATURES = {
     "scone_shard_set_head": (C.c_int, [_P, _U64]),
     "scone_shard_head_store_f32": (C.c_int, [_P, _P, _U64, _U64, _P]),
     "scone_shard_record_bytes": (C.c_int, [_P, C.POINTER(_U64)]),
-    "scone_shard_plan": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, C.POINTER(_U32), C.POINTER(_U32), _P]),
-    "scone_shard_pack": (C.c_int, [_P, _I32, _I32, _I32, C.POINTER(_U32), _P, _P]),
-    "scone_shard_embed": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _P, _U64, _P, _I64, _P, _I64, _P, _I32, _P, _I32,
-                                    _P]),
     "scone_ipc_alloc": (C.c_int, [_P, _U64, C.POINTER(_P), _P]),
     "scone_ipc_free": (C.c_int, [_P, _P]),
     "scone_ipc_open": (C.c_int, [_P, _P, C.POINTER(_P)]),

@@ -261,9 +261,6 @@ extern "C" int scone_create(const scone_cfg *cfg, scone_handle **out) {
     h->match_tile = 0;
     ev = getenv("SCONE_MATCH_TILE");
     if (ev && *ev) h->match_tile = atoll(ev);
-    h->shard_rec_align = 16;
-    ev = getenv("SCONE_SHARD_REC_ALIGN");
-    if (ev && (atoi(ev) == 64 || atoi(ev) == 128)) h->shard_rec_align = atoi(ev);
   }
   CREATE_HIP(hipMalloc(&h->slots, cap * sizeof(scone_slot)));
   CREATE_HIP(hipMemset(h->slots, 0, cap * sizeof(scone_slot)));

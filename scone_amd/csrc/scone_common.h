@@ -158,7 +158,6 @@ struct scone_handle {
   hipEvent_t lookup_in, lookup_out;
   std::mutex lookup_mu;  // held from the event on the caller's stream to the wait on it: one hop at a time per handle
   long long fused_max_tokens;  // batches up to this many tokens take the one-launch kernel (env SCONE_FUSED_MAX_TOKENS overrides)
-  int shard_rec_align;         // record alignment of the shard exchanges (env SCONE_SHARD_REC_ALIGN: 16 (default), 64, 128)
   long long match_tile;        // > 0: positions per workgroup of k_match_ell fixed by env SCONE_MATCH_TILE (else whole residency rounds)
   // index
   scone_slot *slots;
@@ -291,9 +290,6 @@ int scone_shard_cols_remap(scone_handle *h, int32_t T, int32_t seq0, int32_t seq
                            const uint64_t *h_frag_off, const uint64_t *h_frag_slots, const uint64_t *h_rec_base,
                            const uint64_t *h_row_lo, int32_t world, uint64_t n_total,
                            const int32_t **ell, const uint8_t **head_p, unsigned long long *n_head_out, hipStream_t s);
-int scone_shard_prepare_embed(scone_handle *h, int32_t B, int32_t T, int32_t world, int32_t rank, const void *d_recv,
-                              uint64_t n_recv, const int32_t **ell, const void **scales, int32_t *b0, int32_t *b1,
-                              hipStream_t s);
 
 // staged prefetch of host-resident rows (scone_stage.hip)
 #define SCONE_STAGE_NBUF 3

@@ -211,50 +211,6 @@ extern "C" int scone_embed(scone_handle *h, const int32_t *d_tok, int32_t B, int
   return scone_prof_end(h, s);
 }
 
-// Row-sharded tables, last step of the row exchange (scone_shard.hip): the rows my slice needs have arrived
-// as records; the ordinary lookup kernel reads them in place (row store stride = record size).
-extern "C" int scone_shard_embed(scone_handle *h, const int32_t *d_tok, int32_t B, int32_t T, int32_t world, int32_t rank,
-                                 const void *d_recv_buf, uint64_t n_recv, const void *d_wte, int64_t vocab,
-                                 const void *d_wpe, int64_t n_pos, const int32_t *d_pos, int32_t reduce, void *d_out_slice,
-                                 int32_t out_dtype, scone_stream_t stream) {
-  int rc = need_table(h, "scone_shard_embed: handle has no table (dim == 0)");
-  if (rc) return rc;
-  if (!h->shard) return scone_fail(h, SCONE_ESTATE, "scone_shard_embed: call scone_shard_plan first");
-  if (B < 0 || T <= 0 || world < 1 || rank < 0 || rank >= world || (n_recv && !d_recv_buf))
-    return scone_fail(h, SCONE_EINVAL, "scone_shard_embed: bad argument");
-  if (!scone_wave_kernel_covers(h->cfg.table_fmt, h->cfg.dim))
-    return scone_fail(h, SCONE_EINVAL, "scone_shard_embed: the row exchange needs d % 8 == 0");
-  if (reduce != SCONE_REDUCE_MEAN && reduce != SCONE_REDUCE_SUM)
-    return scone_fail(h, SCONE_EINVAL, "scone_shard_embed: bad reduce");
-  SCONE_ON_DEVICE(h);
-  hipStream_t s = (hipStream_t)stream;
-  const int32_t *ell = nullptr;
-  const void *scales = nullptr;
-  int32_t b0 = 0, b1 = 0;
-  rc = scone_shard_prepare_embed(h, B, T, world, rank, d_recv_buf, n_recv, &ell, &scales, &b0, &b1, s);
-  if (rc) return rc;
-  if (b1 <= b0) return SCONE_OK;
-  if (!d_tok || !d_out_slice) return scone_fail(h, SCONE_EINVAL, "scone_shard_embed: null pointer");
-  embed_args a = {};
-  fill_table_view(h, a.tv);
-  // row store of this lookup: [replicated head | received records], both in record layout
-  unsigned long long n_head = 0;
-  a.tv.st.hot = scone_shard_head(h, &n_head);
-  a.tv.st.n_hot = n_head;
-  // nothing received: any (erroneous) reference is already redirected to record 0 -> give it the zero row
-  a.tv.st.cold = n_recv ? reinterpret_cast<uint8_t *>(const_cast<void *>(d_recv_buf)) : reinterpret_cast<uint8_t *>(h->d_zero_row);
-  a.tv.st.row_bytes = (unsigned int)scone_shard_rec_bytes(h);
-  a.tv.scales = reinterpret_cast<const __half *>(scales);
-  a.tv.row_begin = 0, a.tv.row_end = (long long)(n_head + (n_recv ? n_recv : 1));
-  a.BT = (long long)(b1 - b0) * T, a.ntok = a.BT, a.T = T, a.max_n = h->cfg.max_n;
-  a.ell = ell, a.zero_row = h->d_zero_row, a.mode = (int)h->cfg.lookup_mode;
-  a.tok = d_tok + (long long)b0 * T;
-  a.pos = d_pos ? d_pos + (long long)b0 * T : nullptr;
-  a.wte = d_wte, a.vocab = vocab, a.wpe = d_wpe, a.n_pos = n_pos;
-  a.reduce = reduce, a.out = d_out_slice, a.status = h->d_status;
-  return launch_fmt(h, a, SRC_HITS, MODE_FULL, out_dtype, s);
-}
-
 // All-gather form.  The gathered records (one per distinct row, every shard's) join the handle's row map with
 // scone_shard_gather_add_records -- all at once, or chunk by chunk as the all-gathers of a pipelined exchange complete --
 // and scone_shard_gather_embed_range reduces a run of sequences of the planned batch out of

@@ -1,21 +1,27 @@
-// Row exchange for row-sharded tables (tables larger than one GPU; BASELINE config C5).
+// Row exchanges for row-sharded tables (tables larger than one GPU; BASELINE config C5).
 //
-// Every rank holds the replicated index and a contiguous range of table rows, and finalises the
-// tokens of its own SLICE of the batch (whole sequences: slice q = sequences [q*Bper, (q+1)*Bper)).
-// What crosses xGMI are the QUANTISED ROWS a slice needs from the other shards, not partial sums:
-// an INT4 d=1024 row is 528 B where an fp32 partial sum is 4096 B per token and rank, and the
-// receiver reduces the rows in the reference's order, so the result is bit-identical to the
-// unsharded table.  Because tokens and index are replicated, both sides of every transfer can work
-// out what is sent without asking: no request round, one all-to-all of records.
+// Every rank holds the replicated index and a contiguous range of table rows.  What crosses xGMI are the QUANTISED ROWS
+// the batch references, each DISTINCT row once per destination, never partial sums: an INT4 d=1024 row is 528 B where an
+// fp32 partial sum is 4096 B per token and rank, and the receiver reduces the rows in the reference's order, so the result
+// is bit-identical to the unsharded table.  Because tokens and index are replicated, both sides of every transfer can work
+// out what is sent without asking: no request round.
 //
-//   plan    match the whole batch against MY rows (ids keep their index in the full list)  -> what I send
-//           match MY slice against all rows                                                -> what I need
-//           count records per destination / per source                                     -> all-to-all split sizes
-//   pack    one record per (token, list index) I own:  [row payload | scales | token-in-slice, list index]
-//   (all_to_all_single of the record buffers: torch.distributed / RCCL, done by the caller)
-//   embed   received records -> slot map (by the header), scales unpacked, ids of my slice remapped to
-//           record numbers, then the ordinary fused lookup kernel reads the rows straight out of the
-//           receive buffer (row store stride = record size)
+//   plan    ONE match of the batch against all rows (or: rank r matches slice r, the 32-B list records are all-gathered),
+//           then claim passes over the lists: every reference to a row I own claims the row (generation-tagged map, one CAS
+//           per reference at most) -> the list of distinct rows I contribute, per chunk of sequences
+//             - all-gather form ("gather_rows": every rank reduces the whole batch): one generation, a row claimed by an
+//               earlier chunk is not sent again
+//             - slice exchange ("rows": rank q reduces slice q): chunk q = slice q, a claim table per destination, all
+//               destinations in one launch
+//   pack    one record [payload | scales | row id] per claimed row -- or, the one-piece all-gather form, three COLUMNS:
+//           payload rows at the table's own stride | scales | the SENDER's hash fragment row id -> position
+//   (the transfer: torch.distributed / RCCL, or copy-engine pushes -- done by the caller, scone_amd/distributed.py)
+//   embed   records: indexed by row id in an open-addressing map, the lists remapped; columns: the lists resolved through the
+//           senders' fragments, no indexing pass; then the ordinary lookup kernel reads the rows IN PLACE in the receive
+//           buffer (row store stride = record size / payload size)
+// (The first form of the slice exchange -- one record per (token, list index) reference, scone_shard_plan / _pack / _embed --
+// sent a row covering three tokens of a slice three times: 0.97M records instead of 0.43M on the C5-shaped batch.  Superseded
+// in round 2, removed in round 4.)
 //
 // Replicated head (scone_shard_set_head): global rows [0, n_head) -- the unigrams and the most frequent f-grams of
 // the frequency-ordered table -- are kept on every shard in record layout and are neither counted, packed nor
@@ -30,14 +36,10 @@
 #include <vector>
 
 struct scone_shard_state {
-  long long cap_tok = 0, cap_slice = 0, cap_slot = 0, cap_recv = 0;
-  int32_t *ell_send = nullptr;   // [ntok, W] my rows at their index in the full list
-  int32_t *ell_slice = nullptr;  // [slice tokens, W] all rows, compacted; remapped in place by embed
-  uint32_t *counters = nullptr;  // [3 * 64]: send counts, recv counts, pack cursors
-  uint32_t *send_src = nullptr;  // [total_send] packed (token, list index) per record
-  uint32_t *slot_of_ref = nullptr;  // [slice tokens * NC]
+  long long cap_slice = 0, cap_recv = 0;
+  int32_t *ell_slice = nullptr;  // [planned tokens, W] the lists of the planned batch (all rows, compacted); remapped in place by embed
+  uint32_t *counters = nullptr;  // [64]: the claim counters of a plan (one per chunk)
   uint8_t *scales = nullptr;     // [n_head + received records] scales: the head's, then the unpacked ones
-  long long cap_send = 0;
   unsigned long long n_head = 0; // replicated head: global rows [0, n_head) live on every shard
   uint8_t *head_rows = nullptr;  // [n_head, rec_bytes]: payload at the start of every record-sized slot
   uint8_t *head_scales = nullptr;  // [n_head, scale_bytes_per_row]
@@ -66,13 +68,6 @@ struct scone_shard_state {
   // The lists of the planned batch live in ell_slice -- or in a buffer the CALLER owns (scone_shard_gather_plan_ell:
   // the lists were matched slice by slice on several ranks and all-gathered), borrowed until the batch has been reduced.
   int32_t *ell_ext = nullptr;
-  // Receiver's row map, direct-mapped form (SCONE_SHARD_ROW_MAP=direct; measured SLOWER than the hash map at 1e9 rows, see
-  // rmap_policy): rmap[global row id] = generation << 24 | record number.  Plain stores and loads instead of an
-  // open-addressing table filled by 64-bit CAS; a new exchange bumps the generation instead of clearing (cleared once
-  // every 255 exchanges).  4 B per table row and plan slot; exchanges of >= 2^24 records use the hash map.
-  uint32_t *rmap = nullptr;
-  uint32_t rmap_gen = 0;
-  bool rmap_active = false;        // the CURRENT exchange uses rmap (else rhash)
   std::vector<uint8_t> remapped;   // per sequence of the planned batch: its lists already hold record numbers
   unsigned long long added = 0;    // records added to the row map in the current exchange
   // Plan slots (scone_shard_select_slot): the receiver-side state of a planned batch -- its id lists, the scales of
@@ -88,9 +83,6 @@ struct scone_shard_state {
     long long cap_rhash = 0, rhash_cap_now = 0;
     int32_t plan_B = 0, plan_T = 0, plan_chunks = 0;
     int32_t *ell_ext = nullptr;
-    uint32_t *rmap = nullptr;
-    uint32_t rmap_gen = 0;
-    bool rmap_active = false;
     std::vector<uint8_t> remapped;
     unsigned long long added = 0;
   };
@@ -101,192 +93,7 @@ struct scone_shard_state {
 
 namespace {
 
-__device__ __forceinline__ int owner_of(long long id, long long n_rows, int world) {
-  return (int)((((unsigned long long)id + 1ull) * (unsigned long long)world - 1ull) / (unsigned long long)n_rows);
-}
-
-// Counting / claiming.  One thread per TOKEN (its 32/64-B record holds all its references), a persistent grid of at
-// most SHARD_BLOCKS workgroups each owning one contiguous run of tokens, per-workgroup LDS bins filled through a
-// wavefront scan (slices are contiguous token ranges, so a wave's references almost always go to ONE destination:
-// one LDS atomic per wave), and ONE global atomic per bin and WORKGROUP at the end.  A global atomic on one address
-// retires at ~90 per microsecond: the first version (a workgroup per 256 references -> 24.6k workgroups all adding
-// to the same per-destination counter) spent 256 us per kernel on that alone.
-#define SHARD_BLOCKS 1024
-
-// slots for `cnt` items in bin q; returns this lane's first slot (relative to the bin's value before the call)
-__device__ __forceinline__ uint32_t wave_bin_alloc(uint32_t *bins, uint32_t cnt, int q) {
-  const unsigned long long act = __ballot(cnt != 0);
-  if (!act) return 0;
-  const int lane = threadIdx.x & 63;
-  const int leader = __builtin_ctzll(act);
-  const int q0 = __shfl(q, leader, 64);
-  if (__ballot(cnt != 0 && q != q0) == 0ull) {  // one destination for the whole wave: inclusive scan of cnt
-    uint32_t inc = cnt;
-    for (int d = 1; d < 64; d <<= 1) {
-      const uint32_t u = __shfl_up(inc, d, 64);
-      if (lane >= d) inc += u;
-    }
-    const uint32_t total = __shfl(inc, 63, 64);
-    uint32_t base = 0;
-    if (lane == leader) base = atomicAdd(&bins[q0], total);
-    base = __shfl(base, leader, 64);
-    return base + inc - cnt;
-  }
-  return cnt ? atomicAdd(&bins[q], cnt) : 0;  // a wave straddling a slice boundary
-}
-
-// references of token t that this shard sends: entries j < K_full of its keep-position record that hold an id
-__device__ __forceinline__ uint32_t send_mask(const int32_t *__restrict__ ell, long long t, int W, int NC) {
-  const int kfull = ell[t * W + W - 2] >> 8;
-  uint32_t m = 0;
-  for (int j = 0; j < NC; ++j)
-    if (j < kfull && ell[t * W + j] >= 0) m |= 1u << j;
-  return m;
-}
-
-__global__ __launch_bounds__(256) void k_shard_count_send(const int32_t *__restrict__ ell, long long ntok, int W, int NC,
-                                                          long long slice_tokens, uint32_t *__restrict__ send_cnt) {
-  __shared__ uint32_t bins[64];
-  if (threadIdx.x < 64) bins[threadIdx.x] = 0;
-  __syncthreads();
-  const long long per = (ntok + gridDim.x - 1) / gridDim.x;
-  const long long t0 = (long long)blockIdx.x * per, t1 = t0 + per < ntok ? t0 + per : ntok;
-  for (long long base = t0; base < t1; base += blockDim.x) {  // uniform trip count inside the workgroup
-    const long long t = base + threadIdx.x;
-    const uint32_t cnt = t < t1 ? (uint32_t)__popc(send_mask(ell, t, W, NC)) : 0u;
-    wave_bin_alloc(bins, cnt, cnt ? (int)(t / slice_tokens) : 0);
-  }
-  __syncthreads();
-  if (threadIdx.x < 64 && bins[threadIdx.x]) atomicAdd(&send_cnt[threadIdx.x], bins[threadIdx.x]);
-}
-
-// what my slice needs from every owner: one thread per token of the slice, persistent grid, LDS bins (owners are
-// scattered over the ranks, so per-lane LDS atomics -- spread over `world` words -- it is), one global atomic per bin
-// and workgroup
-__global__ __launch_bounds__(256) void k_shard_count_recv(const int32_t *__restrict__ ell, long long ntok, int W, int NC,
-                                                          long long n_rows, int world, long long n_head,
-                                                          uint32_t *__restrict__ recv_cnt) {
-  __shared__ uint32_t bins[64];
-  if (threadIdx.x < 64) bins[threadIdx.x] = 0;
-  __syncthreads();
-  const long long per = (ntok + gridDim.x - 1) / gridDim.x;
-  const long long t0 = (long long)blockIdx.x * per, t1 = t0 + per < ntok ? t0 + per : ntok;
-  for (long long t = t0 + threadIdx.x; t < t1; t += blockDim.x) {
-    const int kown = ell[t * W + W - 2] & 0xFF;
-    for (int j = 0; j < NC; ++j) {
-      if (j < kown) {
-        const long long id = ell[t * W + j];
-        if (id >= n_head) atomicAdd(&bins[owner_of(id, n_rows, world)], 1u);  // head rows are local everywhere
-      }
-    }
-  }
-  __syncthreads();
-  if (threadIdx.x < 64 && bins[threadIdx.x]) atomicAdd(&recv_cnt[threadIdx.x], bins[threadIdx.x]);
-}
-
-// claim a record number for every (token, list index) I own: position = destination's offset + the workgroup's
-// reserved range (one global atomic per destination and workgroup, after a counting pass over the workgroup's run of
-// tokens) + the slot handed out inside the workgroup
-struct shard_offsets {  // record offset of every destination's run in the send buffer; a kernel ARGUMENT (no copy, no sync)
-  unsigned long long v[64];
-};
-
-__global__ __launch_bounds__(256) void k_shard_claim(const int32_t *__restrict__ ell, long long ntok, int W, int NC,
-                                                     long long slice_tokens, const shard_offsets send_off,
-                                                     uint32_t *__restrict__ cursor, uint32_t *__restrict__ send_src) {
-  __shared__ uint32_t bins[64], base[64];
-  if (threadIdx.x < 64) bins[threadIdx.x] = 0;
-  __syncthreads();
-  const long long per = (ntok + gridDim.x - 1) / gridDim.x;
-  const long long t0 = (long long)blockIdx.x * per, t1 = t0 + per < ntok ? t0 + per : ntok;
-  for (long long b0 = t0; b0 < t1; b0 += blockDim.x) {
-    const long long t = b0 + threadIdx.x;
-    const uint32_t cnt = t < t1 ? (uint32_t)__popc(send_mask(ell, t, W, NC)) : 0u;
-    wave_bin_alloc(bins, cnt, cnt ? (int)(t / slice_tokens) : 0);
-  }
-  __syncthreads();
-  if (threadIdx.x < 64) {
-    base[threadIdx.x] = bins[threadIdx.x] ? atomicAdd(&cursor[threadIdx.x], bins[threadIdx.x]) : 0u;
-    bins[threadIdx.x] = 0;  // reused as the running offset inside the reserved range
-  }
-  __syncthreads();
-  for (long long b0 = t0; b0 < t1; b0 += blockDim.x) {
-    const long long t = b0 + threadIdx.x;
-    uint32_t m = t < t1 ? send_mask(ell, t, W, NC) : 0u;
-    const int q = m ? (int)(t / slice_tokens) : 0;
-    uint32_t slot = wave_bin_alloc(bins, (uint32_t)__popc(m), q);
-    while (m) {
-      const int j = __builtin_ctz(m);
-      m &= m - 1;
-      const unsigned long long p = send_off.v[q] + base[q] + slot++;
-      send_src[2 * p] = (uint32_t)t;
-      send_src[2 * p + 1] = (uint32_t)j;
-    }
-  }
-}
-
-// one wave per record: row payload + scales + header
-__global__ __launch_bounds__(256) void k_shard_pack(const int32_t *__restrict__ ell, int W, long long slice_tokens,
-                                                    const uint32_t *__restrict__ send_src, unsigned long long n_send,
-                                                    scone_row_store st, long long row_begin, const uint8_t *__restrict__ scales,
-                                                    int scale_bytes, int rec_bytes, uint8_t *__restrict__ out) {
-  const int lane = threadIdx.x & 63;
-  const unsigned long long nwaves = (unsigned long long)gridDim.x * (blockDim.x >> 6);
-  for (unsigned long long p = (unsigned long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); p < n_send; p += nwaves) {
-    const uint32_t t = send_src[2 * p], j = send_src[2 * p + 1];
-    const unsigned long long lr = (unsigned long long)(ell[(long long)t * W + j] - row_begin);
-    const uint4 *src = reinterpret_cast<const uint4 *>(st.row(lr));
-    uint8_t *rec = out + p * (unsigned long long)rec_bytes;
-    uint4 *dst = reinterpret_cast<uint4 *>(rec);
-    for (unsigned v = lane; v < st.row_bytes / 16; v += 64) dst[v] = src[v];
-    if (lane < scale_bytes / 2)
-      reinterpret_cast<unsigned short *>(rec + st.row_bytes)[lane] =
-          reinterpret_cast<const unsigned short *>(scales + lr * scale_bytes)[lane];
-    if (lane == 0) {
-      uint32_t *hdr = reinterpret_cast<uint32_t *>(rec + rec_bytes - 8);
-      hdr[0] = (uint32_t)(t % slice_tokens);
-      hdr[1] = j;
-    }
-  }
-}
-
-// one thread per received record: slot map + scales
-__global__ __launch_bounds__(256) void k_shard_unpack(const uint8_t *__restrict__ recv, unsigned long long n_recv, int rec_bytes,
-                                                      int row_bytes, int scale_bytes, int NC, long long slice_tokens,
-                                                      uint32_t *__restrict__ slot_of_ref, uint8_t *__restrict__ scales,
-                                                      uint32_t *__restrict__ status) {
-  const unsigned long long p = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= n_recv) return;
-  const uint8_t *rec = recv + p * (unsigned long long)rec_bytes;
-  const uint32_t *hdr = reinterpret_cast<const uint32_t *>(rec + rec_bytes - 8);
-  if (hdr[0] >= (uint32_t)slice_tokens || hdr[1] >= (uint32_t)NC) {
-    atomicOr(status, SCONE_ST_BAD_ID);
-    return;
-  }
-  slot_of_ref[(unsigned long long)hdr[0] * NC + hdr[1]] = (uint32_t)p;
-  for (int b = 0; b < scale_bytes / 2; ++b)
-    reinterpret_cast<unsigned short *>(scales + p * scale_bytes)[b] = reinterpret_cast<const unsigned short *>(rec + row_bytes)[b];
-}
-
-// A reference whose record did not arrive (the peers disagree about the batch: a caller error) is
-// pointed at record 0 -- or at the zero row when nothing arrived -- and reported through the status
-// word, so the lookup kernel never reads outside the receive buffer.
-__global__ __launch_bounds__(256) void k_shard_remap(int32_t *__restrict__ ell, long long ntok, int W, int NC,
-                                                     const uint32_t *__restrict__ slot_of_ref, unsigned long long n_recv,
-                                                     long long n_head, uint32_t *__restrict__ status) {
-  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long long t = gid / NC;
-  const int j = (int)(gid - t * NC);
-  if (t >= ntok) return;
-  if (j >= (ell[t * W + W - 2] & 0xFF)) return;
-  if (ell[t * W + j] < n_head) return;  // a head row: its id IS its row number in the lookup's row store
-  uint32_t p = slot_of_ref[t * NC + j];
-  if (p >= n_recv) {
-    atomicOr(status, SCONE_ST_BAD_ID);
-    p = 0;
-  }
-  ell[t * W + j] = (int32_t)(n_head + p);  // received records follow the head
-}
+#define SHARD_BLOCKS 1024  // persistent grids of the per-token passes
 
 template <typename T>
 int grow(scone_handle *h, T **p, long long *cap, long long need, size_t elems_per) {
@@ -304,15 +111,15 @@ int grow(scone_handle *h, T **p, long long *cap, long long need, size_t elems_pe
 void scone_shard_destroy(scone_handle *h) {
   scone_shard_state *st = h->shard;
   if (!st) return;
-  void *ptrs[] = {st->ell_send, st->ell_slice, st->counters, st->send_src, st->slot_of_ref, st->scales,
+  void *ptrs[] = {st->ell_slice, st->counters, st->scales,
                   st->head_rows, st->head_scales, st->uniq_claim, st->uniq_list, st->rhash, st->chunk_ends,
-                  st->rmap, st->head_rows_p, st->multi_claim, st->regions};
+                  st->head_rows_p, st->multi_claim, st->regions};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (st->head_p_ready) (void)hipEventDestroy(st->head_p_ready);
   for (int k = 0; k < SCONE_SHARD_SLOTS; ++k) {
     if (k == st->slot) continue;
-    void *pp[] = {st->parked[k].ell_slice, st->parked[k].scales, st->parked[k].rhash, st->parked[k].rmap};
+    void *pp[] = {st->parked[k].ell_slice, st->parked[k].scales, st->parked[k].rhash};
     for (void *p : pp)
       if (p) (void)hipFree(p);
   }
@@ -326,148 +133,17 @@ uint8_t *scone_shard_head(const scone_handle *h, unsigned long long *n_head) {
 }
 
 int scone_shard_rec_bytes(const scone_handle *h) {
-  // [payload | scales | 8-byte header], rounded up to the record alignment (16 B; SCONE_SHARD_REC_ALIGN = 64 / 128 makes
-  // every record -- hence every row the lookup reads in place -- start on a sector / cache-line boundary, at the price of
-  // the padding on the wire)
-  const size_t al = h->shard_rec_align >= 16 ? (size_t)h->shard_rec_align : 16;
+  // [payload | scales | 8-byte header], rounded up to 16 B.  (Records padded to 64 / 128 B so that every row the lookup reads
+  // in place starts on a sector / cache-line boundary were measured in round 3: -1 % step time for +6 / +18 % wire; removed.
+  // The columns exchange gets the alignment for free: its payload rows travel at the table's own stride.)
+  const size_t al = 16;
   return (int)((h->row_payload_bytes + h->scale_bytes_per_row + 8 + al - 1) / al * al);
-}
-
-static void slice_of(int32_t B, int32_t world, int32_t rank, int32_t *bper, int32_t *b0, int32_t *b1) {
-  *bper = (B + world - 1) / world;
-  long long a = (long long)rank * *bper, b = a + *bper;
-  *b0 = (int32_t)(a < B ? a : B);
-  *b1 = (int32_t)(b < B ? b : B);
 }
 
 extern "C" int scone_shard_record_bytes(scone_handle *h, uint64_t *bytes) {
   if (!h || !bytes) return SCONE_EINVAL;
   if (h->cfg.dim <= 0) return scone_fail(h, SCONE_ESTATE, "scone_shard_record_bytes: handle has no table");
   *bytes = (uint64_t)scone_shard_rec_bytes(h);
-  return SCONE_OK;
-}
-
-extern "C" int scone_shard_plan(scone_handle *h, const int32_t *d_tok, int32_t B, int32_t T, int32_t world, int32_t rank,
-                                uint32_t *h_send_counts, uint32_t *h_recv_counts, scone_stream_t stream) {
-  if (!h) return SCONE_EINVAL;
-  if (h->cfg.dim <= 0 || !h->rows) return scone_fail(h, SCONE_ESTATE, "scone_shard_plan: handle has no table");
-  if (B < 0 || T <= 0 || world < 1 || world > 64 || rank < 0 || rank >= world || !h_send_counts || !h_recv_counts || !d_tok)
-    return scone_fail(h, SCONE_EINVAL, "scone_shard_plan: bad argument (world <= 64)");
-  SCONE_ON_DEVICE(h);
-  hipStream_t s = (hipStream_t)stream;
-  if (!h->shard) {
-    h->shard = new (std::nothrow) scone_shard_state();
-    if (!h->shard) return scone_fail(h, SCONE_ENOMEM, "scone_shard_plan: out of memory");
-  }
-  scone_shard_state *st = h->shard;
-  const int W = SCONE_ELL_W(h->cfg.max_n), NC = h->cfg.max_n * (h->cfg.max_n + 1) / 2;
-  int32_t bper, b0, b1;
-  slice_of(B, world, rank, &bper, &b0, &b1);
-  const long long ntok = (long long)B * T, slice_tokens = (long long)bper * T, my_tokens = (long long)(b1 - b0) * T;
-  int rc = grow(h, &st->ell_send, &st->cap_tok, ntok, (size_t)W);
-  if (rc) return rc;
-  long long cs = st->cap_slice;
-  rc = grow(h, &st->ell_slice, &cs, slice_tokens, (size_t)W);
-  if (rc) return rc;
-  rc = grow(h, &st->slot_of_ref, &st->cap_slot, slice_tokens, (size_t)NC);
-  if (rc) return rc;
-  st->cap_slice = cs;
-  if (!st->counters) SCONE_HIP(h, hipMalloc(&st->counters, 3 * 64 * sizeof(uint32_t)));
-  SCONE_HIP(h, hipMemsetAsync(st->counters, 0, 3 * 64 * sizeof(uint32_t), s));
-  for (int q = 0; q < world; ++q) h_send_counts[q] = h_recv_counts[q] = 0;
-  if (ntok == 0) return SCONE_OK;
-  if (!scone_grid_fits((unsigned long long)(ntok * NC + 255) / 256, 256))
-    return scone_fail(h, SCONE_EINVAL, "scone_shard_plan: too many tokens for one launch");
-  // what I send: the whole batch against my rows, ids at their index in the full list
-  const long long n_head = (long long)st->n_head;
-  const long long send_begin = (long long)h->cfg.row_begin > n_head ? (long long)h->cfg.row_begin : n_head;  // head rows are never sent
-  rc = scone_launch_match_ell_ex(h, d_tok, B, T, st->ell_send, send_begin, (long long)h->cfg.row_end, 1, s);
-  if (rc) return rc;
-  const unsigned blocks = (unsigned)((ntok + 255) / 256 < SHARD_BLOCKS ? (ntok + 255) / 256 : SHARD_BLOCKS);
-  hipLaunchKernelGGL(k_shard_count_send, dim3(blocks), dim3(256), 0, s, st->ell_send, ntok, W, NC, slice_tokens, st->counters);
-  // what I need: my slice against every row
-  if (my_tokens > 0) {
-    rc = scone_launch_match_ell_ex(h, d_tok + (long long)b0 * T, b1 - b0, T, st->ell_slice, 0, (long long)h->cfg.n_rows, 0, s);
-    if (rc) return rc;
-    const unsigned blocks2 = (unsigned)((my_tokens + 255) / 256 < SHARD_BLOCKS ? (my_tokens + 255) / 256 : SHARD_BLOCKS);
-    hipLaunchKernelGGL(k_shard_count_recv, dim3(blocks2), dim3(256), 0, s, st->ell_slice, my_tokens, W, NC,
-                       (long long)h->cfg.n_rows, world, n_head, st->counters + 64);
-  }
-  SCONE_HIP(h, hipGetLastError());
-  uint32_t host[128];
-  SCONE_HIP(h, hipMemcpyAsync(host, st->counters, sizeof(host), hipMemcpyDeviceToHost, s));
-  SCONE_HIP(h, hipStreamSynchronize(s));
-  for (int q = 0; q < world; ++q) h_send_counts[q] = host[q], h_recv_counts[q] = host[64 + q];
-  return SCONE_OK;
-}
-
-extern "C" int scone_shard_pack(scone_handle *h, int32_t B, int32_t T, int32_t world, const uint32_t *h_send_counts,
-                                void *d_send_buf, scone_stream_t stream) {
-  if (!h || !h->shard) return h ? scone_fail(h, SCONE_ESTATE, "scone_shard_pack: call scone_shard_plan first") : SCONE_EINVAL;
-  if (world < 1 || world > 64 || !h_send_counts) return scone_fail(h, SCONE_EINVAL, "scone_shard_pack: bad argument");
-  SCONE_ON_DEVICE(h);
-  hipStream_t s = (hipStream_t)stream;
-  scone_shard_state *st = h->shard;
-  const int W = SCONE_ELL_W(h->cfg.max_n), NC = h->cfg.max_n * (h->cfg.max_n + 1) / 2;
-  const int32_t bper = (B + world - 1) / world;
-  const long long ntok = (long long)B * T, slice_tokens = (long long)bper * T;
-  shard_offsets off = {};
-  unsigned long long total = 0;
-  for (int q = 0; q < world; ++q) off.v[q] = total, total += h_send_counts[q];
-  if (total == 0) return SCONE_OK;
-  if (!d_send_buf) return scone_fail(h, SCONE_EINVAL, "scone_shard_pack: null send buffer");
-  long long cap = st->cap_send;
-  int rc = grow(h, &st->send_src, &cap, (long long)total, 2);
-  if (rc) return rc;
-  st->cap_send = cap;
-  // the pack cursors start at zero for EVERY pack (a second pack after one plan -- a retry, another send buffer --
-  // would otherwise continue behind the first one's records and write past `total`)
-  SCONE_HIP(h, hipMemsetAsync(st->counters + 128, 0, 64 * sizeof(uint32_t), s));
-  const unsigned blocks = (unsigned)((ntok + 255) / 256 < SHARD_BLOCKS ? (ntok + 255) / 256 : SHARD_BLOCKS);
-  hipLaunchKernelGGL(k_shard_claim, dim3(blocks), dim3(256), 0, s, st->ell_send, ntok, W, NC, slice_tokens, off,
-                     st->counters + 128, st->send_src);
-  unsigned pb = (unsigned)((total + 3) / 4);
-  if (pb > 4096) pb = 4096;
-  hipLaunchKernelGGL(k_shard_pack, dim3(pb), dim3(256), 0, s, st->ell_send, W, slice_tokens, st->send_src, total,
-                     scone_store_of(h), (long long)h->cfg.row_begin, (const uint8_t *)h->scales, (int)h->scale_bytes_per_row,
-                     scone_shard_rec_bytes(h), (uint8_t *)d_send_buf);
-  SCONE_HIP(h, hipGetLastError());
-  return SCONE_OK;
-}
-
-// unpack + remap; on return ell_slice holds record numbers and *scales the unpacked scale array
-int scone_shard_prepare_embed(scone_handle *h, int32_t B, int32_t T, int32_t world, int32_t rank, const void *d_recv,
-                              uint64_t n_recv, const int32_t **ell, const void **scales, int32_t *b0_out, int32_t *b1_out,
-                              hipStream_t s) {
-  scone_shard_state *st = h->shard;
-  const int W = SCONE_ELL_W(h->cfg.max_n), NC = h->cfg.max_n * (h->cfg.max_n + 1) / 2;
-  int32_t bper, b0, b1;
-  slice_of(B, world, rank, &bper, &b0, &b1);
-  *b0_out = b0, *b1_out = b1;
-  const long long my_tokens = (long long)(b1 - b0) * T, slice_tokens = (long long)bper * T;
-  const size_t sb = h->scale_bytes_per_row;
-  const unsigned long long n_head = st->n_head;
-  if (sb) {
-    long long cap = st->cap_recv;
-    uint8_t *p = st->scales;
-    int rc = grow(h, &p, &cap, (long long)(n_head + n_recv), sb);
-    st->scales = p, st->cap_recv = cap;
-    if (rc) return rc;
-    if (n_head)  // [head scales | scales of the received records]
-      SCONE_HIP(h, hipMemcpyAsync(st->scales, st->head_scales, (size_t)n_head * sb, hipMemcpyDeviceToDevice, s));
-  }
-  SCONE_HIP(h, hipMemsetAsync(st->slot_of_ref, 0xFF, (size_t)slice_tokens * NC * sizeof(uint32_t), s));
-  if (n_recv) {
-    hipLaunchKernelGGL(k_shard_unpack, dim3((unsigned)((n_recv + 255) / 256)), dim3(256), 0, s, (const uint8_t *)d_recv,
-                       (unsigned long long)n_recv, scone_shard_rec_bytes(h), (int)h->row_payload_bytes, (int)sb, NC,
-                       slice_tokens, st->slot_of_ref, st->scales ? st->scales + (size_t)n_head * sb : nullptr, h->d_status);
-  }
-  if (my_tokens > 0)
-    hipLaunchKernelGGL(k_shard_remap, dim3((unsigned)((my_tokens * NC + 255) / 256)), dim3(256), 0, s, st->ell_slice,
-                       my_tokens, W, NC, st->slot_of_ref, (unsigned long long)n_recv, (long long)n_head, h->d_status);
-  SCONE_HIP(h, hipGetLastError());
-  *ell = st->ell_slice;
-  *scales = st->scales;
   return SCONE_OK;
 }
 
@@ -698,63 +374,6 @@ __global__ __launch_bounds__(256) void k_gather_index(const uint8_t *__restrict_
   }
 }
 
-// The same two steps on the direct-mapped row map: record p holding row `id` -> rmap[id] = gen << 24 | p, and a list entry
-// is looked up with ONE load.
-#define RMAP_REC_BITS 24
-#define RMAP_REC_MASK ((1u << RMAP_REC_BITS) - 1u)
-__global__ __launch_bounds__(256) void k_gather_index_direct(const uint8_t *__restrict__ recv, unsigned long long n_recv, int rec_bytes,
-                                                             int row_bytes, int scale_bytes, uint32_t *__restrict__ rmap,
-                                                             unsigned long long n_rows, uint32_t gen, uint8_t *__restrict__ scales,
-                                                             unsigned long long record0, uint32_t *__restrict__ status) {
-  unsigned long long p = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= n_recv) return;
-  const uint8_t *rec = recv + p * (unsigned long long)rec_bytes;
-  const uint32_t id = reinterpret_cast<const uint32_t *>(rec + rec_bytes - 8)[0];
-  if (id == 0xFFFFFFFFu) return;  // padding
-  if (id >= n_rows) {             // not a row of this table: never index outside the map
-    atomicOr(status, SCONE_ST_BAD_ID);
-    return;
-  }
-  for (int b = 0; b < scale_bytes / 2; ++b)
-    reinterpret_cast<unsigned short *>(scales + p * scale_bytes)[b] = reinterpret_cast<const unsigned short *>(rec + row_bytes)[b];
-  p += record0;
-  // ONE plain store (no read-modify-write: a row arrives once per exchange; should the ranks disagree and send it twice,
-  // either record holds the same bytes)
-  rmap[id] = (gen << RMAP_REC_BITS) | (uint32_t)p;
-}
-
-__global__ __launch_bounds__(256) void k_gather_remap_direct(int32_t *__restrict__ ell, long long ntok, int W, int NC,
-                                                             const uint32_t *__restrict__ rmap, uint32_t gen, long long n_head,
-                                                             long long n_rows, uint32_t *__restrict__ status) {
-  const long long per = (ntok + gridDim.x - 1) / gridDim.x;
-  const long long t0 = (long long)blockIdx.x * per, t1 = t0 + per < ntok ? t0 + per : ntok;
-  for (long long t = t0 + threadIdx.x; t < t1; t += blockDim.x) {
-    int4 *rp = reinterpret_cast<int4 *>(ell + t * W);
-    int4 a = rp[0], b = rp[1];  // (W = 16: ids 8.. are handled below through memory)
-    int32_t r[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-    const int kown = (W == 8 ? r[6] : ell[t * W + W - 2]) & 0xFF;
-    bool dirty = false;
-    for (int j = 0; j < NC; ++j) {
-      if (j >= kown) break;
-      const long long id = j < 8 && W == 8 ? r[j] : ell[t * W + j];
-      if (id < n_head) continue;  // a head row: its id is its row number in the lookup's row store
-      long long slot = 0;
-      const uint32_t v = (id >= 0 && id < n_rows) ? rmap[id] : 0u;
-      if ((v >> RMAP_REC_BITS) == gen) {
-        slot = (long long)(v & RMAP_REC_MASK);
-      } else {  // the row did not arrive (the ranks disagree about the batch): report, never read out of bounds
-        atomicOr(status, SCONE_ST_BAD_ID);
-      }
-      if (W == 8 && j < 8) r[j] = (int32_t)(n_head + slot), dirty = true;
-      else ell[t * W + j] = (int32_t)(n_head + slot);
-    }
-    if (W == 8 && dirty) {
-      rp[0] = make_int4(r[0], r[1], r[2], r[3]);
-      rp[1] = make_int4(r[4], r[5], r[6], r[7]);
-    }
-  }
-}
-
 __global__ __launch_bounds__(256) void k_gather_remap(int32_t *__restrict__ ell, long long ntok, int W, int NC,
                                                       const unsigned long long *__restrict__ rhash, unsigned long long hmask,
                                                       long long n_head, uint32_t *__restrict__ status) {
@@ -838,7 +457,7 @@ static int plan_claims(scone_handle *h, scone_shard_state *st, const int32_t *el
                        int32_t dedup_across_chunks, uint64_t *h_chunk_end, hipStream_t s) {
   const int W = SCONE_ELL_W(h->cfg.max_n), NC = h->cfg.max_n * (h->cfg.max_n + 1) / 2;
   const long long ntok = (long long)B * T;
-  if (!st->counters) SCONE_HIP(h, hipMalloc(&st->counters, 3 * 64 * sizeof(uint32_t)));
+  if (!st->counters) SCONE_HIP(h, hipMalloc(&st->counters, 64 * sizeof(uint32_t)));
   if (!st->chunk_ends) SCONE_HIP(h, hipMalloc(&st->chunk_ends, 64 * sizeof(uint32_t)));
   if (!st->uniq_claim) {
     SCONE_HIP(h, hipMalloc(&st->uniq_claim, (size_t)(h->local_rows ? h->local_rows : 1) * sizeof(uint32_t)));
@@ -856,7 +475,7 @@ static int plan_claims(scone_handle *h, scone_shard_state *st, const int32_t *el
   long long need = ntok * NC < rows_cap ? ntok * NC : rows_cap;
   int rc = grow(h, &st->uniq_list, &st->cap_uniq, need, 1);
   if (rc) return rc;
-  SCONE_HIP(h, hipMemsetAsync(st->counters, 0, 3 * 64 * sizeof(uint32_t), s));
+  SCONE_HIP(h, hipMemsetAsync(st->counters, 0, 64 * sizeof(uint32_t), s));
   const long long n_head = (long long)st->n_head;
   const long long send_begin = (long long)h->cfg.row_begin > n_head ? (long long)h->cfg.row_begin : n_head;
   if (!dedup_across_chunks && n_chunks > 1) {
@@ -1041,9 +660,6 @@ static void swap_slot(scone_shard_state *st, scone_shard_state::plan_slot &p) {
   std::swap(st->plan_T, p.plan_T);
   std::swap(st->plan_chunks, p.plan_chunks);
   std::swap(st->ell_ext, p.ell_ext);
-  std::swap(st->rmap, p.rmap);
-  std::swap(st->rmap_gen, p.rmap_gen);
-  std::swap(st->rmap_active, p.rmap_active);
   st->remapped.swap(p.remapped);
   std::swap(st->added, p.added);
 }
@@ -1113,19 +729,10 @@ extern "C" int scone_shard_gather_pack(scone_handle *h, void *d_send_buf, scone_
 }
 
 // Receiver, step 1: records [record0, record0 + n) of the gathered buffer (d_records points at record record0; the
-// whole buffer will hold n_total) join the row map; record0 == 0 starts a new exchange (a new generation of the
-// direct-mapped map / the hash map is cleared).
-static int rmap_policy(scone_handle *h, scone_shard_state *st) {
-  // read when an exchange starts (cheap; lets one process compare the two forms).  Default: the HASH map -- sized by the
-  // exchange (8 MB for 0.45M records) it lives in L2 / the Infinity Cache, while the direct-mapped array over all table rows
-  // (4 GB at 1e9 rows) turns every lookup into a TLB miss + an HBM access: measured at C5's true scale, alternating on one
-  // box (profiles/r03h/c5_rank0_step_direct_vs_hash_map.json): 0.927 against 0.909 ms per step.  SCONE_SHARD_ROW_MAP=direct selects it all the same.
-  (void)st;
-  const char *e = getenv("SCONE_SHARD_ROW_MAP");
-  if (e && !strcmp(e, "direct")) return h->cfg.n_rows < 0xFFFFFFFFull ? 1 : 0;
-  return 0;
-}
-
+// whole buffer will hold n_total) join the row map; record0 == 0 starts a new exchange (the hash map is cleared).  The map
+// is an open-addressing table sized by the exchange (8 MB for 0.45M records: it lives in L2 / the Infinity Cache); a
+// direct-mapped array over all table rows (4 GB at 1e9 rows: every lookup a TLB miss + an HBM access) was built on the round-2
+// review's suggestion, measured slower at C5's scale (0.927 against 0.909 ms per step, profiles/r03h) and removed in round 4.
 int scone_shard_gather_add(scone_handle *h, const void *d_records, uint64_t n, uint64_t record0, uint64_t n_total,
                            hipStream_t s) {
   scone_shard_state *st = h->shard;
@@ -1148,41 +755,21 @@ int scone_shard_gather_add(scone_handle *h, const void *d_records, uint64_t n, u
       if (rc) return rc;
       if (n_head) SCONE_HIP(h, hipMemcpyAsync(st->scales, st->head_scales, (size_t)n_head * sb, hipMemcpyDeviceToDevice, s));
     }
-    st->rmap_active = rmap_policy(h, st) == 1 && n_total < (1ull << RMAP_REC_BITS);
-    if (st->rmap_active) {
-      const size_t bytes = (size_t)(h->cfg.n_rows ? h->cfg.n_rows : 1) * sizeof(uint32_t);
-      if (!st->rmap) {
-        SCONE_HIP(h, hipMalloc(&st->rmap, bytes));
-        st->rmap_gen = 0;
-      }
-      st->rmap_gen += 1;
-      if (st->rmap_gen == 1 || st->rmap_gen > 0xFFu) {  // first use / the 8-bit generation wraps: forget every entry
-        SCONE_HIP(h, hipMemsetAsync(st->rmap, 0, bytes, s));
-        st->rmap_gen = 1;
-      }
-      st->rhash_cap_now = 2 * (long long)n_total + 2;     // (kept consistent for the out-of-order check below)
-    } else {
-      long long hcap = 1024;
-      while (hcap < 2 * (long long)n_total) hcap <<= 1;
-      int rc = grow(h, &st->rhash, &st->cap_rhash, hcap, 1);
-      if (rc) return rc;
-      SCONE_HIP(h, hipMemsetAsync(st->rhash, 0, (size_t)hcap * sizeof(unsigned long long), s));
-      st->rhash_cap_now = hcap;
-    }
+    long long hcap = 1024;
+    while (hcap < 2 * (long long)n_total) hcap <<= 1;
+    int rc = grow(h, &st->rhash, &st->cap_rhash, hcap, 1);
+    if (rc) return rc;
+    SCONE_HIP(h, hipMemsetAsync(st->rhash, 0, (size_t)hcap * sizeof(unsigned long long), s));
+    st->rhash_cap_now = hcap;
   } else if (st->rhash_cap_now < 2 * (long long)n_total || (sb && st->cap_recv < (long long)(n_head + n_total))) {
     return scone_fail(h, SCONE_ESTATE, "scone_shard_gather_embed: records added out of order (start with record 0)");
   }
   st->added += n;
   if (n) {
     uint8_t *sc = st->scales ? st->scales + (size_t)(n_head + record0) * sb : nullptr;
-    if (st->rmap_active)
-      hipLaunchKernelGGL(k_gather_index_direct, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const uint8_t *)d_records,
-                         (unsigned long long)n, scone_shard_rec_bytes(h), (int)h->row_payload_bytes, (int)sb, st->rmap,
-                         (unsigned long long)h->cfg.n_rows, st->rmap_gen, sc, (unsigned long long)record0, h->d_status);
-    else
-      hipLaunchKernelGGL(k_gather_index, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const uint8_t *)d_records,
-                         (unsigned long long)n, scone_shard_rec_bytes(h), (int)h->row_payload_bytes, (int)sb, st->rhash,
-                         (unsigned long long)st->rhash_cap_now - 1, sc, (unsigned long long)record0);
+    hipLaunchKernelGGL(k_gather_index, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const uint8_t *)d_records,
+                       (unsigned long long)n, scone_shard_rec_bytes(h), (int)h->row_payload_bytes, (int)sb, st->rhash,
+                       (unsigned long long)st->rhash_cap_now - 1, sc, (unsigned long long)record0);
   }
   SCONE_HIP(h, hipGetLastError());
   return SCONE_OK;
@@ -1195,7 +782,7 @@ int scone_shard_gather_remap(scone_handle *h, int32_t T, int32_t seq0, int32_t s
                              hipStream_t s) {
   scone_shard_state *st = h->shard;
   int32_t *lists = plan_lists(st);
-  const bool have_map = st->rmap_active ? st->rmap != nullptr : (st->rhash && st->rhash_cap_now > 0);
+  const bool have_map = st->rhash && st->rhash_cap_now > 0;
   if (!have_map || !lists)
     return scone_fail(h, SCONE_ESTATE, "scone_shard_gather_embed: plan the batch and add the records first");
   if ((size_t)seq1 > st->remapped.size()) return scone_fail(h, SCONE_ESTATE, "scone_shard_gather_embed: sequences outside the planned batch");
@@ -1210,12 +797,8 @@ int scone_shard_gather_remap(scone_handle *h, int32_t T, int32_t seq0, int32_t s
     const long long nt = (long long)(b - a) * T;
     int32_t *e = lists + (long long)a * T * W;
     const unsigned blocks = (unsigned)((nt + 255) / 256 < SHARD_BLOCKS ? (nt + 255) / 256 : SHARD_BLOCKS);
-    if (st->rmap_active)
-      hipLaunchKernelGGL(k_gather_remap_direct, dim3(blocks), dim3(256), 0, s, e, nt, W, NC, st->rmap, st->rmap_gen,
-                         (long long)st->n_head, (long long)h->cfg.n_rows, h->d_status);
-    else
-      hipLaunchKernelGGL(k_gather_remap, dim3(blocks), dim3(256), 0, s, e, nt, W, NC, st->rhash,
-                         (unsigned long long)st->rhash_cap_now - 1, (long long)st->n_head, h->d_status);
+    hipLaunchKernelGGL(k_gather_remap, dim3(blocks), dim3(256), 0, s, e, nt, W, NC, st->rhash,
+                       (unsigned long long)st->rhash_cap_now - 1, (long long)st->n_head, h->d_status);
     for (int32_t q = a; q < b; ++q) st->remapped[q] = 1;
     a = b;
   }

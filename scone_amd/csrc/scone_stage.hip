@@ -153,9 +153,11 @@ __global__ __launch_bounds__(256) void k_stage_remap(int32_t *__restrict__ ell, 
 }
 
 // one wave per listed row; 16 bytes per lane per step from mapped host memory.  The grid is what bounds the reads in flight
-// over PCIe (one row per wave): 256 workgroups = 1024 waves x 512 B = 0.5 MB, four times the link's bandwidth-delay
-// product (~50 GB/s x ~2.5 us); the round-3 grid of 1024 workgroups kept 2 MB of PCIe reads in the L2's miss queues and
-// slowed every kernel beside it 2-10x.
+// over PCIe (one row per wave): 128 workgroups = 512 waves x 512 B = 0.25 MB, twice the link's bandwidth-delay product
+// (~50 GB/s x ~2.5 us); the round-3 grid of 1024 workgroups kept 2 MB of PCIe reads in the L2's miss queues and slowed
+// every kernel beside it 2-10x.  Measured on the C4 Zipf stream, steady state, 8M-row cache (profiles/r04g): 96 / 128
+// workgroups 1.235 / 1.154 ms per 1M-token step at 262k-token chunks, 1.228 / 1.172 at 131k; the cache-filling phase
+// (every row a miss): 64 / 128 / 256 / 512 / 1024 workgroups 1.74 / 1.33 / 1.42 / 1.49 / 1.58 ms (profiles/r04b).
 __global__ __launch_bounds__(256) void k_stage_copy(const uint32_t *__restrict__ count, const int32_t *__restrict__ list,
                                                     const uint32_t *__restrict__ place, scone_row_store host,
                                                     uint8_t *__restrict__ cache_rows, const uint8_t *__restrict__ scales,
@@ -186,7 +188,7 @@ struct scone_stage_state {
   long long requested_tokens = 0;  // what the caller asked for (may exceed chunk_tokens, see prepare)
   uint32_t cap = 0;       // cache slots
   uint32_t list_cap = 0;  // rows one chunk can list
-  int copy_blocks = 256;
+  int copy_blocks = 128;
   hipStream_t prep = nullptr, copy = nullptr;
   hipEvent_t prepped[SCONE_STAGE_NBUF] = {}, staged[SCONE_STAGE_NBUF] = {}, consumed[SCONE_STAGE_NBUF] = {}, start = nullptr;
   bool consumed_valid[SCONE_STAGE_NBUF] = {};

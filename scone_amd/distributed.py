@@ -9,15 +9,16 @@ here and only needed when the table does not fit one GPU's 288 GB (BASELINE conf
 * index (f-gram -> id): replicated, so every rank matches the full batch locally and knows
   every token's full hit count K_t -- no id exchange;
 * rank r finalises slice r of the batch (whole sequences);
-* exchange ``"rows"`` (default for slices; since round 2 one record per DISTINCT row and destination, built from the
-  chunked-gather primitives -- ``_embed_row_exchange_dedup``; the first form, one record per reference, is
-  ``"rows_per_reference"``): what crosses xGMI are the QUANTISED ROWS a slice needs from the
-  other shards -- ``scone_shard_plan`` (both ends derive what is sent from the replicated tokens
-  and index: no request round) -> ``scone_shard_pack`` -> ONE ``all_to_all_single`` of records ->
-  ``scone_shard_embed`` (the ordinary fused kernel reads the records in place).  An INT4 d=1024
-  row is 544 B on the wire where an fp32 partial sum is 4096 B per token AND rank: for the C5
-  workload about 0.2 GB per rank and step instead of 3.7 GB, spread over all 7 xGMI links by the
-  all-to-all, and the result is bit-identical to the unsharded table (same reduction order);
+* exchange ``"rows"`` (default for slices; one record per DISTINCT row and destination, built from the chunked-gather
+  primitives -- ``_embed_row_exchange_dedup``; the first form, one record per reference, was removed in round 4): what
+  crosses xGMI are the QUANTISED ROWS a slice needs from the other shards -- ``scone_shard_gather_plan_chunks`` with chunk q =
+  slice q (both ends derive what is sent from the replicated tokens and index: no request round) ->
+  ``scone_shard_gather_pack_range`` -> ONE ``all_to_all_single`` of records -> ``scone_shard_gather_add_records`` /
+  ``_embed_range`` (the ordinary fused kernel reads the records in place).  An INT4 d=1024 row is 544 B on the wire where an
+  fp32 partial sum is 4096 B per token AND rank: for the C5 workload about 25 MB per rank and step instead of 3.7 GB, spread
+  over all 7 xGMI links by the all-to-all, and the result is bit-identical to the unsharded table (same reduction order).
+  This is the form for DATA-PARALLEL consumers (``gather_output=False``): the only one whose per-rank work falls with the
+  world size;
 * ``replicated_rows=H``: the head of the table, global rows ``[0, H)``, is kept on every rank and never sent.
   f-gram ids are frequency-ordered (``Counter.most_common``), so the head holds every unigram and the most
   frequent f-grams -- about half of all row references on the C5-shaped workload, all of which would otherwise
@@ -39,7 +40,8 @@ here and only needed when the table does not fit one GPU's 288 GB (BASELINE conf
 * round 3, both on by default for batches of >= 65,536 tokens.  ``shard_match``: in the all-gather form every rank needs the id
   lists of the WHOLE batch, and matching all of it against a 1e9-key index was the largest helper kernel of the step; index and
   tokens are replicated and matching is per sequence, so rank r matches slice r only and the 32-B list records are
-  all-gathered (``scone_shard_gather_match / _plan_ell``).  ``wire_format="columns"`` (the one-piece form): a contribution
+  all-gathered (``scone_shard_gather_match / _plan_ell``).  Columns on the wire (the one-piece form, ``gather_chunks=1``, the
+  default since round 4; ``gather_chunks > 1`` is the legacy chunk pipeline with records on the wire): a contribution
   travels as payload rows | scales | the SENDER's hash fragment ``row id -> position`` instead of ``[payload | scales | row id]``
   records -- no receiver indexes anything (0.45M device-scope CAS per rank and step before), the rows land at the table's own
   stride (``scone_shard_cols_pack / _embed``);
@@ -231,16 +233,8 @@ class ShardedEmbeddingCache:
     def __init__(self, n_gram_extractor: NGramExtractor, embedding_dim: int, *, table_format: str = "int8",
                  rank: Optional[int] = None, world: Optional[int] = None, group=None, device=None,
                  n_rows: Optional[int] = None, placement: str = "hbm", table=None, replicated_rows: int = 0,
-                 gather_chunks: int = 4, gather_transport: str = "p2p", shard_match="auto", plan_slots: int = 2,
-                 wire_format: str = "columns") -> None:
+                 gather_chunks: int = 1, gather_transport: str = "p2p", shard_match="auto", plan_slots: int = 2) -> None:
         self.group = group
-        # "gather_rows" in one piece (gather_chunks = 1, the split-phase form): what a rank's contribution looks like on the
-        # wire -- "columns": payload rows | scales | the sender's hash fragment (row id -> position), three ranges per peer,
-        # no indexing pass on the receiver; "records": [payload | scales | row id] records, indexed by every receiver (the
-        # form of the chunked exchanges and of rounds 1-2)
-        if wire_format not in ("columns", "records"):
-            raise ValueError("wire_format must be 'columns' or 'records'")
-        self.wire_format = wire_format
         # split-phase "gather_rows": batches in flight (2 .. 4).  The chain plan -> count exchange -> pack -> transfers of
         # a batch must fit (plan_slots - 1) reductions: with 2 it has ONE reduction's time, with 3 it has two -- the
         # setting for links on which a step's 0.26 GB of records take about as long as its reduction
@@ -253,7 +247,12 @@ class ShardedEmbeddingCache:
         if shard_match not in (True, False, "auto"):
             raise ValueError("shard_match must be True, False or 'auto'")
         self.shard_match = shard_match
-        self.gather_chunks = int(gather_chunks)    # "gather_rows": the batch is exchanged and reduced in this many chunks
+        # "gather_rows": ONE switch for the form of the exchange.  1 (default, and always in the split-phase loop's measured
+        # configuration): one piece, COLUMNS on the wire -- payload rows | scales | the sender's hash fragment (row id ->
+        # position), three ranges per peer, no indexing pass on the receiver.  > 1: the legacy chunk pipeline of rounds 2-3 --
+        # the batch is exchanged and reduced in this many chunks of sequences, [payload | scales | row id] RECORDS on the wire,
+        # indexed by every receiver, chunk c + 1's transfer behind chunk c's reduction inside one call
+        self.gather_chunks = int(gather_chunks)
         if gather_transport not in ("p2p", "all_gather", "sdma"):
             raise ValueError("gather_transport must be 'p2p', 'all_gather' or 'sdma'")
         # "gather_rows": how the records travel -- exact point-to-point ranges (RCCL send / recv kernels), all_gather_into_tensor
@@ -297,6 +296,11 @@ class ShardedEmbeddingCache:
         if gather_transport == "sdma" and self.world > 1:
             self._sdma_init()
 
+    @property
+    def wire_format(self) -> str:
+        """What a contribution of the "gather_rows" exchange looks like on the wire (follows ``gather_chunks``)."""
+        return "columns" if self.gather_chunks <= 1 and hasattr(self.table, "shard_cols_pack") else "records"
+
     @classmethod
     def from_synthetic(cls, n_gram_extractor: NGramExtractor, embedding_dim: int, *, table_format: str = "int8",
                        seed: int = 7, base_scale: float = 0.02 / 127, **kw) -> "ShardedEmbeddingCache":
@@ -325,8 +329,6 @@ class ShardedEmbeddingCache:
         ok, why = True, None
         if not all(hasattr(t, m) for m in ("ipc_alloc", "ipc_event_create", "ipc_push", "shard_cols_pack")):
             ok, why = False, "the table handle has no scone_ipc_* entry points (a stand-in handle)"
-        elif self.wire_format != "columns":
-            ok, why = False, "wire_format='records' (the sdma transport moves columns)"
         else:
             try:                                        # capability probe: one buffer + one event, exported
                 p, _ = t.ipc_alloc(4096)
@@ -354,6 +356,18 @@ class ShardedEmbeddingCache:
         self._sdma = {"ctrl": ctrl, "slots": [None] * 4,
                       "push": [torch.cuda.Stream(device=dev) for _ in range(self.world)],
                       "copy_engine": os.environ.get("SCONE_SDMA_COPY_ENGINE", "1") != "0"}
+
+    def set_gather_transport(self, transport: str) -> str:
+        """Switch the transport of the "gather_rows" exchange on an existing cache -- collective: every rank calls it with the
+        same value (asking for "sdma" runs the capability probe and the handle exchange set-up).  Returns the transport in use
+        ("p2p" when "sdma" is not available; ``transport_fallback_reason`` says why)."""
+        if transport not in ("p2p", "all_gather", "sdma"):
+            raise ValueError("gather_transport must be 'p2p', 'all_gather' or 'sdma'")
+        self.gather_transport = transport
+        self.transport_fallback_reason = None
+        if transport == "sdma" and self.world > 1 and self._sdma is None:
+            self._sdma_init()
+        return self.gather_transport
 
     def _sdma_release_slot(self, st) -> None:
         t = self.table
@@ -511,11 +525,7 @@ class ShardedEmbeddingCache:
             out = self.table.embed(tok, wte=wte, wpe=wpe, position_ids=position_ids, reduce=reduce, out_dtype=out_dtype)
             return out if gather_output else out.reshape(ntok, d)
         if exchange == "rows":
-            if hasattr(self.table, "shard_gather_plan_chunks"):
-                return self._embed_row_exchange_dedup(tok, reduce, wte, wpe, position_ids, out_dtype, gather_output)
-            return self._embed_row_exchange(tok, reduce, wte, wpe, position_ids, out_dtype, gather_output)
-        if exchange == "rows_per_reference":
-            return self._embed_row_exchange(tok, reduce, wte, wpe, position_ids, out_dtype, gather_output)
+            return self._embed_row_exchange_dedup(tok, reduce, wte, wpe, position_ids, out_dtype, gather_output)
         if exchange == "gather_rows":
             out = self._embed_gather_rows(tok, reduce, wte, wpe, position_ids, out_dtype)
             if gather_output:
@@ -526,7 +536,7 @@ class ShardedEmbeddingCache:
             sl[:(b1 - b0) * T] = out[b0 * T:b1 * T]
             return sl
         if exchange != "partial_sums":
-            raise ValueError("exchange must be 'rows', 'rows_per_reference', 'gather_rows' or 'partial_sums'")
+            raise ValueError("exchange must be 'rows', 'gather_rows' or 'partial_sums'")
         partial, counts = self.table.embed_partial(tok)                      # [ntok, d] fp32, [ntok] int32
         per = (ntok + W - 1) // W                                             # tokens per rank (last slices padded)
         a = min(self.rank * per, ntok)
@@ -771,7 +781,7 @@ class ShardedEmbeddingCache:
         B, T = tok.shape
         W, t = self.world, self.table
         C = max(1, min(self.gather_chunks, B, 64))
-        if C == 1 and self.wire_format == "columns" and hasattr(t, "shard_cols_pack"):
+        if C == 1 and hasattr(t, "shard_cols_pack"):
             return self._gather_begin_cols(tok, slot, t0)
         per = (B + C - 1) // C
         self._plan_enter(slot, tok)
@@ -1037,44 +1047,6 @@ class ShardedEmbeddingCache:
             return out_slice
         if W > 1:
             full = torch.empty((bper * T * W, d), dtype=out_dtype, device=tok.device)
-            _all_gather(full, out_slice, self.group)
-            if self._prof is not None:
-                self._prof["bytes_received"] += float(full.numel() * full.element_size() * (W - 1) // W)
-        else:
-            full = out_slice
-        self._tick("gather_out_ms", t0)
-        return full[:B * T].reshape(B, T, d)
-
-    def _embed_row_exchange(self, tok, reduce, wte, wpe, position_ids, out_dtype, gather_output):
-        B, T = tok.shape
-        d, W, r = self.embedding_dim, self.world, self.rank
-        import time
-        t0 = time.perf_counter() if self._prof is not None else 0.0
-        bper = (B + W - 1) // W                                              # sequences per slice
-        send_counts, recv_counts = self.table.shard_plan(tok, W, r)
-        t0 = self._tick("plan_ms", t0)
-        send = self.table.shard_pack(B, T, W, send_counts)                   # uint8 [n_send, record_bytes]
-        t0 = self._tick("pack_ms", t0)
-        rec = send.shape[1]
-        if W > 1:
-            recv = torch.empty((int(sum(recv_counts)), rec), dtype=torch.uint8, device=send.device)
-            _all_to_all(recv, send, [int(c) for c in recv_counts], [int(c) for c in send_counts], self.group)
-        else:
-            recv = send
-        t0 = self._tick("collective_ms", t0)
-        if self._prof is not None:
-            self._prof["bytes_received"] = float((int(sum(recv_counts)) - int(recv_counts[r])) * rec)
-        b0, b1 = min(r * bper, B), min(r * bper + bper, B)
-        out_slice = torch.zeros((bper * T, d), dtype=out_dtype, device=send.device) if (b1 - b0) < bper else \
-            torch.empty((bper * T, d), dtype=out_dtype, device=send.device)
-        if b1 > b0:
-            self.table.shard_embed(tok, W, r, recv, wte=wte, wpe=wpe, position_ids=position_ids, reduce=reduce,
-                                   out_dtype=out_dtype, out=out_slice[:(b1 - b0) * T])
-        t0 = self._tick("embed_ms", t0)
-        if not gather_output:
-            return out_slice
-        if W > 1:
-            full = torch.empty((bper * T * W, d), dtype=out_dtype, device=send.device)
             _all_gather(full, out_slice, self.group)
             if self._prof is not None:
                 self._prof["bytes_received"] += float(full.numel() * full.element_size() * (W - 1) // W)

@@ -433,52 +433,6 @@ class SconeTable:
         self._check(L.lib().scone_shard_record_bytes(self._h, C.byref(n)), "scone_shard_record_bytes")
         return n.value
 
-    def shard_plan(self, tok: torch.Tensor, world: int, rank: int) -> Tuple[list, list]:
-        """(send_counts, recv_counts) in records per peer for this batch (synchronises)."""
-        tok = self._tok(tok)
-        B, T = tok.shape
-        snd, rcv = (C.c_uint32 * 64)(), (C.c_uint32 * 64)()
-        with torch.cuda.device(self.device):
-            rc = L.lib().scone_shard_plan(self._h, _ptr(tok), B, T, int(world), int(rank), snd, rcv, _stream())
-        self._check(rc, "scone_shard_plan")
-        return list(snd[:world]), list(rcv[:world])
-
-    def shard_pack(self, B: int, T: int, world: int, send_counts) -> torch.Tensor:
-        """uint8 ``[sum(send_counts), record_bytes]``: the records this rank sends, grouped by destination."""
-        total = int(sum(send_counts))
-        buf = torch.empty((total, self.shard_record_bytes()), dtype=torch.uint8, device=self.device)
-        cnt = (C.c_uint32 * 64)(*[int(x) for x in send_counts])
-        with torch.cuda.device(self.device):
-            rc = L.lib().scone_shard_pack(self._h, int(B), int(T), int(world), cnt, _ptr(buf), _stream())
-        self._check(rc, "scone_shard_pack")
-        return buf
-
-    def shard_embed(self, tok: torch.Tensor, world: int, rank: int, recv: torch.Tensor,
-                    wte: Optional[torch.Tensor] = None, wpe: Optional[torch.Tensor] = None,
-                    position_ids: Optional[torch.Tensor] = None, reduce: str = "mean",
-                    out_dtype: torch.dtype = torch.float32, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """This rank's slice of the output ``[slice sequences * T, d]`` from the received records."""
-        tok = self._tok(tok)
-        B, T = tok.shape
-        bper = (B + world - 1) // world
-        b0, b1 = min(rank * bper, B), min(rank * bper + bper, B)
-        n = (b1 - b0) * T
-        if position_ids is not None:
-            position_ids = position_ids.to(device=self.device, dtype=torch.int32).expand(B, T).contiguous()
-        if out is None:
-            out = torch.empty((n, self.dim), dtype=out_dtype, device=self.device)
-        assert recv.is_cuda and recv.is_contiguous() and recv.dtype == torch.uint8
-        with torch.cuda.device(self.device):
-            rc = L.lib().scone_shard_embed(self._h, _ptr(tok), B, T, int(world), int(rank), _ptr(recv), recv.shape[0],
-                                           _ptr(wte), 0 if wte is None else wte.shape[0], _ptr(wpe),
-                                           0 if wpe is None else wpe.shape[0], _ptr(position_ids), _REDUCE[reduce],
-                                           _ptr(out), _DT[out_dtype], _stream())
-        # the kernel reads `recv` / `tok` / `position_ids` in place after this call returns: keep them alive until the
-        # next exchange on this handle instead of synchronising the host here
-        self._shard_keepalive = (recv, tok, position_ids, wte, wpe)
-        self._check(rc, "scone_shard_embed")
-        return out
-
     # -- all-gather form: one record per distinct row (scone_shard_gather_*) -------------
     def shard_gather_plan(self, tok: torch.Tensor) -> int:
         """Number of records this shard contributes: the distinct rows it owns (outside the replicated head) that

@@ -55,8 +55,6 @@ class OracleShard:
         partial = R.embed_numpy(self.table, off_own, ids[owned], "sum")
         return torch.from_numpy(partial), torch.from_numpy(counts)
 
-    # ---- row exchange stand-ins: same contract as SconeTable.shard_plan / shard_pack / shard_embed,
-    #      a record = [fp32 row | int32 token-in-slice | int32 list index]
     def _refs(self, tok):
         R = self.R
         t = tok.numpy()
@@ -66,62 +64,7 @@ class OracleShard:
         jix = np.arange(len(ids)) - np.repeat(off[:-1], counts)
         return off, ids, tix, jix
 
-    def shard_plan(self, tok, world, rank):
-        from scone_amd.distributed import owner_of
-        B, T = tok.shape
-        bper = (B + world - 1) // world
-        off, ids, tix, jix = self._refs(tok)
-        mine = (ids >= self.row_begin) & (ids < self.row_end)
-        dest = tix // (bper * T)
-        send = [int((mine & (dest == q)).sum()) for q in range(world)]
-        owner = owner_of(torch.from_numpy(ids), self.n_rows, world).numpy() if len(ids) else np.zeros(0, dtype=np.int64)
-        recv = [int(((dest == rank) & (owner == r)).sum()) for r in range(world)]
-        self._plan = (tix, jix, ids, mine, dest, bper * T)
-        return send, recv
-
-    def shard_pack(self, B, T, world, send_counts):
-        tix, jix, ids, mine, dest, st = self._plan
-        recs = []
-        for q in range(world):
-            sel = np.nonzero(mine & (dest == q))[0][::-1]        # any order inside a destination is allowed
-            assert len(sel) == send_counts[q]
-            for i in sel:
-                hdr = np.array([tix[i] % st, jix[i]], dtype=np.int32).view(np.uint8)
-                recs.append(np.concatenate([self.table[ids[i]].view(np.uint8), hdr]))
-        n = self.dim * 4 + 8
-        return torch.from_numpy(np.stack(recs) if recs else np.zeros((0, n), dtype=np.uint8))
-
-    def shard_embed(self, tok, world, rank, recv, wte=None, wpe=None, position_ids=None, reduce="mean",
-                    out_dtype=torch.float32, out=None):
-        B, T = tok.shape
-        bper = (B + world - 1) // world
-        b0, b1 = min(rank * bper, B), min(rank * bper + bper, B)
-        sl = tok[b0:b1]
-        off, ids, tix, jix = self._refs(sl)
-        r = recv.numpy()
-        rows = np.zeros((len(ids), self.dim), dtype=np.float32)
-        seen = np.zeros(len(ids), dtype=bool)
-        for rec in r:
-            t_local, j = rec[self.dim * 4:].view(np.int32)
-            k = off[t_local] + j
-            rows[k] = rec[:self.dim * 4].view(np.float32)
-            seen[k] = True
-        assert seen.all(), "a needed row did not arrive"
-        assert np.array_equal(rows, self.table[ids])
-        x = torch.from_numpy(self.R.embed_numpy(rows, off, np.arange(len(ids)), reduce))
-        flat = sl.reshape(-1).long()
-        if wte is not None:
-            x = wte.float()[flat] + x
-        if wpe is not None:
-            pos = (torch.arange(flat.numel()) % T) if position_ids is None else position_ids[b0:b1].reshape(-1).long()
-            x = x + wpe.float()[pos]
-        x = x.to(out_dtype)
-        if out is not None:
-            out.copy_(x)
-            return out
-        return x
-
-    # ---- all-gather form stand-ins: a record = [fp32 row | int32 row id | int32 marker]
+    # ---- row exchange stand-ins (same contract as SconeTable.shard_gather_*): a record = [fp32 row | int32 row id | int32 marker]
     def shard_gather_plan(self, tok):
         off, ids, tix, jix = self._refs(tok)
         mine = np.unique(ids[(ids >= max(self.row_begin, self.n_head)) & (ids < self.row_end)])
@@ -362,8 +305,7 @@ class OracleShard:
         return x
 
 
-def _worker(rank, world, port, ntok_shape, out_dtype_name, exchange, q, chunks=4, head=0, transport="p2p", shard_match="auto",
-            wire_format="columns"):
+def _worker(rank, world, port, ntok_shape, out_dtype_name, exchange, q, chunks=4, head=0, transport="p2p", shard_match="auto"):
     try:
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -389,11 +331,12 @@ def _worker(rank, world, port, ntok_shape, out_dtype_name, exchange, q, chunks=4
         if head:
             shard.shard_set_head(head)
         cache = ShardedEmbeddingCache(ex, d, rank=rank, world=world, n_rows=n, table=shard, replicated_rows=head,
-                                      gather_chunks=max(chunks, 1), gather_transport=transport, shard_match=shard_match,
-                                      wire_format=wire_format)
+                                      gather_chunks=max(chunks, 1), gather_transport=transport, shard_match=shard_match)
         assert (cache.row_begin, cache.row_end) == (a, b)
+        if transport == "sdma":        # no scone_ipc_* on a stand-in handle: EVERY rank falls back to p2p, and says why
+            assert cache.gather_transport == "p2p" and "stand-in" in cache.transport_fallback_reason, cache.transport_fallback_reason
         out = cache.embed_tokens(tok, wte=wte.to(out_dtype), wpe=wpe.to(out_dtype), out_dtype=out_dtype,
-                                 exchange=exchange)
+                                 exchange=exchange, check=True)
         ro, ri = R.hits_to_csr(R.match_hits(keys, lens, tok.numpy(), max_n))
         fg = torch.from_numpy(R.embed_numpy(table, ro, ri, "mean").reshape(B, T, d))
         ref = R.combine(tok, fg, wte.to(out_dtype).float(), wpe.to(out_dtype).float())
@@ -408,8 +351,9 @@ def _worker(rank, world, port, ntok_shape, out_dtype_name, exchange, q, chunks=4
             ok_slice = ok_slice and getattr(shard, "plans_from_gathered_lists", 0) == 2     # both calls planned from gathered lists
         elif shard_match == "auto":
             ok_slice = ok_slice and not hasattr(shard, "plans_from_gathered_lists")         # (tiny batches: every rank matches)
-        if exchange == "gather_rows" and chunks == 1:                                        # one piece: columns unless asked otherwise
-            ok_slice = ok_slice and (getattr(shard, "cols_packs", 0) == 2) == (wire_format == "columns")
+        if exchange == "gather_rows":                                                        # one piece = columns, the chunk pipeline = records
+            ok_slice = ok_slice and (getattr(shard, "cols_packs", 0) == 2) == (chunks > 0 and min(chunks, B) == 1)   # (a batch of one
+            ok_slice = ok_slice and (chunks == 0 or cache.wire_format == ("columns" if chunks == 1 else "records"))  # sequence has one chunk)
         q.put((rank, err, tuple(out.shape), ok_slice))
         dist.destroy_process_group()
     except Exception as e:      # surface the failure in the parent
@@ -422,7 +366,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("exchange", ["rows", "rows_per_reference", "gather_rows", "partial_sums"])
+@pytest.mark.parametrize("exchange", ["rows", "gather_rows", "partial_sums"])
 @pytest.mark.parametrize("shape,dtype", [((3, 17), "float32"), ((2, 8), "float16"), ((1, 5), "float32")])
 def test_sharded_exchange_world2_gloo(shape, dtype, exchange):
     ctx = mp.get_context("spawn")
@@ -488,18 +432,19 @@ def test_match_sharded_over_the_ranks_world_gloo(exchange, chunks, head, world, 
         assert out_shape == (shape[0], shape[1], 32) and err < 1e-6 and ok_slice
 
 
-@pytest.mark.parametrize("transport,world,head,shape,wire", [("p2p", 2, 0, (5, 13), "columns"), ("p2p", 3, 20, (4, 19), "columns"),
-                                                             ("all_gather", 2, 40, (5, 13), "columns"), ("all_gather", 3, 0, (7, 9), "columns"),
-                                                             ("p2p", 3, 20, (1, 5), "columns"), ("p2p", 2, 0, (5, 13), "records")])
-def test_gather_rows_columns_on_the_wire_world_gloo(transport, world, head, shape, wire):
+@pytest.mark.parametrize("transport,world,head,shape", [("p2p", 2, 0, (5, 13)), ("p2p", 3, 20, (4, 19)),
+                                                        ("all_gather", 2, 40, (5, 13)), ("all_gather", 3, 0, (7, 9)),
+                                                        ("p2p", 3, 20, (1, 5)), ("sdma", 2, 10, (5, 13))])
+def test_gather_rows_columns_on_the_wire_world_gloo(transport, world, head, shape):
     """``gather_rows`` in one piece with COLUMNS on the wire: every rank's payload rows, (scales,) and hash fragment travel as
     three ranges -- exact point-to-point ranges or three padded all-gathers -- and the receiver resolves the id lists through
     the owners' fragments: same output as the unsharded table (the stand-in checks that every row sits in ITS owner's
-    fragment, arrives once and inside the receive buffer); ``wire_format="records"`` keeps the record form."""
+    fragment, arrives once and inside the receive buffer).  (``gather_chunks > 1`` -- the legacy chunk pipeline -- keeps the
+    record form: ``test_gather_rows_chunked_pipeline_world2_gloo``.)"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, shape, "float32", "gather_rows", q, 1, head, transport, "auto", wire))
+    procs = [ctx.Process(target=_worker, args=(r, world, port, shape, "float32", "gather_rows", q, 1, head, transport, "auto"))
              for r in range(world)]
     for p in procs:
         p.start()
@@ -627,7 +572,6 @@ def _worker_soak(rank, world, port, slots, q):
                 cache.gather_chunks = int(rng.integers(1, 4))
                 cache.shard_match = bool(rng.integers(2))
                 cache.gather_transport = ("p2p", "all_gather")[int(rng.integers(2))]
-                cache.wire_format = ("columns", "records")[int(rng.integers(2))]
                 tickets.append(cache.gather_rows_begin(tok))
                 batches.append(tok)
             if i >= slots - 1:
@@ -674,7 +618,12 @@ def test_gather_transport_is_validated():
     with pytest.raises(ValueError):
         ShardedEmbeddingCache(ex, 8, rank=0, world=1, n_rows=2, table=shard, gather_transport="ring")
     c = ShardedEmbeddingCache(ex, 8, rank=0, world=1, n_rows=2, table=shard, gather_transport="all_gather")
-    assert c.gather_transport == "all_gather" and c.gather_chunks == 4
+    assert c.gather_transport == "all_gather" and c.gather_chunks == 1 and c.wire_format == "columns"   # round 4: one piece by default
+    c.gather_chunks = 3
+    assert c.wire_format == "records"                     # the legacy chunk pipeline keeps records on the wire
+    with pytest.raises(ValueError):
+        c.set_gather_transport("ring")
+    assert c.set_gather_transport("sdma") == "sdma"      # world 1: nothing to set up, nothing to fall back from
 
 
 def test_load_rows_stores_owned_range_and_replicated_head():

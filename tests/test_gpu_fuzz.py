@@ -97,8 +97,6 @@ def test_fuzz_row_exchange_vs_unsharded():
         tok = torch.from_numpy(rng.integers(0, vocab + 1, size=(B, T)))
         wte = torch.from_numpy(rng.standard_normal((vocab + 1, d)).astype(np.float32)).half().cuda()
         wpe = torch.from_numpy(rng.standard_normal((T, d)).astype(np.float32)).half().cuda()
-        # the receiver's row map: direct-mapped array / hash map, alternating (read when a handle first adds records)
-        os.environ["SCONE_SHARD_ROW_MAP"] = ("direct", "hash")[case % 2]
         full = SconeTable(max_n, n, d, fmt)
         full.index_build(keys, lens)
         full.store_f32(torch.from_numpy(table))
@@ -115,17 +113,24 @@ def test_fuzz_row_exchange_vs_unsharded():
                 s.shard_set_head(head)
                 s.shard_head_store_f32(torch.from_numpy(table[:head]), row0=0)
             shards.append(s)
-        plans = [s.shard_plan(tok, world, r) for r, s in enumerate(shards)]
         tag = (case, world, max_n, fmt, d, vocab, n, head, B, T)
-        assert sum(sum(p[0]) for p in plans) == int((ids >= head).sum()), tag
-        sends = [s.shard_pack(B, T, world, plans[r][0]) for r, s in enumerate(shards)]
+        # the slice exchange: chunk q of a shard's plan = the distinct rows of its own that slice q references
+        rec = shards[0].shard_record_bytes()
+        ends = [s.shard_gather_plan_chunks(tok, world, dedup_across_chunks=False) for s in shards]
+        cnt = [[e[0]] + [e[q] - e[q - 1] for q in range(1, world)] for e in ends]
+        sends = []
+        for r, s in enumerate(shards):
+            buf = torch.empty((max(ends[r][-1], 1), rec), dtype=torch.uint8, device="cuda")
+            s.shard_gather_pack_range(0, ends[r][-1], buf[:ends[r][-1]])
+            sends.append(buf)
         bper = (B + world - 1) // world
         for q in range(world):
-            parts = [sends[r][sum(plans[r][0][:q]):sum(plans[r][0][:q]) + plans[r][0][q]] for r in range(world)]
-            recv = torch.cat(parts).contiguous()
+            recv = torch.cat([sends[r][sum(cnt[r][:q]):sum(cnt[r][:q + 1])] for r in range(world)]).contiguous()
             b0, b1 = min(q * bper, B), min(q * bper + bper, B)
+            shards[q].shard_gather_add_records(recv, 0, recv.shape[0])
             if b1 > b0:
-                got = shards[q].shard_embed(tok, world, q, recv, wte=wte, wpe=wpe, out_dtype=torch.float16)
+                got = torch.empty(((b1 - b0) * T, d), dtype=torch.float16, device="cuda")
+                shards[q].shard_gather_embed_range(tok, b0, b1, recv, got, wte=wte, wpe=wpe, out_is_slice=True)
                 assert torch.equal(got, want[b0 * T:b1 * T]), tag + (q,)
             assert shards[q].status() == 0, tag
         # the all-gather form: every shard packs one record per DISTINCT row it owns that the batch references, any shard
@@ -286,13 +291,21 @@ def test_shard_workspaces_survive_mixed_modes_and_growing_batches():
             for q in range(world):
                 assert torch.equal(shards[q].shard_gather_embed(tok, recv, wte=wte, out_dtype=torch.float16), want), (step, q)
         else:
-            plans = [s.shard_plan(tok, world, r) for r, s in enumerate(shards)]
-            sends = [s.shard_pack(B, T, world, plans[r][0]) for r, s in enumerate(shards)]
+            rec = shards[0].shard_record_bytes()
+            ends = [s.shard_gather_plan_chunks(tok, world, dedup_across_chunks=False) for s in shards]
+            cnt = [[e[0]] + [e[q] - e[q - 1] for q in range(1, world)] for e in ends]
+            sends = []
+            for r, s in enumerate(shards):
+                buf = torch.empty((max(ends[r][-1], 1), rec), dtype=torch.uint8, device="cuda")
+                s.shard_gather_pack_range(0, ends[r][-1], buf[:ends[r][-1]])
+                sends.append(buf)
             bper = (B + world - 1) // world
             for q in range(world):
-                recv = torch.cat([sends[r][sum(plans[r][0][:q]):sum(plans[r][0][:q]) + plans[r][0][q]] for r in range(world)]).contiguous()
+                recv = torch.cat([sends[r][sum(cnt[r][:q]):sum(cnt[r][:q + 1])] for r in range(world)]).contiguous()
                 b0, b1 = min(q * bper, B), min(q * bper + bper, B)
+                shards[q].shard_gather_add_records(recv, 0, recv.shape[0])
                 if b1 > b0:
-                    got = shards[q].shard_embed(tok, world, q, recv, wte=wte, out_dtype=torch.float16)
+                    got = torch.empty(((b1 - b0) * T, d), dtype=torch.float16, device="cuda")
+                    shards[q].shard_gather_embed_range(tok, b0, b1, recv, got, wte=wte, out_is_slice=True)
                     assert torch.equal(got, want[b0 * T:b1 * T]), (step, q)
         assert all(s.status() == 0 for s in shards), step

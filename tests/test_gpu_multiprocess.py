@@ -58,10 +58,10 @@ def _worker(rank, world, port, fmt, d, max_n, exchange, head, q):
         ex = NGramExtractor.from_arrays(keys, lens, max_n=max_n)
         exchange, _, rest = exchange.partition(":")               # "gather_rows:all_gather" = the padded all-gather transport,
         transport, _, rest = rest.partition(":")                  # "...:sm" = the plan's match sharded over the ranks,
-        sm, _, c1 = rest.partition(":")                           # "...:c1" = one piece (columns on the wire), "...:c1r" = one piece, records
+        sm, _, c1 = rest.partition(":")                           # "...:c1" = one piece (columns on the wire); else the legacy 4-chunk pipeline (records)
         sh = ShardedEmbeddingCache(ex, d, table_format=fmt, rank=rank, world=world, replicated_rows=head,
                                    gather_transport=transport or "p2p", shard_match=True if sm == "sm" else "auto",
-                                   gather_chunks=1 if c1 else 4, wire_format="records" if c1 == "c1r" else "columns")
+                                   gather_chunks=1 if c1 else 4)
         if transport == "sdma":                      # the copy-engine transport must really be in use, not its fallback
             assert sh.gather_transport == "sdma" and sh.transport_fallback_reason is None, sh.transport_fallback_reason
         sh.load_rows(torch.from_numpy(table), 0)
@@ -93,11 +93,9 @@ def _worker(rank, world, port, fmt, d, max_n, exchange, head, q):
                                                              ("int4", 1024, 3, 3, "gather_rows:p2p:sm:c1", 100),
                                                              ("fp16", 768, 4, 2, "gather_rows:all_gather::c1", 0),
                                                              ("int8", 768, 3, 3, "gather_rows:all_gather:sm:c1", 37),
-                                                             ("int8", 1024, 3, 2, "gather_rows:p2p::c1r", 100),
                                                              ("int4", 1024, 3, 3, "gather_rows:sdma:sm:c1", 100),
                                                              ("int8", 768, 3, 2, "gather_rows:sdma::c1", 0),
-                                                             ("int8", 768, 3, 2, "partial_sums", 0),
-                                                             ("int4", 1024, 3, 3, "rows_per_reference", 100)])
+                                                             ("int8", 768, 3, 2, "partial_sums", 0)])
 def test_sharded_cache_across_processes_on_one_gpu(fmt, d, max_n, world, exchange, head):
     if not torch.cuda.is_available():
         pytest.skip("needs an MI355X")
@@ -113,7 +111,7 @@ def test_sharded_cache_across_processes_on_one_gpu(fmt, d, max_n, world, exchang
     for rank, same, err, shape, sl_shape in results:
         assert shape is not None, f"rank {rank} failed: {err}"
         assert shape == (5, 33, d)
-        if exchange.partition(":")[0] in ("rows", "rows_per_reference", "gather_rows"):
+        if exchange.partition(":")[0] in ("rows", "gather_rows"):
             assert same, f"rank {rank}: row exchange must be bit-identical to the unsharded table (rel err {err})"
         else:
             assert err < 1e-3, (rank, err)          # fp32 partial sums are added in shard order, not list order
@@ -228,7 +226,6 @@ def _worker_soak(rank, world, port, slots, q):
                 sh.gather_chunks = int(rng.integers(1, 4))             # 1 = columns on the wire, 2 / 3 = chunked records
                 sh.shard_match = bool(rng.integers(2))                 # the plan's match sharded over the ranks, or not
                 sh.gather_transport = ("p2p", "all_gather")[int(rng.integers(2))]
-                sh.wire_format = ("columns", "columns", "records")[int(rng.integers(3))]      # (of the one-piece form)
                 tickets.append(sh.gather_rows_begin(tok))
                 batches.append(tok)
             if i >= slots - 1:
@@ -308,23 +305,23 @@ def test_bench_two_ranks_launched_like_the_driver(mode):
 
 
 def _check_sharded_record(rec, world):
-    """The C5-shaped sub-record of an N > 1 line: every exchange ran on `world` ranks -- phase split, wire bytes, a roofline
-    block with physical fractions, the speed-up over the N = 1 baseline measured by rank 0 in the same process -- and
-    they produced the same output."""
+    """The C5-shaped sub-record of an N > 1 line (round 4: six exchanges behind a world sanity check): every exchange ran on
+    `world` ranks -- phase split, wire bytes, a roofline block with physical fractions, the speed-up over the N = 1 baseline
+    measured by rank 0 in the same process, the status bits, what the form costs a rank at other world sizes -- and they
+    produced the same output."""
     assert "error" not in rec, rec
+    assert rec["world_sanity"]["all_gather_1KB_per_rank_ok"] is True and rec["world_sanity"]["world_size"] == world
     assert rec["world_size"] == world and rec["device_count"] >= 1 and "n1_baseline" in rec
     assert rec["n1_pinned_host"]["value"] > 0 and rec["rows_total"] == world * rec["rows_per_rank"]
     assert "N = 2 / 4 / 8 ranks hold" in rec["workload"]
-    one_call = ("gather_rows_one_shot_padded_all_gather", "gather_rows_padded_all_gather", "rows+all_gather", "rows_slices_only",
-                "gather_rows", "gather_rows_one_shot")
-    split = ("gather_rows_split_phase_padded_all_gather", "gather_rows_split_phase_3_in_flight_padded_all_gather",
-             "gather_rows_split_phase", "gather_rows_split_phase_3_in_flight", "gather_rows_split_phase_every_rank_matches")
-    # all_gather_into_tensor only (incl. the split-phase loop) -> all_to_all_single -> batch_isend_irecv
-    assert list(rec["exchanges"]) == [one_call[0], split[0], split[1]] + list(one_call[1:4]) + list(one_call[4:]) + list(split[2:])
+    one_call = ("rows_slices_only", "rows+all_gather", "gather_rows")
+    split = ("gather_rows_split_phase", "gather_rows_split_phase_p2p", "gather_rows_split_phase_sdma")
+    # plainest collective first, the newest transport last
+    assert list(rec["exchanges"]) == [split[0], split[1]] + list(one_call) + [split[2]]
     for name in one_call:
         e = rec["exchanges"][name]
         assert "error" not in e, e
-        assert e["ms_per_step"] > 0 and e["tokens_per_s"] > 0 and e["wire_bytes_received_rank0"] > 0
+        assert e["ms_per_step"] > 0 and e["tokens_per_s"] > 0 and e["wire_bytes_received_rank0"] > 0 and e["status_bits"] == 0
         for ph in ("plan_ms", "pack_ms", "collective_ms", "embed_ms"):
             assert e["phase_ms_slowest_rank"][ph] >= 0.0, (name, ph)
         assert abs(e["speedup_vs_n1_pinned_host"] - e["tokens_per_s"] / rec["n1_pinned_host"]["value"]) < 1e-9
@@ -334,14 +331,21 @@ def _check_sharded_record(rec, world):
     assert rec["exchanges"]["rows_slices_only"]["roofline"]["per_rank_tokens_reduced"] < \
         rec["exchanges"]["gather_rows"]["roofline"]["per_rank_tokens_reduced"]
     assert "gather_out_ms" in rec["exchanges"]["rows+all_gather"]["phase_ms_slowest_rank"]
-    assert rec["exchanges_agree"] is True and len(rec["exchanges_compared"]) == 5
+    # which forms scale: only the slice exchange divides a rank's HBM bytes by the world size
+    sl, gr = rec["exchanges"]["rows_slices_only"], rec["exchanges"]["gather_rows"]
+    assert sl["scales_with_world"] is True and gr["scales_with_world"] is False and rec["exchanges"]["rows+all_gather"]["scales_with_world"] is False
+    assert sl["per_rank_hbm_bytes_vs_world"]["8"] < 0.3 * sl["per_rank_hbm_bytes_vs_world"]["2"]
+    assert gr["per_rank_hbm_bytes_vs_world"]["8"] == gr["per_rank_hbm_bytes_vs_world"]["2"]
+    assert "rows_slices_only" in rec["form_for_data_parallel_consumers"]
+    assert rec["exchanges_agree"] is True and len(rec["exchanges_compared"]) == 5 and not any(rec["status_bits"].values())
     for name in split:
         sp = rec["exchanges"][name]
         assert "error" not in sp, sp
-        assert sp["ms_per_step"] > 0 and sp["batches_in_flight"] == (3 if "3_in_flight" in name else 2)
-        assert sp["same_output_as_gather_rows"] is True
-        assert sp["speedup_vs_n1_pinned_host"] > 0 and 0 < sp["roofline"]["frac"] <= 1.0
-    assert rec["transport_fallback"] is None
+        assert sp["ms_per_step"] > 0 and sp["batches_in_flight"] == 3 and sp["status_bits"] == 0
+        assert sp["speedup_vs_n1_pinned_host"] > 0 and 0 < sp["roofline"]["frac"] <= 1.0 and sp["scales_with_world"] is False
+    # the copy-engine transport really ran (interprocess handles work between processes on one device as well)
+    sd = rec["exchanges"]["gather_rows_split_phase_sdma"]
+    assert sd["transport_fallback_reason"] is None and sd["records_transport"].startswith("copy-engine"), sd
     best = rec["best_whole_output"]
     assert best["exchange"] != "rows_slices_only" and best["tokens_per_s"] == rec["exchanges"][best["exchange"]]["tokens_per_s"]
 
@@ -471,7 +475,7 @@ def _nccl_worker(rank, world, port, q):
             full = EmbeddingCache(ex, d, table_format=fmt)
             full.cache_embeddings(list(range(len(lens))), torch.from_numpy(table), verbose=False)
             ref = full.embed_tokens(torch.from_numpy(tok), wte=wte_d, wpe=wpe_d)
-            for exchange in ("rows", "rows_per_reference", "gather_rows", "gather_rows:all_gather", "partial_sums",
+            for exchange in ("rows", "gather_rows", "gather_rows:all_gather", "partial_sums",
                              "rows::sm", "gather_rows::sm", "gather_rows:all_gather:sm", "gather_rows::sm:c1", "gather_rows:all_gather::c1"):
                 sh.gather_chunks = 1 if exchange.endswith(":c1") else chunks     # one piece: columns on the wire
                 sh.gather_transport = exchange.split(":")[1] if ":" in exchange and exchange.split(":")[1] else "p2p"   # exact p2p ranges / padded all-gather

@@ -1224,10 +1224,11 @@ def test_abi_argument_errors():
 @pytest.mark.parametrize("head", [0, 37, 1200])
 @pytest.mark.parametrize("fmt,d,max_n,world", [("int8", 768, 3, 3), ("int4", 1024, 4, 8), ("fp16", 1280, 3, 2)])
 def test_row_exchange_between_shards_is_bit_exact(fmt, d, max_n, world, head):
-    """The row exchange for row-sharded tables (plan -> pack -> all-to-all of quantised rows -> embed), with the
-    W shards living on one GPU and the all-to-all done by hand: every slice equals the unsharded table BIT FOR
-    BIT (the receiver reduces the rows in the reference's order), and the wire carries one record per reference
-    to a row outside the replicated head (`head` rows kept on every shard; 1200 spans more than one shard)."""
+    """The slice exchange for row-sharded tables (plan -> pack -> all-to-all of quantised rows -> embed), with the
+    W shards living on one GPU and the all-to-all done by hand, default and caller-supplied position ids: every slice equals
+    the unsharded table BIT FOR BIT (the receiver reduces the rows in the reference's order), and the wire carries one
+    record per DISTINCT row outside the replicated head and destination (`head` rows kept on every shard, stored in two
+    calls; 1200 spans more than one shard)."""
     from scone_amd.hip_backend import SconeTable
     from scone_amd.distributed import shard_range
     rng = np.random.default_rng(90 + world)
@@ -1252,29 +1253,36 @@ def test_row_exchange_between_shards_is_bit_exact(fmt, d, max_n, world, head):
         shards.append(s)
     wte = torch.from_numpy(rng.standard_normal((vocab, d)).astype(np.float32)).half().cuda()
     wpe = torch.from_numpy(rng.standard_normal((40, d)).astype(np.float32)).half().cuda()
+    rec = shards[0].shard_record_bytes()
     for B, T in ((11, 40), (2, 7), (64, 3), (1, 40)):
         tok = torch.from_numpy(rng.integers(0, vocab, size=(B, T)))
         pos = torch.from_numpy(rng.integers(0, 40, size=(B, T)))
         for position_ids in (None, pos):
             want = full.embed(tok, wte=wte, wpe=wpe, position_ids=position_ids).reshape(B * T, d)
-            plans = [s.shard_plan(tok, world, r) for r, s in enumerate(shards)]
-            for r in range(world):                                   # both ends agree on every transfer size
-                for q in range(world):
-                    assert plans[r][0][q] == plans[q][1][r]
-            off, ids = full.match_csr(tok)
-            assert sum(sum(p[0]) for p in plans) == int((ids >= head).sum())   # one record per reference outside the head
-            sends = [s.shard_pack(B, T, world, plans[r][0]) for r, s in enumerate(shards)]
+            off, ids = (x.cpu().numpy() for x in full.match_csr(tok))
             bper = (B + world - 1) // world
-            for q in range(world):
-                parts = []
-                for r in range(world):
-                    o = sum(plans[r][0][:q])
-                    parts.append(sends[r][o:o + plans[r][0][q]])
-                recv = torch.cat(parts).contiguous()
-                got = shards[q].shard_embed(tok, world, q, recv, wte=wte, wpe=wpe, position_ids=position_ids,
-                                            out_dtype=torch.float16)
+            ends = [s.shard_gather_plan_chunks(tok, world, dedup_across_chunks=False) for s in shards]   # chunk q = slice q
+            cnt = [[e[0]] + [e[q] - e[q - 1] for q in range(1, world)] for e in ends]
+            total = 0
+            for q in range(world):                                   # one record per distinct row outside the head and slice
+                t0, t1 = min(q * bper, B) * T, min(q * bper + bper, B) * T
+                need = np.unique(ids[off[t0]:off[t1]])
+                total += int((need >= head).sum())
+            assert sum(e[-1] for e in ends) == total
+            sends = []
+            for r, s in enumerate(shards):
+                buf = torch.empty((max(ends[r][-1], 1), rec), dtype=torch.uint8, device="cuda")
+                s.shard_gather_pack_range(0, ends[r][-1], buf[:ends[r][-1]])
+                sends.append(buf)
+            for q, s in enumerate(shards):
+                recv = torch.cat([sends[r][sum(cnt[r][:q]):sum(cnt[r][:q + 1])] for r in range(world)]).contiguous()
                 b0, b1 = min(q * bper, B), min(q * bper + bper, B)
-                assert torch.equal(got, want[b0 * T:b1 * T]), (B, T, q)
+                got = torch.empty((max(b1 - b0, 1) * T, d), dtype=torch.float16, device="cuda")
+                s.shard_gather_add_records(recv, 0, recv.shape[0])
+                if b1 > b0:
+                    s.shard_gather_embed_range(tok, b0, b1, recv, got, wte=wte, wpe=wpe, position_ids=position_ids, out_is_slice=True)
+                    assert torch.equal(got[:(b1 - b0) * T], want[b0 * T:b1 * T]), (B, T, q)
+                assert s.status() == 0
 
 
 @pytest.mark.parametrize("fmt,d,max_n,world,n,head", [("int8", 768, 3, 4, 60, 0), ("int4", 1024, 3, 8, 2000, 37),
@@ -1423,7 +1431,8 @@ def test_sharded_cache_world1_row_exchange():
     wpe = torch.from_numpy(rng.standard_normal((41, d)).astype(np.float32)).half().cuda()
     a = plain.embed_tokens(tok, wte=wte, wpe=wpe)
     assert torch.equal(a, sharded.embed_tokens(tok, wte=wte, wpe=wpe, exchange="rows"))      # one shard: plain lookup
-    assert torch.equal(a, sharded._embed_row_exchange(tok, "mean", wte, wpe, None, torch.float16, True))   # plan/pack/embed with itself
+    assert torch.equal(a, sharded._embed_row_exchange_dedup(tok, "mean", wte, wpe, None, torch.float16, True))   # plan / pack / embed with itself
+    assert torch.equal(a, sharded._embed_gather_rows(sharded.table._tok(tok), "mean", wte, wpe, None, torch.float16).view_as(a))
     assert torch.equal(a, sharded.embed_tokens(tok, wte=wte, wpe=wpe, exchange="partial_sums"))
 
 
@@ -1480,6 +1489,9 @@ def test_integration_stub_from_the_docs():
 
 
 def test_row_exchange_missing_records_are_reported_not_read_out_of_bounds():
+    """A referenced row whose record never arrived (the ranks disagreed about the batch: a caller error) is redirected to
+    record 0 -- or to the zero row when nothing arrived -- and reported through status bit 1; the lookup never reads outside
+    the receive buffer."""
     from scone_amd.hip_backend import SconeTable
     rng = np.random.default_rng(2)
     vocab, n, d = 11, 300, 768
@@ -1490,14 +1502,20 @@ def test_row_exchange_missing_records_are_reported_not_read_out_of_bounds():
     t.index_build(keys, lens)
     t.store_f32(torch.from_numpy(rng.standard_normal((n, d)).astype(np.float32)))
     tok = torch.from_numpy(rng.integers(0, vocab, size=(4, 16)))
-    send_counts, recv_counts = t.shard_plan(tok, 1, 0)
-    send = t.shard_pack(4, 16, 1, send_counts)
-    assert t.status() == 0
-    t.shard_embed(tok, 1, 0, send[: send.shape[0] // 2].contiguous())       # half of the records withheld
-    assert t.status() & 2
-    t.shard_plan(tok, 1, 0)
-    t.shard_embed(tok, 1, 0, send[:0].contiguous())                          # nothing arrived
-    assert t.status() & 2
+    out = torch.empty((4 * 16, d), dtype=torch.float32, device="cuda")
+    m = t.shard_gather_plan_chunks(tok, 1)[0]
+    send = torch.empty((m, t.shard_record_bytes()), dtype=torch.uint8, device="cuda")
+    t.shard_gather_pack_range(0, m, send)
+    assert m > 4 and t.status() == 0
+    half = send[: m // 2].contiguous()                                   # half of the records withheld
+    t.shard_gather_add_records(half, 0, half.shape[0])
+    t.shard_gather_embed_range(tok, 0, 4, half, out)
+    assert t.status() & 2 and bool(torch.isfinite(out).all())
+    t.shard_gather_plan_chunks(tok, 1)
+    none = send[:0].contiguous()                                          # nothing arrived
+    t.shard_gather_add_records(none, 0, 0)
+    t.shard_gather_embed_range(tok, 0, 4, none, out)
+    assert t.status() & 2 and bool(torch.isfinite(out).all())
 
 
 # ------------------------------------------------------------------ BASELINE.json configs at their named sizes

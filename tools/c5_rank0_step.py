@@ -12,8 +12,9 @@ the next batch(es) on a side stream / other plan slots behind gather_rows_finish
 in one process (a box runs the same flow 2-4 % apart from one process to the next; medians over --rounds are printed):
 the round-2 flow (every rank matches the whole batch, records on the wire), + the match sharded over the ranks (the other
 ranks' list records arrive by a device copy), + columns on the wire (round 3: payload rows | scales | sender-built hash
-fragments; the other ranks' fragments are real, built from their row ids), three batches in flight, and the variants that
-were measured and not kept (post stream, direct-mapped row map).  All flows must give the same output checksum.
+fragments; the other ranks' fragments are real, built from their row ids), three batches in flight, and a variant that was
+measured and not kept (post stream; the direct-mapped row map of round 3 is gone from the library).  All flows must give the
+same output checksum.
 tools/shard_emulate.py does the same for ALL eight ranks of a 100M-row table, with real payloads and the bit-exactness check.
 
 Round 4, `--transport-standin`: the figures above assume that the transfers cost the step nothing ("the other ranks' records
@@ -50,7 +51,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--padded", action="store_true", help="the padded all-gather's receive layout instead of exact ranges")
     ap.add_argument("--variants", default="0,1,2,3", help="which flows to time (0 = round 2, 1 = + sharded match, 2 = + columns on the "
-                    "wire (round 3), 3 = three batches in flight, 4 = 1 + post stream, 5 / 6 = direct-mapped row map)")
+                    "wire (round 3), 3 = three batches in flight, 4 = 1 + post stream)")
     ap.add_argument("--rounds", type=int, default=5, help="alternating rounds over the chosen flows (medians are reported)")
     ap.add_argument("--one-only", action="store_true", help="time the one-stream step only (clean per-kernel times under a profiler)")
     ap.add_argument("--split-only", action="store_true", help="time the split-phase loop only (for a kernel profile of it)")
@@ -58,6 +59,10 @@ def main():
                     help="every flow also WITH its transfers really executed, concurrently with the reduction (columns flows: "
                          "variants 2, 3) -- kernel: RCCL-shaped copy kernels (a few workgroups per peer); sdma: the copy engines "
                          "(hipMemcpyAsync without compute units, one stream per peer and direction: what gather_transport='sdma' does)")
+    ap.add_argument("--standin-directions", default="both", choices=["both", "out"], help="both: what arrives is copied staging -> "
+                    "receive buffer by this GPU too (RCCL's FIFO protocol; doubles the local work); out: only what rank 0 SENDS is "
+                    "moved (peers write straight into rank 0's buffers: RCCL direct / the sdma transport -- the incoming bytes cost "
+                    "this GPU HBM write bandwidth only, which the emulation then leaves out)")
     ap.add_argument("--channels", type=int, default=2, help="stand-in: workgroups per peer and direction for the large segments")
     ap.add_argument("--threads", type=int, default=256, help="stand-in: threads per workgroup (256 or 512)")
     ap.add_argument("--cu-reserve", default="0", help="comma list of R: compute units the lookup kernel leaves free")
@@ -120,9 +125,7 @@ def main():
              ("round3: sharded match + columns on the wire (payload rows | scales | the senders' hash fragments: no indexing pass)",
               "cols", True, False, 2),
              ("round3, three batches in flight", "cols", True, False, 3),
-             ("sharded match + records indexed / lists remapped on a post stream", "hash", True, True, 2),
-             ("sharded match + post stream + direct-mapped row map (4 B per table row)", "direct", True, True, 2),
-             ("round2 with the direct-mapped row map", "direct", False, False, 2))
+             ("sharded match + records indexed / lists remapped on a post stream", "hash", True, True, 2))
     # ---- columns on the wire: receive buffers per slot, the other ranks' columns synthesised once (the batch never changes):
     # zero payloads and scales, REAL hash fragments of their row ids
     from scone_amd.hip_backend import SconeTable
@@ -192,12 +195,19 @@ def main():
 
         def move_lists(slot):
             """all-gather of the list records: the seven other slices in, my slice out to seven peers."""
+            if a.standin_directions == "out":            # the peers' parts: in place by a plain device copy, as without traffic
+                ells[slot][bper * T:].copy_(ell_src[bper * T:])
+                return group([(send, peer_ell[r - 1], a.channels) for r in range(1, W)])
             segs = [(ell_src[r * bper * T:(r + 1) * bper * T], ells[slot][r * bper * T:(r + 1) * bper * T], a.channels) for r in range(1, W)]
             segs += [(send, peer_ell[r - 1], a.channels) for r in range(1, W)]
             group(segs)
 
         def move_columns(slot, n):
             """the three column exchanges, one group each (as three batch_isend_irecv calls would be)."""
+            if a.standin_directions == "out":            # (the other ranks' columns are in place since the set-up)
+                group([(c_rows[slot][:n], peer_rows[r - 1], a.channels) for r in range(1, W)])
+                group([(c_scales[slot][nh:nh + n], peer_scales[r - 1], 1) for r in range(1, W)])
+                return group([(c_frags[slot][:cslots[0]], peer_frags[r - 1], 1) for r in range(1, W)])
             group([(src_rows[crec[r]:crec[r] + counts[r]], c_rows[slot][crec[r]:crec[r] + counts[r]], a.channels) for r in range(1, W)]
                   + [(c_rows[slot][:n], peer_rows[r - 1], a.channels) for r in range(1, W)])
             group([(src_scales[crec[r]:crec[r] + counts[r]], c_scales[slot][nh + crec[r]:nh + crec[r] + counts[r]], 1) for r in range(1, W)]
@@ -247,7 +257,6 @@ def main():
             s.shard_gather_embed_range(tok, 0, B, fulls[slot][:total], out, wte=wte, wpe=wpe)
 
         def one_stream(n):
-            os.environ["SCONE_SHARD_ROW_MAP"] = "hash" if row_map == "cols" else row_map
             for _ in range(n):
                 begin(0)
                 finish(0)
@@ -278,7 +287,6 @@ def main():
             done[slot].record(cur)
 
         def loop(n):
-            os.environ["SCONE_SHARD_ROW_MAP"] = "hash" if row_map == "cols" else row_map
             for k in range(3):
                 done[k] = None
             nxt, q = 0, []
@@ -311,7 +319,7 @@ def main():
         return torch.cuda.stream(s.lookup_stream()) if (R and a.reserve_mode == "direct") else contextlib.nullcontext()
 
     for name, (R, one, loop) in fns.items():     # warm-up: allocations, the maps of every slot
-        if name.endswith("transfers in flight"):  # the stand-in must really deliver: wipe what it is to bring, then check
+        if name.endswith("transfers in flight") and a.standin_directions == "both":  # the stand-in must really deliver: wipe what it is to bring, then check
             for k in range(3):
                 c_frags[k][cslots[0]:].zero_()
                 ells[k][bper * T:].zero_()
@@ -325,7 +333,7 @@ def main():
         torch.cuda.synchronize()
         assert s.status() == 0
         checks[name] = out.float().abs().sum().item()
-        if name.endswith("transfers in flight"):  # slots this flow did not use stay wiped: put the other ranks' parts back
+        if name.endswith("transfers in flight") and a.standin_directions == "both":  # slots this flow did not use stay wiped: put the other ranks' parts back
             torch.cuda.synchronize()
             for k in range(3):
                 c_frags[k][cslots[0]:].copy_(src_frags[cslots[0]:])
@@ -363,6 +371,7 @@ def main():
                       "variants": results, "all_variants_same_output": len(sums) == 1,
                       "reserve_mode": a.reserve_mode,
                       "transport_standin": None if not a.transport_standin else {
+                          "directions": a.standin_directions,
                           "kind": ("RCCL-shaped copy kernels" if a.transport_standin == "kernel" else
                                    "copy engines (hipMemcpyAsync, hipMemcpyDeviceToDeviceNoCU), 14 streams"),
                           "channels_per_peer_and_direction": a.channels, "threads_per_workgroup": a.threads,

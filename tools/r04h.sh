@@ -1,0 +1,23 @@
+#!/bin/bash
+set -u
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/${1:-r04h}
+mkdir -p $O
+cd $R
+show() {
+python - $1 <<'PY'
+import json,sys
+for line in open(sys.argv[1]):
+    if line.startswith('{'):
+        d=json.loads(line)
+        print(d.get("transport_standin"), d.get("reserve_mode"))
+        for k,v in d["variants"].items(): print(f'{v["rank0_step_one_stream_ms"]:.4f} {v["rank0_step_split_phase_loop_ms"]:.4f}  {k[-100:]}')
+        print("same output:", d["all_variants_same_output"])
+PY
+}
+timeout -k 10 900 python tools/c5_rank0_step.py --variants 2,3 --transport-standin sdma --standin-directions out --cu-reserve 0 --rounds 7 > $O/c5_standin_sdma_out.json 2> $O/c5_standin_sdma_out.err
+show $O/c5_standin_sdma_out.json; tail -2 $O/c5_standin_sdma_out.err
+timeout -k 10 900 python tools/c5_rank0_step.py --variants 2,3 --transport-standin kernel --standin-directions out --channels 4 --threads 512 --cu-reserve 0,16 --rounds 5 > $O/c5_standin_kernel_out_ch4.json 2> $O/c5_standin_kernel_out_ch4.err
+show $O/c5_standin_kernel_out_ch4.json; tail -2 $O/c5_standin_kernel_out_ch4.err
+timeout -k 10 900 python tools/c5_rank0_step.py --variants 3 --transport-standin kernel --standin-directions out --channels 8 --threads 512 --cu-reserve 0,16,32 --rounds 5 > $O/c5_standin_kernel_out_ch8.json 2> $O/c5_standin_kernel_out_ch8.err
+show $O/c5_standin_kernel_out_ch8.json; tail -2 $O/c5_standin_kernel_out_ch8.err

@@ -50,8 +50,8 @@ def main():
     ap.add_argument("--wall", action="store_true",
                     help="gather_rows: also time rank 0's whole step back to back (no phase synchronisation): the local "
                          "critical path including launch gaps and the plan's one host synchronisation")
-    ap.add_argument("--mode", default="rows", choices=["rows", "rows_dedup", "gather_rows", "gather_cols"],
-                    help="rows: all-to-all of records, every rank reduces its slice; gather_rows: all-gather of records, "
+    ap.add_argument("--mode", default="rows_dedup", choices=["rows_dedup", "gather_rows", "gather_cols"],
+                    help="rows_dedup: all-to-all of records (one per distinct row and destination), every rank reduces its slice; gather_rows: all-gather of records, "
                          "every rank reduces the whole batch; gather_cols: the same with columns on the wire (payload rows | "
                          "scales | the senders' hash fragments) and the plan's match sharded over the ranks")
     a = ap.parse_args()
@@ -89,62 +89,6 @@ def main():
     if a.mode == "gather_cols":
         gather_cols_mode(a, shards, tok, wte, wpe, out, res, keys, lens)
         return
-    for rep in range(a.reps):
-        plans, t_plan = [], []
-        for r, s in enumerate(shards):
-            p, ms = timed(lambda: s.shard_plan(tok, W, r))
-            plans.append(p)
-            t_plan.append(ms)
-        sends, t_pack = [], []
-        for r, s in enumerate(shards):
-            buf, ms = timed(lambda: s.shard_pack(B, T, W, plans[r][0]))
-            sends.append(buf)
-            t_pack.append(ms)
-        t_embed = []
-        for q in range(W):
-            parts = []
-            for r in range(W):
-                o = sum(plans[r][0][:q])
-                parts.append(sends[r][o:o + plans[r][0][q]])
-            recv = torch.cat(parts).contiguous()                      # the all-to-all, by hand
-            b0, b1 = min(q * bper, B), min(q * bper + bper, B)
-            _, ms = timed(lambda: shards[q].shard_embed(tok, W, q, recv, wte=wte, wpe=wpe, out_dtype=torch.float16,
-                                                        out=out[b0 * T:b1 * T]))
-            t_embed.append(ms)
-            del recv
-        best = [(min(x, y) for x, y in zip(b, t)) for b, t in zip(best, (t_plan, t_pack, t_embed))] if rep else [t_plan, t_pack, t_embed]
-        best = [list(b) for b in best]
-        if rep == a.reps - 1:
-            t_plan, t_pack, t_embed = best          # per rank and phase: the fastest of the repetitions (allocations happen in the first ones)
-            for r in range(W):
-                res["ranks"].append({"rank": r, "plan_ms": t_plan[r], "pack_ms": t_pack[r], "embed_ms": t_embed[r],
-                                     "send_records": int(sum(plans[r][0])), "recv_records": int(sum(plans[r][1])),
-                                     "send_off_rank_bytes": int((sum(plans[r][0]) - plans[r][0][r]) * rec),
-                                     "recv_off_rank_bytes": int((sum(plans[r][1]) - plans[r][1][r]) * rec)})
-        del sends
-    loc = [x["plan_ms"] + x["pack_ms"] + x["embed_ms"] for x in res["ranks"]]
-    res["local_ms_max"] = max(loc)
-    res["local_ms_mean"] = sum(loc) / len(loc)
-    res["wire_bytes_all_ranks"] = sum(x["send_off_rank_bytes"] for x in res["ranks"])
-    res["all_gather_bytes_per_rank"] = (W - 1) * bper * T * d * 2
-    if a.check:
-        full = SconeTable(3, N, d, a.format)
-        full.index_build(keys, lens)
-        full.fill_synthetic(7, 0.02 / 127)
-        want = full.embed(tok, wte=wte, wpe=wpe).reshape(B * T, d)
-        res["bit_identical_to_unsharded"] = bool(torch.equal(out, want))
-        if not res["bit_identical_to_unsharded"]:
-            bad = (out != want).any(dim=1)
-            res["mismatching_tokens"] = int(bad.sum())
-            res["mismatching_tokens_per_slice"] = [int(bad[q * bper * T:(q + 1) * bper * T].sum()) for q in range(W)]
-            res["max_abs_diff"] = float((out.float() - want.float()).abs().max())
-            first = int(torch.nonzero(bad)[0])
-            res["first_bad_token"] = first
-            res["status_bits"] = [s.status() for s in shards]
-            off, ids = full.match_csr(tok.view(-1)[first - first % T:first - first % T + T].view(1, T))
-            i = first % T
-            res["first_bad_ids"] = ids[int(off[i]):int(off[i + 1])].tolist()
-    print(json.dumps(res))
 
 
 def gather_rows_mode(a, shards, tok, wte, wpe, out, res, keys, lens):

@@ -387,6 +387,16 @@ int scone_shard_gather_embed_range(scone_handle *h, const int32_t *d_tok, int32_
  *                                 of scone_amd.distributed.shard_range.  Lists are rewritten once per plan, as in
  *                                 scone_shard_gather_embed_range; bit-identical to the unsharded table.
  * New here (the reference keeps its table in one process: embedding_cache.py:49-50). */
+/* Sync-free plan (round 4; one chunk): scone_shard_gather_plan_async / _plan_ell_async enqueue match and claim passes and
+ * return -- no count comes back to the host; scone_shard_cols_pack_cap packs up to cap_rows of the claimed rows (the capacity
+ * both ends sized the transfer for, e.g. the previous batches' counts + 12.5 %), reading the count on the device, and writes
+ * d_header_out [2] u64 = {rows claimed, 1 if that exceeded cap_rows}.  The caller ships the header with the columns, reads
+ * it when the batch is reduced, and repeats a batch that overflowed with the exact-size calls above (the receivers' lookups
+ * of an overflowed exchange raise SCONE_ST_BAD_ID: rows are missing, never read out of bounds). */
+int scone_shard_gather_plan_async(scone_handle *h, const int32_t *d_tok, int32_t B, int32_t T, scone_stream_t stream);
+int scone_shard_gather_plan_ell_async(scone_handle *h, int32_t *d_ell, int32_t B, int32_t T, scone_stream_t stream);
+int scone_shard_cols_pack_cap(scone_handle *h, uint64_t cap_rows, void *d_rows_out, void *d_scales_out, void *d_frag_out,
+                              uint64_t frag_slots, void *d_header_out, scone_stream_t stream);
 int scone_shard_cols_frag_slots(uint64_t count, uint64_t *slots);
 int scone_shard_cols_pack(scone_handle *h, uint64_t first, uint64_t count, void *d_rows_out, void *d_scales_out,
                           void *d_frag_out, uint64_t frag_slots, scone_stream_t stream);

@@ -1,7 +1,12 @@
 #!/usr/bin/env python3
 """Build-container check (needs /root/reference): the Python port in ref_port.py gives the
 same outputs as the imported reference on a C1-shaped case (100K f-grams, fp32, d=768,
-T=512 Zipf stream) and runs at the same speed (it is the `cpu_baseline` timed by bench.py).
+T=512 Zipf stream) -- asserted on all 8 sequences -- and runs at a comparable speed (it is the
+`cpu_baseline` timed by bench.py).  The speed ratio is ASSERTED only loosely (0.7 .. 1.5): on
+this container's 8 shared vCPUs the two loops run 5-20 % apart from one invocation to the next
+(the port is usually the faster one: it skips the reference's per-call device argument
+handling), so SURVEY 8d's "within +-10 %" is a typical figure, not a guarantee -- a port that is
+FASTER than the reference only makes the reported CPU baseline generous to the CPU.
 
     python oracle/validate_port.py
 """
@@ -55,7 +60,7 @@ def main():
             out[0, pos] = embedding
         return out
 
-    for s in seqs[:2]:
+    for s in seqs:                                                   # every sequence, bit for bit
         assert torch.equal(reference(s), R.aggregate(port, s, d))
     res = {}
     for name, fn in (("reference", reference), ("port", lambda s: R.aggregate(port, s, d))):
@@ -68,7 +73,11 @@ def main():
         res[name] = len(seqs) * T / best
     k = np.mean([len(v) for v in ex.get_token_f_grams(seqs[0]).values()])
     print(f"f-grams {n}, fit {t_fit:.1f} s, mean hits/token {k:.2f}")
-    print(f"reference {res['reference']:.0f} tok/s, port {res['port']:.0f} tok/s, ratio {res['port'] / res['reference']:.3f} (1 thread)")
+    ratio = res["port"] / res["reference"]
+    print(f"reference {res['reference']:.0f} tok/s, port {res['port']:.0f} tok/s, ratio {ratio:.3f} (1 thread); "
+          f"SURVEY section 6 probed the reference at ~6,000 tok/s on this shape in a loaded container (84 ms / 512 tokens)")
+    assert 0.7 < ratio < 1.5, f"the port no longer runs like the reference (ratio {ratio:.2f}): it is not a fair cpu_baseline"
+    print("outputs identical on all 8 sequences; speed ratio inside (0.7, 1.5)")
 
 
 if __name__ == "__main__":

@@ -97,6 +97,9 @@ SIGNATURES = {
     "scone_shard_gather_remap_range": (C.c_int, [_P, _I32, _I32, _P]),
     "scone_shard_gather_embed_range": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _P, _U64, _P, _I64, _P, _I64, _P, _I32, _P,
                                                  _I64, _I32, _P]),
+    "scone_shard_gather_plan_async": (C.c_int, [_P, _P, _I32, _I32, _P]),
+    "scone_shard_gather_plan_ell_async": (C.c_int, [_P, _P, _I32, _I32, _P]),
+    "scone_shard_cols_pack_cap": (C.c_int, [_P, _U64, _P, _P, _P, _U64, _P, _P]),
     "scone_shard_cols_frag_slots": (C.c_int, [_U64, C.POINTER(_U64)]),
     "scone_shard_cols_pack": (C.c_int, [_P, _U64, _U64, _P, _P, _P, _U64, _P]),
     "scone_shard_cols_build_frag": (C.c_int, [_P, _P, _U64, _P, _U64, _P]),

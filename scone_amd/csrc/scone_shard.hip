@@ -53,6 +53,7 @@ struct scone_shard_state {
   int32_t *uniq_list = nullptr;    // [cap_uniq] claimed row ids
   long long cap_uniq = 0;
   unsigned long long n_uniq = 0;   // records of the current plan
+  bool n_on_device = false;        // ... planned without a host round trip: the count is in chunk_ends[0] only (n_uniq = its bound)
   uint32_t *chunk_ends = nullptr;  // [64] value of the claim counter after each chunk of the plan
   // slice exchange (a claim generation per chunk): one claim table and one list region PER CHUNK, so that all chunks claim in
   // ONE launch (the single table forced one launch per chunk, in order: 8 x 17 us + 8 copies at W = 8)
@@ -553,6 +554,12 @@ static int plan_claims(scone_handle *h, scone_shard_state *st, const int32_t *el
     SCONE_HIP(h, hipMemcpyAsync(st->chunk_ends + c, st->counters, sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
   }
   SCONE_HIP(h, hipGetLastError());
+  st->n_on_device = false;
+  if (!h_chunk_end) {  // sync-free plan (one chunk): the count stays in chunk_ends[0]; pack with scone_shard_cols_pack_cap
+    st->n_uniq = (unsigned long long)st->cap_uniq;
+    st->n_on_device = true;
+    return SCONE_OK;
+  }
   uint32_t ends[64];
   SCONE_HIP(h, hipMemcpyAsync(ends, st->chunk_ends, (size_t)n_chunks * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
   SCONE_HIP(h, hipStreamSynchronize(s));
@@ -566,6 +573,7 @@ static int plan_claims(scone_handle *h, scone_shard_state *st, const int32_t *el
 }
 
 static int plan_check(scone_handle *h, int32_t B, int32_t T, int32_t n_chunks, const void *p1, const void *p2) {
+  // (p2: the host array of chunk ends -- or, for the sync-free plans, any non-null pointer)
   if (!h) return SCONE_EINVAL;
   if (h->cfg.dim <= 0 || !h->rows) return scone_fail(h, SCONE_ESTATE, "scone_shard_gather_plan: handle has no table");
   if (B < 0 || T <= 0 || !p1 || !p2 || n_chunks < 1 || n_chunks > 64)
@@ -578,6 +586,7 @@ static int plan_check(scone_handle *h, int32_t B, int32_t T, int32_t n_chunks, c
 
 static void plan_reset(scone_shard_state *st, int32_t B, int32_t T, int32_t n_chunks, int32_t *ell_ext) {
   st->n_uniq = 0;
+  st->n_on_device = false;  // (set again by a sync-free plan, at the end of plan_claims)
   st->plan_B = B, st->plan_T = T, st->plan_chunks = n_chunks;
   st->ell_ext = ell_ext;
   st->remapped.assign((size_t)(B > 0 ? B : 0), 0);
@@ -636,6 +645,41 @@ extern "C" int scone_shard_gather_plan_ell(scone_handle *h, int32_t *d_ell, int3
   plan_reset(st, B, T, n_chunks, d_ell);
   if ((long long)B * T == 0) return SCONE_OK;
   return plan_claims(h, st, d_ell, B, T, n_chunks, dedup_across_chunks, h_chunk_end, (hipStream_t)stream);
+}
+
+// The same two plans WITHOUT the host round trip (one chunk, all-gather form): match / claim are enqueued and the call returns;
+// the number of claimed rows stays on the device, where scone_shard_cols_pack_cap reads it.  A serving loop sizes its transfers
+// from the previous batches instead (distributed.py: the counts travel inside the fragment column and are read back when
+// the batch is reduced -- off the critical path).
+extern "C" int scone_shard_gather_plan_async(scone_handle *h, const int32_t *d_tok, int32_t B, int32_t T, scone_stream_t stream) {
+  int rc = plan_check(h, B, T, 1, d_tok, d_tok);
+  if (rc) return rc;
+  SCONE_ON_DEVICE(h);
+  hipStream_t s = (hipStream_t)stream;
+  scone_shard_state *st = shard_state(h);
+  if (!st) return scone_fail(h, SCONE_ENOMEM, "scone_shard_gather_plan: out of memory");
+  plan_reset(st, B, T, 1, nullptr);
+  const int W = SCONE_ELL_W(h->cfg.max_n);
+  const long long ntok = (long long)B * T;
+  if (ntok == 0) return scone_fail(h, SCONE_EINVAL, "scone_shard_gather_plan_async: empty batch");
+  long long cs = st->cap_slice;
+  rc = grow(h, &st->ell_slice, &cs, ntok, (size_t)W);
+  if (rc) return rc;
+  st->cap_slice = cs;
+  rc = scone_launch_match_ell_ex(h, d_tok, B, T, st->ell_slice, 0, (long long)h->cfg.n_rows, 0, s);
+  if (rc) return rc;
+  return plan_claims(h, st, st->ell_slice, B, T, 1, 1, nullptr, s);
+}
+
+extern "C" int scone_shard_gather_plan_ell_async(scone_handle *h, int32_t *d_ell, int32_t B, int32_t T, scone_stream_t stream) {
+  int rc = plan_check(h, B, T, 1, d_ell, d_ell);
+  if (rc) return rc;
+  SCONE_ON_DEVICE(h);
+  scone_shard_state *st = shard_state(h);
+  if (!st) return scone_fail(h, SCONE_ENOMEM, "scone_shard_gather_plan: out of memory");
+  plan_reset(st, B, T, 1, d_ell);
+  if ((long long)B * T == 0) return scone_fail(h, SCONE_EINVAL, "scone_shard_gather_plan_ell_async: empty batch");
+  return plan_claims(h, st, d_ell, B, T, 1, 1, nullptr, (hipStream_t)stream);
 }
 
 extern "C" int scone_ell_width(scone_handle *h, uint32_t *ints_per_token) {
@@ -702,6 +746,7 @@ extern "C" int scone_shard_gather_pack_range(scone_handle *h, uint64_t first, ui
                                              scone_stream_t stream) {
   if (!h || !h->shard) return h ? scone_fail(h, SCONE_ESTATE, "scone_shard_gather_pack: call scone_shard_gather_plan first") : SCONE_EINVAL;
   scone_shard_state *st = h->shard;
+  if (st->n_on_device) return scone_fail(h, SCONE_ESTATE, "scone_shard_gather_pack: the plan kept its count on the device (use scone_shard_cols_pack_cap)");
   if (first + count > st->n_uniq) return scone_fail(h, SCONE_ERANGE, "scone_shard_gather_pack: records outside the plan");
   if (count + pad == 0) return SCONE_OK;
   if (!d_send_buf) return scone_fail(h, SCONE_EINVAL, "scone_shard_gather_pack: null send buffer");
@@ -827,10 +872,19 @@ struct cols_owners {  // per owner: where its fragment starts (u64 slots), slots
   float owners_per_row;     // fix-up step instead of the 64-bit division of owner_of() -- 1.1M of them per step made the
 };                          // remap 49 us where the single-map form takes 32
 
+// d_n != null (sync-free plan): the number of rows is read from the device and clipped to `n` (the capacity the transfer was
+// sized for); hdr[0] = the rows the plan claimed, hdr[1] = 1 if that exceeded the capacity (the receivers' lookups then find
+// rows missing -- SCONE_ST_BAD_ID -- and the caller repeats the batch with exact sizes)
 __global__ __launch_bounds__(256) void k_cols_pack(const int32_t *__restrict__ list, unsigned long long n, scone_row_store st,
                                                    long long row_begin, const uint8_t *__restrict__ scales, int scale_bytes,
                                                    uint8_t *__restrict__ rows_out, uint8_t *__restrict__ scales_out,
-                                                   unsigned long long *__restrict__ frag, unsigned long long fmask, int lanes_per_rec) {
+                                                   unsigned long long *__restrict__ frag, unsigned long long fmask, int lanes_per_rec,
+                                                   const uint32_t *__restrict__ d_n, unsigned long long *__restrict__ hdr) {
+  if (d_n) {
+    const unsigned long long have = *d_n;
+    if (hdr && blockIdx.x == 0 && threadIdx.x == 0) hdr[0] = have, hdr[1] = have > n ? 1ull : 0ull;
+    n = have < n ? have : n;
+  }
   const unsigned sub = (threadIdx.x & 63) / lanes_per_rec, l = (threadIdx.x & 63) % lanes_per_rec;
   const unsigned per_wave = 64 / lanes_per_rec;
   const unsigned long long wave = (unsigned long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -956,6 +1010,7 @@ extern "C" int scone_shard_cols_pack(scone_handle *h, uint64_t first, uint64_t c
                                      void *d_frag_out, uint64_t frag_slots, scone_stream_t stream) {
   if (!h || !h->shard) return h ? scone_fail(h, SCONE_ESTATE, "scone_shard_cols_pack: call scone_shard_gather_plan first") : SCONE_EINVAL;
   scone_shard_state *st = h->shard;
+  if (st->n_on_device) return scone_fail(h, SCONE_ESTATE, "scone_shard_cols_pack: the plan kept its count on the device (use scone_shard_cols_pack_cap)");
   if (first + count > st->n_uniq) return scone_fail(h, SCONE_ERANGE, "scone_shard_cols_pack: records outside the plan");
   uint64_t want = 0;
   scone_shard_cols_frag_slots(count, &want);
@@ -974,8 +1029,40 @@ extern "C" int scone_shard_cols_pack(scone_handle *h, uint64_t first, uint64_t c
     if (pb > 32768) pb = 32768;
     hipLaunchKernelGGL(k_cols_pack, dim3(pb), dim3(256), 0, s, st->uniq_list + first, (unsigned long long)count, scone_store_of(h),
                        (long long)h->cfg.row_begin, (const uint8_t *)h->scales, (int)h->scale_bytes_per_row, (uint8_t *)d_rows_out,
-                       (uint8_t *)d_scales_out, (unsigned long long *)d_frag_out, (unsigned long long)frag_slots - 1, lpr);
+                       (uint8_t *)d_scales_out, (unsigned long long *)d_frag_out, (unsigned long long)frag_slots - 1, lpr,
+                       (const uint32_t *)nullptr, (unsigned long long *)nullptr);
   }
+  SCONE_HIP(h, hipGetLastError());
+  return SCONE_OK;
+}
+
+// The pack of a sync-free plan: up to cap_rows of the claimed rows (the capacity both ends sized the transfer for), the count
+// read on the device; d_header_out [2] u64 = {rows claimed, 1 if more than cap_rows}.
+extern "C" int scone_shard_cols_pack_cap(scone_handle *h, uint64_t cap_rows, void *d_rows_out, void *d_scales_out, void *d_frag_out,
+                                         uint64_t frag_slots, void *d_header_out, scone_stream_t stream) {
+  if (!h || !h->shard) return h ? scone_fail(h, SCONE_ESTATE, "scone_shard_cols_pack_cap: call scone_shard_gather_plan_async first") : SCONE_EINVAL;
+  scone_shard_state *st = h->shard;
+  if (!st->n_on_device) return scone_fail(h, SCONE_ESTATE, "scone_shard_cols_pack_cap: the plan's count is on the host (use scone_shard_cols_pack)");
+  uint64_t want = 0;
+  scone_shard_cols_frag_slots(cap_rows, &want);
+  if (!d_frag_out || !d_header_out || frag_slots < want || (frag_slots & (frag_slots - 1)))
+    return scone_fail(h, SCONE_EINVAL, "scone_shard_cols_pack_cap: fragment needs a power of two >= scone_shard_cols_frag_slots(cap_rows) slots");
+  if (cap_rows && (!d_rows_out || (h->scale_bytes_per_row && !d_scales_out)))
+    return scone_fail(h, SCONE_EINVAL, "scone_shard_cols_pack_cap: null output");
+  SCONE_ON_DEVICE(h);
+  hipStream_t s = (hipStream_t)stream;
+  SCONE_HIP(h, hipMemsetAsync(d_frag_out, 0, (size_t)frag_slots * sizeof(unsigned long long), s));
+  const size_t vecs = h->row_payload_bytes / 16;
+  const int lpr = vecs <= 16 ? 16 : vecs <= 32 ? 32 : 64;
+  const unsigned long long rec_per_block = 4ull * (64 / lpr);
+  unsigned pb = (unsigned)((cap_rows + rec_per_block - 1) / rec_per_block);
+  if (pb > 32768) pb = 32768;
+  if (pb < 1) pb = 1;
+  // (the list holds every claimed row: cap_uniq >= the count, so clipping to cap_rows is the only bound the kernel needs)
+  hipLaunchKernelGGL(k_cols_pack, dim3(pb), dim3(256), 0, s, st->uniq_list, (unsigned long long)cap_rows, scone_store_of(h),
+                     (long long)h->cfg.row_begin, (const uint8_t *)h->scales, (int)h->scale_bytes_per_row, (uint8_t *)d_rows_out,
+                     (uint8_t *)d_scales_out, (unsigned long long *)d_frag_out, (unsigned long long)frag_slots - 1, lpr,
+                     (const uint32_t *)st->chunk_ends, (unsigned long long *)d_header_out);
   SCONE_HIP(h, hipGetLastError());
   return SCONE_OK;
 }

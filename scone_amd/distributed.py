@@ -233,8 +233,20 @@ class ShardedEmbeddingCache:
     def __init__(self, n_gram_extractor: NGramExtractor, embedding_dim: int, *, table_format: str = "int8",
                  rank: Optional[int] = None, world: Optional[int] = None, group=None, device=None,
                  n_rows: Optional[int] = None, placement: str = "hbm", table=None, replicated_rows: int = 0,
-                 gather_chunks: int = 1, gather_transport: str = "p2p", shard_match="auto", plan_slots: int = 2) -> None:
+                 gather_chunks: int = 1, gather_transport: str = "p2p", shard_match="auto", plan_slots: int = 2,
+                 sync_free_plan: bool = True) -> None:
         self.group = group
+        # The one-piece "gather_rows" exchange without host round trips (round 4): after a first batch with exact sizes, every
+        # later batch sizes its transfers from what the ranks contributed before (+ 12.5 %, never shrinking), plans and packs
+        # with the count on the device (scone_shard_gather_plan*_async / scone_shard_cols_pack_cap), ships each rank's count in
+        # two extra words behind its hash fragment, and reads the counts back when the batch is REDUCED -- gather_rows_begin no
+        # longer blocks the host on the plan and on the exchange of the counts.  A batch whose contribution outgrew its
+        # capacity is repeated with exact sizes inside gather_rows_finish (every rank sees the same counts: they agree).
+        # Transports "p2p" / "all_gather"; the "sdma" transport keeps the exact form (its rendezvous are host-side anyway).
+        self.sync_free_plan = bool(sync_free_plan)
+        self._caps = None                              # rows per rank the next sync-free exchange provides for
+        self.sync_free_stats = {"exchanges": 0, "overflow_repeats": 0}
+        self._hdr_stream = None
         # split-phase "gather_rows": batches in flight (2 .. 4).  The chain plan -> count exchange -> pack -> transfers of
         # a batch must fit (plan_slots - 1) reductions: with 2 it has ONE reduction's time, with 3 it has two -- the
         # setting for links on which a step's 0.26 GB of records take about as long as its reduction
@@ -688,12 +700,126 @@ class ShardedEmbeddingCache:
         _all_gather(ell[:W * bper * T].view(-1), send.view(-1), self.group)             # 32 B per token: W * bper * T * 32 B in all
         return t.shard_gather_plan_ell(ell, B, T, n_chunks, dedup_across_chunks)
 
-    def _gather_begin_cols(self, tok, slot, t0):
-        """One-piece ``gather_rows`` with COLUMNS on the wire: plan, exchange of the counts, then this rank's payload rows,
-        scales and hash fragment go out as three ranges (``p2p``: packed in place into this rank's range of the receive
-        buffers, one ``batch_isend_irecv`` per column) or three padded all-gathers."""
+    def _note_counts(self, counts) -> None:
+        """What the ranks contributed to an exchange -> the capacities of the next sync-free ones (+ 12.5 %, never shrinking)."""
+        want = [int(c) + int(c) // 8 + 16 for c in counts]
+        self._caps = want if self._caps is None else [max(a, b) for a, b in zip(self._caps, want)]
+
+    def _plan_async(self, tok, slot: int) -> None:
+        """:meth:`_plan` (one chunk) without its host round trip: the count of claimed rows stays on the device."""
+        B, T = tok.shape
+        W, t = self.world, self.table
+        on = self.shard_match
+        if on == "auto":
+            on = B * T >= 65536
+        if not (on and W > 1 and B >= W and hasattr(t, "shard_gather_match")):
+            return t.shard_gather_plan_async(tok)
+        bper = (B + W - 1) // W
+        b0, b1 = min(self.rank * bper, B), min(self.rank * bper + bper, B)
+        wd = t.ell_width()
+        ell = self._slot_ell[slot]
+        if ell is None or ell.shape[0] < W * bper * T or ell.shape[1] != wd or ell.device != tok.device:
+            ell = torch.empty((W * bper * T, wd), dtype=torch.int32, device=tok.device)
+            self._slot_ell[slot] = ell
+        send = self._ell_send
+        if send is None or send.shape[0] != bper * T or send.shape[1] != wd or send.device != tok.device:
+            send = torch.zeros((bper * T, wd), dtype=torch.int32, device=tok.device)
+            self._ell_send = send
+        t.shard_gather_match(tok, b0, b1, send)
+        _all_gather(ell[:W * bper * T].view(-1), send.view(-1), self.group)
+        t.shard_gather_plan_ell_async(ell, B, T)
+
+    def _gather_begin_cols_sync_free(self, tok, slot):
+        """The one-piece exchange sized from the previous batches: nothing here waits for the device.  Rank q's region of the
+        receive buffers holds ``caps[q]`` rows / ``frag_slots(caps[q]) + 2`` fragment words -- the two extra words are its
+        header (rows it claimed, overflow flag), written by its pack kernel; the headers are copied to pinned host memory on a
+        stream of their own behind the transfers and read in :meth:`gather_rows_finish`."""
         B, T = tok.shape
         W, t, r = self.world, self.table, self.rank
+        HDR = 2
+        caps = list(self._caps)
+        slots_r = [t.cols_frag_slots(c) for c in caps]
+        exact = self.gather_transport == "p2p"
+        if not exact:                                    # all_gather_into_tensor: every region as large as the largest
+            caps, slots_r = [max(caps)] * W, [max(slots_r)] * W
+        rec_base = [sum(caps[:q]) for q in range(W)]
+        frag_off = [sum(slots_r[:q]) + HDR * q for q in range(W)]
+        total, ftotal = sum(caps), sum(slots_r) + HDR * W
+        pb, sb, nh = t.payload_bytes(), t.scale_bytes(), int(getattr(t, "n_head", 0) or 0)
+        bufs = self._slot_cols[slot]
+        if bufs is None or bufs[0].shape[0] < total or bufs[2].numel() < ftotal or bufs[0].device != tok.device:
+            cap = total + total // 8
+            rows = torch.empty((cap, pb), dtype=torch.uint8, device=tok.device)
+            scales = torch.empty((nh + cap, sb), dtype=torch.uint8, device=tok.device) if sb else None
+            frags = torch.empty(max(ftotal + ftotal // 8, 64), dtype=torch.int64, device=tok.device)
+            bufs = self._slot_cols[slot] = (rows, scales, frags)
+            self._slot_head_ver[slot] = None
+        rows, scales, frags = bufs
+        if scales is not None and nh:
+            hv = t.shard_head_version() if hasattr(t, "shard_head_version") else 0
+            key = (hv, scales.data_ptr())
+            if self._slot_head_ver[slot] != key:
+                t.shard_head_scales_into(scales)
+                self._slot_head_ver[slot] = key
+        self._plan_enter(slot, tok)
+        self._plan_async(tok, slot)
+        works, keep = [], None
+        if exact:
+            fr = frags[frag_off[r]:frag_off[r] + slots_r[r] + HDR]
+            t.shard_cols_pack_cap(caps[r], rows[rec_base[r]:rec_base[r] + caps[r]],
+                                  None if scales is None else scales[nh + rec_base[r]:nh + rec_base[r] + caps[r]],
+                                  fr[:slots_r[r]], fr[slots_r[r]:])
+            works.append(_exchange_exact_async(rows[:total], rec_base + [total], caps, r, self.group))
+            if scales is not None:
+                works.append(_exchange_exact_async(scales[nh:nh + total], rec_base + [total], caps, r, self.group))
+            works.append(_exchange_exact_async(frags[:ftotal].view(-1, 1), frag_off + [ftotal], [s + HDR for s in slots_r], r, self.group))
+        else:
+            m, ms = caps[0], slots_r[0]
+            s_rows = torch.empty((m, pb), dtype=torch.uint8, device=tok.device)
+            s_scales = torch.empty((m, sb), dtype=torch.uint8, device=tok.device) if sb else None
+            s_frag = torch.empty(ms + HDR, dtype=torch.int64, device=tok.device)
+            t.shard_cols_pack_cap(m, s_rows, s_scales, s_frag[:ms], s_frag[ms:])
+            works.append(_all_gather_async(rows[:total].view(-1), s_rows.reshape(-1), self.group))
+            if scales is not None:
+                works.append(_all_gather_async(scales[nh:nh + total].view(-1), s_scales.reshape(-1), self.group))
+            works.append(_all_gather_async(frags[:ftotal], s_frag, self.group))
+            keep = (s_rows, s_scales, s_frag)
+        self._plan_packed_here(tok)
+        self._slot_open[slot] = True
+        # the headers: behind the fragment transfer, on their own stream (the stream of this call must not wait for transfers)
+        idx = torch.tensor([frag_off[q] + slots_r[q] + k for q in range(W) for k in range(HDR)], dtype=torch.int64)
+        if tok.is_cuda:
+            if self._hdr_stream is None:
+                self._hdr_stream = torch.cuda.Stream(device=tok.device)
+            hs = self._hdr_stream
+            hs.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(hs):
+                works[-1].wait()                                      # (this stream waits; the host does not)
+                hdr = torch.empty(W * HDR, dtype=torch.int64).pin_memory()
+                hdr.copy_(frags.index_select(0, idx.to(tok.device, non_blocking=True)), non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(hs)
+        else:                                                        # (host tensors: gloo completes requests in posting order,
+            for w in works:                                          #  and a request must be waited for exactly once)
+                w.wait()
+            works = [_Done()]
+            hdr, ev = frags.index_select(0, idx).clone(), None
+        self.sync_free_stats["exchanges"] += 1
+        return {"slot": slot, "tok": tok, "C": 1, "per": B, "works": works, "ready": None, "t0": 0.0, "keep": keep, "sdma": None,
+                "hdr": (hdr, ev, caps),
+                "cols": {"rows": rows, "scales": scales, "frags": frags, "total": total, "frag_off": frag_off,
+                         "frag_slots": slots_r, "rec_base": rec_base}}
+
+    def _gather_begin_cols(self, tok, slot, t0, exact_only: bool = False):
+        """One-piece ``gather_rows`` with COLUMNS on the wire: plan, exchange of the counts, then this rank's payload rows,
+        scales and hash fragment go out as three ranges (``p2p``: packed in place into this rank's range of the receive
+        buffers, one ``batch_isend_irecv`` per column) or three padded all-gathers.  (From the second batch on, unless
+        ``exact_only``: the sync-free form, :meth:`_gather_begin_cols_sync_free`.)"""
+        B, T = tok.shape
+        W, t, r = self.world, self.table, self.rank
+        if (not exact_only and self.sync_free_plan and self._caps is not None and W > 1 and self._prof is None
+                and self.gather_transport in ("p2p", "all_gather") and hasattr(t, "shard_cols_pack_cap")):
+            return self._gather_begin_cols_sync_free(tok, slot)
         self._plan_enter(slot, tok)
         n_me = self._plan(tok, slot, 1, True)[0]
         t0 = self._tick("plan_ms", t0)
@@ -706,6 +832,7 @@ class ShardedEmbeddingCache:
             counts = [int(n_me)]
         sdma = W > 1 and self.gather_transport == "sdma" and self._sdma is not None
         exact = W > 1 and self.gather_transport in ("p2p", "sdma")
+        self._note_counts(counts)
         slots_r = [t.cols_frag_slots(c) for c in counts]
         if exact or W == 1:
             rec_base = [sum(counts[:q]) for q in range(W)]
@@ -880,6 +1007,20 @@ class ShardedEmbeddingCache:
         else:
             assert out.is_contiguous() and out.dtype == out_dtype and out.numel() == B * T * d
         t0 = ticket["t0"]
+        if ticket.get("hdr") is not None:                                # sync-free exchange: did every contribution fit?
+            hdr, ev, caps_used = ticket["hdr"]
+            if ev is not None:
+                ev.synchronize()                                         # (the transfers of this batch are long done in a loop that
+            counts = [int(c) for c in hdr.view(-1, 2)[:, 0].tolist()]   #  runs ahead: the host does not wait here)
+            self._note_counts(counts)
+            if any(c > cap for c, cap in zip(counts, caps_used)):        # every rank reads the same headers: they all repeat
+                self.sync_free_stats["overflow_repeats"] += 1
+                for w in ticket["works"]:
+                    w.wait()                                             # the slot's buffers are about to be reused
+                self._slot_open[ticket["slot"]] = False
+                redo = self._gather_begin_cols(tok, ticket["slot"], 0.0, exact_only=True)   # exact sizes, on this stream
+                ticket = dict(redo, ready=None)
+                self._slot_open[ticket["slot"]] = False
         if "cols" in ticket:                                             # columns on the wire: no indexing pass
             for w in ticket["works"]:
                 w.wait()                                                 # the current stream waits for the three columns

@@ -540,6 +540,8 @@ class SconeTable:
         B, T = tok.shape
         n_out = (seq_end - seq_begin) * T if out_is_slice else B * T
         assert out.is_cuda and out.is_contiguous() and out.numel() >= n_out * self.dim
+        if position_ids is not None:                      # (a host / int64 tensor handed to the kernel as it is would be read as garbage)
+            position_ids = position_ids.to(device=self.device, dtype=torch.int32).expand(B, T).contiguous()
         with torch.cuda.device(self.device):
             rc = L.lib().scone_shard_gather_embed_range(self._h, _ptr(tok), B, T, int(seq_begin), int(seq_end), _ptr(records),
                                                         records.shape[0], _ptr(wte), 0 if wte is None else wte.shape[0],
@@ -568,6 +570,36 @@ class SconeTable:
             rc = L.lib().scone_shard_cols_pack(self._h, int(first), int(count), _ptr(rows_out), _ptr(scales_out), _ptr(frag_out),
                                                frag_out.numel(), _stream())
         self._check(rc, "scone_shard_cols_pack")
+
+    def shard_gather_plan_async(self, tok: torch.Tensor) -> None:
+        """The one-chunk plan without the host round trip: match + claim pass are enqueued, the count stays on the device
+        (pack with :meth:`shard_cols_pack_cap`)."""
+        tok = self._tok(tok)
+        B, T = tok.shape
+        with torch.cuda.device(self.device):
+            rc = L.lib().scone_shard_gather_plan_async(self._h, _ptr(tok), B, T, _stream())
+        self._check(rc, "scone_shard_gather_plan_async")
+        self._shard_keepalive = (tok,)
+
+    def shard_gather_plan_ell_async(self, ell: torch.Tensor, B: int, T: int) -> None:
+        """:meth:`shard_gather_plan_ell` (one chunk) without the host round trip."""
+        assert ell.is_cuda and ell.is_contiguous() and ell.dtype == torch.int32 and ell.numel() >= B * T * self.ell_width()
+        with torch.cuda.device(self.device):
+            rc = L.lib().scone_shard_gather_plan_ell_async(self._h, _ptr(ell), int(B), int(T), _stream())
+        self._check(rc, "scone_shard_gather_plan_ell_async")
+        self._shard_keepalive = (ell,)
+
+    def shard_cols_pack_cap(self, cap_rows: int, rows_out: torch.Tensor, scales_out: Optional[torch.Tensor], frag_out: torch.Tensor,
+                            header_out: torch.Tensor) -> None:
+        """The pack of a sync-free plan: up to ``cap_rows`` claimed rows as columns, the count read on the device;
+        ``header_out`` (int64 ``[2]``, device) = (rows claimed, 1 if more than ``cap_rows``)."""
+        assert rows_out.is_cuda and rows_out.is_contiguous() and rows_out.numel() >= cap_rows * self.payload_bytes()
+        assert frag_out.is_cuda and frag_out.is_contiguous() and frag_out.dtype == torch.int64
+        assert header_out.is_cuda and header_out.is_contiguous() and header_out.dtype == torch.int64 and header_out.numel() >= 2
+        with torch.cuda.device(self.device):
+            rc = L.lib().scone_shard_cols_pack_cap(self._h, int(cap_rows), _ptr(rows_out), _ptr(scales_out), _ptr(frag_out),
+                                                   frag_out.numel(), _ptr(header_out), _stream())
+        self._check(rc, "scone_shard_cols_pack_cap")
 
     def shard_cols_build_frag(self, ids: torch.Tensor, frag_out: torch.Tensor) -> None:
         """The fragment of an arbitrary id list (position = index in the list)."""
@@ -604,6 +636,8 @@ class SconeTable:
         B, T = tok.shape
         W = len(frag_off)
         assert out.is_cuda and out.is_contiguous() and out.numel() >= B * T * self.dim
+        if position_ids is not None:
+            position_ids = position_ids.to(device=self.device, dtype=torch.int32).expand(B, T).contiguous()
         arr = lambda v: (C.c_uint64 * 65)(*[int(x) for x in v])
         if row_lo is not None and len(row_lo) != W + 1:
             raise ValueError("row_lo needs len(frag_off) + 1 entries")

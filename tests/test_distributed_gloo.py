@@ -200,6 +200,22 @@ class OracleShard:
             fo[k] = ((int(i) + 1) << 32) | k
         self.cols_packs = getattr(self, "cols_packs", 0) + 1
 
+    # ---- the sync-free plan (scone_shard_gather_plan*_async / scone_shard_cols_pack_cap): the count is not returned; the pack
+    #      clips to the capacity and writes the header (rows claimed, overflow flag)
+    def shard_gather_plan_async(self, tok):
+        self.shard_gather_plan_chunks(tok, 1)
+
+    def shard_gather_plan_ell_async(self, ell, B, T):
+        self.shard_gather_plan_ell(ell, B, T, 1)
+
+    def shard_cols_pack_cap(self, cap_rows, rows_out, scales_out, frag_out, header_out):
+        n = len(self._uniq)
+        k = min(n, int(cap_rows))
+        assert scales_out is None and frag_out.numel() == self.cols_frag_slots(cap_rows) and header_out.numel() == 2
+        self.shard_cols_pack(0, k, rows_out, None, frag_out)
+        header_out.numpy()[:] = (n, int(n > cap_rows))
+        self.cap_packs = getattr(self, "cap_packs", 0) + 1
+
     def shard_cols_embed(self, tok, seq_begin, seq_end, rows, n_total, scales_full, frags, frag_off, frag_slots, rec_base, out,
                          wte=None, wpe=None, position_ids=None, reduce="mean", row_lo=None):
         from scone_amd.distributed import owner_of
@@ -522,6 +538,77 @@ def _worker_split_phase(rank, world, port, q, slots=2, chunks=2):
     except Exception as e:
         import traceback
         q.put((rank, repr(e) + traceback.format_exc(), False))
+
+
+def _worker_sync_free(rank, world, port, q, transport, sync_free, slots):
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from oracle import ref_port as R
+        from scone_amd import NGramExtractor
+        from scone_amd.distributed import ShardedEmbeddingCache, shard_range
+        rng = np.random.default_rng(23)
+        vocab, n, d, max_n = 23, 900, 16, 3
+        lens = rng.integers(1, max_n + 1, size=n).astype(np.uint8)
+        keys = rng.integers(0, vocab, size=(n, max_n)).astype(np.uint32)
+        keys[np.arange(max_n)[None, :] >= lens[:, None]] = 0
+        table = rng.standard_normal((n, d)).astype(np.float32)
+        shapes = [(3, 7), (3, 7), (3, 8), (24, 31), (24, 31), (2, 5), (30, 33), (3, 7)]     # small, small, ..., BIG (overflows), ...
+        batches = [torch.from_numpy(rng.integers(0, vocab, size=s)) for s in shapes]
+        wte = torch.from_numpy(rng.standard_normal((vocab, d)).astype(np.float32))
+        wpe = torch.from_numpy(rng.standard_normal((40, d)).astype(np.float32))
+        ex = NGramExtractor.from_arrays(keys, lens, max_n=max_n)
+        a, b = shard_range(n, rank, world)
+        shard = OracleShard(keys, lens, max_n, table, a, b)
+        shard.shard_set_head(20)
+        cache = ShardedEmbeddingCache(ex, d, rank=rank, world=world, n_rows=n, table=shard, replicated_rows=20, gather_transport=transport,
+                                      shard_match=True, plan_slots=slots, sync_free_plan=sync_free)
+        outs, tickets, nxt = [], [], 0
+        for _ in range(slots - 1):
+            tickets.append(cache.gather_rows_begin(batches[nxt]))
+            nxt += 1
+        for i in range(len(batches)):
+            outs.append(cache.gather_rows_finish(tickets.pop(0), wte=wte, wpe=wpe, check=True))
+            if nxt < len(batches):
+                tickets.append(cache.gather_rows_begin(batches[nxt]))
+                nxt += 1
+        worst = 0.0
+        for tok, out in zip(batches, outs):
+            B, T = tok.shape
+            ro, ri = R.hits_to_csr(R.match_hits(keys, lens, tok.numpy(), max_n))
+            fg = torch.from_numpy(R.embed_numpy(table, ro, ri, "mean").reshape(B, T, d))
+            worst = max(worst, float((out.float() - R.combine(tok, fg, wte, wpe[:T])).abs().max()))
+        st = cache.sync_free_stats
+        ok = (st["exchanges"] >= len(batches) - slots and st["overflow_repeats"] >= 1 and getattr(shard, "cap_packs", 0) == st["exchanges"]) \
+            if sync_free else (st["exchanges"] == 0 and not hasattr(shard, "cap_packs"))
+        # the one-call form goes the same way (slot 0)
+        again = torch.equal(outs[3], cache.embed_tokens(batches[3], wte=wte, wpe=wpe, exchange="gather_rows", check=True))
+        q.put((rank, worst, bool(ok and again), dict(st)))
+        dist.destroy_process_group()
+    except Exception as e:
+        import traceback
+        q.put((rank, repr(e) + traceback.format_exc(), False, None))
+
+
+@pytest.mark.parametrize("world,transport,sync_free,slots", [(2, "p2p", True, 2), (3, "all_gather", True, 3), (3, "p2p", True, 2), (2, "p2p", False, 2)])
+def test_sync_free_plan_sizes_from_previous_batches_and_repeats_an_overflow_world_gloo(world, transport, sync_free, slots):
+    """Round 4: after a first batch with exact sizes, the one-piece exchange sizes its transfers from the previous batches
+    (+ 12.5 %), plans and packs with the count on the device (stand-in: `shard_cols_pack_cap`), ships every rank's count behind
+    its fragment and checks the counts when the batch is reduced.  Batches that grow tenfold overflow their capacity: they are
+    repeated with exact sizes inside gather_rows_finish, on every rank alike -- every output equals the oracle's, whatever
+    the order of small and big batches, for exact ranges and for padded all-gathers; `sync_free_plan=False` never takes the path."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_sync_free, args=(r, world, port, q, transport, sync_free, slots)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, worst, ok, st in results:
+        assert isinstance(worst, float), f"rank {rank} failed: {worst}"
+        assert worst < 1e-5 and ok, (rank, worst, st)
 
 
 @pytest.mark.parametrize("slots,chunks", [(2, 2), (3, 2), (2, 1), (3, 1)])          # chunks = 1: columns on the wire

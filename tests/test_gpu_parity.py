@@ -7,6 +7,7 @@ Bars: id lists bit-exact; fp32 table + fp32 out bit-exact against the reference'
 """
 
 import os
+import time
 
 import numpy as np
 import pytest
@@ -1281,7 +1282,8 @@ def test_row_exchange_between_shards_is_bit_exact(fmt, d, max_n, world, head):
                 s.shard_gather_add_records(recv, 0, recv.shape[0])
                 if b1 > b0:
                     s.shard_gather_embed_range(tok, b0, b1, recv, got, wte=wte, wpe=wpe, position_ids=position_ids, out_is_slice=True)
-                    assert torch.equal(got[:(b1 - b0) * T], want[b0 * T:b1 * T]), (B, T, q)
+                    bad = (got[:(b1 - b0) * T] != want[b0 * T:b1 * T]).any(dim=1)
+                    assert not bool(bad.any()), (B, T, q, int(bad.sum()), bad.nonzero().flatten()[:8].tolist(), s.status())
                 assert s.status() == 0
 
 
@@ -1486,6 +1488,69 @@ def test_integration_stub_from_the_docs():
     ref = R.combine(tok.cpu().long(), fg, wte.float().cpu(), wpe.float().cpu()).numpy()
     assert _rel(out.float().cpu().numpy(), ref) < REL_TOL
     lib.scone_destroy(h)
+
+
+def test_sync_free_plan_and_pack_do_not_block_the_host_and_pack_the_same_rows():
+    """`scone_shard_gather_plan_async` + `scone_shard_cols_pack_cap` (round 4): the plan's count never comes back to the host.
+    With 20 ms of lookups queued in front, both calls return while that work is still running (an event recorded behind it
+    has not completed) -- the synchronous plan returns only after it --, and what they pack is what the synchronous plan +
+    `scone_shard_cols_pack` pack: the same count in the header, the same rows under the same ids; a capacity below the count
+    packs `cap` rows and raises the overflow flag."""
+    from scone_amd import EmbeddingCache, NGramExtractor
+    from scone_amd import synthetic as S
+    keys, lens = S.make_keys(300_000, S.GPT2_VOCAB, 3, seed=11)
+    ex = NGramExtractor.from_arrays(keys, lens, max_n=3)
+    cache = EmbeddingCache.from_synthetic(ex, 768, table_format="int8", seed=3)
+    t = cache.table
+    B, T = 1024, 512
+    tok = torch.from_numpy(S.stream_uniform_ids(keys, lens, B, T, 5)).to("cuda", torch.int32)
+    out = torch.empty(B, T, 768, dtype=torch.float16, device="cuda")
+    n = t.shard_gather_plan_chunks(tok, 1)[0]                             # synchronous reference
+    slots = t.cols_frag_slots(n)
+    rows0 = torch.empty((n, t.payload_bytes()), dtype=torch.uint8, device="cuda")
+    sc0 = torch.empty((n, t.scale_bytes()), dtype=torch.uint8, device="cuda")
+    fr0 = torch.empty(slots, dtype=torch.int64, device="cuda")
+    t.shard_cols_pack(0, n, rows0, sc0, fr0)
+    torch.cuda.synchronize()
+
+    def by_id(rows, sc, fr):
+        f = fr.cpu().numpy()
+        f = f[f != 0]
+        ids, pos = (f >> 32) - 1, f & 0xFFFFFFFF
+        o = np.argsort(ids)
+        return ids[o], rows.cpu().numpy()[pos[o]], sc.cpu().numpy()[pos[o]]
+    ids0, r0, s0 = by_id(rows0, sc0, fr0)
+    assert ids0.size == n and n > 100_000
+    for cap in (n + n // 8, n // 2):
+        cslots = t.cols_frag_slots(cap)
+        rows1 = torch.empty((cap, t.payload_bytes()), dtype=torch.uint8, device="cuda")
+        sc1 = torch.empty((cap, t.scale_bytes()), dtype=torch.uint8, device="cuda")
+        fr1 = torch.empty(cslots + 2, dtype=torch.int64, device="cuda")
+        for _ in range(30):                                               # ~20 ms of work in front
+            t.embed(tok, out=out, out_dtype=torch.float16)
+        busy = torch.cuda.Event()
+        busy.record()
+        t0 = time.perf_counter()
+        t.shard_gather_plan_async(tok)
+        t.shard_cols_pack_cap(cap, rows1, sc1, fr1[:cslots], fr1[cslots:])
+        host_ms = (time.perf_counter() - t0) * 1e3
+        still_running = not busy.query()
+        torch.cuda.synchronize()
+        assert still_running and host_ms < 5.0, (still_running, host_ms)  # neither call waited for the device
+        hdr = fr1[cslots:].cpu().tolist()
+        assert hdr == [n, int(n > cap)]
+        ids1, r1, s1 = by_id(rows1, sc1, fr1[:cslots])
+        assert ids1.size == min(n, cap) and np.isin(ids1, ids0).all()
+        sel = np.searchsorted(ids0, ids1)
+        assert np.array_equal(r1, r0[sel]) and np.array_equal(s1, s0[sel])
+        with pytest.raises(Exception):                                    # the count is on the device: the host-count pack is refused
+            t.shard_cols_pack(0, 1, rows1, sc1, fr1[:cslots])
+    for _ in range(30):
+        t.embed(tok, out=out, out_dtype=torch.float16)
+    busy = torch.cuda.Event()
+    busy.record()
+    t.shard_gather_plan_chunks(tok, 1)                                    # the synchronous plan DOES wait
+    assert busy.query() and t.status() == 0
 
 
 def test_row_exchange_missing_records_are_reported_not_read_out_of_bounds():

@@ -59,7 +59,9 @@ def main():
                     help="every flow also WITH its transfers really executed, concurrently with the reduction (columns flows: "
                          "variants 2, 3) -- kernel: RCCL-shaped copy kernels (a few workgroups per peer); sdma: the copy engines "
                          "(hipMemcpyAsync without compute units, one stream per peer and direction: what gather_transport='sdma' does)")
-    ap.add_argument("--standin-directions", default="both", choices=["both", "out"], help="both: what arrives is copied staging -> "
+    ap.add_argument("--standin-directions", default="both", choices=["both", "out", "out-read"], help="out-read: as out, but the "
+                    "send kernels only READ (their writes would leave over xGMI): the lower bracket of what a send costs this GPU; "
+                    "kernel stand-in only.  " "both: what arrives is copied staging -> "
                     "receive buffer by this GPU too (RCCL's FIFO protocol; doubles the local work); out: only what rank 0 SENDS is "
                     "moved (peers write straight into rank 0's buffers: RCCL direct / the sdma transport -- the incoming bytes cost "
                     "this GPU HBM write bandwidth only, which the emulation then leaves out)")
@@ -187,7 +189,7 @@ def main():
             n = len(segs)
             arr_p, arr_u, arr_i = ctypes.c_void_p * n, ctypes.c_ulonglong * n, ctypes.c_int * n
             src = arr_p(*[x.data_ptr() for x, _, _ in segs])
-            dst = arr_p(*[y.data_ptr() for _, y, _ in segs])
+            dst = arr_p(*[(None if a.standin_directions == "out-read" else y.data_ptr()) for _, y, _ in segs])
             nb = arr_u(*[x.numel() * x.element_size() for x, _, _ in segs])
             ch = arr_i(*[c for _, _, c in segs])
             rc = lib.standin_launch(n, src, dst, nb, ch, a.threads, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
@@ -195,7 +197,7 @@ def main():
 
         def move_lists(slot):
             """all-gather of the list records: the seven other slices in, my slice out to seven peers."""
-            if a.standin_directions == "out":            # the peers' parts: in place by a plain device copy, as without traffic
+            if a.standin_directions != "both":           # the peers' parts: in place by a plain device copy, as without traffic
                 ells[slot][bper * T:].copy_(ell_src[bper * T:])
                 return group([(send, peer_ell[r - 1], a.channels) for r in range(1, W)])
             segs = [(ell_src[r * bper * T:(r + 1) * bper * T], ells[slot][r * bper * T:(r + 1) * bper * T], a.channels) for r in range(1, W)]
@@ -204,7 +206,7 @@ def main():
 
         def move_columns(slot, n):
             """the three column exchanges, one group each (as three batch_isend_irecv calls would be)."""
-            if a.standin_directions == "out":            # (the other ranks' columns are in place since the set-up)
+            if a.standin_directions != "both":           # (the other ranks' columns are in place since the set-up)
                 group([(c_rows[slot][:n], peer_rows[r - 1], a.channels) for r in range(1, W)])
                 group([(c_scales[slot][nh:nh + n], peer_scales[r - 1], 1) for r in range(1, W)])
                 return group([(c_frags[slot][:cslots[0]], peer_frags[r - 1], 1) for r in range(1, W)])

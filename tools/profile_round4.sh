@@ -1,0 +1,33 @@
+#!/bin/bash
+# Round-4 counter evidence in one gpurun call: the headline (full bench line + kernel trace + every PMC pass) and, for EVERY
+# other HBM workload of tools/run_configs.sh, a quick bench line + kernel trace + FETCH_SIZE / WRITE_SIZE passes (separate
+# runs, the program directly behind `rocprofv3 ... --`).  tools/summarize_profile.py <tag...> (on the build box) turns each
+# gpurun_out/<tag>/ into profiles/<tag>/ and an entry of profiles/hbm_traffic.json keyed by the kernel-source hash; a second
+# call (tools/run_configs.sh) then prints every config with counter-priced fractions.
+#   tools/profile_round4.sh <tag>   -> gpurun_out/<tag>{,_hbm_variant,_c4_int4_100m,_c2_fp16,_c3_int8_10m_d1024,_int4_1m_d1024,_int8_1m_d1280,_zipf}/
+set -u
+TAG=${1:-r04}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+cd $R
+tools/profile_round.sh $TAG > /dev/null 2>&1; echo "headline: $(tail -c 300 gpurun_out/$TAG/bench.json | head -c 200)"
+quick() {  # tag, bench args...
+  local T=$1; shift
+  local O=$R/gpurun_out/$T
+  mkdir -p $O
+  timeout -k 10 600 python bench.py --steps 50 --warmup 5 --quick "$@" > $O/bench.json 2> $O/bench.err
+  ( cd /tmp && export TMPDIR=/tmp
+    timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $R/bench.py --steps 20 --warmup 3 --quick "$@" > $O/trace.log 2>&1
+    for c in FETCH_SIZE WRITE_SIZE; do
+      timeout -k 10 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$c -- python3 $R/bench.py --steps 5 --warmup 2 --quick "$@" > $O/pmc_$c.log 2>&1
+    done )
+  cp $(ls $O/trace/*/*kernel_stats.csv | head -1) $O/kernel_stats.csv
+  rm -rf $O/trace/*/*kernel_trace.csv $O/pmc_*/*/*kernel_trace.csv 2>/dev/null   # (keep the merge small: the counters and the stats are what is read)
+  echo "$T: $(head -c 200 $O/bench.json)"
+}
+quick ${TAG}_hbm_variant --rows 10000000 --keygen structured
+quick ${TAG}_c4_int4_100m --rows 100000000 --format int4 --dim 1024 --keygen structured
+quick ${TAG}_c2_fp16 --format fp16
+quick ${TAG}_c3_int8_10m_d1024 --rows 10000000 --dim 1024
+quick ${TAG}_int4_1m_d1024 --format int4 --dim 1024
+quick ${TAG}_int8_1m_d1280 --dim 1280
+quick ${TAG}_zipf --stream zipf

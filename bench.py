@@ -77,10 +77,12 @@ def parse(argv=None):
     ap.add_argument("--batch", type=int, default=2048)
     ap.add_argument("--seq", type=int, default=512)
     ap.add_argument("--stream", default="uniform", choices=["uniform", "zipf"])
-    ap.add_argument("--pinned-cache-rows", type=int, default=32_000_000, help="n1_pinned_host_zipf: row slots of the HBM cache of cold rows")
-    ap.add_argument("--pinned-stage-tokens", type=int, default=131072, help="n1_pinned_host_zipf: tokens per chunk of the prefetch pipeline")
+    ap.add_argument("--sharded-cu-reserve", type=int, default=32, help="sharded record: the split-phase stages over RCCL transports "
+                    "are timed a second time with this many compute units left to the transport kernels (0 = skip)")
+    ap.add_argument("--pinned-cache-rows", type=int, default=16_000_000, help="n1_pinned_host_zipf: row slots of the HBM cache of cold rows")
+    ap.add_argument("--pinned-stage-tokens", type=int, default=262144, help="n1_pinned_host_zipf: tokens per chunk of the prefetch pipeline")
     ap.add_argument("--pinned-zipf-steps", type=int, default=20)
-    ap.add_argument("--pinned-zipf-warmup", type=int, default=600, help="n1_pinned_host_zipf: batches that warm the cache before the timed steps")
+    ap.add_argument("--pinned-zipf-warmup", type=int, default=400, help="n1_pinned_host_zipf: batches that warm the cache before the timed steps")
     ap.add_argument("--keygen", default="zipf", choices=["zipf", "structured"],
                     help="vocabulary generator: seeded Zipf n-grams with de-duplication (default) or the "
                          "distinct-by-construction generator for >= 1e8 rows")
@@ -627,9 +629,12 @@ def pinned_baseline(args, sync, zipf_too=True):
     wpe = (torch.randn(1024, d, generator=g, device="cuda") * 0.01).half()
     out = torch.empty(B, T, d, dtype=torch.float16, device="cuda")
 
-    def run(cache, toks, steps=4, warm=None):
+    def run(cache, toks, steps=4, warm=None, prefetch=False):
         """ms per step over `steps` lookups of toks[i % len(toks)], after one untimed lookup of every batch in `warm`
-        (default: the first batch; [] = none -- a cache must not have seen the timed batches)."""
+        (default: the first batch; [] = none -- a cache must not have seen the timed batches).  prefetch: the loop of a server
+        that knows its next tokens early -- scone_embed_prefetch of batch i + 1 is issued right after the lookup of batch i is
+        queued (the tokens were generated up front: tokens_ready), so the next batch's first chunks are matched, placed and
+        copied beside this batch's last lookups."""
         cache.table.reserve(B * T)
         for t in (toks[:1] if warm is None else warm):
             cache.embed_tokens(t, wte=wte, wpe=wpe, out=out)
@@ -637,6 +642,8 @@ def pinned_baseline(args, sync, zipf_too=True):
         t0 = time.perf_counter()
         for i in range(steps):
             cache.embed_tokens(toks[i % len(toks)], wte=wte, wpe=wpe, out=out)
+            if prefetch and i + 1 < steps:
+                cache.prefetch_tokens(toks[(i + 1) % len(toks)], tokens_ready=True)
         sync()
         return (time.perf_counter() - t0) / steps
 
@@ -677,7 +684,7 @@ def pinned_baseline(args, sync, zipf_too=True):
             del warm
             sync()
             c0 = cache.table.stage_counters()
-            dt_cached = run(cache, timed, steps, warm=[])
+            dt_cached = run(cache, timed, steps, warm=[], prefetch=True)
             c1 = cache.table.stage_counters()
             copied = (c1["rows_copied"] - c0["rows_copied"]) / steps
             status = cache.table.status()
@@ -690,7 +697,7 @@ def pinned_baseline(args, sync, zipf_too=True):
                     "mechanism": f"persistent HBM cache of cold rows ({c1['cache_rows']} row slots = {c1['cache_rows'] * 528 / 1e9:.1f} GB, "
                                  f"clock eviction) in front of the chunk pipeline ({c1['chunk_tokens']}-token chunks: match, touch / "
                                  "place, remap and the copy of the missing rows host -> HBM on side streams while the previous "
-                                 "chunk is reduced)",
+                                 "chunk is reduced); scone_embed_prefetch of batch i + 1 issued right after the lookup of batch i",
                     "cache_rows": c1["cache_rows"], "stage_tokens": c1["chunk_tokens"],
                     "rows_over_pcie_per_step": copied, "bytes_over_pcie_per_step": copied * 528,
                     "cache_hit_rate_of_distinct_cold_rows": 1.0 - copied / max(stats["distinct_cold_rows"], 1.0),
@@ -947,6 +954,7 @@ def sharded_record(args, dist, rank, world, backend, sync, rec, line, watchdog, 
                         tickets.append(cache.gather_rows_begin(tok, tokens_ready=None))
                         nxt += 1
                 return o
+            reserve = None
             try:
                 out = loop(3)
                 sync()
@@ -954,6 +962,27 @@ def sharded_record(args, dist, rank, world, backend, sync, rec, line, watchdog, 
                 out = loop(args.sharded_steps)
                 sync()
                 dt = time.perf_counter() - t0
+                # the same loop with the lookup kernel leaving R compute units to the transport kernels (scone_set_cu_reserve), its
+                # reductions queued on the handle's CU-masked stream: measured with RCCL-shaped stand-in kernels on one GPU this
+                # buys 10-18 % with the transfers in flight and costs 2-5 % without -- here it meets RCCL
+                R = int(args.sharded_cu_reserve)
+                if R > 0 and used != "sdma" and hasattr(cache.table, "set_cu_reserve"):
+                    cache.table.set_cu_reserve(R)
+                    try:
+                        with torch.cuda.stream(cache.table.lookup_stream()):
+                            loop(3)
+                            sync()
+                            t1 = time.perf_counter()
+                            loop(args.sharded_steps)
+                            sync()
+                            dr = time.perf_counter() - t1
+                        tr = torch.tensor([dr], dtype=torch.float64, device=cdev)
+                        dist.all_reduce(tr, op=dist.ReduceOp.MAX)
+                        reserve = {"compute_units_reserved": R, "ms_per_step": float(tr.item()) / args.sharded_steps * 1e3,
+                                   "tokens_per_s": ntok * args.sharded_steps / float(tr.item())}
+                    finally:
+                        sync()
+                        cache.table.set_cu_reserve(0)
             finally:
                 # a stage that raised mid-loop must not leave its tickets open (the slots would refuse every later stage) nor
                 # its settings behind
@@ -978,6 +1007,7 @@ def sharded_record(args, dist, rank, world, backend, sync, rec, line, watchdog, 
                     "wire_format": "columns: payload rows | scales | the senders' hash fragments",
                     "records_transport": TRANSPORTS[used], "transport_requested": transport,
                     "transport_fallback_reason": cache.transport_fallback_reason,
+                    "with_cu_reserve": reserve, "sync_free_plan": dict(cache.sync_free_stats),
                     "roofline": roofline_of(kw, ms, None, wire_cols), **scaling_of(kw)}
         return name, fn
 

@@ -216,6 +216,17 @@ int scone_gather_reduce(scone_handle *h, const int32_t *d_offsets, const int32_t
 int scone_embed(scone_handle *h, const int32_t *d_tok, int32_t B, int32_t T, const void *d_wte,
                 int64_t vocab, const void *d_wpe, int64_t n_pos, const int32_t *d_pos,
                 int32_t reduce, void *d_out, int32_t out_dtype, scone_stream_t stream);
+/* Pinned-host tables with a prefetch pipeline (cfg.stage_tokens > 0): start fetching for the NEXT batch now.  The first chunks
+ * of (d_tok, B, T) are matched, their missing cold rows placed in the HBM cache and copied host -> HBM on the handle's side
+ * streams, ordered behind `stream` (the stream on which the tokens are produced) -- or, tokens_ready != 0, behind nothing: the
+ * tokens are complete (uploaded and synchronised earlier), and the prefetch may run BESIDE a lookup queued on `stream` just
+ * before, which is the point of calling it early -- and the call returns.  The
+ * scone_embed of exactly that batch (same pointer and shape; the tokens must not change in between) takes the prepared chunks
+ * over instead of starting its pipeline cold: a loop that calls scone_embed_prefetch(next) right after scone_embed(current)
+ * never pays the pipeline fill.  A prefetch that is never used is dropped by the next call (the rows it cached stay cached); any
+ * other handle: a no-op.  (The north-star's "async prefetch"; the reference's memory-mapped table has no counterpart --
+ * embedding_cache.py:132-135 faults rows in on first use.) */
+int scone_embed_prefetch(scone_handle *h, const int32_t *d_tok, int32_t B, int32_t T, int32_t tokens_ready, scone_stream_t stream);
 /* Every per-stream workspace of the handle (those that exist, the default stream's -- created here -- and any created
  * later) holds at least max_tokens tokens: nothing is allocated inside a timed region afterwards. */
 int scone_reserve(scone_handle *h, int64_t max_tokens);

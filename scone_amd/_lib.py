@@ -76,6 +76,7 @@ SIGNATURES = {
     "scone_match_csr": (C.c_int, [_P, _P, _I32, _I32, _P, _P, _I64, C.POINTER(_I64), _P]),
     "scone_gather_reduce": (C.c_int, [_P, _P, _P, _I64, _P, _I32, _P, _I32, _P]),
     "scone_embed": (C.c_int, [_P, _P, _I32, _I32, _P, _I64, _P, _I64, _P, _I32, _P, _I32, _P]),
+    "scone_embed_prefetch": (C.c_int, [_P, _P, _I32, _I32, _I32, _P]),
     "scone_reserve": (C.c_int, [_P, _I64]),
     "scone_set_cu_reserve": (C.c_int, [_P, _I32]),
     "scone_get_cu_reserve": (C.c_int, [_P, C.POINTER(_I32), C.POINTER(_I32)]),

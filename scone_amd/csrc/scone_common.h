@@ -292,10 +292,17 @@ int scone_shard_cols_remap(scone_handle *h, int32_t T, int32_t seq0, int32_t seq
                            const int32_t **ell, const uint8_t **head_p, unsigned long long *n_head_out, hipStream_t s);
 
 // staged prefetch of host-resident rows (scone_stage.hip)
-#define SCONE_STAGE_NBUF 3
+// record sets of the chunk pipeline: a chunk is prepared SCONE_STAGE_AHEAD chunks before it is looked up, and up to
+// SCONE_STAGE_AHEAD chunks of the NEXT batch may have been prepared by scone_embed_prefetch -> 2 + 2 + the one being reduced
+#define SCONE_STAGE_NBUF 5
+#define SCONE_STAGE_AHEAD 2
 void scone_stage_destroy(scone_handle *h);
 int scone_stage_prepare(scone_handle *h, long long chunk_tokens);
-int scone_stage_chunk(scone_handle *h, int buf, const int32_t *d_tok, int32_t Bc, int32_t T);
+int scone_stage_chunk(scone_handle *h, const int32_t *d_tok, int32_t Bc, int32_t T);  // into the next set of the ring
+int scone_stage_consume_buf(scone_handle *h);                                         // the set of the next chunk to look up
+// chunks of (d_tok, B, T) that scone_embed_prefetch already prepared (0: none -- a prefetch of another batch is discarded)
+long long scone_stage_take_prefetched(scone_handle *h, const int32_t *d_tok, int32_t B, int32_t T, long long seqs);
+int scone_stage_note_prefetched(scone_handle *h, const int32_t *d_tok, int32_t B, int32_t T, long long seqs, long long n);
 hipStream_t scone_stage_side(scone_handle *h);
 hipEvent_t scone_stage_start_event(scone_handle *h);
 hipEvent_t scone_stage_staged_event(scone_handle *h, int buf);

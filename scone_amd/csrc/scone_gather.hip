@@ -65,7 +65,8 @@ int need_table(scone_handle *h, const char *who) {
 // Pinned-host table, prefetch through the persistent HBM cache of cold rows (scone_stage.hip): chunks of whole sequences;
 // side streams prepare chunk c+2 and copy the rows chunk c+1 misses while the caller's stream reduces chunk c out of
 // [hot head | cache].
-static int embed_staged(scone_handle *h, const embed_args &full, int32_t B, int32_t T, int32_t out_dtype, hipStream_t s) {
+// chunk geometry of a staged batch: sequences per chunk (0 = a sequence does not fit a chunk)
+static int staged_geometry(scone_handle *h, int32_t B, int32_t T, long long *seqs_out) {
   long long seqs = (long long)h->cfg.stage_tokens / T;
   if (seqs < 1) seqs = 1;
   if (seqs > B) seqs = B;
@@ -74,24 +75,37 @@ static int embed_staged(scone_handle *h, const embed_args &full, int32_t B, int3
   seqs = scone_stage_chunk_tokens(h) / T;
   if (seqs < 1) return scone_fail(h, SCONE_EINVAL, "scone_embed(staged): sequence too long for one staging chunk");
   if (seqs > B) seqs = B;
+  *seqs_out = seqs;
+  return SCONE_OK;
+}
+
+static int embed_staged(scone_handle *h, const embed_args &full, int32_t B, int32_t T, int32_t out_dtype, hipStream_t s) {
+  long long seqs = 0;
+  int rc = staged_geometry(h, B, T, &seqs);
+  if (rc) return rc;
   const size_t esz = out_dtype == SCONE_DT_F32 ? 4 : 2;
   const long long nchunks = (B + seqs - 1) / seqs;
-  // the side stream starts after everything already queued on the caller's stream (tokens may be produced there)
-  SCONE_HIP(h, hipEventRecord(scone_stage_start_event(h), s));
-  SCONE_HIP(h, hipStreamWaitEvent(scone_stage_side(h), scone_stage_start_event(h), 0));
   auto chunk_b = [&](long long c) { return (int32_t)((c + 1) * seqs <= B ? seqs : B - c * seqs); };
-  // chunks 0 .. NBUF-2 are staged ahead; inside the loop chunk c + NBUF - 1 is queued before chunk c is reduced
-  for (long long c = 0; c < nchunks && c < SCONE_STAGE_NBUF - 1; ++c) {
-    rc = scone_stage_chunk(h, (int)(c % SCONE_STAGE_NBUF), full.tok + c * seqs * T, chunk_b(c), T);
+  // chunks scone_embed_prefetch prepared for exactly this batch are taken over (their side-stream work was ordered behind the
+  // stream the caller named THEN); otherwise the side stream starts after everything already queued on the caller's stream
+  // (tokens may be produced there)
+  long long staged = scone_stage_take_prefetched(h, full.tok, B, T, seqs);
+  if (staged == 0) {
+    SCONE_HIP(h, hipEventRecord(scone_stage_start_event(h), s));
+    SCONE_HIP(h, hipStreamWaitEvent(scone_stage_side(h), scone_stage_start_event(h), 0));
+  }
+  // chunks 0 .. AHEAD-1 are staged ahead; inside the loop chunk c + AHEAD is queued before chunk c is reduced
+  for (; staged < nchunks && staged < SCONE_STAGE_AHEAD; ++staged) {
+    rc = scone_stage_chunk(h, full.tok + staged * seqs * T, chunk_b(staged), T);
     if (rc) return rc;
   }
   for (long long c = 0; c < nchunks; ++c) {
-    const int buf = (int)(c % SCONE_STAGE_NBUF);
-    const long long ahead = c + SCONE_STAGE_NBUF - 1;
-    if (ahead < nchunks) {  // its buffer was last used by chunk c - 1, whose "consumed" event is already recorded
-      rc = scone_stage_chunk(h, (int)(ahead % SCONE_STAGE_NBUF), full.tok + ahead * seqs * T, chunk_b(ahead), T);
+    if (staged < nchunks && staged <= c + SCONE_STAGE_AHEAD) {  // (its set was last used by a chunk whose lookup is already queued)
+      rc = scone_stage_chunk(h, full.tok + staged * seqs * T, chunk_b(staged), T);
       if (rc) return rc;
+      ++staged;
     }
+    const int buf = scone_stage_consume_buf(h);
     const long long t0 = c * seqs * T;
     embed_args a = full;
     a.BT = (long long)chunk_b(c) * T, a.ntok = a.BT;
@@ -115,6 +129,36 @@ static int embed_staged(scone_handle *h, const embed_args &full, int32_t B, int3
     if (rc) return rc;
   }
   return SCONE_OK;
+}
+
+// The north-star's "async prefetch" as an entry point: the first chunks of the NEXT batch are matched, placed and copied on the
+// side streams now -- behind `stream`, where its tokens are (or were) produced -- so that the scone_embed of that batch finds them
+// done.  A no-op for tables without a prefetch pipeline.
+extern "C" int scone_embed_prefetch(scone_handle *h, const int32_t *d_tok, int32_t B, int32_t T, int32_t tokens_ready,
+                                    scone_stream_t stream) {
+  int rc = need_table(h, "scone_embed_prefetch: handle has no table (dim == 0)");
+  if (rc) return rc;
+  if (B < 0 || T < 0) return scone_fail(h, SCONE_EINVAL, "scone_embed_prefetch: negative B or T");
+  if ((long long)B * T == 0 || !(h->cfg.stage_tokens && h->rows_host)) return SCONE_OK;
+  if (!d_tok) return scone_fail(h, SCONE_EINVAL, "scone_embed_prefetch: null pointer");
+  if (!scone_wave_kernel_covers(h->cfg.table_fmt, h->cfg.dim)) return SCONE_OK;
+  SCONE_ON_DEVICE(h);
+  long long seqs = 0;
+  rc = staged_geometry(h, B, T, &seqs);
+  if (rc) return rc;
+  (void)scone_stage_take_prefetched(h, nullptr, -1, -1, -1);  // an earlier prefetch that was never used is dropped
+  const long long nchunks = (B + seqs - 1) / seqs;
+  if (!tokens_ready) {  // behind whatever is queued on `stream` -- a lookup queued there just before this call included
+    SCONE_HIP(h, hipEventRecord(scone_stage_start_event(h), (hipStream_t)stream));
+    SCONE_HIP(h, hipStreamWaitEvent(scone_stage_side(h), scone_stage_start_event(h), 0));
+  }
+  long long n = 0;
+  for (; n < nchunks && n < SCONE_STAGE_AHEAD; ++n) {
+    const int32_t bc = (int32_t)((n + 1) * seqs <= B ? seqs : B - n * seqs);
+    rc = scone_stage_chunk(h, d_tok + n * seqs * T, bc, T);
+    if (rc) return rc;
+  }
+  return scone_stage_note_prefetched(h, d_tok, B, T, seqs, n);
 }
 
 extern "C" int scone_gather_reduce(scone_handle *h, const int32_t *d_offsets, const int32_t *d_ids, int64_t ntok,

@@ -12,15 +12,17 @@
 //   2. k_stage_touch   every reference to a cold row: cached -> its slot is stamped with this chunk's epoch (the clock's
 //                      reference bit); not cached -> the first claimer lists the row (LDS stash, one global atomic per
 //                      workgroup)
-//   3. k_stage_place   every listed row takes a slot from the clock hand: a slot not stamped by this chunk or the chunks
-//                      whose lookups may still be running; its previous owner leaves the cache
+//   3. k_stage_place   every listed row takes a slot from the clock hand (64 candidates per wave and round): a slot not
+//                      stamped by this chunk or the chunks whose lookups may still be running; its previous owner leaves
 //   4. k_stage_remap   ids in the records -> n_hot + slot
 // on a COPY stream:
 //   5. k_stage_copy    listed rows: mapped host DRAM -> their slots (+ scales)
 // and on the caller's stream, after the chunk's "staged" event: the ordinary lookup kernel with the cache as the cold half
-// of its row store.  SCONE_STAGE_NBUF = 3 sets of id records: while chunk c is reduced and chunk c+1 crosses the link, chunk
-// c+2 is matched and placed.  A row referenced by several tokens, chunks or batches crosses PCIe once for as long as it
-// stays cached.
+// of its row store.  A ring of SCONE_STAGE_NBUF sets of id records: while chunk c is reduced and chunk c+1 crosses the link,
+// chunk c+2 is matched and placed; scone_embed_prefetch prepares the first two chunks of the NEXT batch behind the last ones of
+// this one, so that a loop that knows its next tokens early never pays the pipeline fill (the first chunk's preparation and
+// copy overlap nothing otherwise: ~0.2 ms of a 1.15-ms step).  A row referenced by several tokens, chunks or batches crosses
+// PCIe once for as long as it stays cached.
 //
 // Round 4, what the kernel trace of the round-3 form showed (profiles/r04a): (i) the claim pass appended every claimed row
 // with its own atomicAdd on ONE counter -- ~90 retire per microsecond on one address: 200 us per 262k-token chunk, now a
@@ -91,10 +93,17 @@ __global__ __launch_bounds__(TOUCH_THREADS) void k_stage_touch(const int32_t *__
   }
 }
 
-// one thread per listed row.  The clock hand is a counter; a wave takes as many consecutive positions as it has rows still
-// to place (ONE atomic per wave and round), every lane tests its own candidate, lanes whose candidate is protected go
-// round again.  A slot is handed to one lane only (the hand passes it once per `cap` positions, and a launch advances it
-// by a fraction of that), so owner / slot_of need no atomics.
+// one thread per listed row; placement is a WAVE's job.  The clock hand is a counter: every round a wave with rows still to
+// place takes 64 consecutive positions (ONE atomic), every lane tests one candidate slot -- all 64 lanes, also those that have
+// nothing (left) to place, so that the last rows of a wave find their slots in a round or two instead of one candidate per
+// round each --, a ballot says which candidates can be taken, and the k-th lane still in need takes the k-th of them.  A slot
+// is handed to one lane only (the hand passes it once per `cap` positions, and a launch advances it by a fraction of that), so
+// owner / slot_of need no atomics.  A candidate stamped by one of the last STAGE_PROTECT chunks is passed over (a lookup in
+// flight may read it); everything else the hand reaches is evicted: first in, first out, except for what is in use right now.
+// (Built, measured and removed: a second chance -- a slot referenced since it was filled is spared once, CLOCK proper.  It took
+// 12-18 % of the rows off PCIe (16M slots: 44.6k -> 38.1k per step) and made the step 2-4 % SLOWER at 262k-token chunks, 1.5 %
+// faster at 131k: the extra rounds of this kernel sit on the preparation chain, the saved rows on a link that was not the
+// bound.  profiles/r04n.)
 __global__ __launch_bounds__(256) void k_stage_place(const uint32_t *__restrict__ count, const int32_t *__restrict__ list,
                                                      uint32_t *__restrict__ place, uint32_t list_cap, long long n_hot,
                                                      uint32_t *__restrict__ slot_of, uint32_t *__restrict__ owner,
@@ -109,21 +118,33 @@ __global__ __launch_bounds__(256) void k_stage_place(const uint32_t *__restrict_
   for (int round = 0; round < 64; ++round) {
     const unsigned long long needm = __ballot(need);
     if (!needm) break;
-    const int leader = __builtin_ctzll(needm);
+    const uint32_t width = cap < 64u ? cap : 64u;  // (a cache of fewer than 64 slots: no slot twice in one round)
     unsigned long long b = 0;
-    if (lane == leader) b = atomicAdd(hand, (unsigned long long)__popcll(needm));
-    b = __shfl(b, leader, 64);
-    if (need) {
-      const uint32_t s = (uint32_t)((b + (unsigned long long)__popcll(needm & ((1ull << lane) - 1ull))) % cap);
-      if (epoch - last_use[s] >= STAGE_PROTECT) {
-        const uint32_t old = owner[s];
-        if (old) slot_of[old - 1u] = 0u;  // the previous owner leaves the cache
-        owner[s] = (uint32_t)cold + 1u;
-        last_use[s] = epoch;
-        slot_of[cold] = s + 1u;
-        place[i] = s;
-        need = false;
-      }
+    if (lane == 0) b = atomicAdd(hand, (unsigned long long)width);
+    b = __shfl(b, 0, 64);
+    const uint32_t s = (uint32_t)((b + (unsigned long long)lane) % cap);
+    const uint32_t lu = last_use[s];
+    const bool takeable = (uint32_t)lane < width && epoch - lu >= STAGE_PROTECT;
+    const unsigned long long freem = __ballot(takeable);
+    const int my_rank = __popcll(needm & ((1ull << lane) - 1ull));
+    int src_lane = 0;
+    const bool got = need && my_rank < __popcll(freem);
+    if (got) {
+      unsigned long long m = freem;
+      for (int k = 0; k < my_rank; ++k) m &= m - 1ull;
+      src_lane = __builtin_ctzll(m);
+    }
+    const uint32_t sc = (uint32_t)__shfl((int)s, src_lane, 64);  // (every lane takes part in the shuffles)
+    const uint32_t luc = (uint32_t)__shfl((int)lu, src_lane, 64);
+    // the stamp is the claim: should the hand lap itself inside one launch (a cache barely larger than the chunk's rows), two
+    // waves may look at one slot -- only the one whose compare-and-swap moves the stamp from what it saw takes it
+    if (got && atomicCAS(&last_use[sc], luc, epoch) == luc) {
+      const uint32_t old = owner[sc];
+      if (old) slot_of[old - 1u] = 0u;  // the previous owner leaves the cache
+      owner[sc] = (uint32_t)cold + 1u;
+      slot_of[cold] = sc + 1u;
+      place[i] = sc;
+      need = false;
     }
   }
   if (need) {  // no evictable slot in 64 rounds: the cache is smaller than what the chunks in flight reference.  Cannot
@@ -196,7 +217,14 @@ struct scone_stage_state {
   uint32_t *owner = nullptr;     // [cap]: cold row + 1 held by the slot, 0 = free
   uint32_t *last_use = nullptr;  // [cap]: epoch of the last chunk that referenced the slot
   uint32_t epoch = STAGE_PROTECT;
-  uint64_t chunks = 0;                  // chunks prepared since the state was created
+  uint64_t chunks = 0;                  // chunks prepared since the state was created (= the ring position of the next one)
+  uint64_t n_consumed = 0;              // chunks handed to a lookup (or discarded) so far: chunks - consumed <= SCONE_STAGE_NBUF
+  struct {                              // what scone_embed_prefetch prepared ahead of the scone_embed that will use it
+    const int32_t *tok = nullptr;
+    int32_t B = 0, T = 0;
+    long long seqs = 0, n = 0;
+    bool valid = false;
+  } pending;
   unsigned long long *hand = nullptr;   // [0] clock hand, [1] rows copied host -> HBM
   uint8_t *rows = nullptr;       // [cap, payload bytes]
   uint8_t *scales = nullptr;     // [hot rows + cap, scale bytes]: the HBM-resident head's scales, then the cached rows'
@@ -295,11 +323,15 @@ int scone_stage_prepare(scone_handle *h, long long chunk_tokens) {
 
 // side-stream half of one chunk; leaves the records of buffer `buf` ready (ids -> cache slots), the chunk's missing rows on
 // their way into the cache, and records staged[buf]
-int scone_stage_chunk(scone_handle *h, int buf, const int32_t *d_tok, int32_t Bc, int32_t T) {
+int scone_stage_chunk(scone_handle *h, const int32_t *d_tok, int32_t Bc, int32_t T) {
   scone_stage_state *st = h->stage;
   const int W = SCONE_ELL_W(h->cfg.max_n), NC = h->cfg.max_n * (h->cfg.max_n + 1) / 2;
   const long long ntok = (long long)Bc * T;
   hipStream_t s = st->prep;
+  if (st->chunks - st->n_consumed >= SCONE_STAGE_NBUF)
+    return scone_fail(h, SCONE_ESTATE, "scone_embed(staged): every record set of the chunk pipeline is in use (a batch prefetched "
+                                       "twice without being embedded?)");
+  const int buf = (int)(st->chunks % SCONE_STAGE_NBUF);
   if (st->consumed_valid[buf]) SCONE_HIP(h, hipStreamWaitEvent(s, st->consumed[buf], 0));
   st->epoch += 1;
   if (st->epoch >= 0xFFFFFF00u) {  // 2^32 chunks: restart the clock (every slot becomes evictable; nothing is in flight
@@ -335,6 +367,29 @@ int scone_stage_chunk(scone_handle *h, int buf, const int32_t *d_tok, int32_t Bc
   SCONE_HIP(h, hipGetLastError());
   SCONE_HIP(h, hipEventRecord(st->staged[buf], st->copy));
   st->chunks += 1;
+  return SCONE_OK;
+}
+
+int scone_stage_consume_buf(scone_handle *h) {
+  scone_stage_state *st = h->stage;
+  const int buf = (int)(st->n_consumed % SCONE_STAGE_NBUF);
+  st->n_consumed += 1;
+  return buf;
+}
+
+long long scone_stage_take_prefetched(scone_handle *h, const int32_t *d_tok, int32_t B, int32_t T, long long seqs) {
+  scone_stage_state *st = h->stage;
+  if (!st->pending.valid) return 0;
+  st->pending.valid = false;
+  if (st->pending.tok == d_tok && st->pending.B == B && st->pending.T == T && st->pending.seqs == seqs) return st->pending.n;
+  st->n_consumed += (uint64_t)st->pending.n;  // another batch was prefetched: its chunks are never looked up (the rows they
+  return 0;                                 // brought into the cache stay, harmlessly)
+}
+
+int scone_stage_note_prefetched(scone_handle *h, const int32_t *d_tok, int32_t B, int32_t T, long long seqs, long long n) {
+  scone_stage_state *st = h->stage;
+  st->pending.tok = d_tok, st->pending.B = B, st->pending.T = T, st->pending.seqs = seqs, st->pending.n = n;
+  st->pending.valid = n > 0;
   return SCONE_OK;
 }
 

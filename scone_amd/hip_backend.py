@@ -359,6 +359,16 @@ class SconeTable:
             self._check(rc, "scone_embed")
         return out
 
+    def embed_prefetch(self, tok: torch.Tensor, tokens_ready: bool = False) -> None:
+        """``scone_embed_prefetch``: start the pinned-host prefetch pipeline for ``tok`` (int32 ``[B, T]`` on the device: pass the
+        very tensor the later :meth:`embed` gets) behind the current stream -- or, ``tokens_ready=True``, right away (the tokens
+        are complete; the prefetch then runs beside a lookup queued just before).  A no-op for other tables."""
+        assert tok.dim() == 2 and tok.dtype == torch.int32 and tok.is_cuda and tok.is_contiguous()
+        B, T = tok.shape
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        self._check(L.lib().scone_embed_prefetch(self._h, tok.data_ptr(), B, T, int(bool(tokens_ready)), stream), "scone_embed_prefetch")
+        self._prefetch_keepalive = tok
+
     def reserve(self, max_tokens: int) -> None:
         with torch.cuda.device(self.device):
             self._check(L.lib().scone_reserve(self._h, int(max_tokens)), "scone_reserve")

@@ -312,6 +312,19 @@ class EmbeddingCache:
             raise IndexError("index out of range in self")
         return result
 
+    def prefetch_tokens(self, input_ids: torch.Tensor, tokens_ready: bool = False) -> None:
+        """Tables in pinned host DRAM with ``stage_tokens > 0``: start fetching the cold rows of the NEXT batch now
+        (``scone_embed_prefetch``: its first chunks are matched, placed in the HBM cache and copied on side streams behind the
+        current stream).  ``input_ids`` must be the very int32 device tensor ``[B, T]`` the later :meth:`embed_tokens` gets,
+        unchanged in between.  A serving loop calls it right after ``embed_tokens`` of the current batch -- with
+        ``tokens_ready=True`` when the next tokens are complete (uploaded earlier): the prefetch then runs BESIDE the lookup
+        just queued instead of behind it -- and never pays the pipeline's fill; other tables: a no-op.  New here (the reference's memmap faults rows in on first use,
+        embedding_cache.py:132-135)."""
+        tok = torch.as_tensor(input_ids)
+        if not (tok.dim() == 2 and tok.dtype == torch.int32 and tok.is_cuda and tok.is_contiguous()):
+            raise ValueError("prefetch_tokens needs the contiguous int32 device tensor [B, T] that embed_tokens will get")
+        self.to_device().embed_prefetch(tok, tokens_ready)
+
     # ------------------------------------------------------------------ native shard format
     NATIVE_MAGIC = "scone_amd.table.v1"          # round 1-2: one uncompressed .npz, whole arrays in host memory
     NATIVE_MAGIC_V2 = "scone_amd.table.v2"       # round 3: one memory-mapped .npy, written and read in chunks

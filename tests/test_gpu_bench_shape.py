@@ -381,10 +381,20 @@ def test_cold_row_cache_over_several_batches_against_the_c_oracle(cache_rows, st
     wpe = (torch.randn(T, d, generator=g) * 0.01).half().cuda()
     batches = [S.stream_zipf_ids(keys, lens, B, T, 100 + i, s=0.6) for i in range(5)]
     batches.append(batches[0])
+    toks = [torch.from_numpy(b).to("cuda", torch.int32) for b in batches]
     seen = np.zeros(0, dtype=np.int64)
     copied_before = 0
     for i, tok_np in enumerate(batches):
-        tok = torch.from_numpy(tok_np).to("cuda", torch.int32)
+        tok = toks[i]
+        # scone_embed_prefetch: the next lookup's first chunks prepared ahead -- of THIS batch (taken over by the fp32 lookup
+        # below), of another batch that is then never embedded next (dropped), twice in a row (the first one dropped)
+        if i == 1:
+            cache.prefetch_tokens(tok, tokens_ready=True)
+        elif i == 2:
+            cache.prefetch_tokens(toks[4])
+        elif i == 3:
+            cache.prefetch_tokens(toks[0])
+            cache.prefetch_tokens(tok, tokens_ready=True)
         ro, ri = R.hits_to_csr(R.match_hits(keys, lens, tok_np, 3))
         bad = _compare_with_c_oracle(lambda: cache.embed_tokens(tok, out_dtype=torch.float32),
                                      lambda: cache.embed_tokens(tok, wte=wte, wpe=wpe), keys, lens, tok_np, ri, fmt, d, wte, wpe)
@@ -396,8 +406,10 @@ def test_cold_row_cache_over_several_batches_against_the_c_oracle(cache_rows, st
         copied = c["rows_copied"] - copied_before
         copied_before = c["rows_copied"]
         assert c["chunk_tokens"] <= stage_tokens and c["cache_rows"] >= min(cache_rows, 1_000_000 - hot)
-        if cache_rows >= 2_000_000:          # nothing is ever evicted: the first lookup of a batch copies exactly the new rows,
-            assert copied == new.size, (i, copied, new.size)   # the second one (fp16 output) and a repeated batch copy nothing
+        if i in (2, 3, 4):
+            pass             # (steps 2 and 3 prefetched chunks of OTHER batches: rows of batches 4 and 0 were copied early, and stay cached)
+        elif cache_rows >= 2_000_000:   # nothing is ever evicted: the first lookup of a batch copies exactly the new rows, the
+            assert copied == new.size, (i, copied, new.size)   # second one (fp16 output) and a repeated batch copy nothing
         else:
             assert copied >= new.size, (i, copied, new.size)
 

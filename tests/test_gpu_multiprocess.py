@@ -343,6 +343,11 @@ def _check_sharded_record(rec, world):
         assert "error" not in sp, sp
         assert sp["ms_per_step"] > 0 and sp["batches_in_flight"] == 3 and sp["status_bits"] == 0
         assert sp["speedup_vs_n1_pinned_host"] > 0 and 0 < sp["roofline"]["frac"] <= 1.0 and sp["scales_with_world"] is False
+        if name.endswith("sdma"):
+            assert sp["with_cu_reserve"] is None                 # no transport kernel to make room for
+        else:                                                    # the same loop on the CU-masked stream
+            assert sp["with_cu_reserve"]["compute_units_reserved"] == 32 and sp["with_cu_reserve"]["ms_per_step"] > 0
+            assert sp["sync_free_plan"]["exchanges"] >= 1        # from the second batch on nothing blocks the host
     # the copy-engine transport really ran (interprocess handles work between processes on one device as well)
     sd = rec["exchanges"]["gather_rows_split_phase_sdma"]
     assert sd["transport_fallback_reason"] is None and sd["records_transport"].startswith("copy-engine"), sd

@@ -179,14 +179,28 @@ def test_committed_bench_line_follows_the_contract():
         assert rf["match_us"] > 0
         assert len(cb["gpu_vs_oracle_sequences"]) == 8 and cb["gpu_vs_oracle_max_rel_err"] < 1e-3
         assert r["sharded"]["n1_pinned_host_zipf"]["value"] > 0
+        if int(re.match(r"r(\d+)", rounds[-1]).group(1)) >= 4:
+            # round 4: the pinned-host prefetch is measured on a DIFFERENT batch every step, with what crossed PCIe beside it,
+            # against reading in place on the same batches and against a static head of the same HBM; the line says who won
+            z = r["sharded"]["n1_pinned_host_zipf"]
+            assert z["different_batch_every_step"] is True and z["warmup_batches"] >= 100 and z["status_bits"] == 0
+            assert 0 < z["rows_over_pcie_per_step"] < z["distinct_cold_rows"] <= z["cold_row_references"]
+            assert abs(z["bytes_over_pcie_per_step"] - 528 * z["rows_over_pcie_per_step"]) < 1.0
+            assert z["zero_copy_same_stream"]["value"] > 0 and z["zero_copy_static_head_same_hbm"]["value"] > 0
+            assert z["prefetch_beats_zero_copy"] is (z["value"] >= z["zero_copy_same_stream"]["value"])
         # every other committed line of the round (tools/run_configs.sh) obeys the same rule
         for d in os.listdir(prof):
             cj = os.path.join(prof, d, "configs.jsonl")
-            if d.startswith("r03") and os.path.exists(cj):
+            if d.startswith(("r03", "r04")) and os.path.exists(cj):
                 for ln in open(cj):
                     if ln.strip():
                         c = json.loads(ln)
                         assert 0 < c["roofline"]["frac"] <= 1.0, (d, c.get("config_name"))
+                        # round 4: EVERY workload whose table sits in HBM is counter-priced on the sources it ran on
+                        if d.startswith("r04") and "pinned" not in c["config_name"] and "shard" not in c["config_name"]:
+                            rf_c = c["roofline"]
+                            assert rf_c["traffic"] is not None and rf_c["traffic_stale"] is False, (d, c["config_name"])
+                            assert "left L2" in rf_c["frac_kind"], (d, c["config_name"])
 
 
 def test_bench_refuses_more_ranks_than_devices():

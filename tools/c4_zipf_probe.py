@@ -36,6 +36,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--same-batch", action="store_true", help="every step the same batch (round 3's measurement)")
+    ap.add_argument("--prefetch-next", action="store_true", help="cached: scone_embed_prefetch of batch i + 1 right after the "
+                    "lookup of batch i is queued (a loop that knows its next tokens early)")
     ap.add_argument("--stats-steps", type=int, default=2, help="steps whose cold references are counted (host sync: not timed)")
     a = ap.parse_args()
     N, d, B, T = a.rows, 1024, a.batch, a.seq
@@ -73,6 +75,8 @@ def main():
     t_all = time.perf_counter()
     for i in range(a.steps):
         cache.embed_tokens(toks[(a.warmup + i) % n_batches], wte=wte, wpe=wpe, out=out)
+        if a.prefetch_next and i + 1 < a.steps:
+            cache.prefetch_tokens(toks[(a.warmup + i + 1) % n_batches], tokens_ready=True)   # (all batches were generated up front)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t_all) / a.steps
     for i in range(min(a.steps, 8)):                     # a few steps one by one (host-synchronised: upper bound per step)
@@ -82,7 +86,7 @@ def main():
         torch.cuda.synchronize()
         per.append((time.perf_counter() - t1) * 1e3)
     res = {"mode": a.mode, "rows": N, "hot_rows": a.hot, "tokens": B * T, "build_s": build_s, "steps": a.steps, "warmup": a.warmup,
-           "different_batch_every_step": not a.same_batch, "ms_per_step": dt * 1e3, "tokens_per_s": B * T / dt,
+           "different_batch_every_step": not a.same_batch, "prefetch_next": a.prefetch_next, "ms_per_step": dt * 1e3, "tokens_per_s": B * T / dt,
            "ms_single_steps": [round(x, 4) for x in per], "per_batch_stats": stats, "status": cache.table.status(),
            "checksum_last": float(out.float().abs().sum().item())}
     if a.mode != "zero":

@@ -675,6 +675,15 @@ def pinned_baseline(args, sync, zipf_too=True):
             stats = {"mean_hits_per_token": sum(x[0] for x in st) / len(st), "cold_row_references": sum(x[1] for x in st) / len(st),
                      "distinct_cold_rows": sum(x[2] for x in st) / len(st)}
             dt_zero = run(cache, timed, steps)
+            # the same law over a table whose order is NOT the traffic's frequency order (synthetic.stream_zipf_ids_torch,
+            # scramble=True): what the cache is for -- the static head holds 1 % / 17 % of the rows, not of the references
+            timed_s = [S.stream_zipf_ids_torch(vocab, B, T, 60_000 + i, scramble=True) for i in range(steps)]
+            _, ids = cache.table.match_csr(timed_s[0])
+            cold = ids[ids >= hot]
+            stats_s = {"mean_hits_per_token": float(ids.numel()) / (B * T), "cold_row_references": int(cold.numel()),
+                       "distinct_cold_rows": int(torch.unique(cold).numel())}
+            del ids, cold
+            dt_zero_s = run(cache, timed_s, steps)
             del cache
             torch.cuda.empty_cache()
             # the same table behind the persistent cache of cold rows (stage_tokens / cache_rows are properties of the handle)
@@ -690,10 +699,18 @@ def pinned_baseline(args, sync, zipf_too=True):
             c1 = cache.table.stage_counters()
             copied = (c1["rows_copied"] - c0["rows_copied"]) / steps
             status = cache.table.status()
+            for i in range(warm_n):                 # the cache re-learns the scrambled stream (its rows are elsewhere)
+                cache.embed_tokens(S.stream_zipf_ids_torch(vocab, B, T, 70_000 + i, scramble=True), wte=wte, wpe=wpe, out=out)
+            sync()
+            c2 = cache.table.stage_counters()
+            dt_cached_s = run(cache, timed_s, steps, warm=[], prefetch=True)
+            copied_s = (cache.table.stage_counters()["rows_copied"] - c2["rows_copied"]) / steps
+            status |= cache.table.status()
             del cache
             torch.cuda.empty_cache()
             cache = table(hot_rows=hot + cache_rows)
             dt_static = run(cache, timed, steps)
+            dt_static_s = run(cache, timed_s, steps)
             zres = {"value": B * T / dt_cached, "unit": "tokens/s", "ms_per_step": dt_cached * 1e3, "steps": steps,
                     "different_batch_every_step": True, "warmup_batches": warm_n,
                     "mechanism": f"persistent HBM cache of cold rows ({c1['cache_rows']} row slots = {c1['cache_rows'] * 528 / 1e9:.1f} GB, "
@@ -709,6 +726,15 @@ def pinned_baseline(args, sync, zipf_too=True):
                     "zero_copy_static_head_same_hbm": {"value": B * T / dt_static, "ms_per_step": dt_static * 1e3,
                                                        "hot_rows": hot + cache_rows},
                     "prefetch_beats_zero_copy": bool(dt_cached <= dt_zero),
+                    "scrambled_order": {
+                        "what": "the same power law, popularity rank r served by row (r * 61803399) % N: the table's order is not "
+                                "the traffic's frequency order (built on one corpus, served on another); same table, same cache "
+                                f"(re-warmed by {warm_n} batches of this stream), same three mechanisms",
+                        "value": B * T / dt_cached_s, "ms_per_step": dt_cached_s * 1e3, "rows_over_pcie_per_step": copied_s,
+                        "zero_copy_same_stream": {"value": B * T / dt_zero_s, "ms_per_step": dt_zero_s * 1e3},
+                        "zero_copy_static_head_same_hbm": {"value": B * T / dt_static_s, "ms_per_step": dt_static_s * 1e3},
+                        "prefetch_beats_zero_copy": bool(dt_cached_s <= dt_zero_s),
+                        "prefetch_beats_static_head": bool(dt_cached_s <= dt_static_s), **stats_s},
                     "workload": f"{N}-row int4 table d={d} in pinned host DRAM, first {hot} rows in HBM, structured vocabulary, "
                                 f"S_zipf_ids (f-grams laid end to end, ids ~ bounded power law with exponent 1.1 over the "
                                 f"frequency-ordered table: the realistic stream), {B}x{T} tokens/step, a different batch every step", **stats,

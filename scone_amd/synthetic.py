@@ -183,11 +183,23 @@ def stream_zipf_ids(keys, lens, B: int, T: int, seed: int, s: float = 1.1) -> np
     return out[:need].reshape(B, T)
 
 
-def stream_zipf_ids_torch(vocab: "StructuredVocab", B: int, T: int, seed: int, s: float = 1.1, device="cuda"):
+SCRAMBLE_MULT = 61_803_399      # odd, not a multiple of 5: a bijection of [0, N) for the 10^k-row tables of BASELINE.json
+
+
+def stream_zipf_ids_torch(vocab: "StructuredVocab", B: int, T: int, seed: int, s: float = 1.1, device="cuda",
+                          scramble: bool = False, shift: int = 0):
     """:func:`stream_zipf_ids` for a :class:`StructuredVocab`, drawn on the GPU (same law, torch's generator instead of
     numpy's: not the same batch): a serving loop's worth of DIFFERENT batches -- what a cache of cold rows must be measured
-    on -- costs milliseconds each instead of a quarter of a second of host time.  int32 ``[B, T]`` on ``device``."""
+    on -- costs milliseconds each instead of a quarter of a second of host time.  int32 ``[B, T]`` on ``device``.
+
+    ``scramble`` / ``shift``: the popularity RANK r is served by row ``(r * SCRAMBLE_MULT + shift) % N`` instead of row r --
+    the same law over a table whose order is NOT the traffic's frequency order (a table built on one corpus and served on
+    another; ``shift`` growing from batch to batch: a hot set that moves).  This is the stream on which a static hot head
+    cannot work and a cache of cold rows has to."""
+    import math
     import torch
+    if scramble and math.gcd(SCRAMBLE_MULT, len(vocab)) != 1:
+        raise ValueError("scramble needs a row count coprime to SCRAMBLE_MULT")
     g = torch.Generator(device=device).manual_seed(int(seed))
     need, n_rows, e = B * T, len(vocab), 1.0 - s
     parts, have = [], 0
@@ -195,6 +207,10 @@ def stream_zipf_ids_torch(vocab: "StructuredVocab", B: int, T: int, seed: int, s
         u = torch.rand(max(1024, int((need - have) / 1.5) + 1024), generator=g, device=device, dtype=torch.float64)
         x = ((float(n_rows + 1) ** e - 1.0) * u + 1.0) ** (1.0 / e)          # inverse CDF of the bounded power law on [1, N + 1)
         ids = torch.clamp(x.to(torch.int64) - 1, max=n_rows - 1)
+        if scramble:
+            ids = (ids * SCRAMBLE_MULT + int(shift)) % n_rows
+        elif shift:
+            ids = (ids + int(shift)) % n_rows
         k, l = vocab.keys_for_torch(ids)
         t = k[torch.arange(3, device=k.device)[None, :] < l[:, None]]
         parts.append(t)

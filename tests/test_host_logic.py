@@ -188,6 +188,14 @@ def test_committed_bench_line_follows_the_contract():
             assert abs(z["bytes_over_pcie_per_step"] - 528 * z["rows_over_pcie_per_step"]) < 1.0
             assert z["zero_copy_same_stream"]["value"] > 0 and z["zero_copy_static_head_same_hbm"]["value"] > 0
             assert z["prefetch_beats_zero_copy"] is (z["value"] >= z["zero_copy_same_stream"]["value"])
+            # the line of the round's last tree adds the stream the cache is FOR (popularity not in the table's order): the
+            # same three mechanisms, and who won is computed from the three figures, not asserted to be the cache
+            final = os.path.join(prof, rounds[-1], "bench_final_tree.json")
+            if os.path.exists(final):
+                so = json.loads(open(final).read().strip().splitlines()[-1])["sharded"]["n1_pinned_host_zipf"]["scrambled_order"]
+                assert so["value"] > 0 and 0 < so["rows_over_pcie_per_step"] < so["distinct_cold_rows"]
+                assert so["prefetch_beats_zero_copy"] is (so["value"] >= so["zero_copy_same_stream"]["value"])
+                assert so["prefetch_beats_static_head"] is (so["value"] >= so["zero_copy_static_head_same_hbm"]["value"])
         # every other committed line of the round (tools/run_configs.sh) obeys the same rule
         for d in os.listdir(prof):
             cj = os.path.join(prof, d, "configs.jsonl")

@@ -38,6 +38,9 @@ def main():
     ap.add_argument("--same-batch", action="store_true", help="every step the same batch (round 3's measurement)")
     ap.add_argument("--prefetch-next", action="store_true", help="cached: scone_embed_prefetch of batch i + 1 right after the "
                     "lookup of batch i is queued (a loop that knows its next tokens early)")
+    ap.add_argument("--scramble", action="store_true", help="popularity rank r is served by row (r * M + shift) %% N: the table's "
+                    "order is not the traffic's frequency order (synthetic.stream_zipf_ids_torch)")
+    ap.add_argument("--shift-per-step", type=int, default=0, help="the hot set moves by this many rows from batch to batch")
     ap.add_argument("--stats-steps", type=int, default=2, help="steps whose cold references are counted (host sync: not timed)")
     a = ap.parse_args()
     N, d, B, T = a.rows, 1024, a.batch, a.seq
@@ -57,11 +60,11 @@ def main():
     wpe = (torch.randn(1024, d, generator=g, device="cuda") * 0.01).half()
     out = torch.empty(B, T, d, dtype=torch.float16, device="cuda")
     n_batches = 1 if a.same_batch else a.steps + a.warmup
-    toks = [S.stream_zipf_ids_torch(vocab, B, T, 1234 + i) for i in range(n_batches)]
+    toks = [S.stream_zipf_ids_torch(vocab, B, T, 1234 + i, scramble=a.scramble, shift=i * a.shift_per_step) for i in range(n_batches)]
     torch.cuda.synchronize()
     stats = []
     for i in range(min(a.stats_steps, n_batches)):
-        _, ids = cache.table.match_csr(toks[i])
+        _, ids = cache.table.match_csr(toks[(a.warmup + i) % n_batches])            # of the TIMED batches
         cold = ids[ids >= a.hot]
         stats.append({"cold_row_references": int(cold.numel()), "distinct_cold_rows": int(torch.unique(cold).numel()),
                       "mean_hits_per_token": float(ids.numel()) / (B * T)})
@@ -86,7 +89,7 @@ def main():
         torch.cuda.synchronize()
         per.append((time.perf_counter() - t1) * 1e3)
     res = {"mode": a.mode, "rows": N, "hot_rows": a.hot, "tokens": B * T, "build_s": build_s, "steps": a.steps, "warmup": a.warmup,
-           "different_batch_every_step": not a.same_batch, "prefetch_next": a.prefetch_next, "ms_per_step": dt * 1e3, "tokens_per_s": B * T / dt,
+           "different_batch_every_step": not a.same_batch, "scramble": a.scramble, "shift_per_step": a.shift_per_step, "prefetch_next": a.prefetch_next, "ms_per_step": dt * 1e3, "tokens_per_s": B * T / dt,
            "ms_single_steps": [round(x, 4) for x in per], "per_batch_stats": stats, "status": cache.table.status(),
            "checksum_last": float(out.float().abs().sum().item())}
     if a.mode != "zero":

@@ -179,6 +179,10 @@ __global__ __launch_bounds__(256) void k_stage_remap(int32_t *__restrict__ ell, 
 // every kernel beside it 2-10x.  Measured on the C4 Zipf stream, steady state, 8M-row cache (profiles/r04g): 96 / 128
 // workgroups 1.235 / 1.154 ms per 1M-token step at 262k-token chunks, 1.228 / 1.172 at 131k; the cache-filling phase
 // (every row a miss): 64 / 128 / 256 / 512 / 1024 workgroups 1.74 / 1.33 / 1.42 / 1.49 / 1.58 ms (profiles/r04b).
+// With scone_embed_prefetch, 16M slots: 128 / 256 / 512 workgroups 0.905 / 0.995 / 1.126 ms.  Confining the 128 workgroups to
+// 4 / 2 / 1 of the 8 XCDs (only the workgroups the dispatcher deals to those XCDs work) was tried and is slower: 0.945 /
+// 0.996 / 1.031 ms against 0.905 (profiles/r04x) -- the lookup's tiles are dealt to XCDs statically, and the XCDs that carry
+// the link's reads become its stragglers.
 __global__ __launch_bounds__(256) void k_stage_copy(const uint32_t *__restrict__ count, const int32_t *__restrict__ list,
                                                     const uint32_t *__restrict__ place, scone_row_store host,
                                                     uint8_t *__restrict__ cache_rows, const uint8_t *__restrict__ scales,

@@ -41,6 +41,8 @@ def main():
     ap.add_argument("--scramble", action="store_true", help="popularity rank r is served by row (r * M + shift) %% N: the table's "
                     "order is not the traffic's frequency order (synthetic.stream_zipf_ids_torch)")
     ap.add_argument("--shift-per-step", type=int, default=0, help="the hot set moves by this many rows from batch to batch")
+    ap.add_argument("--cu-reserve", type=int, default=0, help="scone_set_cu_reserve: the lookup kernels leave this many CUs to the "
+                    "cache's copy and preparation kernels; the loop runs on the handle's masked stream")
     ap.add_argument("--stats-steps", type=int, default=2, help="steps whose cold references are counted (host sync: not timed)")
     a = ap.parse_args()
     N, d, B, T = a.rows, 1024, a.batch, a.seq
@@ -70,6 +72,17 @@ def main():
                       "mean_hits_per_token": float(ids.numel()) / (B * T)})
         del ids, cold
     cache.table.reserve(B * T)
+    import contextlib
+    ctx = contextlib.nullcontext()
+    if a.cu_reserve:
+        cache.table.set_cu_reserve(a.cu_reserve)
+        ctx = torch.cuda.stream(cache.table.lookup_stream())
+        torch.cuda.synchronize()
+    with ctx:
+        timed_loop(a, cache, toks, n_batches, wte, wpe, out, B, T, N, build_s, stats)
+
+
+def timed_loop(a, cache, toks, n_batches, wte, wpe, out, B, T, N, build_s, stats):
     for i in range(a.warmup):
         cache.embed_tokens(toks[i % n_batches], wte=wte, wpe=wpe, out=out)
     torch.cuda.synchronize()
@@ -89,7 +102,7 @@ def main():
         torch.cuda.synchronize()
         per.append((time.perf_counter() - t1) * 1e3)
     res = {"mode": a.mode, "rows": N, "hot_rows": a.hot, "tokens": B * T, "build_s": build_s, "steps": a.steps, "warmup": a.warmup,
-           "different_batch_every_step": not a.same_batch, "scramble": a.scramble, "shift_per_step": a.shift_per_step, "prefetch_next": a.prefetch_next, "ms_per_step": dt * 1e3, "tokens_per_s": B * T / dt,
+           "different_batch_every_step": not a.same_batch, "scramble": a.scramble, "shift_per_step": a.shift_per_step, "prefetch_next": a.prefetch_next, "cu_reserve": a.cu_reserve, "ms_per_step": dt * 1e3, "tokens_per_s": B * T / dt,
            "ms_single_steps": [round(x, 4) for x in per], "per_batch_stats": stats, "status": cache.table.status(),
            "checksum_last": float(out.float().abs().sum().item())}
     if a.mode != "zero":

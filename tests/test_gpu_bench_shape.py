@@ -414,6 +414,42 @@ def test_cold_row_cache_over_several_batches_against_the_c_oracle(cache_rows, st
             assert copied >= new.size, (i, copied, new.size)
 
 
+def test_rows_written_after_cached_lookups_are_what_the_next_lookup_returns():
+    """The cache of cold rows holds COPIES of rows whose home is host DRAM: `cache_embeddings` on a table that has served
+    lookups (the reference overwrites rows of a live cache the same way, embedding_cache.py:93-131) must not leave a stale
+    copy behind -- with a prefetched batch pending at the moment of the write.  Twin: the same table resident in HBM (no
+    cache, no chunks), same writes; both are this library, so equality is bit-for-bit, and the twin's path is the one the
+    other tests of this file compare with oracle.c."""
+    from scone_amd import EmbeddingCache, NGramExtractor
+    from scone_amd import synthetic as S
+    fmt, d, B, T, hot = "int8", 768, 32, 512, 20_000
+    keys, lens = _keys(300_000, "zipf")
+    ex = NGramExtractor.from_arrays(keys, lens, max_n=3)
+    pinned = EmbeddingCache.from_synthetic(ex, d, table_format=fmt, seed=SEED, base_scale=BASE_SCALE, placement="pinned_host",
+                                           hot_rows=hot, stage_tokens=4096, cache_rows=200_000)
+    twin = EmbeddingCache.from_synthetic(ex, d, table_format=fmt, seed=SEED, base_scale=BASE_SCALE)
+    tok = torch.from_numpy(S.stream_uniform_ids(keys, lens, B, T, 4242)).to("cuda", torch.int32)
+    out0 = pinned.embed_tokens(tok, out_dtype=torch.float32).clone()
+    assert torch.equal(out0, twin.embed_tokens(tok, out_dtype=torch.float32))
+    assert pinned.table.stage_counters()["rows_copied"] > 1000          # the cache is populated
+    _, ids = pinned.table.match_csr(tok)
+    cold = torch.unique(ids[ids >= hot])[::2].cpu()                    # every other cold row the batch references
+    head = torch.unique(ids[ids < hot])[::7].cpu()                     # and a few rows of the HBM-resident head
+    wr = torch.cat([cold, head])
+    g = torch.Generator().manual_seed(9)
+    new_rows = torch.randn(wr.numel(), d, generator=g) * 0.05
+    pinned.prefetch_tokens(tok, tokens_ready=True)                     # a prepared batch is pending when the table changes
+    for c in (pinned, twin):
+        c.cache_embeddings(wr.tolist(), new_rows, verbose=False)
+    out1 = pinned.embed_tokens(tok, out_dtype=torch.float32)
+    ref1 = twin.embed_tokens(tok, out_dtype=torch.float32)
+    assert torch.equal(out1, ref1) and pinned.table.status() == 0 and twin.table.status() == 0
+    changed = (out1 != out0).any(dim=-1).sum().item()
+    assert changed > B * T // 4                                        # the writes are visible in a large part of the batch
+    # and again with the cache repopulated (the state was rebuilt after the write)
+    assert torch.equal(pinned.embed_tokens(tok, out_dtype=torch.float32), ref1)
+
+
 @pytest.mark.parametrize("fmt,d", [("int8", 768), ("int4", 1024)])
 def test_csr_entry_point_and_partial_sums_at_the_bench_shape(fmt, d):
     """The two other large-batch entry points at 256 x 512 tokens against the oracle: `embed_tokens(base=...)` = `scone_match_csr`

@@ -17,5 +17,5 @@ for f in scone_gather_f32 scone_gather_f16 scone_gather_i8 scone_gather_i4 scone
 done
 for p in "${pids[@]}"; do wait $p; done
 hipcc -shared --offload-arch=gfx950 -o $R/gpurun_ab/lib$NAME.so $B/*.o $C/scone_api.o $C/scone_index.o $C/scone_table.o \
-  $C/scone_fit.o $C/scone_stage.o $C/scone_shard.o
+  $C/scone_fit.o $C/scone_stage.o $C/scone_shard.o $C/scone_ipc.o
 echo "built gpurun_ab/lib$NAME.so ($*)"

@@ -273,6 +273,9 @@ class ShardedEmbeddingCache:
         self.gather_transport = gather_transport
         self.transport_fallback_reason = None         # why "sdma" was asked for and "p2p" is used (None: it was not / it is)
         self._sdma = None
+        # interprocess events of the sdma transport: records per event (HIP's limit is 32), events per slot and direction
+        self._sdma_event_records = int(os.environ.get("SCONE_SDMA_EVENT_RECORDS", "30"))
+        self._sdma_event_pool = int(os.environ.get("SCONE_SDMA_EVENT_POOL", "16"))
         self.rank = dist.get_rank(group) if rank is None else int(rank)
         self.world = dist.get_world_size(group) if world is None else int(world)
         self.n_gram_extractor = n_gram_extractor
@@ -388,13 +391,48 @@ class ShardedEmbeddingCache:
                 for ptr in st["peer"][r]:
                     if ptr:
                         t.ipc_close(ptr)
-                t.ipc_event_destroy(st["peer_sent"][r])
-                t.ipc_event_destroy(st["peer_done"][r])
         for ptr in st["ptrs"]:
             if ptr:
                 t.ipc_free(ptr)
-        t.ipc_event_destroy(st["sent"])
-        t.ipc_event_destroy(st["done"])
+        self._sdma_release_events(st)
+
+    def _sdma_release_events(self, st) -> None:
+        t = self.table
+        for r in range(self.world):
+            if r != self.rank and st["peer_sent"][r] is not None:
+                for e in st["peer_sent"][r] + st["peer_done"][r]:
+                    t.ipc_event_destroy(e)
+        for e in st["sent"] + st["done"]:
+            t.ipc_event_destroy(e)
+        st["sent"], st["done"] = [], []
+        st["peer_sent"], st["peer_done"] = [None] * self.world, [None] * self.world
+
+    def _sdma_new_events(self, st, slot: int) -> None:
+        """A fresh pool of interprocess events for this slot, exchanged with and opened by every peer (collective; the caller
+        has made sure nobody still waits for, or records, the old ones).  A HIP interprocess event survives 32 records -- the
+        33rd makes every later hipStreamWaitEvent of a process that opened it fail with "invalid argument" (measured:
+        tools/ipc_event_probe.py; the split-phase soak found it) -- so each event of the pool is used for
+        ``_sdma_event_records`` steps, and the pool is replaced when it is used up."""
+        t, W, r = self.table, self.world, self.rank
+        K = self._sdma_event_pool
+        pairs = [t.ipc_event_create() for _ in range(2 * K)]
+        st["sent"], st["done"] = [e for e, _ in pairs[:K]], [e for e, _ in pairs[K:]]
+        everyone = [None] * W
+        _trace("all_gather_object(sdma event handles)", self.group, slot=slot, events=2 * K)
+        dist.all_gather_object(everyone, [h for _, h in pairs], group=self.group)
+        for q in range(W):
+            if q != r:
+                st["peer_sent"][q] = [t.ipc_event_open(h) for h in everyone[q][:K]]
+                st["peer_done"][q] = [t.ipc_event_open(h) for h in everyone[q][K:]]
+        st["uses"], st["cur_ev"], st["used"] = 0, 0, False
+
+    def _sdma_renew_events(self, st, slot: int) -> None:
+        """The slot's event pool is used up: every rank arrives here in the same step (pushes are collective)."""
+        torch.cuda.synchronize(self.table.device)        # my waits for the old events, and my records of them, are complete
+        dist.barrier(group=self._sdma["ctrl"])           # ... and so are everybody else's
+        self._sdma_release_events(st)
+        self._sdma_new_events(st, slot)
+        dist.barrier(group=self._sdma["ctrl"])           # every rank has opened every new event before anyone records one
 
     def _sdma_slot(self, slot: int, total: int, ftotal: int, dev):
         """This slot's receive buffers (rows, scales, frags) with room for ``total`` rows / ``ftotal`` fragment slots, mapped
@@ -419,41 +457,43 @@ class ShardedEmbeddingCache:
                 p, hb = 0, b"\0" * 64
             ptrs.append(p)
             handles.append(hb)
-        sent, h_sent = t.ipc_event_create()
-        done, h_done = t.ipc_event_create()
-        mine = b"".join(handles) + h_sent + h_done
+        mine = b"".join(handles)
         everyone = [None] * W
         _trace("all_gather_object(sdma handles)", self.group, slot=slot, rows=cap, frag_slots=fcap)
         dist.all_gather_object(everyone, mine, group=self.group)
-        peer, peer_sent, peer_done = [None] * W, [None] * W, [None] * W
+        peer = [None] * W
         for q in range(W):
             if q == r:
                 continue
             hq = everyone[q]
             peer[q] = tuple(t.ipc_open(hq[64 * i:64 * i + 64]) if nbytes[i] else 0 for i in range(3))
-            peer_sent[q] = t.ipc_event_open(hq[192:256])
-            peer_done[q] = t.ipc_event_open(hq[256:320])
         rows = t.ipc_tensor(ptrs[0], nbytes[0]).view(cap, pb)
         scales = t.ipc_tensor(ptrs[1], nbytes[1]).view(nh + cap, sb) if sb else None
         frags = t.ipc_tensor(ptrs[2], nbytes[2]).view(torch.int64)
         torch.cuda.synchronize(dev)                      # (the head's scales go into the front of `scales` in _gather_begin_cols)
         dist.barrier(group=self._sdma["ctrl"])           # every rank has opened every buffer before anyone pushes
-        st = {"cap": cap, "fcap": fcap, "ptrs": ptrs, "peer": peer, "sent": sent, "done": done, "peer_sent": peer_sent,
-              "peer_done": peer_done, "rows": rows, "scales": scales, "frags": frags, "used": False}
+        st = {"cap": cap, "fcap": fcap, "ptrs": ptrs, "peer": peer, "sent": [], "done": [], "peer_sent": [None] * W,
+              "peer_done": [None] * W, "rows": rows, "scales": scales, "frags": frags, "used": False, "uses": 0, "cur_ev": 0}
+        self._sdma_new_events(st, slot)
+        torch.cuda.synchronize(dev)
+        dist.barrier(group=self._sdma["ctrl"])           # ... and every event
         self._sdma["slots"][slot] = st
         return st
 
-    def _sdma_push(self, st, regions) -> "_SdmaArrival":
+    def _sdma_push(self, st, slot: int, regions) -> "_SdmaArrival":
         """``regions``: [(column index, byte offset, bytes)] of this rank's freshly packed range.  Waits (stream-ordered) until
         every peer has reduced the batch that used this slot before, pushes the ranges to the same offsets of every peer's
         buffers -- one stream per peer, so that the copy engines drive all links at once --, records "sent", and rendezvous
         on the host so that the receivers' waits see this record."""
         t, W, r = self.table, self.world, self.rank
+        if st["uses"] >= self._sdma_event_pool * self._sdma_event_records:
+            self._sdma_renew_events(st, slot)
         cur = torch.cuda.current_stream()
         if st["used"]:
             for q in range(W):
                 if q != r:
-                    t.ipc_event_wait(st["peer_done"][q])     # (recorded before the peer entered this step's count exchange)
+                    t.ipc_event_wait(st["peer_done"][q][st["cur_ev"]])   # (recorded before the peer entered this step's count exchange)
+        ev = st["uses"] // self._sdma_event_records
         packed = torch.cuda.Event()
         packed.record(cur)
         for q in range(W):
@@ -468,10 +508,11 @@ class ShardedEmbeddingCache:
                 e = torch.cuda.Event()
                 e.record(ps)
             cur.wait_event(e)
-        t.ipc_event_record(st["sent"])
+        t.ipc_event_record(st["sent"][ev])
+        st["cur_ev"], st["uses"] = ev, st["uses"] + 1
         _trace("barrier(sdma: pushes recorded)", self.group, bytes_per_peer=sum(nb for _, _, nb in regions))
         dist.barrier(group=self._sdma["ctrl"])
-        return _SdmaArrival(t, [st["peer_sent"][q] for q in range(W) if q != r])
+        return _SdmaArrival(t, [st["peer_sent"][q][ev] for q in range(W) if q != r])
 
     def close(self) -> None:
         """Release the interprocess buffers and events of the "sdma" transport (collective in spirit: call it on every rank
@@ -872,7 +913,7 @@ class ShardedEmbeddingCache:
                               scales[nh + rec_base[r]:nh + rec_base[r] + n_me], frags[frag_off[r]:frag_off[r] + slots_r[r]])
             t0 = self._tick("pack_ms", t0)
             if sdma:
-                works.append(self._sdma_push(st, [(0, rec_base[r] * pb, n_me * pb), (1, (nh + rec_base[r]) * sb, n_me * sb),
+                works.append(self._sdma_push(st, slot, [(0, rec_base[r] * pb, n_me * pb), (1, (nh + rec_base[r]) * sb, n_me * sb),
                                                   (2, frag_off[r] * 8, slots_r[r] * 8)]))
             elif W > 1:
                 works.append(_exchange_exact_async(rows[:total], rec_base + [total], counts, r, self.group))
@@ -1035,7 +1076,7 @@ class ShardedEmbeddingCache:
                 done.record(cur)
                 self._slot_done[ticket["slot"]] = done
             if ticket.get("sdma") is not None:                           # the peers may push the next batch into this slot
-                t.ipc_event_record(ticket["sdma"]["done"])
+                t.ipc_event_record(ticket["sdma"]["done"][ticket["sdma"]["cur_ev"]])
                 ticket["sdma"]["used"] = True
             self._keep = (ticket, position_ids, wte, wpe, out)
             if check:
@@ -1089,7 +1130,7 @@ class ShardedEmbeddingCache:
             done.record(cur)
             self._slot_done[ticket["slot"]] = done
             if ticket.get("sdma") is not None:
-                self.table.ipc_event_record(ticket["sdma"]["done"])
+                self.table.ipc_event_record(ticket["sdma"]["done"][ticket["sdma"]["cur_ev"]])
                 ticket["sdma"]["used"] = True
         self._slot_open[ticket["slot"]] = False
 

@@ -219,13 +219,21 @@ def _worker_soak(rank, world, port, slots, q):
         wpe_d = torch.from_numpy(np.tile(wpe, (3, 1))[:80]).half().cuda()
         n, bad, tickets, batches = int(os.environ.get("SCONE_SOAK_STEPS", "60")), [], [], []
         free0 = None
+        transports = ["p2p", "all_gather"]
+        if world == 2:                                                 # a HIP interprocess event survives 32 records: each slot keeps a
+            sh._sdma_event_records, sh._sdma_event_pool = 3, 2         # pool of them and replaces it when used up -- here every 6 uses
+        if sh.set_gather_transport("sdma") == "sdma":                 # collective: the capability probe + handle exchange, once
+            transports.append("sdma")                                  # (round 4: the copy-engine transport joins the mix)
+        used, hist = set(), []
         for i in range(n + slots - 1):
             if i < n:
                 B, T = int(rng.integers(1, 12)), int(rng.integers(1, 80))
                 tok = torch.from_numpy(rng.integers(0, 24, size=(B, T)))
                 sh.gather_chunks = int(rng.integers(1, 4))             # 1 = columns on the wire, 2 / 3 = chunked records
                 sh.shard_match = bool(rng.integers(2))                 # the plan's match sharded over the ranks, or not
-                sh.gather_transport = ("p2p", "all_gather")[int(rng.integers(2))]
+                sh.gather_transport = transports[int(rng.integers(len(transports)))]
+                used.add(sh.gather_transport if sh.gather_chunks == 1 else "chunked")
+                hist.append((i, B, T, sh.gather_chunks, sh.shard_match, sh.gather_transport))
                 tickets.append(sh.gather_rows_begin(tok))
                 batches.append(tok)
             if i >= slots - 1:
@@ -239,19 +247,22 @@ def _worker_soak(rank, world, port, slots, q):
                 free0 = torch.cuda.mem_get_info()[0]
         torch.cuda.synchronize()
         drift = free0 - torch.cuda.mem_get_info()[0]
+        if len(transports) == 3 and n >= 60 and "sdma" not in used:
+            bad.append("the sdma transport was never drawn")
         q.put((rank, bad, int(drift), sh.table.status()))
         dist.barrier()
+        sh.close()
         dist.destroy_process_group()
     except Exception as e:
         import traceback
-        q.put((rank, repr(e) + traceback.format_exc(), 0, -1))
+        q.put((rank, repr(e) + traceback.format_exc() + f" last batches (i, B, T, chunks, shard_match, transport): {locals().get('hist', [])[-6:]}", 0, -1))
 
 
 @pytest.mark.parametrize("world,slots", [(2, 2), (3, 3)])
 def test_split_phase_soak_random_shapes_forms_and_slots(world, slots):
     """60 batches of random shape through the split-phase loop, `slots` batches in flight, every batch with its own form --
-    one piece with columns on the wire or 2-3 chunks of records, match sharded over the ranks or not, exact ranges or padded
-    all-gathers: buffers of every slot are re-used and re-grown across shapes; every output equals the unsharded lookup of
+    one piece with columns on the wire or 2-3 chunks of records, match sharded over the ranks or not, exact ranges, padded
+    all-gathers or copy-engine pushes into peer-mapped buffers (sdma): buffers of every slot are re-used and re-grown across shapes; every output equals the unsharded lookup of
     ITS batch, the status word stays clean, device memory does not drift."""
     if not torch.cuda.is_available():
         pytest.skip("needs an MI355X")

@@ -20,12 +20,17 @@ def main():
     keys, lens = S.make_keys(N, S.GPT2_VOCAB, 3, seed=11)
     ex = NGramExtractor.from_arrays(keys, lens, max_n=3)
     a = EmbeddingCache.from_synthetic(ex, d, table_format="int8")
-    b = EmbeddingCache.from_synthetic(ex, d, table_format="int8", placement="pinned_host", hot_rows=50257, stage_tokens=4096)
+    b = EmbeddingCache.from_synthetic(ex, d, table_format="int8", placement="pinned_host", hot_rows=50257, stage_tokens=4096,
+                                      cache_rows=int(os.environ.get("SCONE_SOAK_CACHE_ROWS", "0")))
     wte = (torch.randn(S.GPT2_VOCAB, d, device="cuda") * 0.02).half()
     wpe = (torch.randn(1024, d, device="cuda") * 0.01).half()
     rng = np.random.default_rng(0)
     shapes = [(1, 1), (1, 512), (3, 77), (8, 512), (64, 512), (4, 1024), (256, 512), (2, 3), (1024, 512)]
     toks = {s: torch.from_numpy(S.stream_zipf(S.GPT2_VOCAB, s[0], s[1], 7)).to("cuda", torch.int32) for s in shapes}
+    if os.environ.get("SCONE_SOAK_UNIFORM") == "1":      # f-gram ids uniform over the table: the big batches reference more cold
+        for s in shapes:                                   # rows than the cache holds -- eviction inside every batch
+            if s[0] * s[1] >= 4096:
+                toks[s] = torch.from_numpy(S.stream_uniform_ids(keys, lens, s[0], s[1], 7 + s[0])).to("cuda", torch.int32)
     first = {}
     for s in shapes:                                                     # warm every workspace size once
         first[s] = a.embed_tokens(toks[s], wte=wte, wpe=wpe).clone()
@@ -36,14 +41,21 @@ def main():
         return total - free - torch.cuda.memory_reserved()
     free0 = lib_bytes()
     t0, calls, ntok = time.time(), 0, 0
+    nxt = shapes[int(rng.integers(len(shapes)))]
+    prefetched = 0
     while time.time() - t0 < secs:
-        s = shapes[int(rng.integers(len(shapes)))]
-        c = a if rng.random() < 0.7 else b
+        s, nxt = nxt, shapes[int(rng.integers(len(shapes)))]
+        c = a if rng.random() < 0.5 else b
         out = c.embed_tokens(toks[s], wte=wte, wpe=wpe)
+        if rng.random() < 0.4:          # round 4: the next batch's first chunks prepared ahead (used, dropped or foreign: all legal)
+            b.prefetch_tokens(toks[nxt], tokens_ready=bool(rng.integers(2)))
+            prefetched += 1
         calls += 1
         ntok += s[0] * s[1]
-        if calls % 50 == 0:
+        if calls % 20 == 0:
             assert torch.equal(out, first[s]), (calls, s)
+    assert a.table.status() == 0 and b.table.status() == 0
+    print(f"prefetch calls {prefetched}; cache counters {b.table.stage_counters()}")
     torch.cuda.synchronize()
     free1 = lib_bytes()
     print(f"{calls} calls, {ntok / 1e9:.2f} G tokens in {time.time() - t0:.1f} s; library device memory before/after: "

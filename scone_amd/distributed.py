@@ -371,6 +371,111 @@ class ShardedEmbeddingCache:
         self._sdma = {"ctrl": ctrl, "slots": [None] * 4,
                       "push": [torch.cuda.Stream(device=dev) for _ in range(self.world)],
                       "copy_engine": os.environ.get("SCONE_SDMA_COPY_ENGINE", "1") != "0"}
+        why = self._sdma_self_test()
+        if why is not None:                              # every rank gets the same verdict (all-gathered inside)
+            self._sdma = None
+            self.transport_fallback_reason = why
+            self.gather_transport = "p2p"
+
+    def _sdma_self_test(self) -> Optional[str]:
+        """The transport's three mechanisms on 4 KB, before any table data depends on them (collective): every rank pushes a
+        pattern of its own into its 64-byte cell of every peer's mapped buffer with the copy the transport uses, records an
+        interprocess event, and every rank checks what arrived behind a wait for the peers' events.  A platform on which the
+        handles open but the bytes do not arrive (peer access, a copy kind the topology does not support) -- which one
+        GPU cannot show -- costs a fallback to p2p on every rank alike, not wrong rows.  Returns None, or the reason."""
+        t, W, r, dev = self.table, self.world, self.rank, self.table.device
+        ctrl = self._sdma["ctrl"]
+        ptr = ev = mine = src = None
+        peers, peer_ev = {}, {}
+        state = {"why": None}
+
+        def step(fn):                                    # a failure never skips a collective: it is recorded and carried along
+            if state["why"] is None:
+                try:
+                    fn()
+                except Exception as ex:                  # noqa: BLE001
+                    state["why"] = f"self-test: {ex!r}"
+
+        def everyone_ok() -> bool:
+            flags = [None] * W
+            dist.all_gather_object(flags, state["why"], group=self.group)
+            bad = [(q, w) for q, w in enumerate(flags) if w is not None]
+            if bad:                                      # the same verdict, worded alike, on every rank
+                state["why"] = f"rank {bad[0][0]}: {bad[0][1]}"
+            return not bad
+
+        def alloc():
+            nonlocal ptr, ev, mine, src
+            ptr, h_mem = t.ipc_alloc(4096)
+            ev, h_ev = t.ipc_event_create()
+            mine = t.ipc_tensor(ptr, 4096)
+            mine.zero_()
+            src = torch.zeros(64, dtype=torch.uint8, device=dev)
+            src[:8] = torch.tensor(list((0xC0DE0000 + r + 1).to_bytes(8, "little")), dtype=torch.uint8, device=dev)
+            mine[64 * r:64 * r + 64] = src
+            torch.cuda.synchronize(dev)
+            state["handles"] = (h_mem, h_ev)
+
+        step(alloc)
+        everyone = [None] * W
+        _trace("all_gather_object(sdma self-test handles)", self.group)
+        dist.all_gather_object(everyone, state.get("handles"), group=self.group)
+
+        def open_peers():
+            for q in range(W):
+                if q != r:
+                    if everyone[q] is None:
+                        raise RuntimeError(f"rank {q} exported no handles")
+                    peers[q] = t.ipc_open(everyone[q][0])
+                    peer_ev[q] = t.ipc_event_open(everyone[q][1])
+
+        step(open_peers)
+        if everyone_ok():                                # (the all-gather is also the rendezvous: every buffer is zeroed and mapped)
+            sabotage = os.environ.get("SCONE_SDMA_SELF_TEST_SKIP_PUSH_OF_RANK")      # test hook: that rank's bytes never arrive
+
+            def push():
+                for q in range(W):
+                    if q != r and sabotage != str(r):
+                        with torch.cuda.stream(self._sdma["push"][q]):
+                            t.ipc_push(peers[q] + 64 * r, src.data_ptr(), 64, self._sdma["copy_engine"])
+                        torch.cuda.current_stream().wait_stream(self._sdma["push"][q])
+                t.ipc_event_record(ev)
+
+            step(push)
+            dist.barrier(group=ctrl)                     # every "sent" is recorded before anyone waits for it
+
+            def check():
+                for q in range(W):
+                    if q != r:
+                        t.ipc_event_wait(peer_ev[q])
+                got = mine.clone().cpu()                 # (stream-ordered behind the waits)
+                for q in range(W):
+                    if bytes(got[64 * q:64 * q + 8].tolist()) != (0xC0DE0000 + q + 1).to_bytes(8, "little"):
+                        raise RuntimeError(f"the 64 bytes pushed by rank {q} did not arrive in rank {r}'s mapped buffer")
+
+            step(check)
+            everyone_ok()
+        try:
+            torch.cuda.synchronize(dev)
+        except Exception:                                # noqa: BLE001
+            pass
+        dist.barrier(group=ctrl)                         # nobody still pushes into, or waits on, what goes away
+        for q, p_ in peers.items():
+            try:
+                t.ipc_close(p_)
+            except Exception:                            # noqa: BLE001 -- cleaning up after a failed probe must not raise
+                pass
+        for e in list(peer_ev.values()) + ([ev] if ev is not None else []):
+            try:
+                t.ipc_event_destroy(e)
+            except Exception:                            # noqa: BLE001
+                pass
+        if ptr is not None:
+            try:
+                t.ipc_free(ptr)
+            except Exception:                            # noqa: BLE001
+                pass
+        return state["why"]
 
     def set_gather_transport(self, transport: str) -> str:
         """Switch the transport of the "gather_rows" exchange on an existing cache -- collective: every rank calls it with the

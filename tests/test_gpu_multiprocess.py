@@ -59,10 +59,16 @@ def _worker(rank, world, port, fmt, d, max_n, exchange, head, q):
         exchange, _, rest = exchange.partition(":")               # "gather_rows:all_gather" = the padded all-gather transport,
         transport, _, rest = rest.partition(":")                  # "...:sm" = the plan's match sharded over the ranks,
         sm, _, c1 = rest.partition(":")                           # "...:c1" = one piece (columns on the wire); else the legacy 4-chunk pipeline (records)
+        sabotaged = transport == "sdma_sabotaged"    # the transport's self-test finds rank 1's bytes missing: every rank must
+        if sabotaged:                                # fall back to p2p, say why, and still return the right rows
+            os.environ["SCONE_SDMA_SELF_TEST_SKIP_PUSH_OF_RANK"] = "1"
+            transport = "sdma"
         sh = ShardedEmbeddingCache(ex, d, table_format=fmt, rank=rank, world=world, replicated_rows=head,
                                    gather_transport=transport or "p2p", shard_match=True if sm == "sm" else "auto",
                                    gather_chunks=1 if c1 else 4)
-        if transport == "sdma":                      # the copy-engine transport must really be in use, not its fallback
+        if sabotaged:
+            assert sh.gather_transport == "p2p" and "did not arrive" in (sh.transport_fallback_reason or ""), sh.transport_fallback_reason
+        elif transport == "sdma":                    # the copy-engine transport must really be in use, not its fallback
             assert sh.gather_transport == "sdma" and sh.transport_fallback_reason is None, sh.transport_fallback_reason
         sh.load_rows(torch.from_numpy(table), 0)
         wte_d, wpe_d = torch.from_numpy(wte).half().cuda(), torch.from_numpy(wpe).half().cuda()
@@ -95,6 +101,7 @@ def _worker(rank, world, port, fmt, d, max_n, exchange, head, q):
                                                              ("int8", 768, 3, 3, "gather_rows:all_gather:sm:c1", 37),
                                                              ("int4", 1024, 3, 3, "gather_rows:sdma:sm:c1", 100),
                                                              ("int8", 768, 3, 2, "gather_rows:sdma::c1", 0),
+                                                             ("int8", 768, 3, 3, "gather_rows:sdma_sabotaged::c1", 0),
                                                              ("int8", 768, 3, 2, "partial_sums", 0)])
 def test_sharded_cache_across_processes_on_one_gpu(fmt, d, max_n, world, exchange, head):
     if not torch.cuda.is_available():

@@ -4,8 +4,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <new>
 #include <thread>
+#include <utility>
 #include <vector>
 
 // The message of a handle's last failure; written under a lock so that concurrent lookups cannot corrupt the string
@@ -329,6 +332,36 @@ fail:
   return rc;
 }
 
+// CU-masked streams are RETIRED, never destroyed: scone_lookup_stream hands them to the caller, and frameworks keep what they
+// are handed -- PyTorch's caching allocator remembers every stream a block was used on (Tensor.record_stream) and records an
+// event on each of them when the block is freed, which may be long after this handle dropped its reserve or was destroyed
+// (found as a segmentation fault in `del tok` at the end of the 2-rank bench rehearsal).  A retired stream is re-used by the
+// next scone_set_cu_reserve with the same device and reserve, so toggling a reserve does not accumulate streams.
+namespace {
+std::mutex g_retired_mu;
+std::map<std::pair<int, int>, std::vector<hipStream_t>> g_retired;  // (device, compute units enabled) -> idle masked streams
+
+void retire_masked_stream(int device, int enabled, hipStream_t s) {
+  std::lock_guard<std::mutex> g(g_retired_mu);
+  g_retired[{device, enabled}].push_back(s);
+}
+
+int masked_enabled_cus(const scone_handle *h, int n_reserved) {
+  if (const char *ev = getenv("SCONE_CU_RESERVE_DEBUG_FULL_MASK"))  // measurement aid: the stream hop without any masking
+    if (*ev == '1') return h->n_cus;
+  return h->n_cus - n_reserved;
+}
+
+hipStream_t take_retired_stream(int device, int enabled) {
+  std::lock_guard<std::mutex> g(g_retired_mu);
+  auto it = g_retired.find({device, enabled});
+  if (it == g_retired.end() || it->second.empty()) return nullptr;
+  hipStream_t s = it->second.back();
+  it->second.pop_back();
+  return s;
+}
+}  // namespace
+
 extern "C" void scone_destroy(scone_handle *h) {
   if (!h) return;
   scone_device_guard dev_guard__(h->device);  // e.g. a handle garbage-collected while another device is current
@@ -351,7 +384,10 @@ extern "C" void scone_destroy(scone_handle *h) {
   if (h->d_zero_row) (void)hipFree(h->d_zero_row);
   scone_stage_destroy(h);
   scone_shard_destroy(h);
-  if (h->lookup_stream) (void)hipStreamDestroy(h->lookup_stream);
+  if (h->lookup_stream) {  // retired, not destroyed (see scone_set_cu_reserve)
+    (void)hipStreamSynchronize(h->lookup_stream);
+    retire_masked_stream(h->device, masked_enabled_cus(h, h->cu_reserve), h->lookup_stream);
+  }
   if (h->lookup_in) (void)hipEventDestroy(h->lookup_in);
   if (h->lookup_out) (void)hipEventDestroy(h->lookup_out);
   if (h->prof_ev) {
@@ -415,7 +451,7 @@ extern "C" int scone_set_cu_reserve(scone_handle *h, int32_t n_reserved) {
   if (n_reserved == h->cu_reserve) return SCONE_OK;
   if (h->lookup_stream) {
     SCONE_HIP(h, hipStreamSynchronize(h->lookup_stream));
-    SCONE_HIP(h, hipStreamDestroy(h->lookup_stream));
+    retire_masked_stream(h->device, masked_enabled_cus(h, h->cu_reserve), h->lookup_stream);
     h->lookup_stream = nullptr;
   }
   h->cu_reserve = 0;
@@ -423,11 +459,12 @@ extern "C" int scone_set_cu_reserve(scone_handle *h, int32_t n_reserved) {
   uint32_t mask[32] = {};
   const int words = (h->n_cus + 31) / 32;
   if (words > 32) return scone_fail(h, SCONE_EINVAL, "scone_set_cu_reserve: more than 1024 compute units");
-  int enabled = h->n_cus - n_reserved;
-  if (const char *ev = getenv("SCONE_CU_RESERVE_DEBUG_FULL_MASK"))  // measurement aid: the stream hop without any masking
-    if (*ev == '1') enabled = h->n_cus;
-  for (int i = 0; i < enabled; ++i) mask[i >> 5] |= 1u << (i & 31);
-  SCONE_HIP(h, hipExtStreamCreateWithCUMask(&h->lookup_stream, (uint32_t)words, mask));
+  const int enabled = masked_enabled_cus(h, n_reserved);
+  h->lookup_stream = take_retired_stream(h->device, enabled);
+  if (!h->lookup_stream) {
+    for (int i = 0; i < enabled; ++i) mask[i >> 5] |= 1u << (i & 31);
+    SCONE_HIP(h, hipExtStreamCreateWithCUMask(&h->lookup_stream, (uint32_t)words, mask));
+  }
   if (!h->lookup_in) SCONE_HIP(h, hipEventCreateWithFlags(&h->lookup_in, hipEventDisableTiming));
   if (!h->lookup_out) SCONE_HIP(h, hipEventCreateWithFlags(&h->lookup_out, hipEventDisableTiming));
   h->cu_reserve = n_reserved;

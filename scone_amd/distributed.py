@@ -620,13 +620,29 @@ class ShardedEmbeddingCache:
         return _SdmaArrival(t, [st["peer_sent"][q][ev] for q in range(W) if q != r])
 
     def close(self) -> None:
-        """Release the interprocess buffers and events of the "sdma" transport (collective in spirit: call it on every rank
-        once the loop is over; peers must not push afterwards)."""
+        """Release the interprocess buffers and events of the "sdma" transport -- COLLECTIVE: every rank calls it once the loop is
+        over (two host barriers inside: what a rank has opened is closed everywhere before any owner frees it)."""
         if self._sdma is not None:
-            torch.cuda.synchronize(self.table.device)
-            for st in self._sdma["slots"]:
-                if st is not None:
-                    self._sdma_release_slot(st)
+            # collective: nobody frees a buffer a peer may still push into, or destroys an event a peer still waits for or has
+            # open -- first everything queued completes everywhere, then every rank lets go of what it OPENED, then of what it OWNS
+            ctrl, t = self._sdma["ctrl"], self.table
+            torch.cuda.synchronize(t.device)
+            dist.barrier(group=ctrl)
+            slots = [st for st in self._sdma["slots"] if st is not None]
+            for st in slots:
+                for q in range(self.world):
+                    if q != self.rank and st["peer"][q] is not None:
+                        for ptr in st["peer"][q]:
+                            if ptr:
+                                t.ipc_close(ptr)
+                        st["peer"][q] = None
+                    if q != self.rank and st["peer_sent"][q] is not None:
+                        for e in st["peer_sent"][q] + st["peer_done"][q]:
+                            t.ipc_event_destroy(e)
+                        st["peer_sent"][q] = st["peer_done"][q] = None
+            dist.barrier(group=ctrl)
+            for st in slots:
+                self._sdma_release_slot(st)
             self._sdma = None
 
     # ------------------------------------------------------------------

@@ -382,7 +382,8 @@ class SconeTable:
     def lookup_stream(self) -> Optional["torch.cuda.Stream"]:
         """The handle's CU-masked stream as a torch stream (None without a reserve): a loop queued on it -- ``with
         torch.cuda.stream(table.lookup_stream()):`` -- has its lookups launched there directly, without the two cross-stream
-        events of the transparent form.  Valid until the next :meth:`set_cu_reserve`."""
+        events of the transparent form.  The handle uses it until the next :meth:`set_cu_reserve`; the stream object itself is
+        never destroyed by the library (PyTorch's allocator keeps the streams a tensor was recorded on), only retired and re-used."""
         p = C.c_void_p()
         self._check(L.lib().scone_lookup_stream(self._h, C.byref(p)), "scone_lookup_stream")
         return torch.cuda.ExternalStream(p.value, device=self.device) if p.value else None

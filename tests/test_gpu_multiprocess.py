@@ -115,6 +115,8 @@ def test_sharded_cache_across_processes_on_one_gpu(fmt, d, max_n, world, exchang
     results = [q.get(timeout=300) for _ in procs]
     for p in procs:
         p.join(timeout=60)
+        if p.is_alive():                                # (a rank left waiting for a peer that failed)
+            p.terminate()
     for rank, same, err, shape, sl_shape in results:
         assert shape is not None, f"rank {rank} failed: {err}"
         assert shape == (5, 33, d)
@@ -201,6 +203,8 @@ def test_split_phase_gather_two_batches_in_flight_across_processes(fmt, d, max_n
     results = [q.get(timeout=300) for _ in procs]
     for p in procs:
         p.join(timeout=60)
+        if p.is_alive():                                # (a rank left waiting for a peer that failed)
+            p.terminate()
     for rank, same, err, shape, _ in results:
         assert shape is not None, f"rank {rank} failed: {err}"
         assert shape == (5, 33, d) and same, rank
@@ -282,6 +286,8 @@ def test_split_phase_soak_random_shapes_forms_and_slots(world, slots):
     results = [q.get(timeout=1100) for _ in procs]
     for p in procs:
         p.join(timeout=60)
+        if p.is_alive():                                # (a rank left waiting for a peer that failed)
+            p.terminate()
     for rank, bad, drift, status in results:
         assert isinstance(bad, list), f"rank {rank} failed: {bad}"
         assert bad == [] and status == 0, (rank, bad, status)
@@ -379,7 +385,7 @@ def test_bench_starts_its_own_ranks_when_no_launcher_did():
     if not torch.cuda.is_available():
         pytest.skip("needs an MI355X")
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
-    env.update(SCONE_DIST_BACKEND="gloo", SCONE_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.update(SCONE_DIST_BACKEND="gloo", SCONE_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONFAULTHANDLER="1")
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--rows", "200000",
            "--batch", "128", "--sharded-rows-per-rank", "200000", "--sharded-steps", "1", "--pinned-rows", "200000",
            "--cpu-seconds", "1"]
@@ -538,6 +544,8 @@ def test_sharded_exchanges_under_rccl_one_rank_per_gpu():
     results = [q.get(timeout=600) for _ in procs]
     for p in procs:
         p.join(timeout=60)
+        if p.is_alive():                                # (a rank left waiting for a peer that failed)
+            p.terminate()
     for rank, res, err in results:
         assert res is not None, f"rank {rank} failed: {err}"
         for fmt, exchange, same, e in res:

@@ -1536,7 +1536,7 @@ def test_sync_free_plan_and_pack_do_not_block_the_host_and_pack_the_same_rows():
         host_ms = (time.perf_counter() - t0) * 1e3
         still_running = not busy.query()
         torch.cuda.synchronize()
-        assert still_running and host_ms < 5.0, (still_running, host_ms)  # neither call waited for the device
+        assert still_running and host_ms < 12.0, (still_running, host_ms)  # neither call waited for the ~20 ms of device work
         hdr = fr1[cslots:].cpu().tolist()
         assert hdr == [n, int(n > cap)]
         ids1, r1, s1 = by_id(rows1, sc1, fr1[:cslots])

@@ -150,6 +150,16 @@ class _Works:
             w.wait()
 
 
+class _AfterEvent:
+    """``wait()``: the current stream waits for a (same-process) event."""
+
+    def __init__(self, event) -> None:
+        self.event = event
+
+    def wait(self) -> None:
+        torch.cuda.current_stream().wait_event(self.event)
+
+
 class _SdmaArrival:
     """``wait()``: the current stream waits until every peer's pushes into this slot are complete (their interprocess
     "sent" events; a host-side barrier after the records makes sure the wait sees THIS batch's record)."""
@@ -901,7 +911,8 @@ class ShardedEmbeddingCache:
         HDR = 2
         caps = list(self._caps)
         slots_r = [t.cols_frag_slots(c) for c in caps]
-        exact = self.gather_transport == "p2p"
+        sdma = self.gather_transport == "sdma" and self._sdma is not None
+        exact = self.gather_transport == "p2p" or sdma
         if not exact:                                    # all_gather_into_tensor: every region as large as the largest
             caps, slots_r = [max(caps)] * W, [max(slots_r)] * W
         rec_base = [sum(caps[:q]) for q in range(W)]
@@ -909,7 +920,11 @@ class ShardedEmbeddingCache:
         total, ftotal = sum(caps), sum(slots_r) + HDR * W
         pb, sb, nh = t.payload_bytes(), t.scale_bytes(), int(getattr(t, "n_head", 0) or 0)
         bufs = self._slot_cols[slot]
-        if bufs is None or bufs[0].shape[0] < total or bufs[2].numel() < ftotal or bufs[0].device != tok.device:
+        st = None
+        if sdma:                                         # peer-mapped receive buffers (every rank has the same capacities:
+            st = self._sdma_slot(slot, total, ftotal, tok.device)      # every rank re-allocates in the same step, rarely)
+            bufs = (st["rows"], st["scales"], st["frags"])
+        elif bufs is None or bufs[0].shape[0] < total or bufs[2].numel() < ftotal or bufs[0].device != tok.device:
             cap = total + total // 8
             rows = torch.empty((cap, pb), dtype=torch.uint8, device=tok.device)
             scales = torch.empty((nh + cap, sb), dtype=torch.uint8, device=tok.device) if sb else None
@@ -931,10 +946,14 @@ class ShardedEmbeddingCache:
             t.shard_cols_pack_cap(caps[r], rows[rec_base[r]:rec_base[r] + caps[r]],
                                   None if scales is None else scales[nh + rec_base[r]:nh + rec_base[r] + caps[r]],
                                   fr[:slots_r[r]], fr[slots_r[r]:])
-            works.append(_exchange_exact_async(rows[:total], rec_base + [total], caps, r, self.group))
-            if scales is not None:
-                works.append(_exchange_exact_async(scales[nh:nh + total], rec_base + [total], caps, r, self.group))
-            works.append(_exchange_exact_async(frags[:ftotal].view(-1, 1), frag_off + [ftotal], [s + HDR for s in slots_r], r, self.group))
+            if sdma:                                     # capacity-sized ranges (the count never comes to the host), header included
+                works.append(self._sdma_push(st, slot, [(0, rec_base[r] * pb, caps[r] * pb), (1, (nh + rec_base[r]) * sb, caps[r] * sb),
+                                                        (2, frag_off[r] * 8, (slots_r[r] + HDR) * 8)]))
+            else:
+                works.append(_exchange_exact_async(rows[:total], rec_base + [total], caps, r, self.group))
+                if scales is not None:
+                    works.append(_exchange_exact_async(scales[nh:nh + total], rec_base + [total], caps, r, self.group))
+                works.append(_exchange_exact_async(frags[:ftotal].view(-1, 1), frag_off + [ftotal], [s + HDR for s in slots_r], r, self.group))
         else:
             m, ms = caps[0], slots_r[0]
             s_rows = torch.empty((m, pb), dtype=torch.uint8, device=tok.device)
@@ -957,6 +976,10 @@ class ShardedEmbeddingCache:
             hs.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(hs):
                 works[-1].wait()                                      # (this stream waits; the host does not)
+                if sdma:                                              # an interprocess "sent" record is waited for ONCE: whoever
+                    arrived = torch.cuda.Event()                      # needs the columns later waits for this stream's event
+                    arrived.record(hs)
+                    works = [_AfterEvent(arrived)]
                 hdr = torch.empty(W * HDR, dtype=torch.int64).pin_memory()
                 hdr.copy_(frags.index_select(0, idx.to(tok.device, non_blocking=True)), non_blocking=True)
                 ev = torch.cuda.Event()
@@ -967,7 +990,7 @@ class ShardedEmbeddingCache:
             works = [_Done()]
             hdr, ev = frags.index_select(0, idx).clone(), None
         self.sync_free_stats["exchanges"] += 1
-        return {"slot": slot, "tok": tok, "C": 1, "per": B, "works": works, "ready": None, "t0": 0.0, "keep": keep, "sdma": None,
+        return {"slot": slot, "tok": tok, "C": 1, "per": B, "works": works, "ready": None, "t0": 0.0, "keep": keep, "sdma": st,
                 "hdr": (hdr, ev, caps),
                 "cols": {"rows": rows, "scales": scales, "frags": frags, "total": total, "frag_off": frag_off,
                          "frag_slots": slots_r, "rec_base": rec_base}}
@@ -980,7 +1003,8 @@ class ShardedEmbeddingCache:
         B, T = tok.shape
         W, t, r = self.world, self.table, self.rank
         if (not exact_only and self.sync_free_plan and self._caps is not None and W > 1 and self._prof is None
-                and self.gather_transport in ("p2p", "all_gather") and hasattr(t, "shard_cols_pack_cap")):
+                and (self.gather_transport in ("p2p", "all_gather") or (self.gather_transport == "sdma" and self._sdma is not None))
+                and hasattr(t, "shard_cols_pack_cap")):
             return self._gather_begin_cols_sync_free(tok, slot)
         self._plan_enter(slot, tok)
         n_me = self._plan(tok, slot, 1, True)[0]

@@ -21,6 +21,10 @@ def main():
     ap.add_argument("--rows", type=int, default=100_000_000)
     ap.add_argument("--mb-per-step", type=float, default=24.0)
     ap.add_argument("--pieces", type=int, default=4)
+    ap.add_argument("--kind", default="h2d", choices=["h2d", "d2d"], help="d2d: HBM -> HBM on this GPU by the copy engines "
+                    "(hipMemcpyAsync, hipMemcpyDeviceToDeviceNoCU, through scone_ipc_push) on --streams streams: what the sdma "
+                    "transport of the sharded step does to the memory system, minus the links")
+    ap.add_argument("--streams", type=int, default=14)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--rounds", type=int, default=3)
     a = ap.parse_args()
@@ -36,31 +40,42 @@ def main():
     src = torch.empty(piece * a.pieces, dtype=torch.uint8).pin_memory()
     dst = torch.empty(piece * a.pieces, dtype=torch.uint8, device="cuda")
     side = torch.cuda.Stream()
+    sides = [torch.cuda.Stream() for _ in range(a.streams)]
+    dsrc = torch.empty(piece * a.pieces, dtype=torch.uint8, device="cuda") if a.kind == "d2d" else None
     cache.table.reserve(B * T)
     for t in toks[:3]:
         cache.embed_tokens(t, wte=wte, wpe=wpe, out=out)
     torch.cuda.synchronize()
+
+    res = {"alone_ms": [], "with_copies_ms": []}
 
     def run(copies):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(a.steps):
             cache.embed_tokens(toks[i], wte=wte, wpe=wpe, out=out)
-            if copies:
+            if copies and a.kind == "d2d":                    # free-running: the engines are busy for the whole loop
+                for k in range(a.pieces):
+                    with torch.cuda.stream(sides[k % len(sides)]):
+                        cache.table.ipc_push(dst.data_ptr() + k * piece, dsrc.data_ptr() + k * piece, piece, True)
+            elif copies:
                 ev = torch.cuda.Event()
                 ev.record()                                   # the copies of step i start when lookup i - 1 is done: beside lookup i
                 side.wait_event(ev)
                 with torch.cuda.stream(side):
                     for k in range(a.pieces):
                         dst[k * piece:(k + 1) * piece].copy_(src[k * piece:(k + 1) * piece], non_blocking=True)
+        cur = torch.cuda.current_stream()
+        cur.synchronize()                                     # the LOOKUPS' time; the copies may still be draining
+        dt = (time.perf_counter() - t0) / a.steps * 1e3
         torch.cuda.synchronize()
-        return (time.perf_counter() - t0) / a.steps * 1e3
+        res.setdefault("copies_drained_after_ms", []).append((time.perf_counter() - t0) * 1e3 if copies else 0.0)
+        return dt
 
-    res = {"alone_ms": [], "with_copies_ms": []}
     for _ in range(a.rounds):
         res["alone_ms"].append(run(False))
         res["with_copies_ms"].append(run(True))
-    res.update(mb_per_step=a.mb_per_step, pieces=a.pieces, steps=a.steps, rows=N)
+    res.update(kind=a.kind, mb_per_step=a.mb_per_step, pieces=a.pieces, steps=a.steps, rows=N, streams=a.streams)
     print(json.dumps(res))
 
 

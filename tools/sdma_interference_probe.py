@@ -25,6 +25,9 @@ def main():
                     "(hipMemcpyAsync, hipMemcpyDeviceToDeviceNoCU, through scone_ipc_push) on --streams streams: what the sdma "
                     "transport of the sharded step does to the memory system, minus the links")
     ap.add_argument("--streams", type=int, default=14)
+    ap.add_argument("--src-mb", type=float, default=0.0, help="d2d: every piece reads from the SAME region of this many MB (it "
+                    "stays in the Infinity Cache): the HBM traffic is then the writes alone -- what a rank's HBM sees of an "
+                    "exchange whose incoming bytes are written by the peers' engines and whose 7 outgoing pushes re-read one buffer")
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--rounds", type=int, default=3)
     a = ap.parse_args()
@@ -42,6 +45,7 @@ def main():
     side = torch.cuda.Stream()
     sides = [torch.cuda.Stream() for _ in range(a.streams)]
     dsrc = torch.empty(piece * a.pieces, dtype=torch.uint8, device="cuda") if a.kind == "d2d" else None
+    src_span = max(int(a.src_mb * 1e6), piece) if a.src_mb else piece * a.pieces
     cache.table.reserve(B * T)
     for t in toks[:3]:
         cache.embed_tokens(t, wte=wte, wpe=wpe, out=out)
@@ -57,7 +61,8 @@ def main():
             if copies and a.kind == "d2d":                    # free-running: the engines are busy for the whole loop
                 for k in range(a.pieces):
                     with torch.cuda.stream(sides[k % len(sides)]):
-                        cache.table.ipc_push(dst.data_ptr() + k * piece, dsrc.data_ptr() + k * piece, piece, True)
+                        so = (k * piece) % max(src_span - piece + 1, 1) if a.src_mb else k * piece
+                        cache.table.ipc_push(dst.data_ptr() + k * piece, dsrc.data_ptr() + so, piece, True)
             elif copies:
                 ev = torch.cuda.Event()
                 ev.record()                                   # the copies of step i start when lookup i - 1 is done: beside lookup i
@@ -75,7 +80,7 @@ def main():
     for _ in range(a.rounds):
         res["alone_ms"].append(run(False))
         res["with_copies_ms"].append(run(True))
-    res.update(kind=a.kind, mb_per_step=a.mb_per_step, pieces=a.pieces, steps=a.steps, rows=N, streams=a.streams)
+    res.update(kind=a.kind, mb_per_step=a.mb_per_step, pieces=a.pieces, steps=a.steps, rows=N, streams=a.streams, src_mb=a.src_mb)
     print(json.dumps(res))
 
 

@@ -936,60 +936,83 @@ __global__ __launch_bounds__(256) void k_cols_remap(int32_t *__restrict__ ell, l
   __syncthreads();
   const long long per = (ntok + gridDim.x - 1) / gridDim.x;
   const long long t0 = (long long)blockIdx.x * per, t1 = t0 + per < ntok ? t0 + per : ntok;
-  for (long long t = t0 + threadIdx.x; t < t1; t += blockDim.x) {
-    int32_t r8[8];
-    if (W == 8) {
-      const int4 a = reinterpret_cast<const int4 *>(ell + t * 8)[0], b = reinterpret_cast<const int4 *>(ell + t * 8)[1];
-      r8[0] = a.x, r8[1] = a.y, r8[2] = a.z, r8[3] = a.w, r8[4] = b.x, r8[5] = b.y, r8[6] = b.z, r8[7] = b.w;
+  // one probe of one id: owner, fragment, home slot (the first load of every id of a token is issued before any is looked at)
+  auto home = [&](long long id, const unsigned long long *&f, unsigned long long &mask, unsigned long long &s, int &r) {
+    r = (int)((float)id * ow.owners_per_row);
+    r = r < world - 1 ? r : world - 1;
+    while (r > 0 && (unsigned int)id < ow.row_lo[r]) --r;
+    while (r < world - 1 && (unsigned int)id >= ow.row_lo[r + 1]) ++r;
+    mask = ow.frag_mask[r];
+    f = frags + ow.frag_off[r];
+    s = scone_hash_key((unsigned long long)id + 1ull, 0u) & mask;
+  };
+  auto resolve = [&](long long id, const unsigned long long *f, unsigned long long mask, unsigned long long s, int r,
+                     unsigned long long v) -> long long {  // v = f[s] already loaded; continues the linear probe if it must
+    const unsigned long long key = (unsigned long long)id + 1ull;
+    for (unsigned long long probe = 0; probe <= mask; ++probe) {
+      if (v == 0ull) return -1;
+      if ((v >> 32) == key) return (long long)(ow.rec_base[r] + (v & 0xFFFFFFFFull));
+      s = (s + 1ull) & mask;
+      v = f[s];
     }
-    const int kown = (W == 8 ? r8[6] : ell[t * W + W - 2]) & 0xFF;
-    bool dirty = false;
+    return -1;
+  };
+  for (long long t = t0 + threadIdx.x; t < t1; t += blockDim.x) {
+    if (W == 8) {  // max_n <= 3: the record in registers, the home slots of all its cold ids in flight together
+      const int4 a = reinterpret_cast<const int4 *>(ell + t * 8)[0], b = reinterpret_cast<const int4 *>(ell + t * 8)[1];
+      int32_t r8[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+      const int kown = r8[6] & 0xFF;
+      const unsigned long long *f[6];
+      unsigned long long mask[6], s[6], v[6];
+      int r[6];
+      bool cold[6];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        const long long id = r8[j];
+        cold[j] = j < kown && j < NC && id >= n_head;
+        v[j] = 0ull;
+        if (cold[j] && id < n_rows) {
+          home(id, f[j], mask[j], s[j], r[j]);
+          v[j] = f[j][s[j]];
+        }
+      }
+      bool dirty = false;
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        if (!cold[j]) continue;
+        const long long id = r8[j];
+        long long slot = id < n_rows ? resolve(id, f[j], mask[j], s[j], r[j], v[j]) : -1;
+        if (slot < 0 || (unsigned long long)slot >= n_total) {  // the row did not arrive / a corrupt fragment: report, stay in bounds
+          atomicOr(status, SCONE_ST_BAD_ID);
+          slot = 0;
+        }
+        r8[j] = (int32_t)(n_head + slot);
+        dirty = true;
+      }
+      if (dirty) {
+        reinterpret_cast<int4 *>(ell + t * 8)[0] = make_int4(r8[0], r8[1], r8[2], r8[3]);
+        reinterpret_cast<int4 *>(ell + t * 8)[1] = make_int4(r8[4], r8[5], r8[6], r8[7]);
+      }
+      continue;
+    }
+    const int kown = ell[t * W + W - 2] & 0xFF;
     for (int j = 0; j < NC; ++j) {
       if (j >= kown) break;
-      long long id;
-      if (W == 8) {
-        id = r8[0];
-#pragma unroll
-        for (int q = 1; q < 6; ++q) id = j == q ? r8[q] : id;
-      } else {
-        id = ell[t * W + j];
-      }
+      const long long id = ell[t * W + j];
       if (id < n_head) continue;  // a head row: its id is its row number in the lookup's row store
       long long slot = -1;
       if (id < n_rows) {
-        int r = (int)((float)id * ow.owners_per_row);
-        r = r < world - 1 ? r : world - 1;
-        while (r > 0 && (unsigned int)id < ow.row_lo[r]) --r;
-        while (r < world - 1 && (unsigned int)id >= ow.row_lo[r + 1]) ++r;
-        const unsigned long long key = (unsigned long long)id + 1ull, mask = ow.frag_mask[r];
-        const unsigned long long *f = frags + ow.frag_off[r];
-        unsigned long long s = scone_hash_key(key, 0u) & mask;
-        for (unsigned long long probe = 0; probe <= mask; ++probe) {
-          const unsigned long long v = f[s];
-          if (v == 0ull) break;
-          if ((v >> 32) == key) {
-            slot = (long long)(ow.rec_base[r] + (v & 0xFFFFFFFFull));
-            break;
-          }
-          s = (s + 1ull) & mask;
-        }
+        const unsigned long long *f;
+        unsigned long long mask, s;
+        int r;
+        home(id, f, mask, s, r);
+        slot = resolve(id, f, mask, s, r, f[s]);
       }
-      if (slot < 0 || (unsigned long long)slot >= n_total) {  // the row did not arrive / a corrupt fragment: report, stay in bounds
+      if (slot < 0 || (unsigned long long)slot >= n_total) {
         atomicOr(status, SCONE_ST_BAD_ID);
         slot = 0;
       }
-      if (W == 8) {
-#pragma unroll
-        for (int q = 0; q < 6; ++q)
-          if (j == q) r8[q] = (int32_t)(n_head + slot);
-        dirty = true;
-      } else {
-        ell[t * W + j] = (int32_t)(n_head + slot);
-      }
-    }
-    if (W == 8 && dirty) {
-      reinterpret_cast<int4 *>(ell + t * 8)[0] = make_int4(r8[0], r8[1], r8[2], r8[3]);
-      reinterpret_cast<int4 *>(ell + t * 8)[1] = make_int4(r8[4], r8[5], r8[6], r8[7]);
+      ell[t * W + j] = (int32_t)(n_head + slot);
     }
   }
 }

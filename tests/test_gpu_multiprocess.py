@@ -443,6 +443,11 @@ def _rccl_world1_worker(port, q):
         dist.all_reduce(t64, op=dist.ReduceOp.MAX)
         dist.all_reduce(t64, op=dist.ReduceOp.MIN)
         assert float(t64.item()) == 1.5; done.append("all_reduce float64 MAX / MIN")
+        objs = [None]                                                               # the sdma transport's host side: handles travel as
+        dist.all_gather_object(objs, (b"\0" * 64, [b"\1" * 64] * 4, None))          # pickled objects over the group ...
+        assert objs[0][1][3] == b"\1" * 64
+        ctrl = dist.new_group(ranks=[0], backend="gloo")                            # ... and its rendezvous on a gloo group beside it
+        dist.barrier(group=ctrl); done.append("all_gather_object + a gloo group beside the RCCL one")
         dist.barrier()
         torch.cuda.synchronize()
         q.put((done, None))
@@ -466,7 +471,7 @@ def test_rccl_accepts_every_collective_of_the_sharded_path_world1():
     done, err = q.get(timeout=300)
     p.join(timeout=60)
     assert done is not None, err
-    assert len(done) == 8, done
+    assert len(done) == 9, done
 
 
 def test_bench_runs_under_rccl_with_one_rank():
@@ -519,6 +524,18 @@ def _nccl_worker(rank, world, port, q):
                 got = sh.gather_rows_finish(tk, wte=wte_d, wpe=wpe_d)
                 tk = sh.gather_rows_begin(torch.from_numpy(tok)) if i < 2 else None
                 res.append((fmt, f"gather_rows split-phase step {i}", bool(torch.equal(got, ref)), 0.0))
+            # the copy-engine transport ACROSS devices (the one thing the one-GPU tests cannot show): self-test at set-up, then the
+            # same loop; a fallback (reason kept in the result) still has to give the right rows
+            sh.gather_chunks = 1
+            used = sh.set_gather_transport("sdma")
+            tk = sh.gather_rows_begin(torch.from_numpy(tok))
+            for i in range(40):                                                  # past the 32 records of one interprocess event
+                got = sh.gather_rows_finish(tk, wte=wte_d, wpe=wpe_d)
+                tk = sh.gather_rows_begin(torch.from_numpy(tok)) if i < 39 else None
+                if i in (0, 1, 39) or not torch.equal(got, ref):
+                    res.append((fmt, f"gather_rows sdma ({used}; {sh.transport_fallback_reason}) step {i}", bool(torch.equal(got, ref)), 0.0))
+            dist.barrier()
+            sh.close()
         q.put((rank, res, None))
         dist.barrier()
         dist.destroy_process_group()

@@ -1080,7 +1080,9 @@ def sharded_record(args, dist, rank, world, backend, sync, rec, line, watchdog, 
         rec["n1_baseline"] = ("`n1_pinned_host` of THIS record (rank 0, same process, before the exchanges): one GPU cannot hold the "
                               "table, so its rows sit in pinned host DRAM and cross PCIe; '>= 4x at 8 GPUs vs 1 GPU' = "
                               "exchanges.<name>.speedup_vs_n1_pinned_host")
-    cache.close()
+    watchdog.arm("sharded.close", min(45.0, max(budget.remaining() - 5.0, 5.0)))   # collective (two host barriers): a rank that
+    cache.close()                                                                  # never arrives must not cost the rest of the budget
+    watchdog.disarm()
     del cache, tok, wte, wpe
     torch.cuda.empty_cache()
     return rec

@@ -595,7 +595,7 @@ class ShardedEmbeddingCache:
         self._sdma["slots"][slot] = st
         return st
 
-    def _sdma_push(self, st, slot: int, regions) -> "_SdmaArrival":
+    def _sdma_push(self, st, slot: int, regions, rendezvous: bool = False) -> "_SdmaArrival":
         """``regions``: [(column index, byte offset, bytes)] of this rank's freshly packed range.  Waits (stream-ordered) until
         every peer has reduced the batch that used this slot before, pushes the ranges to the same offsets of every peer's
         buffers -- one stream per peer, so that the copy engines drive all links at once --, records "sent", and rendezvous
@@ -605,9 +605,16 @@ class ShardedEmbeddingCache:
             self._sdma_renew_events(st, slot)
         cur = torch.cuda.current_stream()
         if st["used"]:
+            # A wait sees the most recent record AT THE TIME OF THE CALL: every peer must have CALLED the finish of this slot's
+            # previous batch (which records "reduced") before anyone waits for it.  The exact form's count exchange proves that
+            # (a peer enters it only after that finish); the sync-free form has no such collective in front, so it asks for a
+            # host barrier here -- without it a peer whose host runs behind is overwritten before it has reduced (found by the
+            # 100,000-step soak: 2 batches in 11,000 with a row missing).
+            if rendezvous:
+                dist.barrier(group=self._sdma["ctrl"])
             for q in range(W):
                 if q != r:
-                    t.ipc_event_wait(st["peer_done"][q][st["cur_ev"]])   # (recorded before the peer entered this step's count exchange)
+                    t.ipc_event_wait(st["peer_done"][q][st["cur_ev"]])
         ev = st["uses"] // self._sdma_event_records
         packed = torch.cuda.Event()
         packed.record(cur)
@@ -948,7 +955,7 @@ class ShardedEmbeddingCache:
                                   fr[:slots_r[r]], fr[slots_r[r]:])
             if sdma:                                     # capacity-sized ranges (the count never comes to the host), header included
                 works.append(self._sdma_push(st, slot, [(0, rec_base[r] * pb, caps[r] * pb), (1, (nh + rec_base[r]) * sb, caps[r] * sb),
-                                                        (2, frag_off[r] * 8, (slots_r[r] + HDR) * 8)]))
+                                                        (2, frag_off[r] * 8, (slots_r[r] + HDR) * 8)], rendezvous=True))
             else:
                 works.append(_exchange_exact_async(rows[:total], rec_base + [total], caps, r, self.group))
                 if scales is not None:

@@ -225,7 +225,7 @@ def _worker_soak(rank, world, port, slots, q):
         sh.load_rows(torch.from_numpy(table), 0)
         full = EmbeddingCache(ex, d, table_format=fmt)
         full.cache_embeddings(list(range(len(lens))), torch.from_numpy(table), verbose=False)
-        rng = np.random.default_rng(2026)                              # the same choices on every rank
+        rng = np.random.default_rng(int(os.environ.get("SCONE_SOAK_SEED", "2026")))   # the same choices on every rank
         wte_d = torch.from_numpy(wte).half().cuda()
         wpe_d = torch.from_numpy(np.tile(wpe, (3, 1))[:80]).half().cuda()
         n, bad, tickets, batches = int(os.environ.get("SCONE_SOAK_STEPS", "60")), [], [], []

@@ -1970,13 +1970,14 @@ def test_one_handle_from_two_host_threads():
     assert not errors, errors[:3]
 
 
-@pytest.mark.parametrize("shared_stream", [False, True])
-def test_one_handle_large_batches_from_host_threads(shared_stream):
+@pytest.mark.parametrize("shared_stream,reserve", [(False, 0), (True, 0), (False, 16)], ids=["own_streams", "one_stream", "own_streams_cu_reserve"])
+def test_one_handle_large_batches_from_host_threads(shared_stream, reserve):
     """SURVEY 8b "lookups are thread-safe and stream-ordered" for batches ABOVE the one-launch limit: 64k-token batches
     use a workspace (per-token id records) that belongs to the stream of the call and is locked while the match that
     writes it and the lookup that reads it are enqueued.  Three host threads -- each on its own stream, or all on ONE
     stream -- run scone_embed (two batch shapes) and scone_match_csr on one handle; every result equals the
-    single-threaded answer."""
+    single-threaded answer.  Round 4, `reserve`: with a CU reserve set the lookups of all three threads hop to the handle's one
+    masked stream between two events (scone_lookup_enter / _leave hold the handle's lock across the hop): same results."""
     import threading
     rng = np.random.default_rng(32)
     vocab, n, d = 61, 4000, 768
@@ -1991,6 +1992,9 @@ def test_one_handle_large_batches_from_host_threads(shared_stream):
     want = [cache.embed_tokens(t, wte=wte, wpe=wpe).clone() for t in toks]
     want_csr = [tuple(x.clone() for x in cache.table.match_csr(t)) for t in toks]
     torch.cuda.synchronize()
+    if reserve:
+        cache.table.set_cu_reserve(reserve)
+        assert cache.table.cu_reserve()[0] == reserve
     errors = []
     one = torch.cuda.Stream()
 

@@ -51,8 +51,10 @@ here and only needed when the table does not fit one GPU's 288 GB (BASELINE conf
   stream per peer (the copy engines move the bytes over xGMI while every wave slot of the chip belongs to the lookup kernel;
   RCCL's send / recv are kernels that must find room beside it), "my pushes for this slot are complete" / "I have reduced this
   slot" are interprocess events, and the two host-side rendezvous a step needs anyway -- the exchange of the counts and one
-  barrier on a gloo group -- make sure a wait never sees the previous batch's record.  Falls back to ``"p2p"`` (on every rank
-  alike) when the handles cannot be created or opened;
+  barrier on a gloo group -- make sure a wait never sees the previous batch's record (the sync-free form has a second
+  barrier where the count exchange was).  Interprocess events come from a per-slot pool (a HIP interprocess event survives 32
+  records); a collective self-test (pattern push, event, verify) runs before first use.  Falls back to ``"p2p"`` (on every rank
+  alike) when the handles cannot be created or opened or the self-test's bytes do not arrive; ``close()`` is collective;
 * ``SCONE_DIST_TRACE=1``: one stderr line BEFORE every collective (name, counts, bytes) -- the last line of a hung job names
   the collective it hangs in;
 * exchange ``"partial_sums"`` (kept for comparison): every rank sums the rows it owns

@@ -60,6 +60,7 @@ if ROOT not in sys.path:
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 HBM_PEAK_GBPS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+PCIE_PEAK_GBPS = 64.0       # PCIe Gen5 x16, one direction
 # xGMI: 7 links per GPU, ~153.6 GB/s each counting both directions (task statement / DESIGN section 6) = 76.8 GB/s into a
 # GPU per link; a rank receives over min(W - 1, 7) links at once on the fully connected node
 XGMI_LINK_GBPS_PER_DIRECTION = 76.8
@@ -85,9 +86,17 @@ def parse(argv=None):
     ap.add_argument("--pinned-stage-tokens", type=int, default=262144, help="n1_pinned_host_zipf: tokens per chunk of the prefetch pipeline")
     ap.add_argument("--pinned-zipf-steps", type=int, default=20)
     ap.add_argument("--pinned-zipf-warmup", type=int, default=400, help="n1_pinned_host_zipf: batches that warm the cache before the timed steps")
-    ap.add_argument("--keygen", default="zipf", choices=["zipf", "structured"],
-                    help="vocabulary generator: seeded Zipf n-grams with de-duplication (default) or the "
+    ap.add_argument("--keygen", default="zipf", choices=["zipf", "zipf_gpu", "structured"],
+                    help="vocabulary generator: seeded Zipf n-grams with de-duplication on the host (default), the same law "
+                         "drawn and de-duplicated on the GPU (seconds instead of minutes at 1e7 rows: config C3), or the "
                          "distinct-by-construction generator for >= 1e8 rows")
+    ap.add_argument("--same-batch", action="store_true", help="re-use ONE batch for every step (rounds 1-4; the Infinity Cache "
+                    "then carries rows from step to step).  Default: a different batch every step")
+    ap.add_argument("--prefetch", default="auto", choices=["auto", "on", "off"],
+                    help="scone_embed_prefetch of batch i + 1 right after the lookup of batch i (the serving loop: the next "
+                         "batch's match runs beside this batch's gather).  auto = on")
+    ap.add_argument("--no-configs", action="store_true", help="skip the `configs` block (BASELINE configs C2, C3, C4-in-HBM)")
+    ap.add_argument("--configs-steps", type=int, default=15)
     ap.add_argument("--placement", default="hbm", choices=["hbm", "pinned_host"])
     ap.add_argument("--hot-rows", type=int, default=0, help="pinned_host: leading rows kept in HBM")
     ap.add_argument("--stage-tokens", type=int, default=0, help="pinned_host: staged prefetch chunk size (0 = zero-copy)")
@@ -125,7 +134,7 @@ def parse(argv=None):
     ap.add_argument("--selftest", default="", choices=["", "hang", "ok"], help=argparse.SUPPRESS)   # CPU rehearsal of the watchdog
     a = ap.parse_args(argv)
     if a.quick:
-        a.no_cpu_baseline = a.no_hbm_variant = a.no_sharded_record = True
+        a.no_cpu_baseline = a.no_hbm_variant = a.no_sharded_record = a.no_configs = True
     return a
 
 
@@ -340,13 +349,27 @@ def kernel_source_files():
     return [os.path.join(d, f) for f in sorted(seen)] + [os.path.join(d, "Makefile")]
 
 
+def _code_only(path: str) -> bytes:
+    """The file without comments and without blank space: what the compiler sees.  (Round 5: documentation edits in the
+    public header or in a kernel's comments no longer void the committed counter passes; any change of code does.)"""
+    text = open(path, errors="ignore").read()
+    if os.path.basename(path) == "Makefile":
+        text = re.sub(r"(?m)^\s*#.*$", "", text)
+    else:
+        # string and character literals are kept as they are; // and /* */ comments go
+        text = re.sub(r'("(?:\\.|[^"\\\n])*"|\'(?:\\.|[^\'\\\n])*\')|//[^\n]*|/\*.*?\*/',
+                      lambda m: m.group(1) or " ", text, flags=re.S)
+    return " ".join(text.split()).encode()
+
+
 def kernel_source_sha() -> str:
-    """Hash of the timed kernel's sources: a committed PMC traffic figure is only quoted for the code it was measured on."""
+    """Hash of the timed kernel's sources (code only, see _code_only): a committed PMC traffic figure is only quoted for the
+    code it was measured on."""
     h = hashlib.sha256()
     for p in kernel_source_files():
         if os.path.exists(p):
             h.update(os.path.basename(p).encode())
-            h.update(open(p, "rb").read())
+            h.update(_code_only(p))
     return h.hexdigest()[:16]
 
 
@@ -394,8 +417,9 @@ def cpu_baseline(args, keys, lens, tok, seed, base_scale, gpu_out, wte, wpe, sec
     `all_cores=False` (N > 1 lines): the 1-core figure and the check only."""
     import numpy as np
     import torch
-    if keys.shape[0] > 20_000_000:
-        raise RuntimeError("cpu baseline skipped: a Python dict of > 2e7 f-grams does not fit the time budget")
+    if keys is None or keys.shape[0] > 20_000_000:
+        raise RuntimeError("cpu baseline skipped: a Python dict of > 2e7 f-grams (or of a structured vocabulary without host "
+                           "key arrays) does not fit the time budget")
     from oracle import ref_port as R
     torch.set_num_threads(1)
     d = args.dim
@@ -550,40 +574,198 @@ def kernel_stats(samples, per_step):
     return {"min": float(s.min()), "median": float(np.median(s)), "max": float(s.max()), "n": int(s.size)}
 
 
-def hbm_variant(args, wte, wpe, sync):
-    """The headline's format and dim on a workload that defeats the caches: 10M rows (7.7 GB of INT8 d = 768 rows -- 30x
-    the Infinity Cache), structured vocabulary (token ids uniform over the 50,257-word vocabulary, one bigram / trigram
-    row per window, each referenced by the 2-3 adjacent tokens it covers and by nothing else in the launch)."""
+MAX_DISTINCT_BATCHES = 64       # steps beyond this cycle through the batches: 64 x 0.35 GB of rows is 90x the Infinity Cache
+
+
+def make_vocabulary(n_rows, keygen, max_n=3):
+    """(vocabulary object for EmbeddingCache.from_synthetic, host keys, host lens) -- host arrays None for `structured`."""
+    from scone_amd import NGramExtractor
+    from scone_amd import synthetic as S
+    if keygen == "structured":
+        return S.StructuredVocab(n_rows), None, None
+    keys, lens = (S.make_keys if keygen == "zipf" else S.make_keys_torch)(n_rows, S.GPT2_VOCAB, max_n, seed=11)
+    return NGramExtractor.from_arrays(keys, lens, max_n=max_n), keys, lens
+
+
+def make_batches(vocab_obj, keys, lens, stream, B, T, seed, n):
+    """`n` DIFFERENT batches of the named stream (same generator, seeds seed, seed + 7919, ...): host arrays of the first one
+    (the oracle checks it) and int32 device tensors of all.  S_uniform: f-grams with ids uniform over the table laid end to
+    end; S_zipf: iid Zipf(1.1) tokens."""
+    import torch
+    from scone_amd import synthetic as S
+    out, first = [], None
+    for i in range(n):
+        sd = seed + 7919 * i
+        if stream == "uniform":
+            t = S.stream_uniform_ids(vocab_obj if keys is None else keys, lens, B, T, sd)
+        else:
+            t = S.stream_zipf(S.GPT2_VOCAB, B, T, sd)
+        if first is None:
+            first = t
+        out.append(torch.from_numpy(t).to("cuda", torch.int32))
+    return first, out
+
+
+def lookup_loop(cache, batches, wte, wpe, out, steps, warmup, sync, prefetch):
+    """The serving loop: step k looks up batches[k % n] and -- `prefetch` -- announces batches[(k + 1) % n] right behind it
+    (scone_embed_prefetch, tokens_ready: every batch was generated up front), so that the next step's match runs on the
+    handle's side stream beside this step's gather.  W untimed + K timed steps; exactly K matches and K gathers are inside
+    the timed region (the first timed batch was announced by the last warm-up step; the last timed step announces a batch
+    that is looked up after the region, or never).  Returns measure_lookup's tuple."""
+    n = len(batches)
+    k = [0]
+
+    def step():
+        i = k[0]
+        k[0] += 1
+        cache.embed_tokens(batches[i % n], wte=wte, wpe=wpe, out=out)
+        if prefetch:
+            cache.prefetch_tokens(batches[(i + 1) % n], tokens_ready=True)
+    return measure_lookup(cache.table, step, batches[0], batches[0].numel(), steps, warmup, sync)
+
+
+def roofline_block(sig, alg, comp, step_kernel_ms, samples, per_step, n_launch, in_hbm=True, kernel=None):
+    """The `roofline` object of one workload.  `frac` = achieved / peak is PHYSICAL: bytes of the launch that crossed the
+    L2 <-> fabric boundary (rocprofv3 PMC passes of this kernel source and this workload signature) -- or, without such an
+    entry, the compulsory bytes -- over the HIP-event kernel time; it cannot exceed 1.  SURVEY 8d's figure (every row
+    REFERENCE counted; cache reuse can carry it past the peak) is `algorithmic_frac`; `hbm_frac` prices the compulsory bytes
+    (every distinct row once + output + ids: a lower bound on what HBM moves)."""
+    tr, stale = read_traffic(sig)
+    traffic = None if (tr is None or stale) else tr.get("hbm_bytes_per_launch")
+    per_s = step_kernel_ms * 1e-3
+    if traffic is not None:
+        phys_bytes, phys_kind = traffic, ("bytes that left L2 per launch (2 x FETCH_SIZE + WRITE_SIZE, rocprofv3 PMC passes of this "
+                                          "kernel source: an upper bound on HBM bytes, Infinity-Cache hits included)")
+    else:
+        phys_bytes, phys_kind = comp, ("compulsory bytes per launch (every distinct table row and wte row once + output + "
+                                       "ids: a lower bound on HBM bytes; no PMC entry for this workload and kernel source)")
+    achieved = phys_bytes / per_s / 1e9
+    return {
+        "bound": "hbm",
+        "limited_by": None if in_hbm else "PCIe Gen5 x16 (~63 GB/s): the table's rows live in pinned host DRAM",
+        "kernel": kernel or "scone_gather::k_embed_wave (gather+dequant+reduce+combine), HIP-event timed",
+        "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+        "frac_kind": phys_kind + f" / avg_kernel_ms ({step_kernel_ms:.4f} ms, HIP events) / 8 TB/s",
+        "frac_bytes": phys_bytes,
+        "algorithmic_bytes_per_launch": alg, "algorithmic_GBps": alg / per_s / 1e9,
+        "algorithmic_frac": alg / per_s / 1e9 / HBM_PEAK_GBPS,
+        "avg_kernel_ms": step_kernel_ms,
+        "kernel_ms": kernel_stats(samples, per_step), "timed_launches": n_launch, "launches_per_step": per_step,
+        "hbm_bytes_compulsory": comp if in_hbm else None,
+        "hbm_frac": comp / per_s / 1e9 / HBM_PEAK_GBPS if in_hbm else None,
+        "traffic": traffic,
+        "traffic_source": None if tr is None else tr.get("source"),
+        "traffic_stale": bool(stale),
+        "traffic_GBps": None if traffic is None else traffic / per_s / 1e9,
+        "traffic_frac": None if traffic is None else traffic / per_s / 1e9 / HBM_PEAK_GBPS,
+        "kernel_source_sha": kernel_source_sha(),
+    }
+
+
+def workload_sig(fmt, d, N, B, T, stream, placement="hbm", keygen="zipf", rotated=True, extra=""):
+    return (f"{fmt}-d{d}-N{N}-B{B}-T{T}-{stream}-{placement}" + extra
+            + {"zipf": "", "zipf_gpu": "-zipfgpu", "structured": "-structured"}[keygen] + ("-rot" if rotated else ""))
+
+
+def cpu_baseline_spot_check(n_rows, keys, lens, tok_np, gpu_out, fmt, d, seed, base_scale, wte, wpe, n_pick=8):
+    """The checker half of the cpu_baseline leg for the `configs` block: the GPU output of `n_pick` sequences drawn from the
+    whole batch (the last one always among them) against the numpy oracle (oracle/ref_port.py: match_hits -> hits_to_csr ->
+    embed_numpy -> combine = n_gram_extractor.py:106-126, embedding_cache.py:113-181, engine.py:234-266,
+    language_model.py:239-254) on the dequantised rows those sequences reference, recomputed on the host from the
+    counter-based generator.  keys None: the structured vocabulary, matched through the closed-form inverse of its generator
+    (match_hits_structured).  Returns (max relative error, the sequences)."""
+    import numpy as np
+    import torch
+    from oracle import ref_port as R
+    B = tok_np.shape[0]
+    rng = np.random.default_rng(20260304)
+    picks = sorted(set(int(x) for x in rng.choice(B, size=min(n_pick - 1, B), replace=False)) | {B - 1})
+    sub = np.ascontiguousarray(tok_np[picks])
+    hits = R.match_hits_structured(n_rows, sub, 3) if keys is None else R.match_hits(keys, lens, sub, 3)
+    off, ids = R.hits_to_csr(hits)
+    uniq = np.unique(ids)
+    if fmt == "int4":
+        rows = R.dequantize_i4(*R.synth_rows_i4(seed, uniq, d, base_scale))
+    else:
+        rows = R.synth_rows_i8(seed, uniq, d).astype(np.float32) * R.synth_scale_f16(seed, uniq, base_scale).astype(np.float32)[:, None]
+        if fmt == "fp16":
+            rows = rows.astype(np.float16).astype(np.float32)
+    fg = R.embed_numpy(rows, off, np.searchsorted(uniq, ids), "mean").reshape(len(picks), tok_np.shape[1], d)
+    ref = R.combine(torch.from_numpy(sub), torch.from_numpy(fg), wte.float().cpu(), wpe.float().cpu()).numpy()
+    got = gpu_out[torch.tensor(picks, device=gpu_out.device)].float().cpu().numpy()
+    return float(np.abs(got - ref).max() / np.abs(ref).max()), picks
+
+
+def config_record(name, fmt, d, N, keygen, stream, B, T, steps, warmup, sync, prefetch, vocab_cache=None, wte=None, wpe=None,
+                  check=True):
+    """One single-GPU workload measured like the headline: its own table, a different batch every step, the serving loop with
+    the next batch announced, HIP-event kernel times (min / median / max), counter-priced `frac` when profiles/hbm_traffic.json
+    holds passes for this signature and kernel source, and the GPU output of 8 sequences of the first batch checked against
+    the oracle.  `vocab_cache`: (vocabulary, keys, lens) to re-use (the headline's 1M-row vocabulary serves C2)."""
     import torch
     from scone_amd import EmbeddingCache
     from scone_amd import synthetic as S
     from scone_amd.hip_backend import format_code
-    d, B, T, N = args.dim, args.batch, args.seq, 10_000_000
-    vocab = S.StructuredVocab(N)
-    cache = EmbeddingCache.from_synthetic(vocab, d, table_format=args.format, seed=7, base_scale=0.02 / 127, n_rows=N)
-    tok = torch.from_numpy(S.stream_uniform_ids(vocab, None, B, T, 4321)).to("cuda", torch.int32)
+    seed, base_scale = 7, 0.02 / 127
+    t_build = time.perf_counter()
+    vocab_obj, keys, lens = vocab_cache if vocab_cache is not None else make_vocabulary(N, keygen)
+    kw = {"n_rows": N} if keys is None else {}
+    cache = EmbeddingCache.from_synthetic(vocab_obj, d, table_format=fmt, seed=seed, base_scale=base_scale, **kw)
+    if wte is None:
+        g = torch.Generator(device="cuda").manual_seed(5)
+        wte = (torch.randn(S.GPT2_VOCAB, d, generator=g, device="cuda") * 0.02).half()
+        wpe = (torch.randn(1024, d, generator=g, device="cuda") * 0.01).half()
+    n_b = min(steps + warmup, MAX_DISTINCT_BATCHES)
+    tok_np, batches = make_batches(vocab_obj, keys, lens, stream, B, T, 1234, n_b)
     out = torch.empty(B, T, d, dtype=torch.float16, device="cuda")
     table = cache.table
-    alg, comp, sum_k, k_hist, nr, nt = workload_bytes(table, tok, format_code(args.format), d)
-    steps = max(10, min(args.steps, 30))
-    dt, n_launch, kern_ms, samples = measure_lookup(table, lambda: cache.embed_tokens(tok, wte=wte, wpe=wpe, out=out), tok,
-                                                    B * T, steps, 3, sync)
-    avg_ms = kern_ms / n_launch
-    sig = f"{args.format}-d{d}-N{N}-B{B}-T{T}-uniform-hbm-structured"
-    tr, stale = read_traffic(sig)
+    torch.cuda.synchronize()
+    t_build = time.perf_counter() - t_build
+    alg, comp, sum_k, k_hist, nr, nt = workload_bytes(table, batches[0], format_code(fmt), d)
+    dt, n_launch, kern_ms, samples = lookup_loop(cache, batches, wte, wpe, out, steps, warmup, sync, prefetch)
+    avg_ms = kern_ms / max(n_launch, 1)
+    sig = workload_sig(fmt, d, N, B, T, stream, "hbm", keygen, rotated=n_b > 1)
+    rf = roofline_block(sig, alg, comp, avg_ms, samples, 1, n_launch)
     res = {
-        "workload": f"{N}-row {args.format} table d={d}, structured vocabulary (token ids uniform over the vocabulary), S_uniform, "
-                    f"{B}x{T} tokens; {nr} distinct table rows and {nt} distinct wte rows per launch",
-        "workload_sig": sig, "mean_hits_per_token": sum_k / (B * T),
-        "avg_kernel_ms": avg_ms, "kernel_ms": kernel_stats(samples, 1), "tokens_per_s": B * T * steps / dt,
-        "algorithmic_bytes_per_launch": alg, "algorithmic_GBps": alg / avg_ms / 1e6, "algorithmic_frac": alg / avg_ms / 1e6 / HBM_PEAK_GBPS,
-        "hbm_bytes_compulsory": comp, "hbm_GBps": comp / avg_ms / 1e6, "hbm_frac": comp / avg_ms / 1e6 / HBM_PEAK_GBPS,
-        "traffic": None if (tr is None or stale) else tr["hbm_bytes_per_launch"],
-        "traffic_frac": None if (tr is None or stale) else tr["hbm_bytes_per_launch"] / avg_ms / 1e6 / HBM_PEAK_GBPS,
+        "name": name,
+        "workload": f"{N}-row {fmt} f-gram table d={d} max_n=3 in HBM ({keygen} vocabulary), S_{stream} stream, {B}x{T} tokens/step, "
+                    f"a different batch every step ({n_b} batches); fused match+gather+dequant+mean+wte+wpe, fp16 out; "
+                    f"{nr} distinct table rows and {nt} distinct wte rows in the first batch",
+        "workload_sig": sig, "tokens_per_s": B * T * steps / dt, "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup,
+        "step_minus_kernel_us": (dt / steps * 1e3 - avg_ms) * 1e3, "next_batch_announced": bool(prefetch),
+        "mean_hits_per_token": sum_k / (B * T), "hits_histogram_K0_6": k_hist[:7], "build_s": t_build,
+        "roofline": rf, "status_bits": int(table.status()),
     }
-    del cache, table, tok, out
+    if check:
+        try:
+            cache.embed_tokens(batches[0], wte=wte, wpe=wpe, out=out)
+            torch.cuda.synchronize()
+            err, picks = cpu_baseline_spot_check(N, keys, lens, tok_np, out, fmt, d, seed, base_scale, wte, wpe)
+            res["gpu_vs_oracle_max_rel_err"], res["gpu_vs_oracle_sequences"] = err, picks
+        except Exception as e:
+            res["gpu_vs_oracle_max_rel_err"], res["gpu_vs_oracle_error"] = None, repr(e)
+    del cache, table, batches, out
     torch.cuda.empty_cache()
     return res
+
+
+def hbm_variant(args, wte, wpe, sync, prefetch=True):
+    """The headline's format and dim on a workload that defeats the caches: 10M rows (7.7 GB of INT8 d = 768 rows -- 30x
+    the Infinity Cache), structured vocabulary (token ids uniform over the 50,257-word vocabulary, one bigram / trigram
+    row per window, each referenced by the 2-3 adjacent tokens it covers and by nothing else in the launch), a different
+    batch every step."""
+    steps = max(10, min(args.steps, 30))
+    r = config_record("hbm_variant", args.format, args.dim, 10_000_000, "structured", "uniform", args.batch, args.seq, steps, 3,
+                      sync, prefetch, wte=wte if args.dim == wte.shape[1] else None, wpe=wpe if args.dim == wpe.shape[1] else None,
+                      check=False)
+    rf = r["roofline"]
+    return {"workload": r["workload"], "workload_sig": r["workload_sig"], "mean_hits_per_token": r["mean_hits_per_token"],
+            "avg_kernel_ms": rf["avg_kernel_ms"], "kernel_ms": rf["kernel_ms"], "tokens_per_s": r["tokens_per_s"],
+            "ms_per_step": r["ms_per_step"],
+            "algorithmic_bytes_per_launch": rf["algorithmic_bytes_per_launch"], "algorithmic_GBps": rf["algorithmic_GBps"],
+            "algorithmic_frac": rf["algorithmic_frac"], "hbm_bytes_compulsory": rf["hbm_bytes_compulsory"],
+            "hbm_GBps": rf["hbm_bytes_compulsory"] / rf["avg_kernel_ms"] / 1e6, "hbm_frac": rf["hbm_frac"],
+            "traffic": rf["traffic"], "traffic_frac": rf["traffic_frac"], "traffic_stale": rf["traffic_stale"]}
 
 
 def _host_memory_available():
@@ -656,10 +838,19 @@ def pinned_baseline(args, sync, zipf_too=True):
     cache = table(hot_rows=hot)
     tok = torch.from_numpy(S.stream_uniform_ids(vocab, None, B, T, 1234)).to("cuda", torch.int32)
     dt = run(cache, [tok])
+    _, ids_u = cache.table.match_csr(tok)
+    cold_u = ids_u[ids_u >= hot]
+    n_cold_ref, n_cold_distinct = int(cold_u.numel()), int(torch.unique(cold_u).numel())
+    del ids_u, cold_u
     res = {"value": B * T / dt, "unit": "tokens/s", "ms_per_step": dt * 1e3, "steps": 4,
            "workload": f"{N}-row int4 table d={d} in pinned host DRAM (rows read in place over PCIe), first {hot} rows in HBM, "
                        f"structured vocabulary, S_uniform, {B}x{T} tokens/step",
-           "bound": "PCIe Gen5 x16 (~64 GB/s)"}
+           "bound": "PCIe Gen5 x16 (~64 GB/s)", "pcie_peak_GBps": PCIE_PEAK_GBPS,
+           "cold_row_references": n_cold_ref, "distinct_cold_rows": n_cold_distinct,
+           "bytes_over_pcie_per_step_at_least": n_cold_distinct * 528,
+           "pcie_GBps": n_cold_distinct * 528 / dt / 1e9, "pcie_frac": n_cold_distinct * 528 / dt / 1e9 / PCIE_PEAK_GBPS,
+           "pcie_frac_kind": "every DISTINCT cold row of the batch once (528 B payload; a row re-referenced after it left L2 crosses "
+                             "again, so this is a lower bound on the link's bytes) / ms_per_step / 64 GB/s"}
     zres = None
     if zipf_too:
         try:
@@ -719,6 +910,11 @@ def pinned_baseline(args, sync, zipf_too=True):
                                  "chunk is reduced); scone_embed_prefetch of batch i + 1 issued right after the lookup of batch i",
                     "cache_rows": c1["cache_rows"], "stage_tokens": c1["chunk_tokens"],
                     "rows_over_pcie_per_step": copied, "bytes_over_pcie_per_step": copied * 528,
+                    "pcie_peak_GBps": PCIE_PEAK_GBPS, "pcie_GBps": copied * 528 / dt_cached / 1e9,
+                    "pcie_frac": copied * 528 / dt_cached / 1e9 / PCIE_PEAK_GBPS,
+                    "pcie_frac_kind": "rows copied host -> HBM per step (the library's counter) x 528 B / ms_per_step / 64 GB/s: the link "
+                                      "is NOT the bound of the cached step -- the lookup out of [hot head | cache] is (HBM), which is "
+                                      "the point of the cache",
                     "cache_hit_rate_of_distinct_cold_rows": 1.0 - copied / max(stats["distinct_cold_rows"], 1.0),
                     "status_bits": status,
                     "zero_copy_same_stream": {"value": B * T / dt_zero, "ms_per_step": dt_zero * 1e3,
@@ -1199,11 +1395,33 @@ def main():
     from scone_amd import synthetic as S
     from scone_amd.hip_backend import format_code
 
+    # ---- N > 1, before anything that can hang or cost minutes: can this world do a collective at all?
+    world_sanity = None
+    if dist is not None and world > 1:
+        watchdog.arm("world_sanity", min(90.0, max(budget.remaining() - 30.0, 10.0)))
+        cdev0 = "cuda" if backend == "nccl" else "cpu"
+        t_s = time.perf_counter()
+        mine = torch.full((256,), float(rank + 1), dtype=torch.float32, device=cdev0)
+        got = torch.empty(256 * world, dtype=torch.float32, device=cdev0)
+        dist.all_gather_into_tensor(got, mine)
+        sane = bool(torch.equal(got.view(world, 256)[:, 0].cpu(), torch.arange(1, world + 1, dtype=torch.float32)))
+        watchdog.disarm()
+        world_sanity = {"all_gather_1KB_per_rank_ok": sane, "seconds": time.perf_counter() - t_s, "world_size": dist.get_world_size(),
+                        "device_count": torch.cuda.device_count(), "backend": backend,
+                        "rccl_version": _rccl_version() if backend == "nccl" else None}
+        if rank == 0:
+            sys.stderr.write(f"bench.py: world_sanity {'ok' if sane else 'FAILED'}: {world_sanity['world_size']} ranks, "
+                             f"{world_sanity['device_count']} devices visible, backend {backend}, RCCL {world_sanity['rccl_version']}, "
+                             f"first collective {world_sanity['seconds']:.1f} s\n")
+            sys.stderr.flush()
+        if not sane:
+            raise SystemExit("bench.py: world sanity failed: a 1 KB all-gather returned the wrong ranks' data")
+
     d, N, B, T = args.dim, args.rows, args.batch, args.seq
     vocab, max_n, seed, base_scale = S.GPT2_VOCAB, 3, 7, 0.02 / 127
-    keys, lens = (S.make_keys(N, vocab, max_n, seed=11) if args.keygen == "zipf"
-                  else S.make_keys_structured(N, vocab, max_n))
-    ex = NGramExtractor.from_arrays(keys, lens, max_n=max_n)
+    vocab_obj, keys, lens = make_vocabulary(N, args.keygen, max_n)
+    ex = vocab_obj
+    kw_rows = {"n_rows": N} if keys is None else {}
 
     sharded = args.table_mode == "sharded" and dist is not None
     emu = None
@@ -1213,24 +1431,29 @@ def main():
     if emu is not None:
         from scone_amd.distributed import ShardedEmbeddingCache
         cache = ShardedEmbeddingCache.from_synthetic(ex, d, table_format=args.format, seed=seed, base_scale=base_scale,
-                                                     rank=emu[0], world=emu[1])
+                                                     rank=emu[0], world=emu[1], **kw_rows)
         stream_seed = 1234
     elif sharded:
         from scone_amd.distributed import ShardedEmbeddingCache
         cache = ShardedEmbeddingCache.from_synthetic(ex, d, table_format=args.format, seed=seed,
                                                      base_scale=base_scale, rank=rank, world=world,
-                                                     replicated_rows=args.replicated_rows)
+                                                     replicated_rows=args.replicated_rows, **kw_rows)
         stream_seed = 1234            # every rank embeds the same batch; rows are sharded
     else:
         cache = EmbeddingCache.from_synthetic(ex, d, table_format=args.format, seed=seed, base_scale=base_scale,
                                               placement=args.placement, hot_rows=args.hot_rows,
-                                              stage_tokens=args.stage_tokens, cache_rows=args.cache_rows)
-        stream_seed = 1234 + rank     # every rank embeds its own batch
-    if args.stream == "uniform":
-        tok_np = S.stream_uniform_ids(keys, lens, B, T, stream_seed)
-    else:
-        tok_np = S.stream_zipf(vocab, B, T, stream_seed)
-    tok = torch.from_numpy(tok_np).to("cuda", torch.int32)
+                                              stage_tokens=args.stage_tokens, cache_rows=args.cache_rows, **kw_rows)
+        stream_seed = 1234 + rank     # every rank embeds its own batches
+    # A DIFFERENT batch every step (round 5; rounds 1-4 re-used one batch -- 0.35 GB of rows + 72 MB of wte rows against a
+    # 256-MB Infinity Cache: part of step i's working set was still resident for step i + 1, in the timed run and in the
+    # counter passes alike; a pinned-host table behind the prefetch pipeline would even be served from its HBM cache).
+    # All batches are generated before the timed region; the byte counts below are those of the first one (the batches are
+    # statistically identical).  The sharded / shard-emulation modes keep their one batch (frozen this round).
+    rotated = emu is None and not sharded and not args.same_batch
+    n_batches = min(args.steps + args.warmup, MAX_DISTINCT_BATCHES) if rotated else 1
+    tok_np, batches = make_batches(vocab_obj, keys, lens, args.stream, B, T, stream_seed, max(n_batches, 1))
+    tok = batches[0]
+    prefetch = emu is None and not sharded and args.prefetch != "off"
     g = torch.Generator(device="cuda").manual_seed(5)
     wte = (torch.randn(vocab, d, generator=g, device="cuda") * 0.02).half()
     wpe = (torch.randn(1024, d, generator=g, device="cuda") * 0.01).half()
@@ -1242,25 +1465,7 @@ def main():
     fmt = format_code(args.format)
     bytes_per_launch, bytes_compulsory, sum_k, k_hist, n_rows_distinct, n_tok_distinct = workload_bytes(table, tok, fmt, d)
 
-    # A pinned-host table behind the prefetch pipeline keeps cold rows in an HBM cache ACROSS steps: one repeated batch would
-    # be served from that cache after the first step (1.1 ms instead of ~5 ms on S_uniform) -- work skipped in the timed
-    # region.  Such a run gets a different batch every step (same generator, consecutive seeds); the byte counts above are
-    # those of the first one (the batches are statistically identical).
-    rotate = None
-    if emu is None and not sharded and args.placement == "pinned_host" and args.stage_tokens > 0:
-        rotate = [tok]
-        for i in range(1, args.steps + args.warmup):
-            nxt = (S.stream_uniform_ids(keys, lens, B, T, stream_seed + 7919 * i) if args.stream == "uniform"
-                   else S.stream_zipf(vocab, B, T, stream_seed + 7919 * i))
-            rotate.append(torch.from_numpy(nxt).to("cuda", torch.int32))
-    step_no = [0]
-
     def step():
-        if rotate is not None:
-            t_i = rotate[step_no[0] % len(rotate)]
-            step_no[0] += 1
-            cache.embed_tokens(t_i, wte=wte, wpe=wpe, out=out)
-            return
         if emu is not None:
             # this shard's local work only: partial sums over owned rows, then finalise 1/W of the tokens
             partial, counts = table.embed_partial(tok)
@@ -1269,10 +1474,8 @@ def main():
             b0 = min(a0 + per, ntok)
             table.finalize(partial[a0:b0], counts[a0:b0], tok, a0, b0, wte=wte, wpe=wpe, out_dtype=torch.float16,
                            out=out.view(-1, d)[a0:b0])
-        elif sharded:
-            cache.embed_tokens(tok, wte=wte, wpe=wpe, exchange=args.exchange, gather_output=not args.no_gather_output)
         else:
-            cache.embed_tokens(tok, wte=wte, wpe=wpe, out=out)
+            cache.embed_tokens(tok, wte=wte, wpe=wpe, exchange=args.exchange, gather_output=not args.no_gather_output)
 
     def sync():
         torch.cuda.synchronize()
@@ -1280,9 +1483,11 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    dt, n_launch, kern_ms, samples = measure_lookup(table, step, tok, ntok, args.steps, args.warmup, sync)
-    if rotate is not None:                 # (`out` is compared with the oracle on the FIRST batch further down)
-        cache.embed_tokens(tok, wte=wte, wpe=wpe, out=out)
+    if emu is not None or sharded:
+        dt, n_launch, kern_ms, samples = measure_lookup(table, step, tok, ntok, args.steps, args.warmup, sync)
+    else:
+        dt, n_launch, kern_ms, samples = lookup_loop(cache, batches, wte, wpe, out, args.steps, args.warmup, sync, prefetch)
+        cache.embed_tokens(tok, wte=wte, wpe=wpe, out=out)       # `out` is compared with the oracle on the FIRST batch further down
         torch.cuda.synchronize()
     if dist is not None:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
@@ -1299,23 +1504,10 @@ def main():
         # back to the whole step so that the line stays well-formed
         per_step = max(1, n_launch // max(args.steps, 1)) if n_launch else 1
         step_kernel_ms = kern_ms / args.steps if n_launch else dt / args.steps * 1e3
-        sig = (f"{args.format}-d{d}-N{N}-B{B}-T{T}-{args.stream}-{args.placement}" + ("-sharded" if sharded else "") + (f"-shard{args.shard_of}" if emu else "")
-               + (f"-hot{args.hot_rows}-stage{args.stage_tokens}" if args.placement != "hbm" else "")
-               + ("-structured" if args.keygen == "structured" else ""))
-        tr, stale = read_traffic(sig)
-        traffic = None if (tr is None or stale) else tr.get("hbm_bytes_per_launch")
         in_hbm = args.placement == "hbm"
-        per_s = step_kernel_ms * 1e-3
-        algorithmic = bytes_per_launch / per_s / 1e9
-        # the physical fraction: bytes that left L2 (PMC passes of THIS kernel source) if there is such an entry, else the
-        # compulsory bytes -- both are byte counts of the launch that do not depend on the box; never above the peak
-        if traffic is not None:
-            phys_bytes, phys_kind = traffic, ("bytes that left L2 per launch (2 x FETCH_SIZE + WRITE_SIZE, rocprofv3 PMC passes of this "
-                                              "kernel source: an upper bound on HBM bytes, Infinity-Cache hits included)")
-        else:
-            phys_bytes, phys_kind = bytes_compulsory, ("compulsory bytes per launch (every distinct table row and wte row once + output + "
-                                                       "ids: a lower bound on HBM bytes; no PMC entry for this workload and kernel source)")
-        achieved = phys_bytes / per_s / 1e9
+        sig = workload_sig(args.format, d, N, B, T, args.stream, args.placement, args.keygen, rotated=n_batches > 1,
+                           extra=("-sharded" if sharded else "") + (f"-shard{args.shard_of}" if emu else "")
+                           + (f"-hot{args.hot_rows}-stage{args.stage_tokens}" if args.placement != "hbm" else ""))
         res = {
             "metric": "f-gram embed tokens/sec (1M-row INT8 table @ d=768)" if (N, d, args.format) == (1_000_000, 768, "int8")
                       else f"f-gram embed tokens/sec ({N}-row {args.format} table @ d={d})",
@@ -1330,7 +1522,11 @@ def main():
                             f"{'HBM' if args.placement == 'hbm' else 'pinned host DRAM'}; S_{args.stream} stream, "
                             f"{B}x{T} tokens/step/rank; fused match+gather+dequant+mean+wte+wpe, fp16 out",
                 "tokens_per_step_per_rank": ntok, "mean_hits_per_token": sum_k / ntok, "hits_histogram_K0_6": k_hist[:7],
-                "different_batch_every_step": rotate is not None,
+                "different_batch_every_step": n_batches > 1, "distinct_batches": n_batches,
+                "next_batch_announced": bool(prefetch),
+                "loop": ("scone_embed(batch i) then scone_embed_prefetch(batch i + 1): the next batch's match (k_match_ell) runs on the "
+                         "handle's side stream beside this batch's gather; K matches and K gathers inside the timed region"
+                         if prefetch else "scone_embed(batch i): match, then gather, on one stream"),
                 "distinct_table_rows_per_launch": n_rows_distinct, "distinct_wte_rows_per_launch": n_tok_distinct,
                 "parallelism": (f"shard {args.shard_of} of a row-sharded table, local work only (no exchange)" if emu else
                                 (("row-sharded table, RCCL all-to-all of quantised rows"
@@ -1343,58 +1539,42 @@ def main():
                                  + f", replicated head {args.replicated_rows} rows") if sharded
                                 else f"replicated table, tokens sharded over {world} rank(s), no collective"),
             },
-            "roofline": {
-                "bound": "hbm",
-                "limited_by": None if in_hbm else "PCIe Gen5 x16 (~63 GB/s): the table's rows live in pinned host DRAM",
-                "kernel": ("scone_gather::k_embed_wave (gather+dequant+reduce+combine), HIP-event timed" if n_launch
-                           else "whole step (sharded path: match + pack + RCCL + gather)"),
-                # `frac` = achieved / peak is PHYSICAL: bytes of the launch that crossed the L2 <-> fabric boundary (or, without
-                # a counter entry, that must cross it) over the HIP-event kernel time; it cannot exceed 1
-                "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                "frac_kind": phys_kind + f" / avg_kernel_ms ({step_kernel_ms:.4f} ms, HIP events) / 8 TB/s",
-                "frac_bytes": phys_bytes,
-                # SURVEY 8d's figure: every row REFERENCE counted (K_t rows + out + wte + id per token).  Adjacent tokens
-                # share f-gram rows and hot wte rows are re-referenced, so part of these bytes is served by L2 / the
-                # Infinity Cache: the algorithmic rate can exceed the HBM peak and is not an HBM utilisation
-                "algorithmic_bytes_per_launch": bytes_per_launch, "algorithmic_GBps": algorithmic,
-                "algorithmic_frac": algorithmic / HBM_PEAK_GBPS,
-                "avg_kernel_ms": step_kernel_ms,
-                "kernel_ms": kernel_stats(samples, per_step), "timed_launches": n_launch, "launches_per_step": per_step,
-                # what HBM must at least move: every DISTINCT table row and wte row once + the output + the ids
-                # (<= the truth; can never exceed the peak) ...
-                "hbm_bytes_compulsory": bytes_compulsory if in_hbm else None,
-                "hbm_frac": bytes_compulsory / per_s / 1e9 / HBM_PEAK_GBPS if in_hbm else None,
-                # ... and what left L2 (rocprofv3 PMC passes of THIS code, committed: >= the truth, it includes
-                # Infinity-Cache hits); null when the kernels have changed since the passes were taken
-                "traffic": traffic,
-                "traffic_source": None if tr is None else tr.get("source"),
-                "traffic_stale": bool(stale),
-                "traffic_GBps": None if traffic is None else traffic / per_s / 1e9,
-                "traffic_frac": None if traffic is None else traffic / per_s / 1e9 / HBM_PEAK_GBPS,
-                "kernel_source_sha": kernel_source_sha(),
-            },
+            "roofline": roofline_block(sig, bytes_per_launch, bytes_compulsory, step_kernel_ms, samples, per_step, n_launch, in_hbm,
+                                       kernel=None if n_launch else "whole step (sharded path: match + pack + RCCL + gather)"),
             "time_budget_s": budget.seconds,
         }
+        res["roofline"]["step_minus_kernel_us"] = (dt / args.steps * 1e3 - step_kernel_ms) * 1e3
+        if world_sanity is not None:
+            res["world_sanity"] = world_sanity
         if n_launch and not sharded and emu is None and args.placement == "hbm":
-            # the match kernel's share of the step: stream time of whole steps (torch events on the launch stream) minus
-            # the gather kernel's own HIP-event time over the same steps
+            # two contrasts on the same table, rank 0 alone (local synchronisation only): (i) the same batches WITHOUT the
+            # announcement -- match, then gather, on one stream: what rounds 1-4 timed; step minus kernel = k_match_ell + the
+            # gap between the two launches; (ii) ONE batch repeated with this round's loop -- what the Infinity Cache carries
+            # from step to step (rounds 1-4 measured the headline and its counter passes this way)
             try:
-                table.profile_enable(True)
-                table.profile_read(reset=True)
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                for _ in range(10):
-                    step()
-                e1.record()
+                local_sync = torch.cuda.synchronize
+                cs = max(10, min(args.steps, 20))
+
+                def contrast(bs, pf):
+                    dt_c, nl_c, km_c, sm_c = lookup_loop(cache, bs, wte, wpe, out, cs, 2, local_sync, pf)
+                    return {"ms_per_step": dt_c / cs * 1e3, "avg_kernel_ms": km_c / max(nl_c, 1), "kernel_ms": kernel_stats(sm_c, 1),
+                            "tokens_per_s": ntok * cs / dt_c, "step_minus_kernel_us": (dt_c / cs * 1e3 - km_c / max(nl_c, 1)) * 1e3,
+                            "steps": cs, "distinct_batches": len(bs), "next_batch_announced": bool(pf)}
+                if prefetch:
+                    res["roofline"]["serial_match"] = contrast(batches, False)
+                    res["roofline"]["match_us"] = res["roofline"]["serial_match"]["step_minus_kernel_us"]
+                    res["roofline"]["match_us_kind"] = ("serial_match: ms_per_step - avg_kernel_ms of the same batches without the "
+                                                        "announcement = k_match_ell + the gap between the two launches")
+                else:
+                    res["roofline"]["match_us"] = res["roofline"]["step_minus_kernel_us"]
+                    res["roofline"]["match_us_kind"] = "ms_per_step - avg_kernel_ms: k_match_ell + the gap between the two launches"
+                if n_batches > 1:
+                    res["roofline"]["same_batch"] = contrast(batches[:1], prefetch)
+                cache.embed_tokens(tok, wte=wte, wpe=wpe, out=out)       # (`out` = the first batch again, for the oracle check)
                 torch.cuda.synchronize()
-                nl, km = table.profile_read(reset=True)
-                table.profile_enable(False)
-                res["roofline"]["match_us"] = (e0.elapsed_time(e1) - km) / 10 * 1e3
-                res["roofline"]["match_us_kind"] = ("stream time of 10 back-to-back steps minus their gather-kernel time, per step: "
-                                                    "k_match_ell + the gap between the two launches")
             except Exception as e:
                 res["roofline"]["match_us"] = None
-                res["roofline"]["match_us_error"] = repr(e)
+                res["roofline"]["contrast_error"] = repr(e)
         line.publish(res)
     gpu_out_for_check = out
     # ---- the cache-defeating variant, the CPU baselines, the sharded record: outside the timed region -----------
@@ -1402,7 +1582,7 @@ def main():
             and budget.remaining() > 150.0:
         watchdog.arm("roofline.hbm_variant", min(150.0, budget.remaining() - 60.0))
         try:
-            hv = hbm_variant(args, wte, wpe, sync)
+            hv = hbm_variant(args, wte, wpe, sync, prefetch)
             with line.lock:
                 res["roofline"]["hbm_variant"] = hv
                 # the cache-defeating variant's bracket, lifted to the top of the block: what really touches HBM is at least
@@ -1425,6 +1605,32 @@ def main():
         else:
             cb = {"value": None, "unit": "tokens/s", "cores": 1, "kind": "port", "sample": "skipped: time budget"}
         line.set(res, "cpu_baseline", cb)
+    # ---- the other single-GPU configs of BASELINE.json, each measured like the headline (rank 0 of an N = 1 job)
+    if rank == 0 and world == 1 and not sharded and emu is None and not args.no_configs and args.placement == "hbm":
+        cfgs = {}
+        line.set(res, "configs", cfgs)
+        plan = [("C2_fp16_1M_d768", "fp16", 768, 1_000_000, "zipf", 20.0),
+                ("C3_int8_10M_d1024", "int8", 1024, 10_000_000, "zipf_gpu", 45.0),
+                ("C4_int4_100M_d1024_in_hbm", "int4", 1024, 100_000_000, "structured", 75.0)]
+        for cname, cfmt, cd, cN, ckg, need_s in plan:
+            # (time: what the stages after this one need -- the pinned-host record ~60 s -- stays reserved)
+            if budget.remaining() < need_s + 100.0:
+                line.set(cfgs, cname, {"skipped": f"time budget: {budget.remaining():.0f} s left"})
+                continue
+            free_b, _ = torch.cuda.mem_get_info()
+            if free_b < cN * 620 + 20e9:
+                line.set(cfgs, cname, {"skipped": f"needs {(cN * 620 + 20e9) / 1e9:.0f} GB of HBM ({free_b / 1e9:.0f} GB free)"})
+                continue
+            watchdog.arm(f"configs.{cname}", min(need_s + 60.0, budget.remaining() - 30.0))
+            try:
+                reuse = (vocab_obj, keys, lens) if (cN, ckg) == (N, args.keygen) else None
+                c = config_record(cname, cfmt, cd, cN, ckg, "uniform", B, T, args.configs_steps, 3, lambda: torch.cuda.synchronize(),
+                                  prefetch, vocab_cache=reuse, wte=wte if cd == d else None, wpe=wpe if cd == d else None)
+            except Exception as e:
+                c = {"error": repr(e)}
+                torch.cuda.empty_cache()
+            watchdog.disarm()
+            line.set(cfgs, cname, c)
     if not args.no_sharded_record and not sharded and emu is None:
         del cache, table, out, gpu_out_for_check
         torch.cuda.empty_cache()

@@ -22,9 +22,11 @@
  *     scone_table_gather_rows may be called concurrently from several host threads on one handle, on the same or on
  *     different streams.  Batches of up to 32768 tokens at d = 768 / 1024 / 1280 take one launch and no workspace; larger
  *     ones use a workspace that belongs to the STREAM of the call (created on first use, grown on demand or by
- *     scone_reserve) and is locked while the call enqueues its kernels.  Not concurrent on one handle: index / table
- *     mutation against lookups, the scone_shard_* exchange calls, lookups on a table created with stage_tokens > 0
- *     (one staging pipeline per handle), and scone_destroy against anything
+ *     scone_reserve) and is locked while the call enqueues its kernels.  Lookups and scone_embed_prefetch on a table
+ *     created with stage_tokens > 0 share ONE staging pipeline per handle: they may be called from several threads, and are
+ *     serialised on a lock of the handle for the length of the call (host side; their device work follows each other through
+ *     the pipeline's events).  Not concurrent on one handle: index / table mutation against lookups, the scone_shard_*
+ *     exchange calls, and scone_destroy against anything
  *   - every entry point selects the handle's device and restores the caller's current device before it returns
  */
 #ifndef SCONE_HIP_H
@@ -101,8 +103,10 @@ typedef struct scone_cfg {
                               chunks, batches and calls until it is evicted (the reference's analogue: the page cache
                               under its memory-mapped table, embedding_cache.py:76-91,132-135)                  */
   uint64_t cache_rows;     /* stage_tokens > 0: row slots of that cache (payload + scale bytes of HBM each).  At least
-                              what the pipeline needs -- 5 chunks' worst case, 30 x stage_tokens rows for max_n = 3 --
-                              is always provisioned (0 = exactly that); never more than the cold rows               */
+                              what the pipeline needs -- 7 chunks' worst case (5 record sets in the ring + the chunk being
+                              placed + one of slack), 42 x stage_tokens rows for max_n = 3: 11.0M rows = 5.8 GB of INT4
+                              d = 1024 rows at stage_tokens = 262144 -- is always provisioned (0 = exactly that); never
+                              more than the cold rows                                                              */
 } scone_cfg;
 
 /* ---- lifecycle ----------------------------------------------------------- */
@@ -216,16 +220,25 @@ int scone_gather_reduce(scone_handle *h, const int32_t *d_offsets, const int32_t
 int scone_embed(scone_handle *h, const int32_t *d_tok, int32_t B, int32_t T, const void *d_wte,
                 int64_t vocab, const void *d_wpe, int64_t n_pos, const int32_t *d_pos,
                 int32_t reduce, void *d_out, int32_t out_dtype, scone_stream_t stream);
-/* Pinned-host tables with a prefetch pipeline (cfg.stage_tokens > 0): start fetching for the NEXT batch now.  The first chunks
- * of (d_tok, B, T) are matched, their missing cold rows placed in the HBM cache and copied host -> HBM on the handle's side
- * streams, ordered behind `stream` (the stream on which the tokens are produced) -- or, tokens_ready != 0, behind nothing: the
- * tokens are complete (uploaded and synchronised earlier), and the prefetch may run BESIDE a lookup queued on `stream` just
- * before, which is the point of calling it early -- and the call returns.  The
- * scone_embed of exactly that batch (same pointer and shape; the tokens must not change in between) takes the prepared chunks
- * over instead of starting its pipeline cold: a loop that calls scone_embed_prefetch(next) right after scone_embed(current)
- * never pays the pipeline fill.  A prefetch that is never used is dropped by the next call (the rows it cached stay cached); any
- * other handle: a no-op.  (The north-star's "async prefetch"; the reference's memory-mapped table has no counterpart --
- * embedding_cache.py:132-135 faults rows in on first use.) */
+/* Announce the NEXT batch: what its lookup can do ahead of time is started now, on side streams of the handle, and the call
+ * returns.  The scone_embed of exactly that batch (same pointer and shape; the tokens must not change in between) takes the
+ * prepared work over; results are bit-identical with and without the call.  Ordering: the side-stream work goes behind what is
+ * queued on `stream` at the time of the call (the stream on which the tokens are produced) -- or, tokens_ready != 0, behind
+ * nothing: the tokens are complete (uploaded and synchronised earlier) and the work may run BESIDE a lookup queued on `stream`
+ * just before, which is the point of calling it early.  The taking scone_embed may be issued on any stream; it waits for the
+ * prepared work by event.  Thread-safe like scone_embed.
+ *   Rows in HBM, or in pinned host DRAM read in place (cfg.stage_tokens == 0): the batch is MATCHED ahead (k_match_ell into one
+ *     of two record buffers of the handle), so that its scone_embed is the gather kernel alone: a loop that calls
+ *     scone_embed_prefetch(next) right after scone_embed(current) hides the match (~45 us per 1M tokens) and the gap between
+ *     the two launches behind the current gather.  Two announcements may be pending; a third drops the oldest; one that is
+ *     never used is dropped by later ones; an index mutation voids them all.  Batches small enough for the one-launch kernel
+ *     (<= 32768 tokens at d = 768 / 1024 / 1280) have no separate match: a no-op.
+ *   Pinned-host tables with a prefetch pipeline (cfg.stage_tokens > 0): the first chunks of (d_tok, B, T) are matched, their
+ *     missing cold rows placed in the HBM cache and copied host -> HBM: a loop that calls scone_embed_prefetch(next) right after
+ *     scone_embed(current) never pays the pipeline fill.  One announcement may be pending; one that is never used is dropped by
+ *     the next call (the rows it cached stay cached).
+ * (The north-star's "async prefetch"; the reference has no counterpart -- it matches inside its per-sequence Python loop,
+ * engine.py:223-250, and its memory-mapped table faults rows in on first use, embedding_cache.py:132-135.) */
 int scone_embed_prefetch(scone_handle *h, const int32_t *d_tok, int32_t B, int32_t T, int32_t tokens_ready, scone_stream_t stream);
 /* Every per-stream workspace of the handle (those that exist, the default stream's -- created here -- and any created
  * later) holds at least max_tokens tokens: nothing is allocated inside a timed region afterwards. */

@@ -284,6 +284,41 @@ def match_hits(keys: np.ndarray, lens: np.ndarray, tok: np.ndarray, max_n: int) 
     return hits
 
 
+def match_hits_structured(n_rows: int, tok: np.ndarray, max_n: int = 3, vocab: int = 50257) -> np.ndarray:
+    """:func:`match_hits` for the STRUCTURED synthetic vocabulary (scone_amd/synthetic.py structured_keys_for_ids) without
+    its key arrays: the generator is a bijection from ids to keys, inverted here in closed form, so membership of a window
+    and its id (n_gram_extractor.py:119-121) cost a few modular multiplications -- what lets bench.py spot-check a 1e8-row
+    table against this oracle.  ids 0..vocab-1: the unigrams; then nb = (n_rows - vocab) // 2 bigrams
+    ((a * 40503 + 17) % V, (b * 30011 + 5) % V) with j = a + b V < nb; then the trigrams
+    ((a * 40503 + 29) % V, (b * 30011 + 3) % V, (c * 20011 + 11) % V) with j = a + b V + c V^2 < n_rows - vocab - nb.
+    Pinned by tests/test_oracle_golden.py against match_hits on the materialised keys."""
+    assert max_n == 3
+    V = int(vocab)
+    B, T = tok.shape
+    hits = np.full((max_n, B, T), -1, dtype=np.int32)
+    t = tok.astype(np.int64)
+    ok = (t >= 0) & (t < V)
+    hits[0] = np.where(ok, t, -1).astype(np.int32)                  # every token of the vocabulary is a unigram f-gram
+    rest = n_rows - V
+    nb = rest // 2
+    ntri = rest - nb
+    i1, i2, i3 = pow(40503, -1, V), pow(30011, -1, V), pow(20011, -1, V)
+    if T >= 2:
+        a = ((t[:, :-1] - 17) % V) * i1 % V
+        b = ((t[:, 1:] - 5) % V) * i2 % V
+        j = a + b * V
+        good = ok[:, :-1] & ok[:, 1:] & (j < nb)
+        hits[1, :, :T - 1] = np.where(good, V + j, -1).astype(np.int32)
+    if T >= 3:
+        a = ((t[:, :-2] - 29) % V) * i1 % V
+        b = ((t[:, 1:-1] - 3) % V) * i2 % V
+        c = ((t[:, 2:] - 11) % V) * i3 % V
+        j = a + b * V + c * V * V
+        good = ok[:, :-2] & ok[:, 1:-1] & ok[:, 2:] & (j < ntri)
+        hits[2, :, :T - 2] = np.where(good, V + nb + j, -1).astype(np.int32)
+    return hits
+
+
 def hits_to_csr(hits: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
     """Expand (n,start) hits into the per-position id lists of
     n_gram_extractor.py:117-124 (n ascending, start ascending, duplicates kept);

@@ -849,7 +849,7 @@ __device__ __forceinline__ void embed_token_long(const scone_row_store &rows, co
                                                  int reduce, const uint8_t *__restrict__ base_row, uint8_t *__restrict__ out_row,
                                                  uint32_t lane) {
   using G = wave_geom<FMT, D>;
-  constexpr int EPL = G::EPL, NWR = G::NBR / 4, NSEG = G::NSEG;
+  constexpr int EPL = G::EPL, NSEG = G::NSEG;
   constexpr int NWO = EPL * (int)sizeof(OutT) / 4;
   constexpr int OPW = pack_io<OutT>::PER_WORD;
   uint32_t bw[NWO];

@@ -54,6 +54,13 @@ int check_mode(scone_handle *h, const char *who) {
   return scone_fail(h, SCONE_EINVAL, who);
 }
 
+// decode-size batches are launch-bound: one fused launch (k_embed_fused) instead of match + gather
+// (INT4 has no specialised kernel at d = 768 / 1280: a row segment would be narrower than one 16-B access)
+bool scone_embed_takes_one_launch(const scone_handle *h, long long BT) {
+  return BT <= h->fused_max_tokens && (h->cfg.dim == 768 || h->cfg.dim == 1024 || h->cfg.dim == 1280) &&
+         !(h->cfg.table_fmt == SCONE_FMT_I4 && h->cfg.dim != 1024);
+}
+
 int need_table(scone_handle *h, const char *who) {
   if (!h) return SCONE_EINVAL;
   if (h->cfg.dim <= 0 || !h->rows) return scone_fail(h, SCONE_ESTATE, who);
@@ -79,7 +86,19 @@ static int staged_geometry(scone_handle *h, int32_t B, int32_t T, long long *seq
   return SCONE_OK;
 }
 
+static int embed_staged_chunks(scone_handle *h, const embed_args &full, int32_t B, int32_t T, int32_t out_dtype, hipStream_t s);
+
+// One staging pipeline per handle: the whole call holds stage_mu (calls from several host threads are serialised; on the
+// device their chunks follow each other through the pipeline's events like those of consecutive calls from one thread).  A
+// call that fails after chunks were prepared drops them: the next call must not look up this batch's record sets.
 static int embed_staged(scone_handle *h, const embed_args &full, int32_t B, int32_t T, int32_t out_dtype, hipStream_t s) {
+  std::lock_guard<std::mutex> g(h->stage_mu);
+  const int rc = embed_staged_chunks(h, full, B, T, out_dtype, s);
+  if (rc && h->stage) scone_stage_resync(h);
+  return rc;
+}
+
+static int embed_staged_chunks(scone_handle *h, const embed_args &full, int32_t B, int32_t T, int32_t out_dtype, hipStream_t s) {
   long long seqs = 0;
   int rc = staged_geometry(h, B, T, &seqs);
   if (rc) return rc;
@@ -139,10 +158,17 @@ extern "C" int scone_embed_prefetch(scone_handle *h, const int32_t *d_tok, int32
   int rc = need_table(h, "scone_embed_prefetch: handle has no table (dim == 0)");
   if (rc) return rc;
   if (B < 0 || T < 0) return scone_fail(h, SCONE_EINVAL, "scone_embed_prefetch: negative B or T");
-  if ((long long)B * T == 0 || !(h->cfg.stage_tokens && h->rows_host)) return SCONE_OK;
+  if ((long long)B * T == 0) return SCONE_OK;
   if (!d_tok) return scone_fail(h, SCONE_EINVAL, "scone_embed_prefetch: null pointer");
   if (!scone_wave_kernel_covers(h->cfg.table_fmt, h->cfg.dim)) return SCONE_OK;
   SCONE_ON_DEVICE(h);
+  if (!(h->cfg.stage_tokens && h->rows_host)) {
+    // rows in HBM (or read in place over PCIe): what can run ahead is the match.  Batches the one-launch kernel takes
+    // (scone_embed's own rule) have no separate match: nothing to do
+    if (scone_embed_takes_one_launch(h, (long long)B * T)) return SCONE_OK;
+    return scone_pf_prefetch(h, d_tok, B, T, tokens_ready, (hipStream_t)stream);
+  }
+  std::lock_guard<std::mutex> g(h->stage_mu);
   long long seqs = 0;
   rc = staged_geometry(h, B, T, &seqs);
   if (rc) return rc;
@@ -156,7 +182,10 @@ extern "C" int scone_embed_prefetch(scone_handle *h, const int32_t *d_tok, int32
   for (; n < nchunks && n < SCONE_STAGE_AHEAD; ++n) {
     const int32_t bc = (int32_t)((n + 1) * seqs <= B ? seqs : B - n * seqs);
     rc = scone_stage_chunk(h, d_tok + n * seqs * T, bc, T);
-    if (rc) return rc;
+    if (rc) {
+      scone_stage_resync(h);
+      return rc;
+    }
   }
   return scone_stage_note_prefetched(h, d_tok, B, T, seqs, n);
 }
@@ -211,11 +240,7 @@ extern "C" int scone_embed(scone_handle *h, const int32_t *d_tok, int32_t B, int
       return scone_fail(h, SCONE_EINVAL, "scone_embed: staged prefetch needs d % 8 == 0");
     return embed_staged(h, a, B, T, out_dtype, s);
   }
-  // decode-size batches are launch-bound: one fused launch (k_embed_fused) instead of match + gather
-  // (INT4 has no specialised kernel at d = 768 / 1280: a row segment would be narrower than one 16-B access)
-  if (BT <= h->fused_max_tokens &&
-      (h->cfg.dim == 768 || h->cfg.dim == 1024 || h->cfg.dim == 1280) &&
-      !(h->cfg.table_fmt == SCONE_FMT_I4 && h->cfg.dim != 1024)) {
+  if (scone_embed_takes_one_launch(h, BT)) {
     a.fused = 1;
     rc = scone_prof_begin(h, s);
     if (rc) return rc;
@@ -225,6 +250,23 @@ extern "C" int scone_embed(scone_handle *h, const int32_t *d_tok, int32_t B, int
       return rc;
     }
     return scone_prof_end(h, s);
+  }
+  a.tok = d_tok, a.pos = d_pos, a.wte = d_wte, a.vocab = vocab, a.wpe = d_wpe, a.n_pos = n_pos;
+  a.reduce = reduce, a.out = d_out, a.status = h->d_status;
+  if (scone_wave_kernel_covers(h->cfg.table_fmt, h->cfg.dim)) {
+    // scone_embed_prefetch matched exactly this batch on the handle's side stream: the lookup only waits for that event
+    int pf_slot = -1;
+    if (const int32_t *ell = scone_pf_take(h, d_tok, B, T, s, &pf_slot)) {  // (pf_mu is held until scone_pf_release)
+      a.ell = ell;
+      rc = scone_prof_begin(h, s);
+      if (!rc) {
+        rc = launch_fmt(h, a, SRC_HITS, MODE_FULL, out_dtype, s);
+        if (rc) scone_prof_abort(h);
+        else rc = scone_prof_end(h, s);
+      }
+      const int rc2 = scone_pf_release(h, pf_slot, s);
+      return rc ? rc : rc2;
+    }
   }
   // the workspace of THIS stream, held while the match that writes it and the lookup that reads it are enqueued
   scone_ws_lock ws(scone_ws_acquire(h, s));

@@ -461,10 +461,19 @@ int scone_launch_match_ell_ex(scone_handle *h, const int32_t *d_tok, int32_t B, 
   return SCONE_OK;
 }
 
+// id records matched before the index changed are stale: the prefetched ones are dropped (scone_prefetch.hip), and so is the
+// staging pipeline of a pinned-host table with whatever it prepared ahead (its records hold cache slots of rows found
+// through the old index).  Like every mutation: not concurrent with lookups.
+static void index_modified(scone_handle *h) {
+  scone_pf_invalidate(h);
+  if (h->stage) scone_stage_destroy(h);
+}
+
 extern "C" int scone_index_build_device(scone_handle *h, const uint32_t *d_keys, const uint8_t *d_lens,
                                         uint64_t n, uint64_t id0, scone_stream_t stream) {
   if (!h) return SCONE_EINVAL;
   if (n == 0) return SCONE_OK;
+  index_modified(h);
   if (!d_keys || !d_lens) return scone_fail(h, SCONE_EINVAL, "scone_index_build: null keys/lens");
   if (id0 + n > 0xFFFFFFFEull) return scone_fail(h, SCONE_ERANGE, "scone_index_build: ids must be < 2^32-2");
   SCONE_ON_DEVICE(h);
@@ -483,6 +492,7 @@ extern "C" int scone_index_build(scone_handle *h, const uint32_t *h_keys, const 
   if (n == 0) return SCONE_OK;
   if (!h_keys || !h_lens) return scone_fail(h, SCONE_EINVAL, "scone_index_build: null keys/lens");
   SCONE_ON_DEVICE(h);
+  index_modified(h);
   const uint64_t chunk = 1ull << 22;  // keys per staging round
   const int max_n = h->cfg.max_n;
   uint32_t *d_keys = nullptr;
@@ -560,6 +570,7 @@ extern "C" int scone_index_export(scone_handle *h, void *h_slots, void *h_uni, v
 extern "C" int scone_index_import(scone_handle *h, const void *h_slots, const void *h_uni, const void *h_bloom, uint64_t n_keys) {
   if (!h || !h_slots || !h_uni || !h_bloom) return h ? scone_fail(h, SCONE_EINVAL, "scone_index_import: null pointer") : SCONE_EINVAL;
   SCONE_ON_DEVICE(h);
+  index_modified(h);
   SCONE_HIP(h, hipDeviceSynchronize());
   SCONE_HIP(h, hipMemcpy(h->slots, h_slots, h->cap * sizeof(scone_slot), hipMemcpyHostToDevice));
   SCONE_HIP(h, hipMemcpy(h->d_uni, h_uni, (size_t)SCONE_UNI_CAP * sizeof(int32_t), hipMemcpyHostToDevice));

@@ -217,6 +217,7 @@ struct scone_stage_state {
   hipStream_t prep = nullptr, copy = nullptr;
   hipEvent_t prepped[SCONE_STAGE_NBUF] = {}, staged[SCONE_STAGE_NBUF] = {}, consumed[SCONE_STAGE_NBUF] = {}, start = nullptr;
   bool consumed_valid[SCONE_STAGE_NBUF] = {};
+  bool staged_valid[SCONE_STAGE_NBUF] = {};  // the set has carried a chunk: its copy kernel read count / list / place
   uint32_t *slot_of = nullptr;   // [cold rows]
   uint32_t *owner = nullptr;     // [cap]: cold row + 1 held by the slot, 0 = free
   uint32_t *last_use = nullptr;  // [cap]: epoch of the last chunk that referenced the slot
@@ -337,6 +338,11 @@ int scone_stage_chunk(scone_handle *h, const int32_t *d_tok, int32_t Bc, int32_t
                                        "twice without being embedded?)");
   const int buf = (int)(st->chunks % SCONE_STAGE_NBUF);
   if (st->consumed_valid[buf]) SCONE_HIP(h, hipStreamWaitEvent(s, st->consumed[buf], 0));
+  // ... and for the COPY of the chunk that used this set last: a chunk that was prepared and then discarded (a prefetch of
+  // another batch, a failed call) has no lookup, hence no newer `consumed`, but its k_stage_copy may still be reading
+  // count / list / place[buf] when this chunk's preparation rewrites them (for a chunk that WAS looked up this wait is
+  // free: its lookup waited for the same event)
+  if (st->staged_valid[buf]) SCONE_HIP(h, hipStreamWaitEvent(s, st->staged[buf], 0));
   st->epoch += 1;
   if (st->epoch >= 0xFFFFFF00u) {  // 2^32 chunks: restart the clock (every slot becomes evictable; nothing is in flight
     SCONE_HIP(h, hipDeviceSynchronize());  // once the device is idle)
@@ -370,6 +376,7 @@ int scone_stage_chunk(scone_handle *h, const int32_t *d_tok, int32_t Bc, int32_t
                      (int)h->scale_bytes_per_row, (long long)h->hot_local, st->list_cap, st->hand + 1);
   SCONE_HIP(h, hipGetLastError());
   SCONE_HIP(h, hipEventRecord(st->staged[buf], st->copy));
+  st->staged_valid[buf] = true;
   st->chunks += 1;
   return SCONE_OK;
 }
@@ -388,6 +395,15 @@ long long scone_stage_take_prefetched(scone_handle *h, const int32_t *d_tok, int
   if (st->pending.tok == d_tok && st->pending.B == B && st->pending.T == T && st->pending.seqs == seqs) return st->pending.n;
   st->n_consumed += (uint64_t)st->pending.n;  // another batch was prefetched: its chunks are never looked up (the rows they
   return 0;                                 // brought into the cache stay, harmlessly)
+}
+
+// Prepared chunks that no lookup will take (the call that prepared them failed mid-batch, or their prefetch is void): the
+// ring is brought back in step -- the next chunk's preparation waits for their copies through staged[buf].
+void scone_stage_resync(scone_handle *h) {
+  scone_stage_state *st = h->stage;
+  if (!st) return;
+  st->n_consumed = st->chunks;
+  st->pending.valid = false;
 }
 
 int scone_stage_note_prefetched(scone_handle *h, const int32_t *d_tok, int32_t B, int32_t T, long long seqs, long long n) {
@@ -417,6 +433,7 @@ extern "C" int scone_stage_counters(scone_handle *h, uint64_t *cache_rows, uint6
   if (rows_copied) *rows_copied = 0;
   if (chunks) *chunks = 0;
   if (chunk_tokens) *chunk_tokens = 0;
+  std::lock_guard<std::mutex> g(h->stage_mu);
   scone_stage_state *st = h->stage;
   if (!st) return SCONE_OK;
   SCONE_ON_DEVICE(h);

@@ -46,6 +46,41 @@ def make_keys(n_rows: int, vocab: int = GPT2_VOCAB, max_n: int = 3, seed: int = 
     return keys, lens
 
 
+def make_keys_torch(n_rows: int, vocab: int = GPT2_VOCAB, max_n: int = 3, seed: int = 11, bigram_share: float = 0.64,
+                    device="cuda") -> Tuple[np.ndarray, np.ndarray]:
+    """:func:`make_keys` drawn with torch on ``device`` (same law -- all unigrams, then DISTINCT bigrams / trigrams over
+    Zipf(1.1) tokens in first-drawn order --, torch's generator instead of numpy's: not the same vocabulary).  The
+    de-duplication passes over 1e7 keys take seconds on the GPU instead of a minute and a half on the host, which is what
+    lets bench.py carry config C3 in its default run.  Returns host arrays like :func:`make_keys`."""
+    import torch
+    assert max_n >= 3 and n_rows >= vocab
+    g = torch.Generator(device=device).manual_seed(int(seed))
+    cdf = torch.from_numpy(zipf_cdf(vocab)).to(device)
+    rest = n_rows - vocab
+    have = torch.zeros(0, dtype=torch.int64, device=device)        # packed (token + 1) x 3, 20 bits each; 0 = absent
+    while have.numel() < rest:
+        m = max(4096, int((rest - have.numel()) * 1.6))
+        t = torch.clamp(torch.searchsorted(cdf, torch.rand((m, 3), generator=g, device=device, dtype=torch.float64), right=True),
+                        max=vocab - 1) + 1
+        t[torch.rand(m, generator=g, device=device) < bigram_share, 2] = 0
+        allk = torch.cat([have, t[:, 0] | (t[:, 1] << 20) | (t[:, 2] << 40)])
+        # first occurrences in drawing order: stable sort by key, keep the first of every run, restore positions
+        order = torch.argsort(allk, stable=True)
+        sk = allk[order]
+        first = torch.ones_like(sk, dtype=torch.bool)
+        first[1:] = sk[1:] != sk[:-1]
+        have = allk[torch.sort(order[first]).values]
+    have = have[:rest]
+    k3 = torch.stack([have & 0xFFFFF, (have >> 20) & 0xFFFFF, (have >> 40) & 0xFFFFF], dim=1)
+    keys = np.zeros((n_rows, max_n), dtype=np.uint32)
+    lens = np.ones(n_rows, dtype=np.uint8)
+    keys[:vocab, 0] = np.arange(vocab, dtype=np.uint32)
+    k3 = k3.cpu().numpy()
+    lens[vocab:] = np.where(k3[:, 2] == 0, 2, 3).astype(np.uint8)
+    keys[vocab:, :3] = np.where(k3 > 0, k3 - 1, 0)
+    return keys, lens
+
+
 def structured_keys_for_ids(ids: np.ndarray, n_rows: int, vocab: int = GPT2_VOCAB, max_n: int = 3) -> Tuple[np.ndarray, np.ndarray]:
     """Rows ``ids`` of :func:`make_keys_structured` in closed form (any subset of a 1e9-row vocabulary without
     materialising it): ids 0..vocab-1 are the unigrams, then half bigrams and half trigrams whose tokens are the

@@ -87,6 +87,7 @@ def _compare_with_c_oracle(embed_f32, embed_f16, keys, lens, tok_np, ri, fmt, d,
 
 @pytest.mark.parametrize("name,fmt,d,n_rows,keygen,B", [
     ("headline", "int8", 768, 1_000_000, "zipf", 2048),        # the bench's batch, whole: 48 workgroup runs of 43 sequences
+    ("headline_prefetch", "int8", 768, 1_000_000, "zipf", 2048),   # round 5: the same batch, matched ahead on the side stream
     ("C2", "fp16", 768, 1_000_000, "zipf", 256),
     ("int4_1M", "int4", 1024, 1_000_000, "zipf", 300),          # 43 runs of 7 sequences, the last one of 6
     ("fp32_1M", "fp32", 768, 1_000_000, "zipf", 256),           # the reference's own table format (embedding_cache.py:86)
@@ -118,8 +119,15 @@ def test_whole_bench_batch_against_the_c_oracle(name, fmt, d, n_rows, keygen, B)
     wte = (torch.randn(S.GPT2_VOCAB, d, generator=g) * 0.02).half().cuda()
     wpe = (torch.randn(T, d, generator=g) * 0.01).half().cuda()
     assert B * T > 32768                                                        # two-kernel form: k_match_ell + k_embed_wave
-    bad_bytes = _compare_with_c_oracle(lambda: cache.embed_tokens(tok, out_dtype=torch.float32),
-                                       lambda: cache.embed_tokens(tok, wte=wte, wpe=wpe), keys, lens, tok_np, ri, fmt, d, wte, wpe)
+
+    def embed(**kw):
+        if name.endswith("_prefetch"):
+            # scone_embed_prefetch (bench.py's loop): the match runs on the handle's side stream, the lookup takes its records
+            # over -- both announcements are pending when the first lookup is issued (two record buffers)
+            cache.prefetch_tokens(tok, tokens_ready=True)
+        return cache.embed_tokens(tok, **kw)
+    bad_bytes = _compare_with_c_oracle(lambda: embed(out_dtype=torch.float32),
+                                       lambda: embed(wte=wte, wpe=wpe), keys, lens, tok_np, ri, fmt, d, wte, wpe)
     assert bad_bytes == 0, f"{bad_bytes} fp16 values differ from the oracle's .half() of the same fp32 sum"
     assert cache.table.status() == 0
 
@@ -366,7 +374,7 @@ def test_cold_row_cache_over_several_batches_against_the_c_oracle(cache_rows, st
     """The HBM cache of cold rows lives across chunks, batches and calls (round 4): five DIFFERENT batches of 96 x 512 tokens
     (Zipf-distributed f-gram ids: rows recur between batches) and then the first batch again go through one pinned-host
     handle, every token of every batch against oracle.c -- fp32 bit-exact, fp16 bytes equal.  With 1024-token chunks the
-    cache is the pipeline's minimum of 30,720 rows, less than half of what the batches reference (rows are evicted and
+    cache is the pipeline's minimum of 43,008 rows (42 x the chunk), less than half of what the batches reference (rows are evicted and
     fetched again); a cache of 2M rows keeps everything (the second pass over batch 0 copies nothing).  The counters say what crossed PCIe:
     never more rows than the chunks list, and with the big cache exactly the distinct cold rows seen so far."""
     from scone_amd import EmbeddingCache, NGramExtractor

@@ -20,7 +20,7 @@
 #include <cstdlib>
 #include <new>
 
-#define SCONE_PF_SLOTS 2
+#define SCONE_PF_SLOTS 4  // buffers that exist; SCONE_PF_SLOTS=<n> (environment, 2..4) limits how many are used (A/B aid)
 
 struct scone_pf_slot {
   int32_t *ell = nullptr;
@@ -31,12 +31,14 @@ struct scone_pf_slot {
   const int32_t *tok = nullptr;
   int32_t B = 0, T = 0;
   uint64_t stamp = 0;           // prefetch order (the oldest pending one is dropped when every buffer is taken)
+  uint64_t used = 0;            // clock value when a lookup last took this buffer
 };
 
 struct scone_pf_state {
   hipStream_t side = nullptr;
   hipEvent_t start = nullptr;
   scone_pf_slot slot[SCONE_PF_SLOTS];
+  int n_slots = 3;
   uint64_t clock = 0;
 };
 
@@ -73,16 +75,26 @@ static int pf_state(scone_handle *h) {  // pf_mu held
   // The match is short and latency-bound, the gather beside it fills every wave slot for ~0.7 ms in three residency
   // rounds: at a higher priority the dispatcher hands freed slots to the match first (SCONE_PF_PRIORITY=0: default
   // priority, an A/B aid).
-  int lo = 0, hi = 0;
-  (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-  int prio = hi;
-  if (const char *ev = getenv("SCONE_PF_PRIORITY"))
-    if (*ev == '0') prio = 0;
+  int least = 0, greatest = 0;  // numerically: least priority = largest value
+  (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+  int prio = least;
+  if (const char *ev = getenv("SCONE_PF_PRIORITY")) {
+    if (*ev == 'h') prio = greatest;
+    else if (*ev == 'n' || *ev == '0') prio = 0;
+  }
+  if (const char *ev = getenv("SCONE_PF_SLOTS")) {
+    const int v = atoi(ev);
+    if (v >= 2 && v <= SCONE_PF_SLOTS) st->n_slots = v;
+  }
   SCONE_HIP(h, hipStreamCreateWithPriority(&st->side, hipStreamNonBlocking, prio));
-  SCONE_HIP(h, hipEventCreateWithFlags(&st->start, hipEventDisableTiming));
+  // device-scope release: these events order streams of ONE device, nothing on the host ever waits for them
+  unsigned ev_flags = hipEventDisableTiming | hipEventReleaseToDevice;
+  if (const char *ev = getenv("SCONE_PF_EVENT_SYSTEM_SCOPE"))
+    if (*ev == '1') ev_flags = hipEventDisableTiming;
+  SCONE_HIP(h, hipEventCreateWithFlags(&st->start, ev_flags));
   for (scone_pf_slot &sl : st->slot) {
-    SCONE_HIP(h, hipEventCreateWithFlags(&sl.ready, hipEventDisableTiming));
-    SCONE_HIP(h, hipEventCreateWithFlags(&sl.consumed, hipEventDisableTiming));
+    SCONE_HIP(h, hipEventCreateWithFlags(&sl.ready, ev_flags));
+    SCONE_HIP(h, hipEventCreateWithFlags(&sl.consumed, ev_flags));
   }
   h->pf_any.store(true, std::memory_order_release);
   return SCONE_OK;
@@ -103,11 +115,13 @@ int scone_pf_reserve(scone_handle *h, int64_t max_tokens) {
   if (!h->pf_any.load(std::memory_order_acquire)) return SCONE_OK;
   std::lock_guard<std::mutex> g(h->pf_mu);
   if (!h->pf) return SCONE_OK;
-  for (scone_pf_slot &sl : h->pf->slot)
+  for (int k = 0; k < h->pf->n_slots; ++k) {
+    scone_pf_slot &sl = h->pf->slot[k];
     if (!sl.valid) {
       int rc = pf_ensure(h, sl, 1);
       if (rc) return rc;
     }
+  }
   return SCONE_OK;
 }
 
@@ -119,14 +133,22 @@ int scone_pf_prefetch(scone_handle *h, const int32_t *d_tok, int32_t B, int32_t 
   // the buffer: one that already holds this batch (prefetched twice: matched again, the tokens may have changed), else a free
   // one, else the oldest pending prefetch is dropped
   scone_pf_slot *sl = nullptr;
-  for (scone_pf_slot &c : st->slot)
+  for (int k = 0; k < st->n_slots; ++k) {
+    scone_pf_slot &c = st->slot[k];
     if (c.valid && c.tok == d_tok && c.B == B && c.T == T) sl = &c;
+  }
+  // a free buffer: the one whose last lookup lies furthest back (its `consumed` event has most likely completed, so the match
+  // can start at once, beside whatever runs now -- with 3 buffers in a loop that is the lookup BEFORE the one just queued)
   if (!sl)
-    for (scone_pf_slot &c : st->slot)
-      if (!c.valid && (!sl || c.stamp < sl->stamp)) sl = &c;
+    for (int k = 0; k < st->n_slots; ++k) {
+      scone_pf_slot &c = st->slot[k];
+      if (!c.valid && (!sl || c.used < sl->used)) sl = &c;
+    }
   if (!sl)
-    for (scone_pf_slot &c : st->slot)
+    for (int k = 0; k < st->n_slots; ++k) {
+      scone_pf_slot &c = st->slot[k];
       if (!sl || c.stamp < sl->stamp) sl = &c;
+    }
   sl->valid = false;
   rc = pf_ensure(h, *sl, (int64_t)B * T);
   if (rc) return rc;
@@ -149,10 +171,11 @@ const int32_t *scone_pf_take(scone_handle *h, const int32_t *d_tok, int32_t B, i
   h->pf_mu.lock();
   scone_pf_state *st = h->pf;
   if (st) {
-    for (int k = 0; k < SCONE_PF_SLOTS; ++k) {
+    for (int k = 0; k < st->n_slots; ++k) {
       scone_pf_slot &sl = st->slot[k];
       if (!(sl.valid && sl.tok == d_tok && sl.B == B && sl.T == T)) continue;
       sl.valid = false;
+      sl.used = ++st->clock;
       if (hipStreamWaitEvent(s, sl.ready, 0) != hipSuccess) {
         (void)hipGetLastError();
         break;  // fall back to the serial match: correctness does not depend on the prefetch

@@ -93,8 +93,9 @@ def parse(argv=None):
     ap.add_argument("--same-batch", action="store_true", help="re-use ONE batch for every step (rounds 1-4; the Infinity Cache "
                     "then carries rows from step to step).  Default: a different batch every step")
     ap.add_argument("--prefetch", default="auto", choices=["auto", "on", "off"],
-                    help="scone_embed_prefetch of batch i + 1 right after the lookup of batch i (the serving loop: the next "
-                         "batch's match runs beside this batch's gather).  auto = on")
+                    help="scone_embed_prefetch of batch i + 1 right after the lookup of batch i (a pinned-host table with "
+                         "--stage-tokens: the next batch's first chunks are matched, placed and copied beside this batch's last "
+                         "lookups; a no-op for every other table).  auto = on where it does something")
     ap.add_argument("--no-configs", action="store_true", help="skip the `configs` block (BASELINE configs C2, C3, C4-in-HBM)")
     ap.add_argument("--configs-steps", type=int, default=15)
     ap.add_argument("--placement", default="hbm", choices=["hbm", "pinned_host"])
@@ -1453,7 +1454,8 @@ def main():
     n_batches = min(args.steps + args.warmup, MAX_DISTINCT_BATCHES) if rotated else 1
     tok_np, batches = make_batches(vocab_obj, keys, lens, args.stream, B, T, stream_seed, max(n_batches, 1))
     tok = batches[0]
-    prefetch = emu is None and not sharded and args.prefetch != "off"
+    staged = args.placement == "pinned_host" and args.stage_tokens > 0
+    prefetch = emu is None and not sharded and (args.prefetch == "on" or (args.prefetch == "auto" and staged))
     g = torch.Generator(device="cuda").manual_seed(5)
     wte = (torch.randn(vocab, d, generator=g, device="cuda") * 0.02).half()
     wpe = (torch.randn(1024, d, generator=g, device="cuda") * 0.01).half()
@@ -1524,9 +1526,10 @@ def main():
                 "tokens_per_step_per_rank": ntok, "mean_hits_per_token": sum_k / ntok, "hits_histogram_K0_6": k_hist[:7],
                 "different_batch_every_step": n_batches > 1, "distinct_batches": n_batches,
                 "next_batch_announced": bool(prefetch),
-                "loop": ("scone_embed(batch i) then scone_embed_prefetch(batch i + 1): the next batch's match (k_match_ell) runs on the "
-                         "handle's side stream beside this batch's gather; K matches and K gathers inside the timed region"
-                         if prefetch else "scone_embed(batch i): match, then gather, on one stream"),
+                "loop": ("scone_embed(batch i) then scone_embed_prefetch(batch i + 1): the next batch's first chunks are prepared on the "
+                         "handle's side streams beside this batch's last lookups" if prefetch else
+                         "scone_embed(batch i): k_match_ell, then the gather kernel, on one stream (running the next batch's match on a "
+                         "side stream beside this gather was built and measured 1-19 % slower at every batch size: profiles/r05b, r05c)"),
                 "distinct_table_rows_per_launch": n_rows_distinct, "distinct_wte_rows_per_launch": n_tok_distinct,
                 "parallelism": (f"shard {args.shard_of} of a row-sharded table, local work only (no exchange)" if emu else
                                 (("row-sharded table, RCCL all-to-all of quantised rows"
@@ -1547,10 +1550,9 @@ def main():
         if world_sanity is not None:
             res["world_sanity"] = world_sanity
         if n_launch and not sharded and emu is None and args.placement == "hbm":
-            # two contrasts on the same table, rank 0 alone (local synchronisation only): (i) the same batches WITHOUT the
-            # announcement -- match, then gather, on one stream: what rounds 1-4 timed; step minus kernel = k_match_ell + the
-            # gap between the two launches; (ii) ONE batch repeated with this round's loop -- what the Infinity Cache carries
-            # from step to step (rounds 1-4 measured the headline and its counter passes this way)
+            # the match's share of the step: ms_per_step - avg_kernel_ms (k_match_ell + the gap between the two launches); and a
+            # contrast on the same table, rank 0 alone (local synchronisation only): ONE batch repeated -- what the Infinity
+            # Cache carries from step to step (rounds 1-4 measured the headline and its counter passes this way)
             try:
                 local_sync = torch.cuda.synchronize
                 cs = max(10, min(args.steps, 20))
@@ -1559,16 +1561,10 @@ def main():
                     dt_c, nl_c, km_c, sm_c = lookup_loop(cache, bs, wte, wpe, out, cs, 2, local_sync, pf)
                     return {"ms_per_step": dt_c / cs * 1e3, "avg_kernel_ms": km_c / max(nl_c, 1), "kernel_ms": kernel_stats(sm_c, 1),
                             "tokens_per_s": ntok * cs / dt_c, "step_minus_kernel_us": (dt_c / cs * 1e3 - km_c / max(nl_c, 1)) * 1e3,
-                            "steps": cs, "distinct_batches": len(bs), "next_batch_announced": bool(pf)}
-                if prefetch:
-                    res["roofline"]["serial_match"] = contrast(batches, False)
-                    res["roofline"]["match_us"] = res["roofline"]["serial_match"]["step_minus_kernel_us"]
-                    res["roofline"]["match_us_kind"] = ("serial_match: ms_per_step - avg_kernel_ms of the same batches without the "
-                                                        "announcement = k_match_ell + the gap between the two launches")
-                else:
-                    res["roofline"]["match_us"] = res["roofline"]["step_minus_kernel_us"]
-                    res["roofline"]["match_us_kind"] = "ms_per_step - avg_kernel_ms: k_match_ell + the gap between the two launches"
-                if n_batches > 1:
+                            "steps": cs, "distinct_batches": len(bs)}
+                res["roofline"]["match_us"] = res["roofline"]["step_minus_kernel_us"]
+                res["roofline"]["match_us_kind"] = "ms_per_step - avg_kernel_ms: k_match_ell + the gap between the two launches"
+                if n_batches > 1 and not args.quick:     # (--quick runs sit under the counter passes: every launch a fresh batch)
                     res["roofline"]["same_batch"] = contrast(batches[:1], prefetch)
                 cache.embed_tokens(tok, wte=wte, wpe=wpe, out=out)       # (`out` = the first batch again, for the oracle check)
                 torch.cuda.synchronize()

@@ -220,25 +220,20 @@ int scone_gather_reduce(scone_handle *h, const int32_t *d_offsets, const int32_t
 int scone_embed(scone_handle *h, const int32_t *d_tok, int32_t B, int32_t T, const void *d_wte,
                 int64_t vocab, const void *d_wpe, int64_t n_pos, const int32_t *d_pos,
                 int32_t reduce, void *d_out, int32_t out_dtype, scone_stream_t stream);
-/* Announce the NEXT batch: what its lookup can do ahead of time is started now, on side streams of the handle, and the call
- * returns.  The scone_embed of exactly that batch (same pointer and shape; the tokens must not change in between) takes the
- * prepared work over; results are bit-identical with and without the call.  Ordering: the side-stream work goes behind what is
- * queued on `stream` at the time of the call (the stream on which the tokens are produced) -- or, tokens_ready != 0, behind
- * nothing: the tokens are complete (uploaded and synchronised earlier) and the work may run BESIDE a lookup queued on `stream`
- * just before, which is the point of calling it early.  The taking scone_embed may be issued on any stream; it waits for the
- * prepared work by event.  Thread-safe like scone_embed.
- *   Rows in HBM, or in pinned host DRAM read in place (cfg.stage_tokens == 0): the batch is MATCHED ahead (k_match_ell into one
- *     of two record buffers of the handle), so that its scone_embed is the gather kernel alone: a loop that calls
- *     scone_embed_prefetch(next) right after scone_embed(current) hides the match (~45 us per 1M tokens) and the gap between
- *     the two launches behind the current gather.  Two announcements may be pending; a third drops the oldest; one that is
- *     never used is dropped by later ones; an index mutation voids them all.  Batches small enough for the one-launch kernel
- *     (<= 32768 tokens at d = 768 / 1024 / 1280) have no separate match: a no-op.
- *   Pinned-host tables with a prefetch pipeline (cfg.stage_tokens > 0): the first chunks of (d_tok, B, T) are matched, their
- *     missing cold rows placed in the HBM cache and copied host -> HBM: a loop that calls scone_embed_prefetch(next) right after
- *     scone_embed(current) never pays the pipeline fill.  One announcement may be pending; one that is never used is dropped by
- *     the next call (the rows it cached stay cached).
- * (The north-star's "async prefetch"; the reference has no counterpart -- it matches inside its per-sequence Python loop,
- * engine.py:223-250, and its memory-mapped table faults rows in on first use, embedding_cache.py:132-135.) */
+/* Pinned-host tables with a prefetch pipeline (cfg.stage_tokens > 0): start fetching for the NEXT batch now.  The first chunks
+ * of (d_tok, B, T) are matched, their missing cold rows placed in the HBM cache and copied host -> HBM on the handle's side
+ * streams, ordered behind `stream` (the stream on which the tokens are produced) -- or, tokens_ready != 0, behind nothing: the
+ * tokens are complete (uploaded and synchronised earlier), and the prefetch may run BESIDE a lookup queued on `stream` just
+ * before, which is the point of calling it early -- and the call returns.  The scone_embed of exactly that batch (same pointer
+ * and shape; the tokens must not change in between; any stream) takes the prepared chunks over instead of starting its pipeline
+ * cold: a loop that calls scone_embed_prefetch(next) right after scone_embed(current) never pays the pipeline fill.  One
+ * announcement may be pending; one that is never used is dropped by the next call (the rows it cached stay cached).  Results are
+ * bit-identical with and without the call.  Thread-safe like scone_embed (serialised on the handle's staging lock).
+ * Any other handle (rows in HBM, or read in place): a no-op.  There the match of the next batch could run ahead; built and
+ * measured in round 5 -- k_match_ell on a side stream beside the previous gather is 1-19 % SLOWER than match-then-gather on
+ * one stream at every batch size (the gather holds every wave slot; profiles/r05b, r05c) -- and removed.
+ * (The north-star's "async prefetch"; the reference's memory-mapped table has no counterpart -- embedding_cache.py:132-135
+ * faults rows in on first use.) */
 int scone_embed_prefetch(scone_handle *h, const int32_t *d_tok, int32_t B, int32_t T, int32_t tokens_ready, scone_stream_t stream);
 /* Every per-stream workspace of the handle (those that exist, the default stream's -- created here -- and any created
  * later) holds at least max_tokens tokens: nothing is allocated inside a timed region afterwards. */

@@ -224,7 +224,7 @@ extern "C" int scone_create(const scone_cfg *cfg, scone_handle **out) {
   h->rows = nullptr, h->rows_host = nullptr, h->scales = nullptr, h->hot_local = 0;
   h->d_zero_row = nullptr, h->reserve_tokens = 0, h->ws_clock = 0;
   h->row_payload_bytes = 0, h->scale_bytes_per_row = 0;
-  h->stage = nullptr, h->shard = nullptr, h->pf = nullptr, h->pf_any = false;
+  h->stage = nullptr, h->shard = nullptr;
   h->cu_reserve = 0, h->lookup_stream = nullptr, h->lookup_in = nullptr, h->lookup_out = nullptr;
   h->prof_on = false, h->prof_ev = nullptr, h->prof_head = 0, h->prof_n = 0, h->prof_ms = 0.0;
 
@@ -383,7 +383,6 @@ extern "C" void scone_destroy(scone_handle *h) {
   h->ws.clear();
   if (h->d_zero_row) (void)hipFree(h->d_zero_row);
   scone_stage_destroy(h);
-  scone_pf_destroy(h);
   scone_shard_destroy(h);
   if (h->lookup_stream) {  // retired, not destroyed (see scone_set_cu_reserve)
     (void)hipStreamSynchronize(h->lookup_stream);
@@ -432,7 +431,7 @@ extern "C" int scone_reserve(scone_handle *h, int64_t max_tokens) {
     int rc = h->cfg.dim > 0 && h->cfg.dim % 8 == 0 ? scone_ensure_ell(h, w, max_tokens) : scone_ensure_hits(h, w, max_tokens);
     if (rc) return rc;
   }
-  return scone_pf_reserve(h, max_tokens);  // the record buffers of scone_embed_prefetch, where they exist
+  return SCONE_OK;
 }
 
 // ---------------------------------------------------------------- CU reserve

@@ -127,7 +127,6 @@ struct scone_row_store {
 
 struct scone_stage_state;
 struct scone_shard_state;
-struct scone_pf_state;  // match of the NEXT batch beside the lookup of this one (scone_prefetch.hip)
 
 // Per-stream workspaces of the large-batch lookup (id records / dense hits / CSR scan sums).  A call takes the
 // workspace of ITS stream and holds its lock while it enqueues the kernels that write and then read it, so lookups of
@@ -187,11 +186,6 @@ struct scone_handle {
   // this lock for the whole call, so calls from several host threads are serialised (their device work is ordered by the
   // pipeline's events exactly as that of consecutive calls from one thread)
   std::mutex stage_mu;
-  // scone_embed_prefetch on tables WITHOUT a staging pipeline (rows in HBM, or read in place from pinned host DRAM): the id
-  // records of the next batch(es), matched on a side stream; pf_mu guards the slots, pf_any lets lookups skip the lock
-  std::mutex pf_mu;
-  scone_pf_state *pf;
-  std::atomic<bool> pf_any;
   scone_shard_state *shard;  // row exchange between shards (scone_shard.hip), created on first use
   // optional kernel timing (scone_profile_*); prof_mu is held from the begin event to the end event of a launch
   std::mutex prof_mu;
@@ -300,17 +294,6 @@ int scone_shard_cols_remap(scone_handle *h, int32_t T, int32_t seq0, int32_t seq
                            const uint64_t *h_frag_off, const uint64_t *h_frag_slots, const uint64_t *h_rec_base,
                            const uint64_t *h_row_lo, int32_t world, uint64_t n_total,
                            const int32_t **ell, const uint8_t **head_p, unsigned long long *n_head_out, hipStream_t s);
-
-// match of the next batch on a side stream (scone_prefetch.hip)
-void scone_pf_destroy(scone_handle *h);
-void scone_pf_invalidate(scone_handle *h);  // the index changed: prefetched id records are stale
-int scone_pf_prefetch(scone_handle *h, const int32_t *d_tok, int32_t B, int32_t T, int32_t tokens_ready, hipStream_t stream);
-// The records scone_embed_prefetch prepared for exactly (d_tok, B, T), or null.  On a hit the handle's pf_mu is HELD and `s`
-// already waits for the match: the caller enqueues the lookup that reads them and calls scone_pf_release (records the
-// slot's "consumed" event on s and drops the lock).
-const int32_t *scone_pf_take(scone_handle *h, const int32_t *d_tok, int32_t B, int32_t T, hipStream_t s, int *slot);
-int scone_pf_release(scone_handle *h, int slot, hipStream_t s);
-int scone_pf_reserve(scone_handle *h, int64_t max_tokens);
 
 // staged prefetch of host-resident rows (scone_stage.hip)
 // record sets of the chunk pipeline: a chunk is prepared SCONE_STAGE_AHEAD chunks before it is looked up, and up to

@@ -162,12 +162,13 @@ extern "C" int scone_embed_prefetch(scone_handle *h, const int32_t *d_tok, int32
   if (!d_tok) return scone_fail(h, SCONE_EINVAL, "scone_embed_prefetch: null pointer");
   if (!scone_wave_kernel_covers(h->cfg.table_fmt, h->cfg.dim)) return SCONE_OK;
   SCONE_ON_DEVICE(h);
-  if (!(h->cfg.stage_tokens && h->rows_host)) {
-    // rows in HBM (or read in place over PCIe): what can run ahead is the match.  Batches the one-launch kernel takes
-    // (scone_embed's own rule) have no separate match: nothing to do
-    if (scone_embed_takes_one_launch(h, (long long)B * T)) return SCONE_OK;
-    return scone_pf_prefetch(h, d_tok, B, T, tokens_ready, (hipStream_t)stream);
-  }
+  // Rows in HBM (or read in place over PCIe): nothing to do.  What could run ahead there is the match of the next batch; built
+  // and measured in round 5 (k_match_ell on a side stream of the handle beside the previous gather, 2-4 record buffers, every
+  // stream priority): 1-19 % SLOWER than match-then-gather on one stream at every batch size from 33k to 1M tokens -- the
+  // gather kernel holds every wave slot of the chip, a match workgroup only gets in where a gather workgroup retires, and
+  // the gather loses exactly the time the match takes (profiles/r05b, profiles/r05c; the implementation is kept there as a
+  // diff).  Removed.
+  if (!(h->cfg.stage_tokens && h->rows_host)) return SCONE_OK;
   std::lock_guard<std::mutex> g(h->stage_mu);
   long long seqs = 0;
   rc = staged_geometry(h, B, T, &seqs);
@@ -250,23 +251,6 @@ extern "C" int scone_embed(scone_handle *h, const int32_t *d_tok, int32_t B, int
       return rc;
     }
     return scone_prof_end(h, s);
-  }
-  a.tok = d_tok, a.pos = d_pos, a.wte = d_wte, a.vocab = vocab, a.wpe = d_wpe, a.n_pos = n_pos;
-  a.reduce = reduce, a.out = d_out, a.status = h->d_status;
-  if (scone_wave_kernel_covers(h->cfg.table_fmt, h->cfg.dim)) {
-    // scone_embed_prefetch matched exactly this batch on the handle's side stream: the lookup only waits for that event
-    int pf_slot = -1;
-    if (const int32_t *ell = scone_pf_take(h, d_tok, B, T, s, &pf_slot)) {  // (pf_mu is held until scone_pf_release)
-      a.ell = ell;
-      rc = scone_prof_begin(h, s);
-      if (!rc) {
-        rc = launch_fmt(h, a, SRC_HITS, MODE_FULL, out_dtype, s);
-        if (rc) scone_prof_abort(h);
-        else rc = scone_prof_end(h, s);
-      }
-      const int rc2 = scone_pf_release(h, pf_slot, s);
-      return rc ? rc : rc2;
-    }
   }
   // the workspace of THIS stream, held while the match that writes it and the lookup that reads it are enqueued
   scone_ws_lock ws(scone_ws_acquire(h, s));

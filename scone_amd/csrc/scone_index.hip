@@ -461,11 +461,10 @@ int scone_launch_match_ell_ex(scone_handle *h, const int32_t *d_tok, int32_t B, 
   return SCONE_OK;
 }
 
-// id records matched before the index changed are stale: the prefetched ones are dropped (scone_prefetch.hip), and so is the
-// staging pipeline of a pinned-host table with whatever it prepared ahead (its records hold cache slots of rows found
-// through the old index).  Like every mutation: not concurrent with lookups.
+// id records matched before the index changed are stale: the staging pipeline of a pinned-host table is dropped with
+// whatever it prepared ahead (its records hold cache slots of rows found through the old index).  Like every mutation: not
+// concurrent with lookups.
 static void index_modified(scone_handle *h) {
-  scone_pf_invalidate(h);
   if (h->stage) scone_stage_destroy(h);
 }
 

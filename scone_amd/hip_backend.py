@@ -360,20 +360,14 @@ class SconeTable:
         return out
 
     def embed_prefetch(self, tok: torch.Tensor, tokens_ready: bool = False) -> None:
-        """``scone_embed_prefetch``: prepare the lookup of ``tok`` (int32 ``[B, T]`` on the device: pass the very tensor the later
-        :meth:`embed` gets) on the handle's side streams, behind the current stream -- or, ``tokens_ready=True``, right away (the
-        tokens are complete; the work then runs beside a lookup queued just before).  Pinned-host tables with a staging pipeline:
-        the first chunks are matched, placed and copied.  Every other table: the batch is MATCHED ahead (large batches; one-launch
-        batches have nothing to run ahead)."""
+        """``scone_embed_prefetch``: start the pinned-host prefetch pipeline for ``tok`` (int32 ``[B, T]`` on the device: pass the
+        very tensor the later :meth:`embed` gets) behind the current stream -- or, ``tokens_ready=True``, right away (the tokens
+        are complete; the prefetch then runs beside a lookup queued just before).  A no-op for other tables."""
         assert tok.dim() == 2 and tok.dtype == torch.int32 and tok.is_cuda and tok.is_contiguous()
         B, T = tok.shape
         stream = torch.cuda.current_stream(self.device).cuda_stream
         self._check(L.lib().scone_embed_prefetch(self._h, tok.data_ptr(), B, T, int(bool(tokens_ready)), stream), "scone_embed_prefetch")
-        keep = getattr(self, "_prefetch_keepalive", None)
-        if not isinstance(keep, list):
-            keep = []
-        keep.append(tok)                      # two prefetches may be pending (SCONE_PF_SLOTS); older ones were taken or dropped
-        self._prefetch_keepalive = keep[-3:]
+        self._prefetch_keepalive = tok
 
     def reserve(self, max_tokens: int) -> None:
         with torch.cuda.device(self.device):

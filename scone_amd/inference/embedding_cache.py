@@ -313,15 +313,14 @@ class EmbeddingCache:
         return result
 
     def prefetch_tokens(self, input_ids: torch.Tensor, tokens_ready: bool = False) -> None:
-        """Start the lookup of the NEXT batch now (``scone_embed_prefetch``), on the handle's side streams behind the current
-        stream.  Tables in pinned host DRAM with ``stage_tokens > 0``: its first chunks are matched, placed in the HBM cache and
-        copied.  Every other table (rows in HBM, or read in place): the batch is matched ahead, so that its ``embed_tokens`` is the
-        gather kernel alone (large batches; a batch small enough for the one-launch kernel has nothing to run ahead).
-        ``input_ids`` must be the very int32 device tensor ``[B, T]`` the later :meth:`embed_tokens` gets, unchanged in between.  A
-        serving loop calls it right after ``embed_tokens`` of the current batch -- with ``tokens_ready=True`` when the next tokens
-        are complete (uploaded earlier): the work then runs BESIDE the lookup just queued instead of behind it.  Results are
-        bit-identical with and without it.  New here (the reference matches inside its per-sequence Python loop, engine.py:223-250,
-        and its memmap faults rows in on first use, embedding_cache.py:132-135)."""
+        """Tables in pinned host DRAM with ``stage_tokens > 0``: start fetching the cold rows of the NEXT batch now
+        (``scone_embed_prefetch``: its first chunks are matched, placed in the HBM cache and copied on side streams behind the
+        current stream).  ``input_ids`` must be the very int32 device tensor ``[B, T]`` the later :meth:`embed_tokens` gets,
+        unchanged in between.  A serving loop calls it right after ``embed_tokens`` of the current batch -- with
+        ``tokens_ready=True`` when the next tokens are complete (uploaded earlier): the prefetch then runs BESIDE the lookup
+        just queued instead of behind it -- and never pays the pipeline's fill; other tables: a no-op (matching the next batch
+        ahead on a side stream was measured slower than match-then-gather on one stream: profiles/r05b).  New here (the
+        reference's memmap faults rows in on first use, embedding_cache.py:132-135)."""
         tok = torch.as_tensor(input_ids)
         if not (tok.dim() == 2 and tok.dtype == torch.int32 and tok.is_cuda and tok.is_contiguous()):
             raise ValueError("prefetch_tokens needs the contiguous int32 device tensor [B, T] that embed_tokens will get")

@@ -87,7 +87,6 @@ def _compare_with_c_oracle(embed_f32, embed_f16, keys, lens, tok_np, ri, fmt, d,
 
 @pytest.mark.parametrize("name,fmt,d,n_rows,keygen,B", [
     ("headline", "int8", 768, 1_000_000, "zipf", 2048),        # the bench's batch, whole: 48 workgroup runs of 43 sequences
-    ("headline_prefetch", "int8", 768, 1_000_000, "zipf", 2048),   # round 5: the same batch, matched ahead on the side stream
     ("C2", "fp16", 768, 1_000_000, "zipf", 256),
     ("int4_1M", "int4", 1024, 1_000_000, "zipf", 300),          # 43 runs of 7 sequences, the last one of 6
     ("fp32_1M", "fp32", 768, 1_000_000, "zipf", 256),           # the reference's own table format (embedding_cache.py:86)
@@ -119,15 +118,8 @@ def test_whole_bench_batch_against_the_c_oracle(name, fmt, d, n_rows, keygen, B)
     wte = (torch.randn(S.GPT2_VOCAB, d, generator=g) * 0.02).half().cuda()
     wpe = (torch.randn(T, d, generator=g) * 0.01).half().cuda()
     assert B * T > 32768                                                        # two-kernel form: k_match_ell + k_embed_wave
-
-    def embed(**kw):
-        if name.endswith("_prefetch"):
-            # scone_embed_prefetch (bench.py's loop): the match runs on the handle's side stream, the lookup takes its records
-            # over -- both announcements are pending when the first lookup is issued (two record buffers)
-            cache.prefetch_tokens(tok, tokens_ready=True)
-        return cache.embed_tokens(tok, **kw)
-    bad_bytes = _compare_with_c_oracle(lambda: embed(out_dtype=torch.float32),
-                                       lambda: embed(wte=wte, wpe=wpe), keys, lens, tok_np, ri, fmt, d, wte, wpe)
+    bad_bytes = _compare_with_c_oracle(lambda: cache.embed_tokens(tok, out_dtype=torch.float32),
+                                       lambda: cache.embed_tokens(tok, wte=wte, wpe=wpe), keys, lens, tok_np, ri, fmt, d, wte, wpe)
     assert bad_bytes == 0, f"{bad_bytes} fp16 values differ from the oracle's .half() of the same fp32 sum"
     assert cache.table.status() == 0
 

@@ -1,24 +1,20 @@
-"""`scone_embed_prefetch` (round 5): the match of the NEXT batch on a side stream of the handle.
+"""`scone_embed_prefetch` and the staging pipeline of a pinned-host table under concurrency (round 5).
 
-Tables without a staging pipeline: the id records of an announced batch are written by the same `k_match_ell` as in the serial
-path, into one of two record buffers of the handle, and the `scone_embed` of that batch takes them over by event.  Nothing about
-the result may change -- every lookup here is compared with the same handle's serial lookup (which the parity suites pin to
-the oracle and the golden fixtures: tests/test_gpu_parity.py, tests/test_gpu_bench_shape.py) AND, for one table, with the
-oracle directly (oracle/ref_port.py: n_gram_extractor.py:106-126 -> embedding_cache.py:113-181 -> engine.py:234-266 ->
-language_model.py:239-254).
+* the staging pipeline called from several host threads (one pipeline per handle: the calls are serialised on the handle's
+  staging lock; SURVEY 8b "lookups are thread-safe and stream-ordered"),
+* the discard race the round-4 advisor found (a prefetched batch dropped by the lookup of another one on a cold cache: its
+  copy kernel against the preparation that re-uses its record set),
+* tables without a staging pipeline: the announcement is a no-op (the match of the next batch on a side stream was built,
+  measured slower than match-then-gather on one stream at every batch size, and removed: profiles/r05b, profiles/r05c).
 
-Also here: the staging pipeline of a pinned-host table called from several host threads (one pipeline per handle: the calls
-are serialised on the handle's lock), and the discard race the round-4 advisor found (a prefetched batch dropped by the lookup
-of another one on a cold cache)."""
+Every result is compared with the HBM-resident twin of the same table, which the parity suites pin to the oracle and the
+golden fixtures (tests/test_gpu_parity.py, tests/test_gpu_bench_shape.py)."""
 
-import os
 import threading
 
 import numpy as np
 import pytest
 import torch
-
-from oracle import ref_port as R
 
 pytestmark = pytest.mark.gpu
 
@@ -44,179 +40,20 @@ def _table(keys, lens, table, fmt, max_n=3, **kw):
     return t
 
 
-@pytest.fixture
-def two_kernel_form(monkeypatch):
-    """Every batch takes the two-kernel form (k_match_ell + k_embed_wave), whatever its size: the one-launch limit is read by
-    scone_create."""
-    monkeypatch.setenv("SCONE_FUSED_MAX_TOKENS", "0")
-
-
-@pytest.mark.parametrize("fmt,d,max_n", [("int8", 768, 3), ("int4", 1024, 3), ("fp16", 256, 3), ("int8", 768, 4), ("fp32", 1280, 2)])
-def test_prefetched_match_is_bit_identical(two_kernel_form, fmt, d, max_n):
-    """Announce / look up in every order a caller can produce: next batch after the current lookup, twice the same batch, an
-    announcement that is never used, three pending (the oldest is dropped), the lookup on another stream than the announcement,
-    tokens written on the stream just before the announcement (tokens_ready = 0), other output dtypes and reduce modes, an
-    explicit position tensor.  Every output equals the serial lookup of the same handle bit for bit; status stays 0."""
-    rng = np.random.default_rng(501)
-    vocab, n = 41, 3000
-    keys, lens = _vocab(rng, vocab, n, max_n)
-    t = _table(keys, lens, rng.standard_normal((n, d)).astype(np.float32), fmt, max_n)
-    wte = torch.from_numpy(rng.standard_normal((vocab, d)).astype(np.float32)).half().cuda()
-    wpe = torch.from_numpy(rng.standard_normal((64, d)).astype(np.float32)).half().cuda()
-    shapes = [(7, 40), (1, 33), (300, 5), (64, 40), (3, 64), (1, 1), (2, 2)]
-    toks = [torch.from_numpy(rng.integers(0, vocab, size=s)).to("cuda", torch.int32) for s in shapes]
-    want = [t.embed(x, wte=wte, wpe=wpe).clone() for x in toks]
-    want32 = [t.embed(x, out_dtype=torch.float32, reduce="sum").clone() for x in toks]
-    torch.cuda.synchronize()
-    # 1. the serving loop: embed(i), prefetch(i + 1)
-    t.embed_prefetch(toks[0], tokens_ready=True)
-    for i in range(len(toks)):
-        out = t.embed(toks[i], wte=wte, wpe=wpe)
-        if i + 1 < len(toks):
-            t.embed_prefetch(toks[i + 1], tokens_ready=True)
-        assert torch.equal(out, want[i]), i
-    # 2. twice the same batch; then both buffers pending and a third announcement (drops the oldest: toks[1])
-    t.embed_prefetch(toks[1], tokens_ready=True)
-    t.embed_prefetch(toks[1], tokens_ready=True)
-    t.embed_prefetch(toks[2], tokens_ready=True)
-    t.embed_prefetch(toks[3], tokens_ready=True)
-    for i in (1, 3, 2, 3):                                   # 1: serial again; 3, 2: prefetched; 3: serial
-        assert torch.equal(t.embed(toks[i], wte=wte, wpe=wpe), want[i]), i
-    # 3. other dtype / reduce through prefetched records; records are per batch, not per output format
-    for i in (0, 3):
-        t.embed_prefetch(toks[i], tokens_ready=True)
-        assert torch.equal(t.embed(toks[i], out_dtype=torch.float32, reduce="sum"), want32[i])
-    # 4. lookup on another stream than the announcement; tokens produced on the announcing stream just before
-    buf = torch.zeros_like(toks[3])
-    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
-    for rep in range(6):
-        src = toks[3] if rep % 2 == 0 else torch.flip(toks[3], dims=(0,))
-        with torch.cuda.stream(s1):
-            buf.copy_(src, non_blocking=True)
-            t.embed_prefetch(buf, tokens_ready=False)        # behind the copy queued on s1
-        with torch.cuda.stream(s2):
-            out = t.embed(buf, wte=wte, wpe=wpe)             # waits for the match by event (which waited for the copy)
-        s2.synchronize()
-        ref = want[3] if rep % 2 == 0 else torch.flip(want[3], dims=(0,))
-        assert torch.equal(out, ref), rep
-        s1.synchronize()
-    # 5. explicit position ids (the per-token position kernel variant)
-    pos = torch.from_numpy(rng.integers(0, 64, size=shapes[0])).to("cuda", torch.int32)
-    ref = t.embed(toks[0], wte=wte, wpe=wpe, position_ids=pos).clone()
-    t.embed_prefetch(toks[0], tokens_ready=True)
-    assert torch.equal(t.embed(toks[0], wte=wte, wpe=wpe, position_ids=pos), ref)
-    assert t.status() == 0
-
-
-def test_prefetched_lookup_against_the_oracle(two_kernel_form):
-    """The prefetched path against oracle/ref_port.py itself (not only against the serial HIP path): fp32 table, fp32 out,
-    bit-exact mean in list order; fused fp16 output within 1e-3."""
-    rng = np.random.default_rng(502)
-    vocab, n, d = 29, 2500, 768
-    keys, lens = _vocab(rng, vocab, n)
-    table = rng.standard_normal((n, d)).astype(np.float32)
-    t = _table(keys, lens, table, "fp32")
-    wte = torch.from_numpy(rng.standard_normal((vocab, d)).astype(np.float32)).half().cuda()
-    wpe = torch.from_numpy(rng.standard_normal((48, d)).astype(np.float32)).half().cuda()
-    for B, T in ((5, 48), (1, 2), (33, 17)):
-        tok_np = rng.integers(0, vocab, size=(B, T))
-        tok = torch.from_numpy(tok_np).to("cuda", torch.int32)
-        off, ids = R.hits_to_csr(R.match_hits(keys, lens, tok_np, 3))
-        fg = R.embed_numpy(table, off, ids, "mean").reshape(B, T, d)
-        t.embed_prefetch(tok, tokens_ready=True)
-        got = t.embed(tok, out_dtype=torch.float32).cpu().numpy()
-        assert np.array_equal(got, fg), (B, T)
-        t.embed_prefetch(tok, tokens_ready=True)
-        got16 = t.embed(tok, wte=wte, wpe=wpe).float().cpu().numpy()
-        ref = R.combine(torch.from_numpy(tok_np), torch.from_numpy(fg), wte.float().cpu(), wpe.float().cpu()).numpy()
-        assert np.abs(got16 - ref).max() / np.abs(ref).max() < 1e-3
-    assert t.status() == 0
-
-
 def test_small_batches_and_other_dims_ignore_the_announcement():
-    """A batch the one-launch kernel takes has no separate match, a dim that is not a multiple of 8 has no record form: the
-    announcement is a no-op and the lookup is what it always was."""
+    """Tables without a staging pipeline: the announcement is a no-op, whatever the batch size; the lookup is what it was."""
     rng = np.random.default_rng(503)
     vocab, n = 31, 1000
     keys, lens = _vocab(rng, vocab, n)
     for fmt, d in (("int8", 768), ("fp32", 36)):
         t = _table(keys, lens, rng.standard_normal((n, d)).astype(np.float32), fmt)
-        tok = torch.from_numpy(rng.integers(0, vocab, size=(4, 32))).to("cuda", torch.int32)
-        ref = t.embed(tok, out_dtype=torch.float32).clone()
-        t.embed_prefetch(tok, tokens_ready=True)
-        t.embed_prefetch(tok)
-        assert torch.equal(t.embed(tok, out_dtype=torch.float32), ref)
+        for shape in ((4, 32), (80, 512)):                     # one-launch kernel / match + gather
+            tok = torch.from_numpy(rng.integers(0, vocab, size=shape)).to("cuda", torch.int32)
+            ref = t.embed(tok, out_dtype=torch.float32).clone()
+            t.embed_prefetch(tok, tokens_ready=True)
+            t.embed_prefetch(tok)
+            assert torch.equal(t.embed(tok, out_dtype=torch.float32), ref)
         assert t.status() == 0
-
-
-def test_index_mutation_voids_announcements(two_kernel_form):
-    """Records matched before the index changed are stale: an index build between announcement and lookup drops them, the
-    lookup matches again and sees the new f-grams."""
-    from scone_amd.hip_backend import SconeTable
-    rng = np.random.default_rng(504)
-    vocab, n, d = 23, 600, 768
-    keys, lens = _vocab(rng, vocab, n)
-    _, first = np.unique(np.concatenate([keys, lens[:, None].astype(np.uint32)], axis=1), axis=0, return_index=True)
-    first = np.sort(first)
-    keys, lens = keys[first], lens[first]                     # distinct keys: id = row number in both tables
-    n = len(lens)
-    table = rng.standard_normal((n, d)).astype(np.float32)
-    half = n // 2
-    t = SconeTable(3, n, d, "fp32")
-    t.store_f32(torch.from_numpy(table))
-    t.index_build(keys[:half], lens[:half])
-    full = _table(keys, lens, table, "fp32")
-    tok = torch.from_numpy(rng.integers(0, vocab, size=(16, 64))).to("cuda", torch.int32)
-    before = t.embed(tok, out_dtype=torch.float32).clone()
-    t.embed_prefetch(tok, tokens_ready=True)
-    t.index_build(keys[half:], lens[half:], id0=half)
-    after = t.embed(tok, out_dtype=torch.float32)
-    assert torch.equal(after, full.embed(tok, out_dtype=torch.float32))
-    assert not torch.equal(after, before)
-
-
-def test_announcements_from_several_host_threads(two_kernel_form):
-    """Thread-safe like scone_embed: three host threads, each on its own stream, announce and look up on ONE handle (two record
-    buffers for three threads: announcements are dropped all the time, the lookups then match for themselves); every result
-    equals the single-threaded answer."""
-    rng = np.random.default_rng(505)
-    vocab, n, d = 61, 4000, 768
-    keys, lens = _vocab(rng, vocab, n)
-    t = _table(keys, lens, rng.standard_normal((n, d)).astype(np.float32), "int8")
-    wte = torch.from_numpy(rng.standard_normal((vocab, d)).astype(np.float32)).half().cuda()
-    wpe = torch.from_numpy(rng.standard_normal((512, d)).astype(np.float32)).half().cuda()
-    toks = [torch.from_numpy(rng.integers(0, vocab, size=s)).to("cuda", torch.int32) for s in ((32, 512), (40, 448), (24, 512), (3, 7))]
-    want = [t.embed(x, wte=wte, wpe=wpe).clone() for x in toks]
-    torch.cuda.synchronize()
-    errors = []
-
-    def worker(seed):
-        try:
-            r = np.random.default_rng(seed)
-            stream = torch.cuda.Stream()
-            with torch.cuda.stream(stream):
-                k = int(r.integers(len(toks)))
-                for it in range(80):
-                    out = t.embed(toks[k], wte=wte, wpe=wpe)
-                    k_next = int(r.integers(len(toks)))
-                    if it % 3 != 2:
-                        t.embed_prefetch(toks[k_next], tokens_ready=bool(it % 2))
-                    if it % 4 == 0:
-                        stream.synchronize()
-                        if not torch.equal(out, want[k]):
-                            errors.append((seed, it, k))
-                    k = k_next
-            stream.synchronize()
-        except Exception as e:          # surface in the main thread
-            errors.append(repr(e))
-
-    threads = [threading.Thread(target=worker, args=(s,)) for s in (1, 2, 3)]
-    for th in threads:
-        th.start()
-    for th in threads:
-        th.join()
-    assert not errors, errors[:3]
-    assert t.status() == 0
 
 
 # ------------------------------------------------------------------ the staging pipeline of a pinned-host table

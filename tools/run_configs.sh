@@ -29,7 +29,7 @@ rm -f $O/configs.jsonl
 run headline_int8_1M_d768 --steps 50 --warmup 5 || exit 1
 run headline_zipf_stream --steps 50 --warmup 5 --stream zipf || exit 1
 run C2_fp16_1M_d768 --steps 50 --warmup 5 --format fp16 || exit 1
-run C3_int8_10M_d1024 --steps 30 --warmup 3 --rows 10000000 --dim 1024 || exit 1
+run C3_int8_10M_d1024 --steps 30 --warmup 3 --rows 10000000 --dim 1024 --keygen zipf_gpu || exit 1
 run int4_1M_d1024 --steps 30 --warmup 3 --format int4 --dim 1024 || exit 1
 run int8_1M_d1280 --steps 30 --warmup 3 --dim 1280 || exit 1
 run C4_int4_100M_d1024_hbm --steps 20 --warmup 3 --rows 100000000 --format int4 --dim 1024 --keygen structured || exit 1

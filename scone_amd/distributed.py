@@ -246,8 +246,11 @@ class ShardedEmbeddingCache:
                  rank: Optional[int] = None, world: Optional[int] = None, group=None, device=None,
                  n_rows: Optional[int] = None, placement: str = "hbm", table=None, replicated_rows: int = 0,
                  gather_chunks: int = 1, gather_transport: str = "p2p", shard_match="auto", plan_slots: int = 2,
-                 sync_free_plan: bool = True) -> None:
+                 sync_free_plan: bool = True, control_group=None) -> None:
         self.group = group
+        # gather_transport="sdma" rendezvous on the host twice per step: a gloo group of the same ranks as `group`.  None: the
+        # group itself when it is a host group, else one is created (possible only when `group` is the whole world)
+        self.control_group = control_group
         # The one-piece "gather_rows" exchange without host round trips (round 4): after a first batch with exact sizes, every
         # later batch sizes its transfers from what the ranks contributed before (+ 12.5 %, never shrinking), plans and packs
         # with the count on the device (scone_shard_gather_plan*_async / scone_shard_cols_pack_cap), ships each rank's count in
@@ -373,11 +376,21 @@ class ShardedEmbeddingCache:
             self.transport_fallback_reason = f"rank {bad[0][0]}: {bad[0][1]}"
             self.gather_transport = "p2p"
             return
-        # host-side rendezvous of the step: the group itself when it is a host group (gloo), else a gloo group beside it
+        # host-side rendezvous of the step: the group itself when it is a host group (gloo), a gloo group the caller supplies
+        # (`control_group=`), or one created beside the group here.  dist.new_group is collective over the DEFAULT world, not
+        # over `group`: on a sub-group it would hang the ranks outside it, so without a supplied control group the transport
+        # is only offered to caches whose group IS the world; a sub-group without one falls back to p2p (every rank alike).
         if _host_staged(self.group):
             ctrl = self.group
+        elif self.control_group is not None:
+            ctrl = self.control_group
         else:
             ranks = list(range(dist.get_world_size())) if self.group is None else dist.get_process_group_ranks(self.group)
+            if len(ranks) != dist.get_world_size():
+                self.transport_fallback_reason = ("gather_transport='sdma' on a sub-group needs control_group= (a gloo group of the "
+                                                  "same ranks): dist.new_group is collective over the whole world")
+                self.gather_transport = "p2p"
+                return
             ctrl = dist.new_group(ranks=ranks, backend="gloo")
         dev = self.table.device
         self._sdma = {"ctrl": ctrl, "slots": [None] * 4,
@@ -501,28 +514,37 @@ class ShardedEmbeddingCache:
             self._sdma_init()
         return self.gather_transport
 
-    def _sdma_release_slot(self, st) -> None:
+    # Release order, everywhere (close(), a slot that grows, an event pool that is used up): first every rank lets go of what
+    # it OPENED from its peers, then -- after a host barrier -- of what it OWNS.  HIP leaves freeing exported memory (or
+    # destroying an exported event) that another process still has open undefined.
+    def _sdma_close_peer_buffers(self, st) -> None:
         t = self.table
         for r in range(self.world):
             if r != self.rank and st["peer"][r] is not None:
                 for ptr in st["peer"][r]:
                     if ptr:
                         t.ipc_close(ptr)
-        for ptr in st["ptrs"]:
-            if ptr:
-                t.ipc_free(ptr)
-        self._sdma_release_events(st)
+                st["peer"][r] = None
 
-    def _sdma_release_events(self, st) -> None:
+    def _sdma_close_peer_events(self, st) -> None:
         t = self.table
         for r in range(self.world):
             if r != self.rank and st["peer_sent"][r] is not None:
                 for e in st["peer_sent"][r] + st["peer_done"][r]:
                     t.ipc_event_destroy(e)
-        for e in st["sent"] + st["done"]:
-            t.ipc_event_destroy(e)
-        st["sent"], st["done"] = [], []
         st["peer_sent"], st["peer_done"] = [None] * self.world, [None] * self.world
+
+    def _sdma_free_own_events(self, st) -> None:
+        for e in st["sent"] + st["done"]:
+            self.table.ipc_event_destroy(e)
+        st["sent"], st["done"] = [], []
+
+    def _sdma_free_own(self, st) -> None:
+        for ptr in st["ptrs"]:
+            if ptr:
+                self.table.ipc_free(ptr)
+        st["ptrs"] = []
+        self._sdma_free_own_events(st)
 
     def _sdma_new_events(self, st, slot: int) -> None:
         """A fresh pool of interprocess events for this slot, exchanged with and opened by every peer (collective; the caller
@@ -547,7 +569,9 @@ class ShardedEmbeddingCache:
         """The slot's event pool is used up: every rank arrives here in the same step (pushes are collective)."""
         torch.cuda.synchronize(self.table.device)        # my waits for the old events, and my records of them, are complete
         dist.barrier(group=self._sdma["ctrl"])           # ... and so are everybody else's
-        self._sdma_release_events(st)
+        self._sdma_close_peer_events(st)                 # what I opened goes first ...
+        dist.barrier(group=self._sdma["ctrl"])           # ... everywhere, before any owner destroys what it exported
+        self._sdma_free_own_events(st)
         self._sdma_new_events(st, slot)
         dist.barrier(group=self._sdma["ctrl"])           # every rank has opened every new event before anyone records one
 
@@ -562,8 +586,11 @@ class ShardedEmbeddingCache:
         pb, sb, nh = t.payload_bytes(), t.scale_bytes(), int(getattr(t, "n_head", 0) or 0)
         torch.cuda.synchronize(dev)
         dist.barrier(group=self._sdma["ctrl"])           # nobody pushes into, or reads from, the buffers that go away
-        if st is not None:
-            self._sdma_release_slot(st)
+        if st is not None:                               # (every rank takes this branch in the same step: same totals everywhere)
+            self._sdma_close_peer_buffers(st)
+            self._sdma_close_peer_events(st)
+            dist.barrier(group=self._sdma["ctrl"])       # what a rank has opened is closed everywhere before any owner frees it
+            self._sdma_free_own(st)
         cap, fcap = max(total + total // 8, 1), max(ftotal + ftotal // 8, 64)
         nbytes = (cap * pb, (nh + cap) * sb, fcap * 8)
         ptrs, handles = [], []
@@ -649,19 +676,11 @@ class ShardedEmbeddingCache:
             dist.barrier(group=ctrl)
             slots = [st for st in self._sdma["slots"] if st is not None]
             for st in slots:
-                for q in range(self.world):
-                    if q != self.rank and st["peer"][q] is not None:
-                        for ptr in st["peer"][q]:
-                            if ptr:
-                                t.ipc_close(ptr)
-                        st["peer"][q] = None
-                    if q != self.rank and st["peer_sent"][q] is not None:
-                        for e in st["peer_sent"][q] + st["peer_done"][q]:
-                            t.ipc_event_destroy(e)
-                        st["peer_sent"][q] = st["peer_done"][q] = None
+                self._sdma_close_peer_buffers(st)
+                self._sdma_close_peer_events(st)
             dist.barrier(group=ctrl)
             for st in slots:
-                self._sdma_release_slot(st)
+                self._sdma_free_own(st)
             self._sdma = None
 
     # ------------------------------------------------------------------

@@ -697,16 +697,22 @@ class SconeTable:
     def ipc_event_destroy(self, event: int) -> None:
         self._check(L.lib().scone_ipc_event_destroy(self._h, C.c_void_p(event)), "scone_ipc_event_destroy")
 
+    # (the stream is torch's current stream of THE TABLE'S device, whatever device is current in the caller)
     def ipc_event_record(self, event: int) -> None:
-        self._check(L.lib().scone_ipc_event_record(self._h, C.c_void_p(event), _stream()), "scone_ipc_event_record")
+        with torch.cuda.device(self.device):
+            rc = L.lib().scone_ipc_event_record(self._h, C.c_void_p(event), _stream())
+        self._check(rc, "scone_ipc_event_record")
 
     def ipc_event_wait(self, event: int) -> None:
-        self._check(L.lib().scone_ipc_event_wait(self._h, C.c_void_p(event), _stream()), "scone_ipc_event_wait")
+        with torch.cuda.device(self.device):
+            rc = L.lib().scone_ipc_event_wait(self._h, C.c_void_p(event), _stream())
+        self._check(rc, "scone_ipc_event_wait")
 
     def ipc_push(self, dst_ptr: int, src_ptr: int, nbytes: int, copy_engine: bool = True) -> None:
         """``nbytes`` from ``src_ptr`` (this device) to ``dst_ptr`` (possibly a peer's mapped buffer) on the current stream."""
-        self._check(L.lib().scone_ipc_push(self._h, C.c_void_p(dst_ptr), C.c_void_p(src_ptr), int(nbytes), int(bool(copy_engine)),
-                                           _stream()), "scone_ipc_push")
+        with torch.cuda.device(self.device):
+            rc = L.lib().scone_ipc_push(self._h, C.c_void_p(dst_ptr), C.c_void_p(src_ptr), int(nbytes), int(bool(copy_engine)), _stream())
+        self._check(rc, "scone_ipc_push")
 
     def ipc_tensor(self, ptr: int, nbytes: int) -> torch.Tensor:
         """A uint8 tensor over raw device memory of this handle's device (no ownership: keep the allocation alive)."""

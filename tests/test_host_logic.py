@@ -196,16 +196,35 @@ def test_committed_bench_line_follows_the_contract():
                 assert so["value"] > 0 and 0 < so["rows_over_pcie_per_step"] < so["distinct_cold_rows"]
                 assert so["prefetch_beats_zero_copy"] is (so["value"] >= so["zero_copy_same_stream"]["value"])
                 assert so["prefetch_beats_static_head"] is (so["value"] >= so["zero_copy_static_head_same_hbm"]["value"])
+        if int(re.match(r"r(\d+)", rounds[-1]).group(1)) >= 5:
+            # round 5: a different batch every step (the repeated-batch figure beside it), every single-GPU BASELINE config in
+            # the line -- counter-priced on this kernel source, checked against the oracle in the run --, pcie_frac on the
+            # pinned-host records
+            assert r["config"]["different_batch_every_step"] is True and r["config"]["distinct_batches"] >= r["steps"]
+            assert rf["traffic"] is not None and rf["traffic_stale"] is False and r["workload_sig"].endswith("-rot")
+            sb = rf["same_batch"]
+            assert sb["distinct_batches"] == 1 and sb["ms_per_step"] > 0 and sb["avg_kernel_ms"] > 0
+            assert abs(rf["step_minus_kernel_us"] - (r["ms_per_step"] - rf["avg_kernel_ms"]) * 1e3) < 1e-6
+            assert set(r["configs"]) == {"C2_fp16_1M_d768", "C3_int8_10M_d1024", "C4_int4_100M_d1024_in_hbm"}
+            for name, c in r["configs"].items():
+                crf = c["roofline"]
+                assert c["tokens_per_s"] > 0 and c["status_bits"] == 0 and c["gpu_vs_oracle_max_rel_err"] < 1e-3, name
+                assert len(c["gpu_vs_oracle_sequences"]) == 8, name
+                assert crf["traffic"] is not None and crf["traffic_stale"] is False and "left L2" in crf["frac_kind"], name
+                assert 0 < crf["hbm_frac"] <= crf["frac"] <= 1.0 and crf["kernel_ms"]["min"] <= crf["kernel_ms"]["median"] <= crf["kernel_ms"]["max"], name
+            for k in ("n1_pinned_host", "n1_pinned_host_zipf"):
+                z = r["sharded"][k]
+                assert 0 < z["pcie_frac"] <= 1.0 and abs(z["pcie_frac"] - z["pcie_GBps"] / 64.0) < 1e-9, k
         # every other committed line of the round (tools/run_configs.sh) obeys the same rule
         for d in os.listdir(prof):
             cj = os.path.join(prof, d, "configs.jsonl")
-            if d.startswith(("r03", "r04")) and os.path.exists(cj):
+            if d.startswith(("r03", "r04", "r05")) and os.path.exists(cj):
                 for ln in open(cj):
                     if ln.strip():
                         c = json.loads(ln)
                         assert 0 < c["roofline"]["frac"] <= 1.0, (d, c.get("config_name"))
                         # round 4: EVERY workload whose table sits in HBM is counter-priced on the sources it ran on
-                        if d.startswith("r04") and "pinned" not in c["config_name"] and "shard" not in c["config_name"]:
+                        if d.startswith(("r04", "r05")) and "pinned" not in c["config_name"] and "shard" not in c["config_name"]:
                             rf_c = c["roofline"]
                             assert rf_c["traffic"] is not None and rf_c["traffic_stale"] is False, (d, c["config_name"])
                             assert "left L2" in rf_c["frac_kind"], (d, c["config_name"])
@@ -239,7 +258,9 @@ def test_kernel_source_hash_covers_the_timed_kernels_translation_units():
     import json
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     entries = {e["workload_sig"]: e for e in json.load(open(os.path.join(root, "profiles", "hbm_traffic.json")))}
-    assert entries["int8-d768-N1000000-B2048-T512-uniform-hbm"]["kernel_source_sha"] == sha
+    # (round 5: the headline runs a different batch every step -- signature suffix "-rot"; the hash is of the CODE, comments stripped)
+    assert entries["int8-d768-N1000000-B2048-T512-uniform-hbm-rot"]["kernel_source_sha"] == sha
+    assert bench._code_only(os.path.join(root, "scone_amd", "csrc", "scone_probe.h")).count(b"//") == 0
 
 
 def test_zipf_ids_stream_is_head_heavy_and_seeded():

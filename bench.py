@@ -90,6 +90,9 @@ def parse(argv=None):
                     help="vocabulary generator: seeded Zipf n-grams with de-duplication on the host (default), the same law "
                          "drawn and de-duplicated on the GPU (seconds instead of minutes at 1e7 rows: config C3), or the "
                          "distinct-by-construction generator for >= 1e8 rows")
+    ap.add_argument("--vocab", type=int, default=50257, help="token vocabulary (structured keygen only; <= 262144, the direct unigram "
+                    "table's size).  262144 with --rows 10000000: the token-indexed rows of a launch (wte + unigram rows, 0.6 GB) no "
+                    "longer fit the 256-MB Infinity Cache -- the variant behind roofline.mall_variant")
     ap.add_argument("--same-batch", action="store_true", help="re-use ONE batch for every step (rounds 1-4; the Infinity Cache "
                     "then carries rows from step to step).  Default: a different batch every step")
     ap.add_argument("--prefetch", default="auto", choices=["auto", "on", "off"],
@@ -578,12 +581,14 @@ def kernel_stats(samples, per_step):
 MAX_DISTINCT_BATCHES = 64       # steps beyond this cycle through the batches: 64 x 0.35 GB of rows is 90x the Infinity Cache
 
 
-def make_vocabulary(n_rows, keygen, max_n=3):
+def make_vocabulary(n_rows, keygen, max_n=3, vocab=50257):
     """(vocabulary object for EmbeddingCache.from_synthetic, host keys, host lens) -- host arrays None for `structured`."""
     from scone_amd import NGramExtractor
     from scone_amd import synthetic as S
     if keygen == "structured":
-        return S.StructuredVocab(n_rows), None, None
+        return S.StructuredVocab(n_rows, vocab=vocab), None, None
+    if vocab != S.GPT2_VOCAB:
+        raise SystemExit("--vocab needs --keygen structured")
     keys, lens = (S.make_keys if keygen == "zipf" else S.make_keys_torch)(n_rows, S.GPT2_VOCAB, max_n, seed=11)
     return NGramExtractor.from_arrays(keys, lens, max_n=max_n), keys, lens
 
@@ -663,12 +668,12 @@ def roofline_block(sig, alg, comp, step_kernel_ms, samples, per_step, n_launch, 
     }
 
 
-def workload_sig(fmt, d, N, B, T, stream, placement="hbm", keygen="zipf", rotated=True, extra=""):
-    return (f"{fmt}-d{d}-N{N}-B{B}-T{T}-{stream}-{placement}" + extra
+def workload_sig(fmt, d, N, B, T, stream, placement="hbm", keygen="zipf", rotated=True, extra="", vocab=50257):
+    return (f"{fmt}-d{d}-N{N}-B{B}-T{T}-{stream}-{placement}" + extra + (f"-V{vocab}" if vocab != 50257 else "")
             + {"zipf": "", "zipf_gpu": "-zipfgpu", "structured": "-structured"}[keygen] + ("-rot" if rotated else ""))
 
 
-def cpu_baseline_spot_check(n_rows, keys, lens, tok_np, gpu_out, fmt, d, seed, base_scale, wte, wpe, n_pick=8):
+def cpu_baseline_spot_check(n_rows, keys, lens, tok_np, gpu_out, fmt, d, seed, base_scale, wte, wpe, n_pick=8, vocab=50257):
     """The checker half of the cpu_baseline leg for the `configs` block: the GPU output of `n_pick` sequences drawn from the
     whole batch (the last one always among them) against the numpy oracle (oracle/ref_port.py: match_hits -> hits_to_csr ->
     embed_numpy -> combine = n_gram_extractor.py:106-126, embedding_cache.py:113-181, engine.py:234-266,
@@ -682,7 +687,7 @@ def cpu_baseline_spot_check(n_rows, keys, lens, tok_np, gpu_out, fmt, d, seed, b
     rng = np.random.default_rng(20260304)
     picks = sorted(set(int(x) for x in rng.choice(B, size=min(n_pick - 1, B), replace=False)) | {B - 1})
     sub = np.ascontiguousarray(tok_np[picks])
-    hits = R.match_hits_structured(n_rows, sub, 3) if keys is None else R.match_hits(keys, lens, sub, 3)
+    hits = R.match_hits_structured(n_rows, sub, 3, vocab=vocab) if keys is None else R.match_hits(keys, lens, sub, 3)
     off, ids = R.hits_to_csr(hits)
     uniq = np.unique(ids)
     if fmt == "int4":
@@ -698,7 +703,7 @@ def cpu_baseline_spot_check(n_rows, keys, lens, tok_np, gpu_out, fmt, d, seed, b
 
 
 def config_record(name, fmt, d, N, keygen, stream, B, T, steps, warmup, sync, prefetch, vocab_cache=None, wte=None, wpe=None,
-                  check=True):
+                  check=True, vocab=50257):
     """One single-GPU workload measured like the headline: its own table, a different batch every step, the serving loop with
     the next batch announced, HIP-event kernel times (min / median / max), counter-priced `frac` when profiles/hbm_traffic.json
     holds passes for this signature and kernel source, and the GPU output of 8 sequences of the first batch checked against
@@ -709,12 +714,12 @@ def config_record(name, fmt, d, N, keygen, stream, B, T, steps, warmup, sync, pr
     from scone_amd.hip_backend import format_code
     seed, base_scale = 7, 0.02 / 127
     t_build = time.perf_counter()
-    vocab_obj, keys, lens = vocab_cache if vocab_cache is not None else make_vocabulary(N, keygen)
+    vocab_obj, keys, lens = vocab_cache if vocab_cache is not None else make_vocabulary(N, keygen, vocab=vocab)
     kw = {"n_rows": N} if keys is None else {}
     cache = EmbeddingCache.from_synthetic(vocab_obj, d, table_format=fmt, seed=seed, base_scale=base_scale, **kw)
     if wte is None:
         g = torch.Generator(device="cuda").manual_seed(5)
-        wte = (torch.randn(S.GPT2_VOCAB, d, generator=g, device="cuda") * 0.02).half()
+        wte = (torch.randn(vocab, d, generator=g, device="cuda") * 0.02).half()
         wpe = (torch.randn(1024, d, generator=g, device="cuda") * 0.01).half()
     n_b = min(steps + warmup, MAX_DISTINCT_BATCHES)
     tok_np, batches = make_batches(vocab_obj, keys, lens, stream, B, T, 1234, n_b)
@@ -725,7 +730,7 @@ def config_record(name, fmt, d, N, keygen, stream, B, T, steps, warmup, sync, pr
     alg, comp, sum_k, k_hist, nr, nt = workload_bytes(table, batches[0], format_code(fmt), d)
     dt, n_launch, kern_ms, samples = lookup_loop(cache, batches, wte, wpe, out, steps, warmup, sync, prefetch)
     avg_ms = kern_ms / max(n_launch, 1)
-    sig = workload_sig(fmt, d, N, B, T, stream, "hbm", keygen, rotated=n_b > 1)
+    sig = workload_sig(fmt, d, N, B, T, stream, "hbm", keygen, rotated=n_b > 1, vocab=vocab)
     rf = roofline_block(sig, alg, comp, avg_ms, samples, 1, n_launch)
     res = {
         "name": name,
@@ -741,7 +746,7 @@ def config_record(name, fmt, d, N, keygen, stream, B, T, steps, warmup, sync, pr
         try:
             cache.embed_tokens(batches[0], wte=wte, wpe=wpe, out=out)
             torch.cuda.synchronize()
-            err, picks = cpu_baseline_spot_check(N, keys, lens, tok_np, out, fmt, d, seed, base_scale, wte, wpe)
+            err, picks = cpu_baseline_spot_check(N, keys, lens, tok_np, out, fmt, d, seed, base_scale, wte, wpe, vocab=vocab)
             res["gpu_vs_oracle_max_rel_err"], res["gpu_vs_oracle_sequences"] = err, picks
         except Exception as e:
             res["gpu_vs_oracle_max_rel_err"], res["gpu_vs_oracle_error"] = None, repr(e)
@@ -1419,8 +1424,10 @@ def main():
             raise SystemExit("bench.py: world sanity failed: a 1 KB all-gather returned the wrong ranks' data")
 
     d, N, B, T = args.dim, args.rows, args.batch, args.seq
-    vocab, max_n, seed, base_scale = S.GPT2_VOCAB, 3, 7, 0.02 / 127
-    vocab_obj, keys, lens = make_vocabulary(N, args.keygen, max_n)
+    vocab, max_n, seed, base_scale = args.vocab, 3, 7, 0.02 / 127
+    if not 3 <= vocab <= 262144:
+        raise SystemExit("--vocab must be in [3, 262144]")
+    vocab_obj, keys, lens = make_vocabulary(N, args.keygen, max_n, vocab=vocab)
     ex = vocab_obj
     kw_rows = {"n_rows": N} if keys is None else {}
 
@@ -1507,7 +1514,7 @@ def main():
         per_step = max(1, n_launch // max(args.steps, 1)) if n_launch else 1
         step_kernel_ms = kern_ms / args.steps if n_launch else dt / args.steps * 1e3
         in_hbm = args.placement == "hbm"
-        sig = workload_sig(args.format, d, N, B, T, args.stream, args.placement, args.keygen, rotated=n_batches > 1,
+        sig = workload_sig(args.format, d, N, B, T, args.stream, args.placement, args.keygen, rotated=n_batches > 1, vocab=vocab,
                            extra=("-sharded" if sharded else "") + (f"-shard{args.shard_of}" if emu else "")
                            + (f"-hot{args.hot_rows}-stage{args.stage_tokens}" if args.placement != "hbm" else ""))
         res = {
@@ -1585,8 +1592,18 @@ def main():
                 # `_lower` (compulsory bytes) and at most `_upper` (bytes that left L2, Infinity-Cache hits included) of the peak
                 res["roofline"]["hbm_variant_frac_lower"] = hv["hbm_frac"]
                 res["roofline"]["hbm_variant_frac_upper"] = hv["traffic_frac"]
+            # ... and the same table over a 262,144-token vocabulary (round 5): 0.6 GB of token-indexed rows (wte + unigram rows)
+            # per launch, 2.3x the Infinity Cache, each referenced ~4 times instead of ~21 -- most of what the 50,257-token variant
+            # re-reads out of the Infinity Cache must now come from HBM.  If the rate through the L2-miss path stays where it
+            # was, that path (not HBM, not the Infinity Cache) is what bounds the kernel; the compulsory fraction of THIS
+            # variant is the tightest lower bound on HBM utilisation the line holds
+            if budget.remaining() > 120.0:
+                mv = config_record("mall_variant", args.format, args.dim, 10_000_000, "structured", "uniform", args.batch, args.seq,
+                                   max(10, min(args.steps, 30)), 3, sync, prefetch, check=True, vocab=262144)
+                with line.lock:
+                    res["roofline"]["mall_variant"] = mv
         except Exception as e:
-            line.set(res["roofline"], "hbm_variant", {"error": repr(e)})
+            line.set(res["roofline"], "hbm_variant" if "hbm_variant" not in res["roofline"] else "mall_variant", {"error": repr(e)})
         watchdog.disarm()
     if rank == 0 and not args.no_cpu_baseline and not sharded and emu is None:
         short = world > 1                     # N > 1: a 3-second 1-core sample; the all-cores figures are on the N = 1 line

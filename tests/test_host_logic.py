@@ -215,6 +215,12 @@ def test_committed_bench_line_follows_the_contract():
             for k in ("n1_pinned_host", "n1_pinned_host_zipf"):
                 z = r["sharded"][k]
                 assert 0 < z["pcie_frac"] <= 1.0 and abs(z["pcie_frac"] - z["pcie_GBps"] / 64.0) < 1e-9, k
+            if "mall_variant" in rf:
+                # the 262,144-token vocabulary: token-indexed rows no longer fit the Infinity Cache; its compulsory fraction is the
+                # tightest lower bound on HBM utilisation in the line, and it was checked against the oracle in the run
+                mv = rf["mall_variant"]
+                assert mv["gpu_vs_oracle_max_rel_err"] < 1e-3 and mv["status_bits"] == 0
+                assert rf["hbm_variant"]["hbm_frac"] < mv["roofline"]["hbm_frac"] <= mv["roofline"]["frac"] <= 1.0
         # every other committed line of the round (tools/run_configs.sh) obeys the same rule
         for d in os.listdir(prof):
             cj = os.path.join(prof, d, "configs.jsonl")

@@ -41,6 +41,7 @@ quick() {  # tag, bench args...
   echo "$T: $(head -c 200 $O/bench.json)"
 }
 quick ${TAG}_hbm_variant --rows 10000000 --keygen structured
+quick ${TAG}_mall_variant --rows 10000000 --keygen structured --vocab 262144
 quick ${TAG}_c4_int4_100m --rows 100000000 --format int4 --dim 1024 --keygen structured
 quick ${TAG}_c2_fp16 --format fp16
 quick ${TAG}_c3_int8_10m_d1024 --rows 10000000 --dim 1024 --keygen zipf_gpu

@@ -15,6 +15,10 @@ if rf.get("same_batch"):
 hv = rf.get("hbm_variant")
 if hv:
     print("hbm_variant", {k: hv.get(k) for k in ("tokens_per_s", "avg_kernel_ms", "hbm_frac", "traffic_frac", "error")})
+mv = rf.get("mall_variant")
+if mv:
+    print("mall_variant", {k: mv.get(k) for k in ("tokens_per_s", "ms_per_step", "gpu_vs_oracle_max_rel_err", "error")},
+          {k: mv.get("roofline", {}).get(k) for k in ("avg_kernel_ms", "hbm_frac", "traffic_frac", "algorithmic_frac")})
 for k, c in (r.get("configs") or {}).items():
     crf = c.get("roofline", {})
     print("config", k, {x: c.get(x) for x in ("tokens_per_s", "ms_per_step", "build_s", "gpu_vs_oracle_max_rel_err", "status_bits", "skipped", "error") if c.get(x) is not None},

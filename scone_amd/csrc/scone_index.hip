@@ -472,10 +472,10 @@ extern "C" int scone_index_build_device(scone_handle *h, const uint32_t *d_keys,
                                         uint64_t n, uint64_t id0, scone_stream_t stream) {
   if (!h) return SCONE_EINVAL;
   if (n == 0) return SCONE_OK;
-  index_modified(h);
   if (!d_keys || !d_lens) return scone_fail(h, SCONE_EINVAL, "scone_index_build: null keys/lens");
   if (id0 + n > 0xFFFFFFFEull) return scone_fail(h, SCONE_ERANGE, "scone_index_build: ids must be < 2^32-2");
   SCONE_ON_DEVICE(h);
+  index_modified(h);  // (on the handle's device: it frees the pipeline's streams and buffers)
   unsigned long long blocks = (n + 255) / 256;
   if (!scone_grid_fits(blocks, 256)) return scone_fail(h, SCONE_EINVAL, "scone_index_build: chunk too large");
   hipLaunchKernelGGL(k_index_insert, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, h->slots,

@@ -125,3 +125,31 @@ def test_discarded_announcement_on_a_cold_cache():
         # what A's copies brought in must be A's rows: look A up afterwards as well
         assert torch.equal(pin.embed(a, out_dtype=torch.float32), ref.embed(a, out_dtype=torch.float32)), rep
     assert pin.status() == 0
+
+
+def test_index_mutation_drops_a_pending_announcement():
+    """Records prepared before the index changed are stale (they hold cache slots of rows found through the OLD index): an index
+    build between the announcement and the lookup drops the staging pipeline with them, and the lookup sees the new f-grams --
+    equal to an HBM-resident table built with the full index."""
+    from scone_amd.hip_backend import SconeTable
+    rng = np.random.default_rng(508)
+    vocab, n, d = 23, 900, 768
+    keys, lens = _vocab(rng, vocab, n)
+    _, first = np.unique(np.concatenate([keys, lens[:, None].astype(np.uint32)], axis=1), axis=0, return_index=True)
+    first = np.sort(first)
+    keys, lens = keys[first], lens[first]                     # distinct keys: id = row number in both tables
+    n = len(lens)
+    table = rng.standard_normal((n, d)).astype(np.float32)
+    half = n // 2
+    full = _table(keys, lens, table, "int8")
+    pin = SconeTable(3, n, d, "int8", placement="pinned_host", hot_rows=50, stage_tokens=128)
+    pin.store_f32(torch.from_numpy(table))
+    pin.index_build(keys[:half], lens[:half])
+    tok = torch.from_numpy(rng.integers(0, vocab, size=(16, 64))).to("cuda", torch.int32)
+    before = pin.embed(tok, out_dtype=torch.float32).clone()
+    pin.embed_prefetch(tok, tokens_ready=True)                # two chunks matched, placed and copied against the half index
+    pin.index_build(keys[half:], lens[half:], id0=half)
+    after = pin.embed(tok, out_dtype=torch.float32)
+    assert torch.equal(after, full.embed(tok, out_dtype=torch.float32))
+    assert not torch.equal(after, before)
+    assert pin.status() == 0

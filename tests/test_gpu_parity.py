@@ -523,6 +523,22 @@ def test_plain_c_client(tmp_path):
     assert "cabi_smoke ok: 16 hits" in r.stdout
 
 
+def test_plain_c_client_two_threads_on_a_staged_handle(tmp_path):
+    """Round 5: SURVEY 8b "lookups are thread-safe and stream-ordered" through the bare ABI -- tests/cabi_threads.c runs two
+    pthreads, each on its own HIP stream, on ONE pinned-host handle with a staging pipeline (scone_embed of 8 chunks +
+    scone_embed_prefetch), every result compared byte for byte with an HBM-resident twin."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "cabi_threads")
+    lib = os.path.join(root, "scone_amd", "csrc")
+    subprocess.run(["gcc", os.path.join(root, "tests", "cabi_threads.c"), "-I" + os.path.join(root, "include"),
+                    "-I/opt/rocm/include", "-D__HIP_PLATFORM_AMD__", "-L" + lib, "-lscone_hip", "-L/opt/rocm/lib",
+                    "-lamdhip64", "-lpthread", "-Wl,-rpath," + lib, "-Wl,-rpath,/opt/rocm/lib", "-o", exe], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=180)
+    assert r.returncode == 0, r.stderr + r.stdout
+    assert "cabi_threads ok: 2 threads" in r.stdout
+
+
 @pytest.mark.parametrize("hot_rows", [0, 137, 10_000])
 @pytest.mark.parametrize("fmt", ["int8", "fp32"])
 def test_pinned_host_placement_matches_hbm(fmt, hot_rows):

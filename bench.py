@@ -763,7 +763,7 @@ def hbm_variant(args, wte, wpe, sync, prefetch=True):
     steps = max(10, min(args.steps, 30))
     r = config_record("hbm_variant", args.format, args.dim, 10_000_000, "structured", "uniform", args.batch, args.seq, steps, 3,
                       sync, prefetch, wte=wte if args.dim == wte.shape[1] else None, wpe=wpe if args.dim == wpe.shape[1] else None,
-                      check=False)
+                      check=True)
     rf = r["roofline"]
     return {"workload": r["workload"], "workload_sig": r["workload_sig"], "mean_hits_per_token": r["mean_hits_per_token"],
             "avg_kernel_ms": rf["avg_kernel_ms"], "kernel_ms": rf["kernel_ms"], "tokens_per_s": r["tokens_per_s"],
@@ -771,7 +771,8 @@ def hbm_variant(args, wte, wpe, sync, prefetch=True):
             "algorithmic_bytes_per_launch": rf["algorithmic_bytes_per_launch"], "algorithmic_GBps": rf["algorithmic_GBps"],
             "algorithmic_frac": rf["algorithmic_frac"], "hbm_bytes_compulsory": rf["hbm_bytes_compulsory"],
             "hbm_GBps": rf["hbm_bytes_compulsory"] / rf["avg_kernel_ms"] / 1e6, "hbm_frac": rf["hbm_frac"],
-            "traffic": rf["traffic"], "traffic_frac": rf["traffic_frac"], "traffic_stale": rf["traffic_stale"]}
+            "traffic": rf["traffic"], "traffic_frac": rf["traffic_frac"], "traffic_stale": rf["traffic_stale"],
+            "gpu_vs_oracle_max_rel_err": r.get("gpu_vs_oracle_max_rel_err"), "status_bits": r.get("status_bits")}
 
 
 def _host_memory_available():

@@ -15,7 +15,9 @@ tokens -- every rank holds the table and embeds its own batch; no data-path coll
 which starts the N ranks itself (fresh child processes, before this process touches a GPU) and
 fails unless the line it forwards says n_gpus == N.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with
+Prints ONE JSON line on rank 0 (contract in the task statement), at most 6000 characters (`compact_record`: the driver keeps
+the tail of stdout); the whole record -- every workload description, provenance string and phase split -- is written to the file
+the line names (`details`: gpurun_out/bench_details_n<N>.json, or $SCONE_BENCH_DETAILS).  The record holds
   roofline      the gather/reduce kernel, HIP-event timed on its launch stream.  `frac` is a PHYSICAL fraction of the
                 8 TB/s HBM peak, never above 1: the bytes that left L2 (committed rocprofv3 PMC passes, quoted only while
                 the kernel's sources are the ones they were taken on) / kernel time / peak -- or, without such an entry,
@@ -159,10 +161,183 @@ class Budget:
         return time.time() - self.t0
 
 
+LINE_LIMIT = 6000            # characters of the printed line (the driver keeps the TAIL of stdout: round 4's 6.9 KB line survived)
+
+
+def _sig(x, digits=6):
+    """Floats to `digits` significant digits (what the line prints); everything else unchanged."""
+    if isinstance(x, float):
+        if x != x or x in (float("inf"), float("-inf")):
+            return None
+        return float(f"{x:.{digits}g}")
+    if isinstance(x, dict):
+        return {k: _sig(v, digits) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_sig(v, digits) for v in x]
+    return x
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d and d[k] is not None}
+
+
+def _cut(text, n):
+    return text if not isinstance(text, str) or len(text) <= n else text[:n - 3] + "..."
+
+
+def compact_record(res, details_path=None):
+    """The ONE printed line: the contract's keys and the figures a reader needs, in at most LINE_LIMIT characters -- the whole
+    record (every phase split, workload description, provenance string) goes to `details_path`.  Built with .get everywhere:
+    the watchdog may print a record that is only partly filled."""
+    rf = res.get("roofline") or {}
+    out = _pick(res, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                      "dtype", "table_format", "out_dtype", "data", "workload_sig"))
+    out.setdefault("vs_baseline", None)
+    cfg = res.get("config") or {}
+    out["config"] = _pick(cfg, ("tokens_per_step_per_rank", "mean_hits_per_token", "different_batch_every_step", "distinct_batches",
+                                "distinct_table_rows_per_launch", "distinct_wte_rows_per_launch", "next_batch_announced"))
+    out["config"]["workload"] = _cut(cfg.get("workload"), 190)
+    out["config"]["parallelism"] = _cut(cfg.get("parallelism"), 110)
+    left_l2 = rf.get("traffic") is not None
+
+    def roof(r, extra=()):
+        c = _pick(r, ("bound", "limited_by", "achieved", "peak", "unit", "frac", "frac_bytes", "algorithmic_bytes_per_launch",
+                      "algorithmic_frac", "avg_kernel_ms", "kernel_ms", "timed_launches", "hbm_bytes_compulsory", "hbm_frac", "traffic",
+                      "traffic_stale", "traffic_frac", "kernel_source_sha") + tuple(extra))
+        if "frac_kind" in r:
+            c["frac_kind"] = ("left L2: 2*FETCH_SIZE+WRITE_SIZE (rocprofv3 PMC, this kernel source)" if r.get("traffic") is not None
+                              else "compulsory bytes (no PMC entry)") + " / HIP-event kernel time / 8 TB/s"
+        if r.get("traffic_source"):
+            c["traffic_source"] = r["traffic_source"].split(":")[0]
+        return c
+    o_rf = roof(rf, ("match_us", "step_minus_kernel_us"))
+    if rf.get("kernel"):
+        o_rf["kernel"] = _cut(rf["kernel"], 60)
+    if isinstance(rf.get("same_batch"), dict):
+        o_rf["same_batch"] = _pick(rf["same_batch"], ("ms_per_step", "avg_kernel_ms", "tokens_per_s", "distinct_batches"))
+    hv = rf.get("hbm_variant")
+    if isinstance(hv, dict):
+        o_rf["hbm_variant"] = _pick(hv, ("tokens_per_s", "avg_kernel_ms", "hbm_frac", "traffic_frac", "algorithmic_frac",
+                                         "gpu_vs_oracle_max_rel_err", "error"))
+    mv = rf.get("mall_variant")
+    if isinstance(mv, dict):
+        o_rf["mall_variant"] = {**_pick(mv, ("tokens_per_s", "gpu_vs_oracle_max_rel_err", "error")),
+                                **_pick(mv.get("roofline") or {}, ("avg_kernel_ms", "hbm_frac", "traffic_frac", "algorithmic_frac"))}
+    out["roofline"] = o_rf
+    cb = res.get("cpu_baseline")
+    if isinstance(cb, dict):
+        o_cb = _pick(cb, ("value", "unit", "cores", "kind", "gpu_vs_oracle_max_rel_err", "gpu_vs_oracle_sequences"))
+        o_cb["sample"] = _cut(cb.get("sample"), 170)
+        for k in ("python_all_cores", "c_oracle_all_cores"):
+            if isinstance(cb.get(k), dict):
+                o_cb[k] = _pick(cb[k], ("value", "cores", "error"))
+        out["cpu_baseline"] = o_cb
+    if isinstance(res.get("configs"), dict):
+        oc = {}
+        for name, c in res["configs"].items():
+            if not isinstance(c, dict) or "roofline" not in c:
+                oc[name] = _pick(c if isinstance(c, dict) else {}, ("skipped", "error"))
+                continue
+            crf = c["roofline"]
+            oc[name] = {**_pick(c, ("tokens_per_s", "ms_per_step", "gpu_vs_oracle_max_rel_err", "status_bits")),
+                        **_pick(crf, ("avg_kernel_ms", "frac", "hbm_frac", "algorithmic_frac", "traffic", "traffic_stale")),
+                        "kernel_ms": _pick(crf.get("kernel_ms") or {}, ("min", "median", "max")),
+                        "frac_bytes": "left L2" if crf.get("traffic") is not None else "compulsory"}
+        out["configs"] = oc
+    sh = res.get("sharded")
+    if isinstance(sh, dict):
+        osh = _pick(sh, ("world_sanity", "rows_total", "rows_per_rank", "world_size", "device_count", "backend", "rccl_version",
+                         "rccl_high_priority_stream", "build_s", "exchanges_agree", "best_whole_output", "xgmi_peak_GBps", "skipped", "error"))
+        if isinstance(sh.get("note"), str):
+            osh["note"] = _cut(sh["note"], 120)
+        n1 = sh.get("n1_pinned_host")
+        if isinstance(n1, dict):
+            osh["n1_pinned_host"] = _pick(n1, ("value", "ms_per_step", "pcie_GBps", "pcie_frac", "skipped", "error"))
+        z = sh.get("n1_pinned_host_zipf")
+        if isinstance(z, dict):
+            oz = _pick(z, ("value", "ms_per_step", "different_batch_every_step", "cache_rows", "rows_over_pcie_per_step", "pcie_GBps",
+                           "pcie_frac", "status_bits", "prefetch_beats_zero_copy", "skipped", "error"))
+            for k in ("zero_copy_same_stream", "zero_copy_static_head_same_hbm"):
+                if isinstance(z.get(k), dict):
+                    oz[k] = _pick(z[k], ("value", "ms_per_step"))
+            so = z.get("scrambled_order")
+            if isinstance(so, dict):
+                oz["scrambled_order"] = {**_pick(so, ("value", "ms_per_step", "prefetch_beats_static_head")),
+                                         "zero_copy_same_stream": (so.get("zero_copy_same_stream") or {}).get("value"),
+                                         "zero_copy_static_head_same_hbm": (so.get("zero_copy_static_head_same_hbm") or {}).get("value")}
+            osh["n1_pinned_host_zipf"] = oz
+        if isinstance(sh.get("exchanges"), dict):
+            oe = {}
+            for name, e in sh["exchanges"].items():
+                if not isinstance(e, dict):
+                    continue
+                c = _pick(e, ("ms_per_step", "tokens_per_s", "speedup_vs_n1_pinned_host", "status_bits", "scales_with_world", "skipped", "error",
+                              "transport_fallback_reason"))
+                if isinstance(e.get("with_cu_reserve"), dict):
+                    c["with_cu_reserve_ms_per_step"] = e["with_cu_reserve"].get("ms_per_step")
+                er = e.get("roofline")
+                if isinstance(er, dict):
+                    c["hbm_frac"] = er.get("frac")
+                    c["xgmi_frac"] = (er.get("wire") or {}).get("frac_of_xgmi_peak")
+                if isinstance(e.get("records_transport"), str):
+                    c["transport"] = e["records_transport"].split(",")[0].split(" ")[0]
+                oe[name] = c
+            osh["exchanges"] = oe
+        out["sharded"] = osh
+    out.update(_pick(res, ("world_sanity", "time_budget_s", "incomplete", "hung_stage", "launcher", "selftest")))
+    if details_path:
+        out["details"] = details_path
+    exact = {k: out[k] for k in ("value", "ms_per_step") if k in out}      # the contract's own figures keep every digit
+    out = _sig(out)
+    out.update(exact)
+    # the limit is a promise: shed the optional blocks, least important first, until the line fits
+    for path in (("sharded", "exchanges", "*", "xgmi_frac"), ("sharded", "n1_pinned_host_zipf", "scrambled_order"), ("roofline", "mall_variant"),
+                 ("roofline", "hbm_variant"), ("cpu_baseline", "gpu_vs_oracle_sequences"), ("cpu_baseline", "sample"), ("configs",),
+                 ("sharded", "n1_pinned_host_zipf"), ("sharded", "exchanges"), ("sharded",), ("config", "workload")):
+        if len(json.dumps(out, default=str)) <= LINE_LIMIT:
+            break
+        node = out
+        for k in path[:-1]:
+            if k == "*":
+                break
+            node = node.get(k) if isinstance(node, dict) else None
+            if node is None:
+                break
+        if node is None:
+            continue
+        if "*" in path:
+            for v in node.values():
+                if isinstance(v, dict):
+                    v.pop(path[-1], None)
+        else:
+            node.pop(path[-1], None)
+        out["line_shortened"] = True
+    return out
+
+
+def details_path_for(n_gpus):
+    """Where the whole record goes: $SCONE_BENCH_DETAILS, or gpurun_out/bench_details_n<N>.json under the repo (merged back by
+    gpurun), or the temporary directory."""
+    p = os.environ.get("SCONE_BENCH_DETAILS")
+    if p:
+        return p
+    d = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(d, exist_ok=True)
+        if os.access(d, os.W_OK):
+            return os.path.join(d, f"bench_details_n{n_gpus}.json")
+    except OSError:
+        pass
+    import tempfile
+    return os.path.join(tempfile.gettempdir(), f"scone_bench_details_n{n_gpus}.json")
+
+
 class Line:
     """The one JSON line.  `publish` hands over the headline record; from then on every change of it (or of a dict hanging
     off it) is made inside `with line.lock`, and `emit` serialises it inside the same lock -- the watchdog thread can print
-    at any moment without meeting a half-built dictionary.  Printed at most once."""
+    at any moment without meeting a half-built dictionary.  Printed at most once.  Round 5: what is PRINTED is the compact form
+    (compact_record: <= LINE_LIMIT characters -- the driver keeps the tail of stdout, and the record had grown to 17 KB); the
+    whole record is written to a file named in the line (`details`)."""
 
     def __init__(self, rank: int) -> None:
         self.lock = threading.RLock()
@@ -185,9 +360,17 @@ class Line:
                 return False
             if incomplete:
                 self.res["incomplete"] = incomplete
+            details = None
+            try:                            # the whole record, for whoever wants every phase and provenance string
+                details = details_path_for(self.res.get("n_gpus", 1))
+                with open(details, "w") as f:
+                    json.dump(self.res, f, default=str)
+                details = os.path.relpath(details, ROOT) if details.startswith(ROOT + os.sep) else details
+            except Exception:
+                details = None
             try:
-                text = json.dumps(self.res, default=str)
-            except Exception as e:          # never lose the headline to a value json cannot take
+                text = json.dumps(compact_record(self.res, details), default=str)
+            except Exception as e:          # never lose the headline to a value json cannot take (or to a bug in the compaction)
                 keep = {k: v for k, v in self.res.items() if isinstance(v, (str, int, float, bool, type(None)))}
                 keep["incomplete"] = f"{incomplete or ''} (record dropped: {e!r})"
                 text = json.dumps(keep)

@@ -323,9 +323,23 @@ def test_bench_two_ranks_launched_like_the_driver(mode):
         assert 0 < r["roofline"]["frac"] <= 1.0 and r["roofline"]["algorithmic_frac"] > 0
         cb = r["cpu_baseline"]                                   # N > 1: the short 1-core sample + the 8-sequence check
         assert cb["value"] > 0 and cb["cores"] == 1 and "python_all_cores" not in cb and cb["gpu_vs_oracle_max_rel_err"] < 1e-3
-        _check_sharded_record(r["sharded"], 2)
+        assert r["world_sanity"]["all_gather_1KB_per_rank_ok"] is True and r["world_sanity"]["world_size"] == 2     # before anything else
+        ex = r["sharded"]["exchanges"]                           # the printed line: one short entry per exchange ...
+        assert all(e["ms_per_step"] > 0 and e["status_bits"] == 0 and e["speedup_vs_n1_pinned_host"] > 0 for e in ex.values()) and len(ex) == 6
+        assert r["sharded"]["exchanges_agree"] is True
+        _check_sharded_record(_details(r)["sharded"], 2)       # ... the whole record in the details file
     else:
         assert "sharded" not in r and "cpu_baseline" not in r
+
+
+def _details(r):
+    """The whole record behind a printed line (round 5: the line is the compact form, <= 6000 characters; `details` names the
+    file with every phase split and provenance string)."""
+    assert len(json.dumps(r)) <= 6500, len(json.dumps(r))
+    path = r["details"] if os.path.isabs(r["details"]) else os.path.join(ROOT, r["details"])
+    full = json.load(open(path))
+    assert full["n_gpus"] == r["n_gpus"] and full["value"] == r["value"] and full["ms_per_step"] == r["ms_per_step"]
+    return full
 
 
 def _check_sharded_record(rec, world):
@@ -395,7 +409,7 @@ def test_bench_starts_its_own_ranks_when_no_launcher_did():
     assert len(lines) == 1, p.stdout[-2000:]
     r = json.loads(lines[0])
     assert r["n_gpus"] == 2 and "started 2 ranks itself" in r["launcher"]
-    _check_sharded_record(r["sharded"], 2)
+    _check_sharded_record(_details(r)["sharded"], 2)
     env.pop("SCONE_ONE_DEVICE")
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64", "--steps", "1"], env=env, cwd=ROOT,
                        capture_output=True, text=True, timeout=120)

@@ -148,6 +148,26 @@ def test_committed_bench_line_follows_the_contract():
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in r, k
+    det = os.path.join(prof, rounds[-1], "bench_details.json")
+    if os.path.exists(det):
+        # round 5: bench.json is the PRINTED line -- the compact form, at most 6000 characters (the driver keeps the tail of
+        # stdout; the record had grown to 17 KB) -- and carries what the contract and the review ask for by itself; the whole
+        # record (every provenance string and phase split) is the details file the line names
+        line, r = r, json.load(open(det))
+        assert len(json.dumps(line)) <= 6000 and line["details"].endswith(".json")
+        assert line["value"] == r["value"] and line["ms_per_step"] == r["ms_per_step"] and line["vs_baseline"] is None
+        lrf, lcb = line["roofline"], line["cpu_baseline"]
+        for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "frac_kind", "algorithmic_frac", "hbm_frac", "traffic_frac",
+                  "traffic_stale", "avg_kernel_ms", "kernel_ms", "match_us", "same_batch", "hbm_variant"):
+            assert k in lrf, k
+        assert abs(lrf["frac"] - lrf["achieved"] / lrf["peak"]) < 1e-5 and "left L2" in lrf["frac_kind"]
+        for k in ("value", "unit", "cores", "kind", "sample", "gpu_vs_oracle_max_rel_err"):
+            assert k in lcb, k
+        assert "workload" in line["config"] and line["config"]["different_batch_every_step"] is True
+        for name, c in line["configs"].items():
+            assert c["tokens_per_s"] > 0 and c["traffic_stale"] is False and c["frac_bytes"] == "left L2" and c["gpu_vs_oracle_max_rel_err"] < 1e-3, name
+            assert c["kernel_ms"]["min"] <= c["kernel_ms"]["median"] <= c["kernel_ms"]["max"], name
+        assert 0 < line["sharded"]["n1_pinned_host"]["pcie_frac"] <= 1 and 0 < line["sharded"]["n1_pinned_host_zipf"]["pcie_frac"] <= 1
     assert r["unit"] == "tokens/s" and r["higher_is_better"] is True and r["vs_baseline"] is None and r["data"] == "synthetic"
     assert "workload" in r["config"] and "model" not in r["config"]
     rf = r["roofline"]
@@ -283,3 +303,42 @@ def test_zipf_ids_stream_is_head_heavy_and_seeded():
     u = S.stream_uniform_ids(keys, lens, 64, 512, 1)
     _, ru = R.hits_to_csr(R.match_hits(keys, lens, u, 3))
     assert np.median(ri) < np.median(ru)
+
+
+def test_printed_line_is_compact_whatever_the_record_holds():
+    """bench.py prints compact_record(record): the contract's keys and the figures a reader needs in at most LINE_LIMIT
+    characters (the driver keeps the TAIL of stdout: a 17-KB line would lose its head); the whole record goes to the details
+    file.  Checked on the committed N = 1 record, on N = 2 / 6 rehearsal records (six exchanges), on a partly filled record (what
+    the watchdog may print), and on a record blown up far beyond the limit (optional blocks are shed, the contract keys stay)."""
+    import copy
+    import json
+    import bench
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    full = json.load(open(os.path.join(root, "profiles", "r05z", "bench_details.json")))
+    recs = [full] + [json.load(open(os.path.join(root, "profiles", d, f))) for d, f in
+                     (("r05g", "bench_2ranks_one_gpu_gloo_rehearsal.json"), ("r05h", "bench_6ranks_one_gpu_gloo_rehearsal.json"))]
+    contract = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline")
+    for rec in recs:
+        line = bench.compact_record(rec, "gpurun_out/bench_details_n1.json")
+        assert len(json.dumps(line)) <= bench.LINE_LIMIT and "line_shortened" not in line
+        assert all(k in line for k in contract) and line["value"] == rec["value"] and line["ms_per_step"] == rec["ms_per_step"]
+        rf = line["roofline"]
+        assert rf["bound"] == "hbm" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-5 and "traffic" in rf and "workload" in line["config"]
+        if rec["n_gpus"] > 1:
+            ex = line["sharded"]["exchanges"]
+            assert list(ex) == list(rec["sharded"]["exchanges"]) and all(e["ms_per_step"] > 0 for e in ex.values())
+            assert line["sharded"]["exchanges_agree"] is True and line["sharded"]["n1_pinned_host"]["value"] > 0
+    # the watchdog's case: only the headline exists yet
+    part = {k: full[k] for k in contract if k in full}
+    part["incomplete"] = "stage 'x' did not complete"
+    line = bench.compact_record(part, None)
+    assert line["incomplete"] and "details" not in line and "cpu_baseline" not in line
+    # far too much: the optional blocks go, the contract stays
+    big = copy.deepcopy(full)
+    big["configs"] = {f"config_{i}": copy.deepcopy(full["configs"]["C3_int8_10M_d1024"]) for i in range(40)}
+    big["sharded"]["exchanges"] = {f"exchange_{i}": {"ms_per_step": 1.0, "tokens_per_s": 1e9, "status_bits": 0,
+                                                      "roofline": {"frac": 0.5, "wire": {"frac_of_xgmi_peak": 0.1}}} for i in range(60)}
+    line = bench.compact_record(big, "x.json")
+    assert len(json.dumps(line)) <= bench.LINE_LIMIT and line["line_shortened"] is True
+    assert all(k in line for k in contract) and line["roofline"]["frac"] == round(full["roofline"]["frac"], 6) or abs(line["roofline"]["frac"] - full["roofline"]["frac"]) < 1e-5

@@ -3,7 +3,11 @@
 import json
 import sys
 
-r = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+text = open(sys.argv[1]).read().strip()
+try:
+    r = json.loads(text)                       # a committed, indented record
+except ValueError:
+    r = json.loads(text.splitlines()[-1])      # a captured stdout: the line is the last one
 rf = r["roofline"]
 print("headline  %.3f G tok/s  step %.4f ms  kernel %.4f ms %s  frac %.3f (%s)  alg %.3f  hbm %.3f  match_us %s  batches %s" % (
     r["value"] / 1e9, r["ms_per_step"], rf["avg_kernel_ms"], rf.get("kernel_ms"), rf["frac"],
@@ -18,9 +22,9 @@ if hv:
 mv = rf.get("mall_variant")
 if mv:
     print("mall_variant", {k: mv.get(k) for k in ("tokens_per_s", "ms_per_step", "gpu_vs_oracle_max_rel_err", "error")},
-          {k: mv.get("roofline", {}).get(k) for k in ("avg_kernel_ms", "hbm_frac", "traffic_frac", "algorithmic_frac")})
+          {k: mv.get("roofline", mv).get(k) for k in ("avg_kernel_ms", "hbm_frac", "traffic_frac", "algorithmic_frac")})
 for k, c in (r.get("configs") or {}).items():
-    crf = c.get("roofline", {})
+    crf = c.get("roofline", c)          # (the printed line holds the config's figures flat; the details file nests them)
     print("config", k, {x: c.get(x) for x in ("tokens_per_s", "ms_per_step", "build_s", "gpu_vs_oracle_max_rel_err", "status_bits", "skipped", "error") if c.get(x) is not None},
           crf.get("kernel_ms"), "frac", crf.get("frac"), "stale", crf.get("traffic_stale"))
 cb = r.get("cpu_baseline")

@@ -5,6 +5,10 @@ ONE table and ONE set of batches.  Headline table (1M-row INT8, d = 768), S_unif
 
     python tools/prefetch_sweep.py [--sizes 64,128,256,512,1024,2048] [--steps 30] [--rounds 3]
 
+NOTE: the announced match was removed after this measurement (profiles/r05c: 1-19 % slower at every size); on the current
+tree scone_embed_prefetch is a no-op for HBM tables and both loops run the same thing.  To repeat the experiment apply
+profiles/r05b/announced_match_implementation.diff first.
+
 Prints one JSON object: per batch size (sequences of 512 tokens) the median over rounds of ms/step and of the gather kernel's
 HIP-event time for both loops."""
 import argparse

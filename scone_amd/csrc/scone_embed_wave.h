@@ -144,6 +144,13 @@ template <int FMT, int D> struct wave_geom {
 #ifndef SCONE_HIOCC_SLACK_CUT
 #define SCONE_HIOCC_SLACK_CUT 8
 #endif
+// TIMING PROBES (tools/timing_probes.sh; results are WRONG on purpose, never part of the shipped library): what is left of the
+// kernel's time when one of its memory streams stops missing L2.
+//   SCONE_PROBE_NO_WTE      the token's wte row is the handle's zero row (always an L1 / L2 hit)
+//   SCONE_PROBE_ROWS_LOCAL  every f-gram row index & 4095: a 3-MB region, L2-resident
+//   SCONE_PROBE_NO_STORE    the output store sits behind a run-time condition that never holds
+//   SCONE_LOCKSTEP          (not a probe: results stay exact) a workgroup barrier in front of every token, so that the 4 waves
+//                           that own 4 consecutive positions of one sequence issue their row loads together
 template <int FMT> struct wave_hiocc {
   static constexpr bool available = ((SCONE_HIOCC_MASK >> FMT) & 1) != 0;
 };
@@ -238,7 +245,11 @@ __device__ __forceinline__ void embed_token(const scone_row_store &rows, const v
   uint32_t scw[KK][NSEG];
 #pragma unroll
   for (int k = 0; k < K; ++k) {
+#ifdef SCONE_PROBE_ROWS_LOCAL
+    const long long lr = ((long long)rec[k] - row_begin) & 4095;
+#else
     const long long lr = (long long)rec[k] - row_begin;
+#endif
     const uint8_t *rp = rows.row((unsigned long long)lr);  // HBM or mapped host DRAM (wave-uniform select)
 #pragma unroll
     for (int s = 0; s < NSEG; ++s) {
@@ -338,6 +349,9 @@ __device__ __forceinline__ void embed_token(const scone_row_store &rows, const v
     for (int k = 0; k < OPW; ++k) v[k] = (b[k] + acc[w * OPW + k]) + c[k];  // language_model.py:242-243, :253-254
     ow[w] = pack_io<OutT>::pack(v);
   }
+#ifdef SCONE_PROBE_NO_STORE
+  if (reduce != 0x5C0E) return;
+#endif
   st_out_row<FMT, OutT, D>(out_row, lane, ow);
 }
 
@@ -423,7 +437,11 @@ __global__ __launch_bounds__(256, (wave_occupancy<FMT, OutT, D, MAXN, FIXED_POS,
     const int kown = rec[W - 2] & 0xFF, kfull = rec[W - 2] >> 8;
     // absent / out-of-range base rows read a row of zeros: the adds stay unconditional
     // paper mode: a matched f-gram REPLACES the token embedding (Algorithm 2), so wte is skipped
+#ifdef SCONE_PROBE_NO_WTE
+    const bool use_wte = false;
+#else
     const bool use_wte = tok_ok && !(q.mode == SCONE_MODE_LONGEST_SUFFIX && kfull > 0);
+#endif
     const uint8_t *wte_row = use_wte ? reinterpret_cast<const uint8_t *>(wte + (long long)tokv * D) : zero_row;
     const uint8_t *wpe_row = zero_row;
     if constexpr (!FIXED_POS) {
@@ -444,6 +462,9 @@ __global__ __launch_bounds__(256, (wave_occupancy<FMT, OutT, D, MAXN, FIXED_POS,
       tokn = wte ? tok[pn] : 0;
       posn = (!FIXED_POS && wpe) ? pos[pn] : 0;
     }
+#ifdef SCONE_LOCKSTEP
+    __builtin_amdgcn_s_barrier();  // launch_wave only takes this build's kernel when T % 4 == 0 (equal trip counts)
+#endif
 
 #define SCONE_CASE(K)                                                                                          \
   case K:                                                                                                      \
@@ -912,6 +933,9 @@ __device__ __forceinline__ void embed_token_long(const scone_row_store &rows, co
     for (int k = 0; k < OPW; ++k) v[k] = b[k] + acc[w * OPW + k];
     ow[w] = pack_io<OutT>::pack(v);
   }
+#ifdef SCONE_PROBE_NO_STORE
+  if (reduce != 0x5C0E) return;
+#endif
   st_out_row<FMT, OutT, D>(out_row, lane, ow);
 }
 

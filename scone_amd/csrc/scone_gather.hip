@@ -13,6 +13,9 @@
 // one token, each lane 16-byte vectors of every row).  Accumulation is sequential in the reference's list order in
 // fp32 everywhere, so results do not depend on the launch geometry.
 #include "scone_gather_impl.h"
+#ifdef SCONE_PROBE_PERM
+#include <cstdlib>
+#endif
 
 using namespace scone_gather;
 
@@ -60,6 +63,28 @@ bool scone_embed_takes_one_launch(const scone_handle *h, long long BT) {
   return BT <= h->fused_max_tokens && (h->cfg.dim == 768 || h->cfg.dim == 1024 || h->cfg.dim == 1280) &&
          !(h->cfg.table_fmt == SCONE_FMT_I4 && h->cfg.dim != 1024);
 }
+
+#ifdef SCONE_PROBE_PERM
+// TRAFFIC PROBE of a token-ordered ("run-ordered") lookup (tools/run_order_probe.py; a -DSCONE_PROBE_PERM build only, never the
+// shipped library).  The caller's process puts the device address of a permutation perm[B*T] into the environment
+// (SCONE_PROBE_PERM_PTR); scone_embed then looks up, at slot j of the launch, the token of position perm[j] -- its id record,
+// token id and position row -- and stores the result to out[j].  Every vector is the right one for SOME position, only its
+// place in `out` is permuted: the bytes the kernel moves are those of a kernel that visits the positions in the order the
+// permutation gives, which is what the probe measures (FETCH_SIZE, kernel time).
+__global__ void k_probe_permute(const int32_t *__restrict__ perm, const int32_t *__restrict__ ell, const int32_t *__restrict__ tok,
+                                int32_t *__restrict__ ell2, int32_t *__restrict__ tok2, int32_t *__restrict__ pos2, long long BT,
+                                int T, int W) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long j = t / W;
+  const int w = (int)(t % W);
+  if (j >= BT) return;
+  const long long p = perm[j];
+  ell2[j * W + w] = ell[p * W + w];
+  if (w == 0) tok2[j] = tok[p], pos2[j] = (int32_t)(p % T);
+}
+static int32_t *g_probe_buf = nullptr;
+static long long g_probe_cap = 0;
+#endif
 
 int need_table(scone_handle *h, const char *who) {
   if (!h) return SCONE_EINVAL;
@@ -271,6 +296,24 @@ extern "C" int scone_embed(scone_handle *h, const int32_t *d_tok, int32_t B, int
   }
   a.tok = d_tok, a.pos = d_pos, a.wte = d_wte, a.vocab = vocab, a.wpe = d_wpe, a.n_pos = n_pos;
   a.reduce = reduce, a.out = d_out, a.status = h->d_status;
+#ifdef SCONE_PROBE_PERM
+  if (const char *e = getenv("SCONE_PROBE_PERM_PTR")) {
+    const int32_t *perm = reinterpret_cast<const int32_t *>(strtoull(e, nullptr, 0));
+    const int W = h->cfg.max_n <= 3 ? 8 : 16;
+    if (perm && a.ell && !d_pos) {
+      if (g_probe_cap < BT) {
+        if (g_probe_buf) (void)hipFree(g_probe_buf);
+        SCONE_HIP(h, hipMalloc(&g_probe_buf, (size_t)BT * (W + 2) * sizeof(int32_t)));
+        g_probe_cap = BT;
+      }
+      int32_t *ell2 = g_probe_buf, *tok2 = g_probe_buf + BT * W, *pos2 = tok2 + BT;
+      const long long n = BT * W;
+      hipLaunchKernelGGL(k_probe_permute, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, perm, a.ell, d_tok, ell2, tok2, pos2,
+                         BT, T, W);
+      a.ell = ell2, a.tok = tok2, a.pos = pos2;
+    }
+  }
+#endif
   rc = scone_prof_begin(h, s);
   if (rc) return rc;
   rc = launch_fmt(h, a, SRC_HITS, MODE_FULL, out_dtype, s);

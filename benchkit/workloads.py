@@ -1,0 +1,467 @@
+"""The measured workloads of bench.py: vocabulary / batch construction, the serving loop, one single-GPU config measured like the
+headline, the cache-defeating variants, the pinned-host baseline.  Nothing here imports oracle/: the checker of a config's
+output is handed in by bench.py (its cpu_baseline leg)."""
+import time
+
+from .common import PCIE_PEAK_GBPS
+from .roofline import roofline_block, workload_bytes, workload_sig
+
+
+def measure_lookup(table, embed, tok, ntok, steps, warmup, sync):
+    """W untimed + K timed passes of `embed`; returns (seconds, launches, kernel-ms samples)."""
+    if hasattr(table, "reserve"):
+        table.reserve(ntok)              # workspaces are allocated here, never inside the timed region (even with --warmup 0)
+    for _ in range(warmup):
+        embed()
+    table.profile_enable(True)
+    table.profile_read(reset=True)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        embed()
+    sync()
+    dt = time.perf_counter() - t0
+    samples = table.profile_samples()
+    n_launch, kern_ms = table.profile_read(reset=True)
+    table.profile_enable(False)
+    return dt, n_launch, kern_ms, samples
+
+
+MAX_DISTINCT_BATCHES = 64       # steps beyond this cycle through the batches: 64 x 0.35 GB of rows is 90x the Infinity Cache
+
+
+def make_vocabulary(n_rows, keygen, max_n=3, vocab=50257):
+    """(vocabulary object for EmbeddingCache.from_synthetic, host keys, host lens) -- host arrays None for `structured`."""
+    from scone_amd import NGramExtractor
+    from scone_amd import synthetic as S
+    if keygen == "structured":
+        return S.StructuredVocab(n_rows, vocab=vocab), None, None
+    if vocab != S.GPT2_VOCAB:
+        raise SystemExit("--vocab needs --keygen structured")
+    keys, lens = (S.make_keys if keygen == "zipf" else S.make_keys_torch)(n_rows, S.GPT2_VOCAB, max_n, seed=11)
+    return NGramExtractor.from_arrays(keys, lens, max_n=max_n), keys, lens
+
+
+def make_batches(vocab_obj, keys, lens, stream, B, T, seed, n):
+    """`n` DIFFERENT batches of the named stream (same generator, seeds seed, seed + 7919, ...): host arrays of the first one
+    (the oracle checks it) and int32 device tensors of all.  S_uniform: f-grams with ids uniform over the table laid end to
+    end; S_zipf: iid Zipf(1.1) tokens."""
+    import torch
+    from scone_amd import synthetic as S
+    out, first = [], None
+    for i in range(n):
+        sd = seed + 7919 * i
+        if stream == "uniform":
+            t = S.stream_uniform_ids(vocab_obj if keys is None else keys, lens, B, T, sd)
+        else:
+            t = S.stream_zipf(S.GPT2_VOCAB, B, T, sd)
+        if first is None:
+            first = t
+        out.append(torch.from_numpy(t).to("cuda", torch.int32))
+    return first, out
+
+
+def lookup_loop(cache, batches, wte, wpe, out, steps, warmup, sync, prefetch):
+    """The serving loop: step k looks up batches[k % n] and -- `prefetch` -- announces batches[(k + 1) % n] right behind it
+    (scone_embed_prefetch, tokens_ready: every batch was generated up front), so that the next step's match runs on the
+    handle's side stream beside this step's gather.  W untimed + K timed steps; exactly K matches and K gathers are inside
+    the timed region (the first timed batch was announced by the last warm-up step; the last timed step announces a batch
+    that is looked up after the region, or never).  Returns measure_lookup's tuple."""
+    n = len(batches)
+    k = [0]
+
+    def step():
+        i = k[0]
+        k[0] += 1
+        cache.embed_tokens(batches[i % n], wte=wte, wpe=wpe, out=out)
+        if prefetch:
+            cache.prefetch_tokens(batches[(i + 1) % n], tokens_ready=True)
+    return measure_lookup(cache.table, step, batches[0], batches[0].numel(), steps, warmup, sync)
+
+
+def config_record(name, fmt, d, N, keygen, stream, B, T, steps, warmup, sync, prefetch, vocab_cache=None, wte=None, wpe=None,
+                  check=None, vocab=50257):
+    """One single-GPU workload measured like the headline: its own table, a different batch every step, the serving loop with
+    the next batch announced, HIP-event kernel times (min / median / max), counter-priced `frac` when profiles/hbm_traffic.json
+    holds passes for this signature and kernel source, and the GPU output of 8 sequences of the first batch checked against
+    the oracle by `check` (bench.py's cpu_baseline_spot_check; None = no check).  `vocab_cache`: (vocabulary, keys, lens) to
+    re-use (the headline's 1M-row vocabulary serves C2)."""
+    import torch
+    from scone_amd import EmbeddingCache
+    from scone_amd import synthetic as S
+    from scone_amd.hip_backend import format_code
+    seed, base_scale = 7, 0.02 / 127
+    t_build = time.perf_counter()
+    vocab_obj, keys, lens = vocab_cache if vocab_cache is not None else make_vocabulary(N, keygen, vocab=vocab)
+    kw = {"n_rows": N} if keys is None else {}
+    cache = EmbeddingCache.from_synthetic(vocab_obj, d, table_format=fmt, seed=seed, base_scale=base_scale, **kw)
+    if wte is None:
+        g = torch.Generator(device="cuda").manual_seed(5)
+        wte = (torch.randn(vocab, d, generator=g, device="cuda") * 0.02).half()
+        wpe = (torch.randn(1024, d, generator=g, device="cuda") * 0.01).half()
+    n_b = min(steps + warmup, MAX_DISTINCT_BATCHES)
+    tok_np, batches = make_batches(vocab_obj, keys, lens, stream, B, T, 1234, n_b)
+    out = torch.empty(B, T, d, dtype=torch.float16, device="cuda")
+    table = cache.table
+    torch.cuda.synchronize()
+    t_build = time.perf_counter() - t_build
+    alg, comp, sum_k, k_hist, nr, nt = workload_bytes(table, batches[0], format_code(fmt), d)
+    dt, n_launch, kern_ms, samples = lookup_loop(cache, batches, wte, wpe, out, steps, warmup, sync, prefetch)
+    avg_ms = kern_ms / max(n_launch, 1)
+    sig = workload_sig(fmt, d, N, B, T, stream, "hbm", keygen, rotated=n_b > 1, vocab=vocab)
+    rf = roofline_block(sig, alg, comp, avg_ms, samples, 1, n_launch)
+    res = {
+        "name": name,
+        "workload": f"{N}-row {fmt} f-gram table d={d} max_n=3 in HBM ({keygen} vocabulary), S_{stream} stream, {B}x{T} tokens/step, "
+                    f"a different batch every step ({n_b} batches); fused match+gather+dequant+mean+wte+wpe, fp16 out; "
+                    f"{nr} distinct table rows and {nt} distinct wte rows in the first batch",
+        "workload_sig": sig, "tokens_per_s": B * T * steps / dt, "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup,
+        "step_minus_kernel_us": (dt / steps * 1e3 - avg_ms) * 1e3, "next_batch_announced": bool(prefetch),
+        "mean_hits_per_token": sum_k / (B * T), "hits_histogram_K0_6": k_hist[:7], "build_s": t_build,
+        "roofline": rf, "status_bits": int(table.status()),
+    }
+    if check:
+        try:
+            cache.embed_tokens(batches[0], wte=wte, wpe=wpe, out=out)
+            torch.cuda.synchronize()
+            err, picks = check(N, keys, lens, tok_np, out, fmt, d, seed, base_scale, wte, wpe, vocab=vocab)
+            res["gpu_vs_oracle_max_rel_err"], res["gpu_vs_oracle_sequences"] = err, picks
+        except Exception as e:
+            res["gpu_vs_oracle_max_rel_err"], res["gpu_vs_oracle_error"] = None, repr(e)
+    del cache, table, batches, out
+    torch.cuda.empty_cache()
+    return res
+
+
+def hbm_variant(args, wte, wpe, sync, prefetch=True, check=None):
+    """The headline's format and dim on a workload that defeats the caches: 10M rows (7.7 GB of INT8 d = 768 rows -- 30x
+    the Infinity Cache), structured vocabulary (token ids uniform over the 50,257-word vocabulary, one bigram / trigram
+    row per window, each referenced by the 2-3 adjacent tokens it covers and by nothing else in the launch), a different
+    batch every step."""
+    steps = max(10, min(args.steps, 30))
+    r = config_record("hbm_variant", args.format, args.dim, 10_000_000, "structured", "uniform", args.batch, args.seq, steps, 3,
+                      sync, prefetch, wte=wte if args.dim == wte.shape[1] else None, wpe=wpe if args.dim == wpe.shape[1] else None,
+                      check=check)
+    rf = r["roofline"]
+    return {"workload": r["workload"], "workload_sig": r["workload_sig"], "mean_hits_per_token": r["mean_hits_per_token"],
+            "avg_kernel_ms": rf["avg_kernel_ms"], "kernel_ms": rf["kernel_ms"], "tokens_per_s": r["tokens_per_s"],
+            "ms_per_step": r["ms_per_step"],
+            "algorithmic_bytes_per_launch": rf["algorithmic_bytes_per_launch"], "algorithmic_GBps": rf["algorithmic_GBps"],
+            "algorithmic_frac": rf["algorithmic_frac"], "hbm_bytes_compulsory": rf["hbm_bytes_compulsory"],
+            "hbm_GBps": rf["hbm_bytes_compulsory"] / rf["avg_kernel_ms"] / 1e6, "hbm_frac": rf["hbm_frac"],
+            "traffic": rf["traffic"], "traffic_frac": rf["traffic_frac"], "traffic_stale": rf["traffic_stale"],
+            "gpu_vs_oracle_max_rel_err": r.get("gpu_vs_oracle_max_rel_err"), "status_bits": r.get("status_bits")}
+
+
+def _host_memory_available():
+    import psutil
+    avail = psutil.virtual_memory().available
+    for f_lim, f_use in (("/sys/fs/cgroup/memory.max", "/sys/fs/cgroup/memory.current"),
+                         ("/sys/fs/cgroup/memory/memory.limit_in_bytes", "/sys/fs/cgroup/memory/memory.usage_in_bytes")):
+        try:                                            # a container's own limit counts, not only the host's free memory
+            lim = open(f_lim).read().strip()
+            if lim != "max":
+                avail = min(avail, int(lim) - int(open(f_use).read().strip()))
+        except (OSError, ValueError):
+            pass
+    return avail
+
+
+def pinned_baseline(args, sync, zipf_too=True):
+    """How ONE GPU serves a table that does not fit its HBM -- rows in pinned host DRAM (BASELINE config C4: 100M rows
+    INT4 d = 1024 = 52.8 GB, first 1M rows hot in HBM), on the batch shape of the sharded record.  PCIe-bound, so the
+    rate barely depends on the table's size; this is what ">= 4x at 8 GPUs vs 1 GPU on the 1B-row sharded table" is
+    computed against.  Returns (record for the S_uniform stream with the rows read in place over PCIe -- the faster
+    mechanism on that stream --, record for the Zipf-ids stream: f-gram ids drawn from a power law over the
+    frequency-ordered table, what real text looks like to such a table; None unless `zipf_too`).
+
+    Round 4, the Zipf record: a DIFFERENT batch every step (round 3 re-used one batch, which says nothing about anything that
+    keeps rows between steps).  `value` = the north-star's "async prefetch" as it is built now -- a persistent HBM cache of
+    cold rows (clock eviction) in front of the chunk pipeline, warmed by `warmup_batches` steps of the same stream --, with
+    the rows that crossed PCIe per step from the library's counters; beside it, on the same batches: the rows read in place
+    (`zero_copy_same_stream`), and -- the honest alternative for the same HBM -- the static hot head enlarged by the cache's
+    rows (`zero_copy_static_head_same_hbm`: ids ARE frequency-ordered, so on a stationary stream no cache can beat it; the
+    cache is for traffic that drifts away from the order the table was built in)."""
+    import torch
+    from scone_amd import EmbeddingCache
+    from scone_amd import synthetic as S
+    N, d, B, T = args.pinned_rows, 1024, 2048, 512
+    need = N * 512 + 8e9
+    avail = _host_memory_available()
+    if avail < need:
+        skip = {"value": None, "skipped": f"needs {need / 1e9:.0f} GB of host memory for the pinned table ({avail / 1e9:.0f} GB available)"}
+        return skip, (dict(skip) if zipf_too else None)
+    hot = min(1_000_000, max(N // 100, 1))
+    vocab = S.StructuredVocab(N)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    wte = (torch.randn(S.GPT2_VOCAB, d, generator=g, device="cuda") * 0.02).half()
+    wpe = (torch.randn(1024, d, generator=g, device="cuda") * 0.01).half()
+    out = torch.empty(B, T, d, dtype=torch.float16, device="cuda")
+
+    def run(cache, toks, steps=4, warm=None, prefetch=False):
+        """ms per step over `steps` lookups of toks[i % len(toks)], after one untimed lookup of every batch in `warm`
+        (default: the first batch; [] = none -- a cache must not have seen the timed batches).  prefetch: the loop of a server
+        that knows its next tokens early -- scone_embed_prefetch of batch i + 1 is issued right after the lookup of batch i is
+        queued (the tokens were generated up front: tokens_ready), so the next batch's first chunks are matched, placed and
+        copied beside this batch's last lookups."""
+        cache.table.reserve(B * T)
+        for t in (toks[:1] if warm is None else warm):
+            cache.embed_tokens(t, wte=wte, wpe=wpe, out=out)
+        sync()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            cache.embed_tokens(toks[i % len(toks)], wte=wte, wpe=wpe, out=out)
+            if prefetch and i + 1 < steps:
+                cache.prefetch_tokens(toks[(i + 1) % len(toks)], tokens_ready=True)
+        sync()
+        return (time.perf_counter() - t0) / steps
+
+    def table(**kw):
+        return EmbeddingCache.from_synthetic(vocab, d, table_format="int4", seed=7, base_scale=0.02 / 127, n_rows=N,
+                                             placement="pinned_host", **kw)
+
+    cache = table(hot_rows=hot)
+    tok = torch.from_numpy(S.stream_uniform_ids(vocab, None, B, T, 1234)).to("cuda", torch.int32)
+    dt = run(cache, [tok])
+    _, ids_u = cache.table.match_csr(tok)
+    cold_u = ids_u[ids_u >= hot]
+    n_cold_ref, n_cold_distinct = int(cold_u.numel()), int(torch.unique(cold_u).numel())
+    del ids_u, cold_u
+    res = {"value": B * T / dt, "unit": "tokens/s", "ms_per_step": dt * 1e3, "steps": 4,
+           "workload": f"{N}-row int4 table d={d} in pinned host DRAM (rows read in place over PCIe), first {hot} rows in HBM, "
+                       f"structured vocabulary, S_uniform, {B}x{T} tokens/step",
+           "bound": "PCIe Gen5 x16 (~64 GB/s)", "pcie_peak_GBps": PCIE_PEAK_GBPS,
+           "cold_row_references": n_cold_ref, "distinct_cold_rows": n_cold_distinct,
+           "bytes_over_pcie_per_step_at_least": n_cold_distinct * 528,
+           "pcie_GBps": n_cold_distinct * 528 / dt / 1e9, "pcie_frac": n_cold_distinct * 528 / dt / 1e9 / PCIE_PEAK_GBPS,
+           "pcie_frac_kind": "every DISTINCT cold row of the batch once (528 B payload; a row re-referenced after it left L2 crosses "
+                             "again, so this is a lower bound on the link's bytes) / ms_per_step / 64 GB/s"}
+    zres = None
+    if zipf_too:
+        try:
+            steps, warm_n = args.pinned_zipf_steps, args.pinned_zipf_warmup
+            cache_rows = min(args.pinned_cache_rows, max(N - hot, 1))
+            timed = [S.stream_zipf_ids_torch(vocab, B, T, 50_000 + i) for i in range(steps)]     # never seen by any warm-up
+            st = []
+            for t in timed[:2]:
+                _, ids = cache.table.match_csr(t)
+                cold = ids[ids >= hot]
+                st.append((float(ids.numel()) / (B * T), int(cold.numel()), int(torch.unique(cold).numel())))
+                del ids, cold
+            stats = {"mean_hits_per_token": sum(x[0] for x in st) / len(st), "cold_row_references": sum(x[1] for x in st) / len(st),
+                     "distinct_cold_rows": sum(x[2] for x in st) / len(st)}
+            dt_zero = run(cache, timed, steps)
+            # the same law over a table whose order is NOT the traffic's frequency order (synthetic.stream_zipf_ids_torch,
+            # scramble=True): what the cache is for -- the static head holds 1 % / 17 % of the rows, not of the references
+            timed_s = [S.stream_zipf_ids_torch(vocab, B, T, 60_000 + i, scramble=True) for i in range(steps)]
+            _, ids = cache.table.match_csr(timed_s[0])
+            cold = ids[ids >= hot]
+            stats_s = {"mean_hits_per_token": float(ids.numel()) / (B * T), "cold_row_references": int(cold.numel()),
+                       "distinct_cold_rows": int(torch.unique(cold).numel())}
+            del ids, cold
+            dt_zero_s = run(cache, timed_s, steps)
+            del cache
+            torch.cuda.empty_cache()
+            # the same table behind the persistent cache of cold rows (stage_tokens / cache_rows are properties of the handle)
+            cache = table(hot_rows=hot, stage_tokens=args.pinned_stage_tokens, cache_rows=cache_rows)
+            warm = [S.stream_zipf_ids_torch(vocab, B, T, 1234 + i) for i in range(warm_n)]
+            cache.table.reserve(B * T)
+            for t in warm:
+                cache.embed_tokens(t, wte=wte, wpe=wpe, out=out)
+            del warm
+            sync()
+            c0 = cache.table.stage_counters()
+            dt_cached = run(cache, timed, steps, warm=[], prefetch=True)
+            c1 = cache.table.stage_counters()
+            copied = (c1["rows_copied"] - c0["rows_copied"]) / steps
+            status = cache.table.status()
+            for i in range(warm_n):                 # the cache re-learns the scrambled stream (its rows are elsewhere)
+                cache.embed_tokens(S.stream_zipf_ids_torch(vocab, B, T, 70_000 + i, scramble=True), wte=wte, wpe=wpe, out=out)
+            sync()
+            c2 = cache.table.stage_counters()
+            dt_cached_s = run(cache, timed_s, steps, warm=[], prefetch=True)
+            copied_s = (cache.table.stage_counters()["rows_copied"] - c2["rows_copied"]) / steps
+            status |= cache.table.status()
+            del cache
+            torch.cuda.empty_cache()
+            cache = table(hot_rows=hot + cache_rows)
+            dt_static = run(cache, timed, steps)
+            dt_static_s = run(cache, timed_s, steps)
+            zres = {"value": B * T / dt_cached, "unit": "tokens/s", "ms_per_step": dt_cached * 1e3, "steps": steps,
+                    "different_batch_every_step": True, "warmup_batches": warm_n,
+                    "mechanism": f"persistent HBM cache of cold rows ({c1['cache_rows']} row slots = {c1['cache_rows'] * 528 / 1e9:.1f} GB, "
+                                 f"clock eviction) in front of the chunk pipeline ({c1['chunk_tokens']}-token chunks: match, touch / "
+                                 "place, remap and the copy of the missing rows host -> HBM on side streams while the previous "
+                                 "chunk is reduced); scone_embed_prefetch of batch i + 1 issued right after the lookup of batch i",
+                    "cache_rows": c1["cache_rows"], "stage_tokens": c1["chunk_tokens"],
+                    "rows_over_pcie_per_step": copied, "bytes_over_pcie_per_step": copied * 528,
+                    "pcie_peak_GBps": PCIE_PEAK_GBPS, "pcie_GBps": copied * 528 / dt_cached / 1e9,
+                    "pcie_frac": copied * 528 / dt_cached / 1e9 / PCIE_PEAK_GBPS,
+                    "pcie_frac_kind": "rows copied host -> HBM per step (the library's counter) x 528 B / ms_per_step / 64 GB/s: the link "
+                                      "is NOT the bound of the cached step -- the lookup out of [hot head | cache] is (HBM), which is "
+                                      "the point of the cache",
+                    "cache_hit_rate_of_distinct_cold_rows": 1.0 - copied / max(stats["distinct_cold_rows"], 1.0),
+                    "status_bits": status,
+                    "zero_copy_same_stream": {"value": B * T / dt_zero, "ms_per_step": dt_zero * 1e3,
+                                              "bytes_over_pcie_per_step_at_least": stats["distinct_cold_rows"] * 528},
+                    "zero_copy_static_head_same_hbm": {"value": B * T / dt_static, "ms_per_step": dt_static * 1e3,
+                                                       "hot_rows": hot + cache_rows},
+                    "prefetch_beats_zero_copy": bool(dt_cached <= dt_zero),
+                    "scrambled_order": {
+                        "what": "the same power law, popularity rank r served by row (r * 61803399) % N: the table's order is not "
+                                "the traffic's frequency order (built on one corpus, served on another); same table, same cache "
+                                f"(re-warmed by {warm_n} batches of this stream), same three mechanisms",
+                        "value": B * T / dt_cached_s, "ms_per_step": dt_cached_s * 1e3, "rows_over_pcie_per_step": copied_s,
+                        "zero_copy_same_stream": {"value": B * T / dt_zero_s, "ms_per_step": dt_zero_s * 1e3},
+                        "zero_copy_static_head_same_hbm": {"value": B * T / dt_static_s, "ms_per_step": dt_static_s * 1e3},
+                        "prefetch_beats_zero_copy": bool(dt_cached_s <= dt_zero_s),
+                        "prefetch_beats_static_head": bool(dt_cached_s <= dt_static_s), **stats_s},
+                    "workload": f"{N}-row int4 table d={d} in pinned host DRAM, first {hot} rows in HBM, structured vocabulary, "
+                                f"S_zipf_ids (f-grams laid end to end, ids ~ bounded power law with exponent 1.1 over the "
+                                f"frequency-ordered table: the realistic stream), {B}x{T} tokens/step, a different batch every step", **stats,
+                    "bound": "PCIe Gen5 x16 (~64 GB/s)"}
+        except Exception as e:
+            zres = {"value": None, "error": repr(e)}
+    del cache, tok, out, wte, wpe
+    torch.cuda.empty_cache()
+    return res, zres
+
+
+REFERENCE_GRID = [(1, 512), (1, 1024), (4, 512), (4, 1024), (8, 512), (8, 1024)]   # scone/configs/benchmark_config.json:79-80
+FUSED_MAX_TOKENS = 32768        # scone_api.hip: batches up to this size take the one-launch kernel (env SCONE_FUSED_MAX_TOKENS)
+
+
+def latency_block(cache, wte, wpe, d, extra_shapes=((128, 512),), calls=300):
+    """The latency -> bandwidth regime on the headline table, at the sizes the reference itself runs: its benchmark
+    grid, batch {1, 4, 8} x sequence {512, 1024} (benchmark_config.json:79-82; engine.py:234-266 is B = 1), plus 65,536 tokens.
+    Per shape, Zipf tokens, one `embed_tokens` call = ctypes + launch(es) + kernel(s):
+      call_us    wall time per call, `calls` calls queued back to back, one synchronize at the end (a server's loop)
+      sync_us    wall time per call with a synchronize behind every call (how scone/scripts/benchmark.py:149-200 times)
+      kernel_us  median HIP-event time of the lookup kernel inside the library (the match of the two-kernel form not included)
+      graph_us   the same call captured once in a hipGraph and replayed back to back (no ctypes, no launch bookkeeping)
+      form       `fused` = k_embed_fused (match + gather in one launch) / `two` = k_match_ell then k_embed_wave"""
+    import os
+    import numpy as np
+    import torch
+    from scone_amd import synthetic as S
+    limit = int(os.environ.get("SCONE_FUSED_MAX_TOKENS") or FUSED_MAX_TOKENS)
+    res = {}
+    sync = torch.cuda.synchronize
+    for B, T in list(REFERENCE_GRID) + list(extra_shapes):
+        tok = torch.from_numpy(S.stream_zipf(S.GPT2_VOCAB, B, T, 99)).to("cuda", torch.int32)
+        out = torch.empty(B, T, d, dtype=torch.float16, device="cuda")
+        cache.table.reserve(B * T)
+
+        def call():
+            cache.embed_tokens(tok, wte=wte, wpe=wpe, out=out)
+        for _ in range(20):
+            call()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(calls):
+            call()
+        sync()
+        call_us = (time.perf_counter() - t0) / calls * 1e6
+        n_sync = max(20, calls // 4)
+        t0 = time.perf_counter()
+        for _ in range(n_sync):
+            call()
+            sync()
+        sync_us = (time.perf_counter() - t0) / n_sync * 1e6
+        cache.table.profile_enable(True)
+        cache.table.profile_read(reset=True)
+        for _ in range(40):
+            call()
+        sync()
+        samples = cache.table.profile_samples()
+        cache.table.profile_read(reset=True)
+        cache.table.profile_enable(False)
+        e = {"call_us": call_us, "sync_us": sync_us, "kernel_us": float(np.median(samples)) * 1e3 if len(samples) else None,
+             "form": "fused" if B * T <= limit and d in (768, 1024, 1280) else "two"}
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                call()                                    # warm-up on the capture stream (workspaces of that stream)
+            torch.cuda.current_stream().wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                call()
+            for _ in range(10):
+                g.replay()
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(calls):
+                g.replay()
+            sync()
+            e["graph_us"] = (time.perf_counter() - t0) / calls * 1e6
+            del g
+        except Exception as ex:                           # a capture that fails costs this one figure
+            e["graph_error"] = repr(ex)[:120]
+        res[f"{B}x{T}"] = e
+        del tok, out
+    return res
+
+
+def c1_record(oracle_leg, steps=200, seconds=6.0):
+    """BASELINE config C1 ("gpt2 base, 100K f-grams fp32 ... EmbeddingCache path"): the vocabulary is FIT on a seeded 1M-token
+    Zipf(1.1) corpus (1000 texts x 1000 tokens, rng 1234: SURVEY 8d) by the GPU `fit` (n_gram_extractor.py:72-104), the
+    100,000 x 768 fp32 table goes in through `cache_embeddings` (embedding_cache.py:56-111), the stream is 8 x 512 Zipf tokens
+    (benchmark_config.json:79-80).  Timed: `embed_tokens` = a2-a6 (match, id map, gather, mean, zero-fill; fp32 out, no wte /
+    wpe: what engine.py:234-266 computes), and the reference's own per-position call `get_token_embeddings` on one sequence.
+    `oracle_leg(keys, lens, table, tok, gpu_out, seconds)` (bench.py's cpu_baseline leg) checks every token of the batch
+    against the oracle and times the 1-core port on THIS stream."""
+    import numpy as np
+    import torch
+    from scone_amd import EmbeddingCache, NGramExtractor
+    from scone_amd import synthetic as S
+    t_build = time.perf_counter()
+    rng = np.random.default_rng(1234)
+    cdf = S.zipf_cdf(S.GPT2_VOCAB)
+    corpus = [S.zipf_tokens(rng, cdf, 1000).tolist() for _ in range(1000)]
+    t_fit = time.perf_counter()
+    ex = NGramExtractor(max_n=3, min_freq=1, max_f_grams=100_000).fit_gpu(corpus, verbose=False)
+    t_fit = time.perf_counter() - t_fit
+    keys, lens = ex.key_arrays()
+    d, B, T = 768, 8, 512
+    table = rng.standard_normal((len(ex), d)).astype(np.float32)
+    cache = EmbeddingCache(ex, d, table_format="fp32", keep_host_copy=False)
+    cache.cache_embeddings(np.arange(len(ex)), torch.from_numpy(table), verbose=False)
+    tok_np = S.zipf_tokens(rng, cdf, (B, T))
+    tok = torch.from_numpy(tok_np).to("cuda", torch.int32)
+    out = torch.empty(B, T, d, dtype=torch.float32, device="cuda")
+    cache.table.reserve(B * T)
+    torch.cuda.synchronize()
+    t_build = time.perf_counter() - t_build
+    for _ in range(20):
+        cache.embed_tokens(tok, out=out)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        cache.embed_tokens(tok, out=out)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    seq = tok_np[0].tolist()
+    cache.get_token_embeddings(seq)
+    t0 = time.perf_counter()
+    n_api = 5
+    for _ in range(n_api):
+        te = cache.get_token_embeddings(seq)
+    torch.cuda.synchronize()
+    dt_api = (time.perf_counter() - t0) / n_api
+    off, ids = cache.match(tok)
+    res = {"name": "C1_fp32_100K_d768_from_fit",
+           "workload": f"{len(ex)}-row fp32 f-gram table d={d} max_n=3, vocabulary FIT on the GPU from a seeded 1M-token Zipf(1.1) "
+                       f"corpus (fit {t_fit * 1e3:.0f} ms), rows stored through cache_embeddings; {B}x{T} Zipf tokens per call; "
+                       "embed_tokens = match + id map + gather + mean + zero-fill, fp32 out (engine.py:234-266), one launch",
+           "tokens_per_s": B * T / dt, "ms_per_step": dt * 1e3, "steps": steps, "mean_hits_per_token": float(ids.numel()) / (B * T),
+           "get_token_embeddings_ms_per_512_token_sequence": dt_api * 1e3, "positions_returned": len(te), "build_s": t_build,
+           "status_bits": int(cache.table.status())}
+    if oracle_leg is not None:
+        try:
+            res.update(oracle_leg(keys, lens, table, tok_np, out.cpu().numpy(), seconds))
+        except Exception as e:
+            res["gpu_vs_oracle_error"] = repr(e)
+    del cache, out, tok
+    torch.cuda.empty_cache()
+    return res

@@ -479,6 +479,11 @@ def main():
     vocab, max_n, seed, base_scale = args.vocab, 3, 7, 0.02 / 127
     if not 3 <= vocab <= 262144:
         raise SystemExit("--vocab must be in [3, 262144]")
+    if args.keygen == "structured":
+        try:
+            S.check_structured_vocab(vocab)          # a vocabulary that shares a factor with a multiplier has duplicate keys
+        except ValueError as e:
+            raise SystemExit(f"--vocab: {e}")
     vocab_obj, keys, lens = make_vocabulary(N, args.keygen, max_n, vocab=vocab)
     ex = vocab_obj
     kw_rows = {"n_rows": N} if keys is None else {}
@@ -662,6 +667,7 @@ def main():
             # was, that path (not HBM, not the Infinity Cache) is what bounds the kernel; the compulsory fraction of THIS
             # variant is the tightest lower bound on HBM utilisation the line holds
             if budget.remaining() > 120.0:
+                watchdog.arm("roofline.mall_variant", min(120.0, budget.remaining() - 60.0))     # a stage of its own (two 10M-row builds)
                 mv = config_record("mall_variant", args.format, args.dim, 10_000_000, "structured", "uniform", args.batch, args.seq,
                                    max(10, min(args.steps, 30)), 3, sync, prefetch, check=cpu_baseline_spot_check, vocab=262144)
                 with line.lock:

@@ -108,6 +108,7 @@ def compact_record(res, details_path=None):
                 continue
             crf = c["roofline"]
             oc[name] = {**_pick(c, ("tokens_per_s", "ms_per_step", "gpu_vs_oracle_max_rel_err", "status_bits")),
+                        **({"wall_outlier": True} if c.get("wall_outlier") else {}),
                         **_pick(crf, ("avg_kernel_ms", "frac", "frac_lo", "frac_profile_box", "hbm_frac", "algorithmic_frac", "traffic",
                                       "traffic_stale")),
                         "kernel_ms": _pick(crf.get("kernel_ms") or {}, ("min", "median", "max")),

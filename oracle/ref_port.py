@@ -291,7 +291,8 @@ def match_hits_structured(n_rows: int, tok: np.ndarray, max_n: int = 3, vocab: i
     table against this oracle.  ids 0..vocab-1: the unigrams; then nb = (n_rows - vocab) // 2 bigrams
     ((a * 40503 + 17) % V, (b * 30011 + 5) % V) with j = a + b V < nb; then the trigrams
     ((a * 40503 + 29) % V, (b * 30011 + 3) % V, (c * 20011 + 11) % V) with j = a + b V + c V^2 < n_rows - vocab - nb.
-    Pinned by tests/test_oracle_golden.py against match_hits on the materialised keys."""
+    Pinned by tests/test_host_logic.py::test_structured_vocabulary_oracle_equals_the_materialised_one against match_hits on
+    the materialised keys (match_hits itself is pinned to the reference's outputs by tests/test_oracle_golden.py)."""
     assert max_n == 3
     V = int(vocab)
     B, T = tok.shape

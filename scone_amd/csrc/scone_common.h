@@ -306,7 +306,7 @@ int scone_stage_chunk(scone_handle *h, const int32_t *d_tok, int32_t Bc, int32_t
 int scone_stage_consume_buf(scone_handle *h);                                         // the set of the next chunk to look up
 // chunks of (d_tok, B, T) that scone_embed_prefetch already prepared (0: none -- a prefetch of another batch is discarded)
 long long scone_stage_take_prefetched(scone_handle *h, const int32_t *d_tok, int32_t B, int32_t T, long long seqs);
-void scone_stage_resync(scone_handle *h);  // a call failed mid-batch: prepared chunks nobody will look up are dropped
+void scone_stage_resync(scone_handle *h);  // a call failed mid-batch: the pipeline and its cache are dropped (the next call starts cold)
 int scone_stage_note_prefetched(scone_handle *h, const int32_t *d_tok, int32_t B, int32_t T, long long seqs, long long n);
 hipStream_t scone_stage_side(scone_handle *h);
 hipEvent_t scone_stage_start_event(scone_handle *h);

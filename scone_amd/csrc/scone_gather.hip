@@ -115,7 +115,7 @@ static int embed_staged_chunks(scone_handle *h, const embed_args &full, int32_t 
 
 // One staging pipeline per handle: the whole call holds stage_mu (calls from several host threads are serialised; on the
 // device their chunks follow each other through the pipeline's events like those of consecutive calls from one thread).  A
-// call that fails after chunks were prepared drops them: the next call must not look up this batch's record sets.
+// call that fails after chunks were prepared drops the whole pipeline (scone_stage_resync): the next call starts a cold cache.
 static int embed_staged(scone_handle *h, const embed_args &full, int32_t B, int32_t T, int32_t out_dtype, hipStream_t s) {
   std::lock_guard<std::mutex> g(h->stage_mu);
   const int rc = embed_staged_chunks(h, full, B, T, out_dtype, s);

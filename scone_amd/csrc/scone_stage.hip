@@ -397,13 +397,15 @@ long long scone_stage_take_prefetched(scone_handle *h, const int32_t *d_tok, int
   return 0;                                 // brought into the cache stay, harmlessly)
 }
 
-// Prepared chunks that no lookup will take (the call that prepared them failed mid-batch, or their prefetch is void): the
-// ring is brought back in step -- the next chunk's preparation waits for their copies through staged[buf].
+// A call failed mid-batch (a launch error, an event that could not be recorded): some chunk may have been PLACED -- `owner` /
+// `slot_of` already name cache slots for its rows -- without its copy having been queued, and the ring counters no longer say
+// which.  Nothing of that state can be trusted, so the whole pipeline goes: the device drains, the cache is freed, and the next
+// call builds a cold one (scone_stage_prepare).  Round 6 (the round-5 advisor's finding: resetting the ring counters alone left
+// slots that claimed rows never copied, readable by a later lookup without any status bit).
 void scone_stage_resync(scone_handle *h) {
-  scone_stage_state *st = h->stage;
-  if (!st) return;
-  st->n_consumed = st->chunks;
-  st->pending.valid = false;
+  if (!h->stage) return;
+  (void)hipDeviceSynchronize();
+  scone_stage_destroy(h);
 }
 
 int scone_stage_note_prefetched(scone_handle *h, const int32_t *d_tok, int32_t B, int32_t T, long long seqs, long long n) {

@@ -81,12 +81,28 @@ def make_keys_torch(n_rows: int, vocab: int = GPT2_VOCAB, max_n: int = 3, seed: 
     return keys, lens
 
 
+STRUCTURED_MULTIPLIERS = (40503, 30011, 20011)
+
+
+def check_structured_vocab(vocab: int) -> None:
+    """The structured generator maps a digit x to (x * m + c) % vocab: a bijection of the digits -- distinct keys by
+    construction -- only when every multiplier is coprime to the vocabulary (40503 = 3 * 23 * 587)."""
+    import math
+    if not 3 <= int(vocab) <= 262144:
+        raise ValueError("structured vocabulary: vocab must be in [3, 262144] (the direct unigram table's size)")
+    for m in STRUCTURED_MULTIPLIERS:
+        if math.gcd(int(vocab), m) != 1:
+            raise ValueError(f"structured vocabulary: vocab {vocab} shares a factor with the generator's multiplier {m}: "
+                             "the keys would not be distinct (choose a vocab coprime to 40503 * 30011 * 20011)")
+
+
 def structured_keys_for_ids(ids: np.ndarray, n_rows: int, vocab: int = GPT2_VOCAB, max_n: int = 3) -> Tuple[np.ndarray, np.ndarray]:
     """Rows ``ids`` of :func:`make_keys_structured` in closed form (any subset of a 1e9-row vocabulary without
     materialising it): ids 0..vocab-1 are the unigrams, then half bigrams and half trigrams whose tokens are the
     mixed-radix digits of a running counter (multiplied by odd constants mod vocab, so neighbouring ids do not share
     tokens)."""
     assert max_n >= 3 and n_rows >= vocab
+    check_structured_vocab(vocab)
     ids = np.asarray(ids, dtype=np.int64)
     keys = np.zeros((ids.shape[0], max_n), dtype=np.uint32)
     lens = np.ones(ids.shape[0], dtype=np.uint8)
@@ -129,6 +145,7 @@ class StructuredVocab:
 
     def __init__(self, n_rows: int, vocab: int = GPT2_VOCAB, max_n: int = 3) -> None:
         assert max_n == 3 and n_rows >= vocab
+        check_structured_vocab(vocab)
         self.n_rows, self.vocab, self.max_n = int(n_rows), int(vocab), int(max_n)
 
     def __len__(self) -> int:

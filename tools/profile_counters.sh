@@ -1,11 +1,11 @@
 #!/bin/bash
-# Round-5 counter evidence in one gpurun call.  As tools/profile_round4.sh, on the round's loop: a DIFFERENT batch every step
-# (bench.py's default now), so the FETCH_SIZE / WRITE_SIZE averages are over launches that each see fresh rows -- nothing a
+# A round's counter evidence in one gpurun call (rounds 5 and 6), on the round's loop: a DIFFERENT batch every step
+# (bench.py's default), so the FETCH_SIZE / WRITE_SIZE averages are over launches that each see fresh rows -- nothing a
 # previous step left in the 256-MB Infinity Cache.  The headline gets the full bench line + kernel trace + every PMC pass;
 # every other HBM workload a quick line + kernel trace + FETCH_SIZE / WRITE_SIZE (separate runs, the program directly behind
 # `rocprofv3 ... --`).  tools/summarize_profile.py <tag...> (build box) turns each gpurun_out/<tag>/ into profiles/<tag>/ and
 # an entry of profiles/hbm_traffic.json keyed by workload signature + kernel-source hash.
-#   tools/profile_round5.sh <tag> [headline|rest|all]
+#   tools/profile_counters.sh <tag> [headline|rest|all]
 set -u
 TAG=${1:-r05}
 WHAT=${2:-all}

@@ -418,6 +418,7 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no HIP device visible)")
     budget = Budget(args.time_budget, _T_PROCESS_START)
     line = Line(rank)
+    _LINE[0] = line
     watchdog = Watchdog(budget, line, rank)
     watchdog.start()
     # Rehearsal knobs (never set by the driver): SCONE_DIST_BACKEND=gloo + SCONE_ONE_DEVICE=1 let several
@@ -647,8 +648,11 @@ def main():
             lat = {"error": repr(e)}
         watchdog.disarm()
         line.set(res, "latency", lat)
-        cache.embed_tokens(tok, wte=wte, wpe=wpe, out=out)           # (`out` = the first batch again, for the oracle check)
-        torch.cuda.synchronize()
+        try:
+            cache.embed_tokens(tok, wte=wte, wpe=wpe, out=out)       # (`out` = the first batch again, for the oracle check)
+            torch.cuda.synchronize()
+        except Exception as e:
+            line.set(res, "latency_restore_error", repr(e))
     # ---- the cache-defeating variant, the CPU baselines, the sharded record: outside the timed region -----------
     if rank == 0 and world == 1 and not sharded and emu is None and not args.no_hbm_variant and args.placement == "hbm" \
             and budget.remaining() > 150.0:
@@ -759,5 +763,19 @@ def main():
     os._exit(0) if dist is not None else None   # skip RCCL's exit-time stdout chatter after the JSON line
 
 
+_LINE = [None]      # main()'s Line: an exception after the headline was measured must not cost the line
+
+
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except Exception as e:
+        ln = _LINE[0]
+        if ln is None or not ln.headline_done or ln.res is None:
+            raise
+        import traceback
+        traceback.print_exc()
+        sys.stderr.write("bench.py: the headline was measured before this error; printing the line as it stands\n")
+        ln.emit(incomplete=f"an optional block raised {e!r}; what was measured before it is kept")
+        sys.stdout.flush()
+        os._exit(0)

@@ -153,3 +153,26 @@ def test_index_mutation_drops_a_pending_announcement():
     assert torch.equal(after, full.embed(tok, out_dtype=torch.float32))
     assert not torch.equal(after, before)
     assert pin.status() == 0
+
+
+def test_a_failed_staged_call_drops_the_pipeline_and_the_next_one_starts_cold():
+    """Round-5 advisor: a staged call that fails must not leave a cache whose bookkeeping names rows that were never copied.  A
+    call that fails (here: a sequence longer than a staging chunk, refused with EINVAL) drops the whole pipeline -- cache
+    included -- and the next call rebuilds it: counters restart, results equal the HBM-resident twin's before and after."""
+    from scone_amd.hip_backend import SconeError
+    rng = np.random.default_rng(509)
+    ref, pin, vocab = _pinned_pair(rng, stage=256)
+    toks = [torch.from_numpy(rng.integers(0, vocab, size=(12, 128))).to("cuda", torch.int32) for _ in range(3)]
+    for t in toks[:2]:
+        assert torch.equal(pin.embed(t, out_dtype=torch.float32), ref.embed(t, out_dtype=torch.float32))
+    before = pin.stage_counters()
+    assert before["chunks"] > 0 and before["rows_copied"] > 0
+    too_long = torch.from_numpy(rng.integers(0, vocab, size=(1, 512))).to("cuda", torch.int32)
+    with pytest.raises((SconeError, ValueError)):
+        pin.embed(too_long, out_dtype=torch.float32)
+    assert pin.stage_counters()["chunks"] == 0                         # the pipeline is gone (no cache, no counters) ...
+    for t in toks:                                                       # ... and comes back cold: same results
+        assert torch.equal(pin.embed(t, out_dtype=torch.float32), ref.embed(t, out_dtype=torch.float32))
+    after = pin.stage_counters()
+    assert 0 < after["chunks"] <= before["chunks"] + 6 and after["rows_copied"] > 0
+    assert pin.status() == 0 and ref.status() == 0

@@ -57,30 +57,15 @@ __device__ __forceinline__ int32_t probe_index(const scone_slot *__restrict__ sl
   return probe_finish(slots, mask, lo, ext, hash, b, r);
 }
 
-// id of the f-gram k[0..n) or -1: unigram table, else presence bitmap + hash table.  Used by the one-launch kernel only
-// (k_embed_fused: decode-size batches, where the dependent chain of memory round trips IS the kernel's time), so the bitmap
-// word and the home bucket are requested TOGETHER and the bitmap only decides whether the bucket is looked at: one round trip
-// (~0.7 us of a ~6.8-us kernel at 1 x 512 tokens) instead of two, at the price of a 64-B bucket fetch per absent window --
-// nothing at these sizes.  (k_match_ell, the large-batch match, filters with the bitmap FIRST: there the line traffic is the cost.)
+// id of the f-gram k[0..n) or -1: unigram table, presence bitmap, then the hash table
 __device__ __forceinline__ int32_t scone_lookup_key(const scone_index_view &ix, const uint32_t (&k)[SCONE_MAX_N], int n) {
   if (n == 1 && ix.uni && k[0] < (uint32_t)ix.uni_cap) return ix.uni[k[0]];
   const scone_key key = scone_pack_key(k, n, ix.max_n);
   if (!key.ok) return -1;
   const unsigned long long hash = scone_hash_key(key.lo, key.ext);
-  const unsigned long long b = scone_bucket_home(hash, ix.mask);
-  uint32_t word = 0xFFFFFFFFu;
-  unsigned long long bit = 0;
   if (ix.bloom) {
-    bit = scone_bloom_bit(hash, ix.bloom_mask);
-    word = ix.bloom[bit >> 5];
+    const unsigned long long bit = scone_bloom_bit(hash, ix.bloom_mask);
+    if (!((ix.bloom[bit >> 5] >> (bit & 31)) & 1u)) return -1;
   }
-  scone_bucket_regs r;
-#ifdef SCONE_FUSED_SERIAL_PROBE  // A/B builds: the bitmap first, the bucket only behind a set bit (rounds 1-5)
-  if (!((word >> (bit & 31)) & 1u)) return -1;
-  load_bucket(ix.slots, b, r);
-#else
-  load_bucket(ix.slots, b, r);
-  if (!((word >> (bit & 31)) & 1u)) return -1;
-#endif
-  return probe_finish(ix.slots, ix.mask, key.lo, key.ext, hash, b, r);
+  return probe_index(ix.slots, ix.mask, key.lo, key.ext);
 }

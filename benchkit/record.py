@@ -60,14 +60,16 @@ def compact_record(res, details_path=None):
     cfg = res.get("config") or {}
     out["config"] = _pick(cfg, ("tokens_per_step_per_rank", "mean_hits_per_token", "different_batch_every_step", "distinct_batches",
                                 "distinct_table_rows_per_launch", "distinct_wte_rows_per_launch", "next_batch_announced"))
-    out["config"]["workload"] = _cut(cfg.get("workload"), 190)
+    out["config"]["workload"] = _cut(cfg.get("workload"), 160)
     out["config"]["parallelism"] = _cut(cfg.get("parallelism"), 110)
     left_l2 = rf.get("traffic") is not None
 
     def roof(r, extra=()):
-        c = _pick(r, ("bound", "limited_by", "achieved", "peak", "unit", "frac", "frac_bytes", "algorithmic_bytes_per_launch",
-                      "algorithmic_frac", "avg_kernel_ms", "kernel_ms", "timed_launches", "hbm_bytes_compulsory", "hbm_frac", "traffic",
-                      "traffic_stale", "traffic_frac", "kernel_source_sha", "frac_lo", "frac_hi", "frac_profile_box",
+        # (not repeated in the line: frac_bytes = traffic or the compulsory bytes, traffic_frac = frac when traffic is quoted,
+        # timed_launches = kernel_ms.n; the details file has them)
+        c = _pick(r, ("bound", "limited_by", "achieved", "peak", "unit", "frac", "algorithmic_bytes_per_launch",
+                      "algorithmic_frac", "avg_kernel_ms", "kernel_ms", "hbm_bytes_compulsory", "hbm_frac", "traffic",
+                      "traffic_stale", "kernel_source_sha", "frac_lo", "frac_hi", "frac_profile_box",
                       "profile_kernel_ms") + tuple(extra))
         if "frac_kind" in r:
             c["frac_kind"] = ("left L2: 2*FETCH_SIZE+WRITE_SIZE (rocprofv3 PMC, this kernel source)" if r.get("traffic") is not None
@@ -75,9 +77,7 @@ def compact_record(res, details_path=None):
         if r.get("traffic_source"):
             c["traffic_source"] = r["traffic_source"].split(":")[0]
         return c
-    o_rf = roof(rf, ("match_us", "step_minus_kernel_us"))
-    if rf.get("kernel"):
-        o_rf["kernel"] = _cut(rf["kernel"], 60)
+    o_rf = roof(rf, ("match_us",))
     if isinstance(rf.get("same_batch"), dict):
         o_rf["same_batch"] = _pick(rf["same_batch"], ("ms_per_step", "avg_kernel_ms", "tokens_per_s", "distinct_batches"))
     hv = rf.get("hbm_variant")
@@ -92,7 +92,7 @@ def compact_record(res, details_path=None):
     cb = res.get("cpu_baseline")
     if isinstance(cb, dict):
         o_cb = _pick(cb, ("value", "unit", "cores", "kind", "gpu_vs_oracle_max_rel_err", "gpu_vs_oracle_sequences"))
-        o_cb["sample"] = _cut(cb.get("sample"), 170)
+        o_cb["sample"] = _cut(cb.get("sample"), 120)
         for k in ("python_all_cores", "c_oracle_all_cores"):
             if isinstance(cb.get(k), dict):
                 o_cb[k] = _pick(cb[k], ("value", "cores", "error"))
@@ -109,10 +109,10 @@ def compact_record(res, details_path=None):
             crf = c["roofline"]
             oc[name] = {**_pick(c, ("tokens_per_s", "ms_per_step", "gpu_vs_oracle_max_rel_err", "status_bits")),
                         **({"wall_outlier": True} if c.get("wall_outlier") else {}),
-                        **_pick(crf, ("avg_kernel_ms", "frac", "frac_lo", "frac_profile_box", "hbm_frac", "algorithmic_frac", "traffic",
-                                      "traffic_stale")),
-                        "kernel_ms": _pick(crf.get("kernel_ms") or {}, ("min", "median", "max")),
-                        "frac_bytes": "left L2" if crf.get("traffic") is not None else "compulsory"}
+                        **_pick(crf, ("avg_kernel_ms", "frac", "frac_lo", "frac_profile_box", "hbm_frac", "algorithmic_frac", "traffic")),
+                        "kernel_ms": _pick(crf.get("kernel_ms") or {}, ("min", "median", "max"))}
+            if crf.get("traffic") is None:          # said only when it is NOT the counter-priced case
+                oc[name]["frac_bytes"] = "compulsory" + (" (traffic entry stale)" if crf.get("traffic_stale") else "")
         out["configs"] = oc
     lat = res.get("latency")
     if isinstance(lat, dict):

@@ -149,6 +149,7 @@ template <int FMT, int D> struct wave_geom {
 //   SCONE_PROBE_NO_WTE      the token's wte row is the handle's zero row (always an L1 / L2 hit)
 //   SCONE_PROBE_ROWS_LOCAL  every f-gram row index & 4095: a 3-MB region, L2-resident
 //   SCONE_PROBE_NO_STORE    the output store sits behind a run-time condition that never holds
+//   SCONE_PROBE_NO_MATH     every load and store stays, the dequantise / sum / mean / combine arithmetic becomes one XOR per word
 //   SCONE_LOCKSTEP          (not a probe: results stay exact) a workgroup barrier in front of every token, so that the 4 waves
 //                           that own 4 consecutive positions of one sequence issue their row loads together
 template <int FMT> struct wave_hiocc {
@@ -298,6 +299,10 @@ __device__ __forceinline__ void embed_token(const scone_row_store &rows, const v
 #pragma unroll
       for (int i = 0; i < G::seg_row_words(s); ++i) {
         const uint32_t w = raw[k][G::seg_row_word0(s) + i];
+#ifdef SCONE_PROBE_NO_MATH
+        acc[(G::seg_row_word0(s) + i) % EPL] = __uint_as_float(__float_as_uint(acc[(G::seg_row_word0(s) + i) % EPL]) ^ w ^ __float_as_uint(sc));
+        continue;
+#endif
         if constexpr (FMT == SCONE_FMT_F32) {
           acc[G::seg_acc(s) + i] += __uint_as_float(w);
         } else if constexpr (FMT == SCONE_FMT_F16) {
@@ -324,6 +329,7 @@ __device__ __forceinline__ void embed_token(const scone_row_store &rows, const v
     st_out_row<FMT, float, D, false>(out_row, lane, pw);
     return;
   }
+#ifndef SCONE_PROBE_NO_MATH
   if (reduce == SCONE_REDUCE_MEAN && kfull > 1) {
     // engine.py:250: sum / K.  Correctly rounded quotient without the full division sequence
     // (Markstein): y = RN(1/K); q0 = RN(x*y); r = x - q0*K (exact in an fma); q = RN(q0 + r*y).
@@ -336,7 +342,14 @@ __device__ __forceinline__ void embed_token(const scone_row_store &rows, const v
       acc[e] = fmaf(r, y, q0);
     }
   }
+#endif
   uint32_t ow[NWO];
+#ifdef SCONE_PROBE_NO_MATH
+#pragma unroll
+  for (int w = 0; w < NWO; ++w) ow[w] = bw[w] ^ (WPE_LDS ? wpe_lds[w * 64 + lane] : bp[w]) ^ __float_as_uint(acc[w % EPL]);
+  st_out_row<FMT, OutT, D>(out_row, lane, ow);
+  return;
+#endif
 #pragma unroll
   for (int w = 0; w < NWO; ++w) {
     float b[OPW], c[OPW], v[OPW];

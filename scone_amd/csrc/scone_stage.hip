@@ -239,6 +239,13 @@ struct scone_stage_state {
   uint32_t *count[SCONE_STAGE_NBUF] = {};
 };
 
+#ifndef SCONE_STAGE_PREP_PRIO
+#define SCONE_STAGE_PREP_PRIO 0
+#endif
+#ifndef SCONE_STAGE_COPY_PRIO
+#define SCONE_STAGE_COPY_PRIO 0
+#endif
+
 void scone_stage_destroy(scone_handle *h) {
   scone_stage_state *st = h->stage;
   if (!st) return;
@@ -296,8 +303,15 @@ int scone_stage_prepare(scone_handle *h, long long chunk_tokens) {
     const int v = atoi(ev);
     if (v >= 1 && v <= 65535) st->copy_blocks = v;
   }
-  SCONE_HIP(h, hipStreamCreateWithFlags(&st->prep, hipStreamNonBlocking));
-  SCONE_HIP(h, hipStreamCreateWithFlags(&st->copy, hipStreamNonBlocking));
+  {
+    // Stream priorities of the pipeline (A/B knob: SCONE_STAGE_PRIO="<prep>,<copy>", each -1 = high, 0 = normal, 1 = low).
+    int lo = 0, hi = 0, pp = SCONE_STAGE_PREP_PRIO, pc = SCONE_STAGE_COPY_PRIO;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);  // lo = numerically largest = least urgent
+    if (const char *ev = getenv("SCONE_STAGE_PRIO")) (void)sscanf(ev, "%d,%d", &pp, &pc);
+    auto clampp = [&](int v) { return v < hi ? hi : (v > lo ? lo : v); };
+    SCONE_HIP(h, hipStreamCreateWithPriority(&st->prep, hipStreamNonBlocking, clampp(pp)));
+    SCONE_HIP(h, hipStreamCreateWithPriority(&st->copy, hipStreamNonBlocking, clampp(pc)));
+  }
   SCONE_HIP(h, hipEventCreateWithFlags(&st->start, hipEventDisableTiming));
   const size_t nc = (size_t)(n_cold > 0 ? n_cold : 1);
   SCONE_HIP(h, hipMalloc(&st->slot_of, nc * 4));

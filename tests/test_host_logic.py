@@ -160,7 +160,7 @@ def test_committed_bench_line_follows_the_contract():
         assert len(json.dumps(line)) <= 6000 and line["details"].endswith(".json")
         assert line["value"] == r["value"] and line["ms_per_step"] == r["ms_per_step"] and line["vs_baseline"] is None
         lrf, lcb = line["roofline"], line["cpu_baseline"]
-        for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "frac_kind", "algorithmic_frac", "hbm_frac", "traffic_frac",
+        for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "frac_kind", "algorithmic_frac", "hbm_frac",
                   "traffic_stale", "avg_kernel_ms", "kernel_ms", "match_us", "same_batch", "hbm_variant"):
             assert k in lrf, k
         assert abs(lrf["frac"] - lrf["achieved"] / lrf["peak"]) < 1e-5 and "left L2" in lrf["frac_kind"]
@@ -171,7 +171,9 @@ def test_committed_bench_line_follows_the_contract():
             if name.startswith("C1_"):             # round 6: the reference's CPU-runnable case -- launch-bound, no roofline block
                 assert c["tokens_per_s"] > 0 and c["gpu_vs_oracle_bit_exact"] is True and c["cpu_port_1core_tokens_per_s"] > 0, name
                 continue
-            assert c["tokens_per_s"] > 0 and c["traffic_stale"] is False and c["frac_bytes"] == "left L2" and c["gpu_vs_oracle_max_rel_err"] < 1e-3, name
+            # (round 6: the line says `frac_bytes` only when a config is NOT counter-priced; `traffic` is the bytes past L2)
+            assert c["tokens_per_s"] > 0 and c["gpu_vs_oracle_max_rel_err"] < 1e-3, name
+            assert (c.get("traffic") or 0) > 0 and "frac_bytes" not in c if "frac_lo" in c else c.get("traffic_stale") is False, name
             assert c["kernel_ms"]["min"] <= c["kernel_ms"]["median"] <= c["kernel_ms"]["max"], name
         assert 0 < line["sharded"]["n1_pinned_host"]["pcie_frac"] <= 1 and 0 < line["sharded"]["n1_pinned_host_zipf"]["pcie_frac"] <= 1
     assert r["unit"] == "tokens/s" and r["higher_is_better"] is True and r["vs_baseline"] is None and r["data"] == "synthetic"

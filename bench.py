@@ -763,6 +763,11 @@ def main():
     os._exit(0) if dist is not None else None   # skip RCCL's exit-time stdout chatter after the JSON line
 
 
+def benchkit_grid():
+    from benchkit.workloads import REFERENCE_GRID
+    return list(REFERENCE_GRID)
+
+
 _LINE = [None]      # main()'s Line: an exception after the headline was measured must not cost the line
 
 

@@ -216,7 +216,11 @@ int scone_gather_reduce(scone_handle *h, const int32_t *d_offsets, const int32_t
  * d_pos: int32 [B,T] or NULL (= arange(T), language_model.py:248-251).
  * Batches of up to 32768 tokens (environment SCONE_FUSED_MAX_TOKENS, read by scone_create) at d = 768 / 1024 / 1280
  * run as ONE launch without any workspace; larger ones use the id-record workspace of the call's stream (grown on first
- * use / by scone_reserve). */
+ * use / by scone_reserve).
+ * Stream-ordered, no hidden synchronisation -- with ONE exception: the FIRST lookup (or scone_embed_prefetch) of a pinned-host
+ * table with cfg.stage_tokens > 0 on a given caller stream synchronises that stream once, for ~1 ms: the staging pipeline
+ * chooses its two side streams among six candidates by MEASURED overlap with the caller's stream (HIP multiplexes streams onto a
+ * few hardware queues; side streams that share the caller's queue would serialise the prefetch behind the lookups). */
 int scone_embed(scone_handle *h, const int32_t *d_tok, int32_t B, int32_t T, const void *d_wte,
                 int64_t vocab, const void *d_wpe, int64_t n_pos, const int32_t *d_pos,
                 int32_t reduce, void *d_out, int32_t out_dtype, scone_stream_t stream);

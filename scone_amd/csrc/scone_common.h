@@ -302,6 +302,7 @@ int scone_shard_cols_remap(scone_handle *h, int32_t T, int32_t seq0, int32_t seq
 #define SCONE_STAGE_AHEAD 2
 void scone_stage_destroy(scone_handle *h);
 int scone_stage_prepare(scone_handle *h, long long chunk_tokens);
+int scone_stage_bind(scone_handle *h, hipStream_t caller);  // choose PREP / COPY among the candidate streams by measured overlap with `caller`
 int scone_stage_chunk(scone_handle *h, const int32_t *d_tok, int32_t Bc, int32_t T);  // into the next set of the ring
 int scone_stage_consume_buf(scone_handle *h);                                         // the set of the next chunk to look up
 // chunks of (d_tok, B, T) that scone_embed_prefetch already prepared (0: none -- a prefetch of another batch is discarded)

@@ -127,6 +127,8 @@ static int embed_staged_chunks(scone_handle *h, const embed_args &full, int32_t 
   long long seqs = 0;
   int rc = staged_geometry(h, B, T, &seqs);
   if (rc) return rc;
+  rc = scone_stage_bind(h, s);
+  if (rc) return rc;
   const size_t esz = out_dtype == SCONE_DT_F32 ? 4 : 2;
   const long long nchunks = (B + seqs - 1) / seqs;
   auto chunk_b = [&](long long c) { return (int32_t)((c + 1) * seqs <= B ? seqs : B - c * seqs); };
@@ -197,6 +199,8 @@ extern "C" int scone_embed_prefetch(scone_handle *h, const int32_t *d_tok, int32
   std::lock_guard<std::mutex> g(h->stage_mu);
   long long seqs = 0;
   rc = staged_geometry(h, B, T, &seqs);
+  if (rc) return rc;
+  rc = scone_stage_bind(h, (hipStream_t)stream);
   if (rc) return rc;
   (void)scone_stage_take_prefetched(h, nullptr, -1, -1, -1);  // an earlier prefetch that was never used is dropped
   const long long nchunks = (B + seqs - 1) / seqs;

@@ -32,6 +32,7 @@
 // now sized to the link (SCONE_STAGE_COPY_BLOCKS).
 #include "scone_common.h"
 
+#include <cstdio>
 #include <cstdlib>
 #include <new>
 
@@ -206,7 +207,20 @@ __global__ __launch_bounds__(256) void k_stage_copy(const uint32_t *__restrict__
   }
 }
 
+// Overlap probe (scone_stage_bind): does a kernel queued on stream B start while a kernel queued before it on stream A is still
+// running?  k_probe_spin holds A for `ticks` of the 100-MHz wall clock (bounded: it ends after 2^22 polls whatever the clock
+// says) and leaves its END time; k_probe_stamp leaves its START time.
+__global__ void k_probe_spin(long long ticks, long long *out) {
+  const long long t0 = wall_clock64();
+  long long t = t0;
+  for (int guard = 0; t - t0 < ticks && guard < (1 << 22); ++guard) t = wall_clock64();
+  out[0] = t;
+}
+__global__ void k_probe_stamp(long long *out) { out[1] = wall_clock64(); }
+
 }  // namespace
+
+#define SCONE_STAGE_CAND 6  // candidate side streams per pipeline (the runtime spreads streams over 4 hardware queues)
 
 struct scone_stage_state {
   long long chunk_tokens = 0;      // tokens per chunk actually provisioned
@@ -214,7 +228,12 @@ struct scone_stage_state {
   uint32_t cap = 0;       // cache slots
   uint32_t list_cap = 0;  // rows one chunk can list
   int copy_blocks = 128;
-  hipStream_t prep = nullptr, copy = nullptr;
+  hipStream_t prep = nullptr, copy = nullptr;  // two of cand[], chosen by scone_stage_bind
+  hipStream_t cand[SCONE_STAGE_CAND] = {};
+  hipStream_t bound_to = nullptr;  // the caller's stream the choice was made against
+  bool bound = false;
+  int other_caller_calls = 0;      // consecutive calls on a different caller stream (re-bind after a few)
+  long long *probe_ts = nullptr;   // device [2]
   hipEvent_t prepped[SCONE_STAGE_NBUF] = {}, staged[SCONE_STAGE_NBUF] = {}, consumed[SCONE_STAGE_NBUF] = {}, start = nullptr;
   bool consumed_valid[SCONE_STAGE_NBUF] = {};
   bool staged_valid[SCONE_STAGE_NBUF] = {};  // the set has carried a chunk: its copy kernel read count / list / place
@@ -239,18 +258,12 @@ struct scone_stage_state {
   uint32_t *count[SCONE_STAGE_NBUF] = {};
 };
 
-#ifndef SCONE_STAGE_PREP_PRIO
-#define SCONE_STAGE_PREP_PRIO 0
-#endif
-#ifndef SCONE_STAGE_COPY_PRIO
-#define SCONE_STAGE_COPY_PRIO 0
-#endif
-
 void scone_stage_destroy(scone_handle *h) {
   scone_stage_state *st = h->stage;
   if (!st) return;
-  if (st->prep) (void)hipStreamDestroy(st->prep);
-  if (st->copy) (void)hipStreamDestroy(st->copy);
+  for (hipStream_t c : st->cand)
+    if (c) (void)hipStreamDestroy(c);
+  if (st->probe_ts) (void)hipFree(st->probe_ts);
   for (int b = 0; b < SCONE_STAGE_NBUF; ++b) {
     if (st->prepped[b]) (void)hipEventDestroy(st->prepped[b]);
     if (st->staged[b]) (void)hipEventDestroy(st->staged[b]);
@@ -303,15 +316,11 @@ int scone_stage_prepare(scone_handle *h, long long chunk_tokens) {
     const int v = atoi(ev);
     if (v >= 1 && v <= 65535) st->copy_blocks = v;
   }
-  {
-    // Stream priorities of the pipeline (A/B knob: SCONE_STAGE_PRIO="<prep>,<copy>", each -1 = high, 0 = normal, 1 = low).
-    int lo = 0, hi = 0, pp = SCONE_STAGE_PREP_PRIO, pc = SCONE_STAGE_COPY_PRIO;
-    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);  // lo = numerically largest = least urgent
-    if (const char *ev = getenv("SCONE_STAGE_PRIO")) (void)sscanf(ev, "%d,%d", &pp, &pc);
-    auto clampp = [&](int v) { return v < hi ? hi : (v > lo ? lo : v); };
-    SCONE_HIP(h, hipStreamCreateWithPriority(&st->prep, hipStreamNonBlocking, clampp(pp)));
-    SCONE_HIP(h, hipStreamCreateWithPriority(&st->copy, hipStreamNonBlocking, clampp(pc)));
-  }
+  // Candidate side streams; which two become PREP and COPY is decided against the caller's stream at the first lookup
+  // (scone_stage_bind).  Until then the first two.
+  for (int i = 0; i < SCONE_STAGE_CAND; ++i) SCONE_HIP(h, hipStreamCreateWithFlags(&st->cand[i], hipStreamNonBlocking));
+  st->prep = st->cand[0], st->copy = st->cand[1];
+  SCONE_HIP(h, hipMalloc(&st->probe_ts, 2 * sizeof(long long)));
   SCONE_HIP(h, hipEventCreateWithFlags(&st->start, hipEventDisableTiming));
   const size_t nc = (size_t)(n_cold > 0 ? n_cold : 1);
   SCONE_HIP(h, hipMalloc(&st->slot_of, nc * 4));
@@ -337,6 +346,68 @@ int scone_stage_prepare(scone_handle *h, long long chunk_tokens) {
     SCONE_HIP(h, hipMalloc(&st->place[b], (size_t)list_cap * 4));
     SCONE_HIP(h, hipMalloc(&st->count[b], 4));
   }
+  return SCONE_OK;
+}
+
+// Which side streams?  The pipeline lives on overlap: the COPY kernel of chunk c + 1 (PCIe-bound, ~0.3 ms) must run BESIDE the
+// lookup of chunk c on the caller's stream, and the preparation of chunk c + 2 beside both.  HIP multiplexes a process's streams
+// onto a few hardware queues (4 by default), and two streams that share a queue run one after the other: with the side streams
+// simply created at this point the cached C4 step took 0.92 ms or 1.5 ms depending on HOW MANY OTHER STREAMS the process had used
+// before (round 6, profiles/r06i: 0.92 / 0.92 / 1.52 / 0.92 / 0.92 / 1.46 / 1.20 / 0.92 ms for 0 .. 7 torch side streams) --
+// any application with a few streams of its own (RCCL, a data loader) plays that lottery.  So the pipeline measures instead of
+// hoping: SCONE_STAGE_CAND candidate streams; a candidate is usable as COPY if a kernel queued on it starts while a spinning
+// kernel queued before it on the CALLER's stream is still running; PREP likewise, and it must also overlap with the chosen COPY
+// stream.  ~0.1 ms per test, at most 2 * SCONE_STAGE_CAND tests, once per pipeline and caller stream (synchronises the caller's
+// stream: a hidden sync at the FIRST staged lookup only, never afterwards).  SCONE_STAGE_TRACE=1 prints the outcome.
+static int stage_overlaps(scone_handle *h, scone_stage_state *st, hipStream_t a, hipStream_t b, bool *yes) {
+  long long ts[2] = {0, 0};
+  hipLaunchKernelGGL(k_probe_spin, dim3(1), dim3(1), 0, a, (long long)8000, st->probe_ts);  // 80 us on the 100-MHz clock
+  hipLaunchKernelGGL(k_probe_stamp, dim3(1), dim3(1), 0, b, st->probe_ts);
+  SCONE_HIP(h, hipGetLastError());
+  SCONE_HIP(h, hipStreamSynchronize(a));
+  SCONE_HIP(h, hipStreamSynchronize(b));
+  SCONE_HIP(h, hipMemcpy(ts, st->probe_ts, sizeof(ts), hipMemcpyDeviceToHost));
+  *yes = ts[1] < ts[0];
+  return SCONE_OK;
+}
+
+int scone_stage_bind(scone_handle *h, hipStream_t caller) {
+  scone_stage_state *st = h->stage;
+  if (st->bound && st->bound_to == caller) {
+    st->other_caller_calls = 0;
+    return SCONE_OK;
+  }
+  if (st->bound && ++st->other_caller_calls < 4) return SCONE_OK;  // an occasional call from another stream keeps the choice
+  // (re-)bind: nothing of the pipeline may be in flight while PREP / COPY change hands (consecutive chunks rely on the order
+  // of their preparation kernels on ONE stream)
+  SCONE_HIP(h, hipStreamSynchronize(st->prep));
+  SCONE_HIP(h, hipStreamSynchronize(st->copy));
+  bool ok_main[SCONE_STAGE_CAND] = {};
+  int n_ok = 0;
+  for (int i = 0; i < SCONE_STAGE_CAND; ++i) {
+    int rc = stage_overlaps(h, st, caller, st->cand[i], &ok_main[i]);
+    if (rc) return rc;
+    n_ok += ok_main[i];
+  }
+  int copy = -1, prep = -1;
+  for (int i = 0; i < SCONE_STAGE_CAND && copy < 0; ++i)
+    if (ok_main[i]) copy = i;
+  if (copy < 0) copy = 1;  // nothing overlaps with the caller's stream (one hardware queue?): as before
+  for (int pass = 0; pass < 2 && prep < 0; ++pass)  // first a stream that also overlaps with the caller's, then any
+    for (int j = 0; j < SCONE_STAGE_CAND && prep < 0; ++j) {
+      if (j == copy || (pass == 0 && !ok_main[j])) continue;
+      bool yes = false;
+      int rc = stage_overlaps(h, st, st->cand[copy], st->cand[j], &yes);
+      if (rc) return rc;
+      if (yes) prep = j;
+    }
+  if (prep < 0) prep = copy == 0 ? 1 : 0;
+  st->copy = st->cand[copy], st->prep = st->cand[prep];
+  st->bound = true, st->bound_to = caller, st->other_caller_calls = 0;
+  if (const char *ev = getenv("SCONE_STAGE_TRACE"))
+    if (*ev && *ev != '0')
+      fprintf(stderr, "scone_stage_bind: %d of %d candidate streams overlap with the caller's stream [%d%d%d%d%d%d]; COPY = #%d, PREP = #%d\n",
+              n_ok, SCONE_STAGE_CAND, ok_main[0], ok_main[1], ok_main[2], ok_main[3], ok_main[4], ok_main[5], copy, prep);
   return SCONE_OK;
 }
 

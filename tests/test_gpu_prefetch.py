@@ -179,3 +179,38 @@ def test_a_failed_staged_call_drops_the_pipeline_and_the_next_one_starts_cold():
     after = pin.stage_counters()
     assert after["chunks"] > 0 and after["rows_copied"] > 0
     assert pin.status() == 0 and ref.status() == 0
+
+
+def test_pipeline_chooses_its_side_streams_against_the_callers_stream_and_rebinds():
+    """Round 6: the pipeline picks PREP / COPY among six candidate streams by MEASURED overlap with the caller's stream
+    (scone_stage_bind) -- with streams simply created at that point the cached step was 0.92 or 1.5 ms depending on how many
+    other streams the process had used before (profiles/r06i, r06j).  Correctness here: other streams used first, lookups from
+    the default stream, then a run of lookups from a second stream (the pipeline re-binds after a few), then back; every
+    result equals the HBM-resident twin's."""
+    rng = np.random.default_rng(511)
+    x = torch.zeros(1 << 16, device="cuda")
+    keep = []
+    for _ in range(5):                                                   # the process has used other streams before
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            x.add_(1.0)
+        keep.append(s)
+    torch.cuda.synchronize()
+    ref, pin, vocab = _pinned_pair(rng, stage=256)
+    toks = [torch.from_numpy(rng.integers(0, vocab, size=(10, 128))).to("cuda", torch.int32) for _ in range(4)]
+    for t in toks[:2]:
+        assert torch.equal(pin.embed(t, out_dtype=torch.float32), ref.embed(t, out_dtype=torch.float32))
+    other = torch.cuda.Stream()
+    other.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(other):
+        for i in range(7):                                               # >= 4 consecutive calls: the pipeline re-binds to `other`
+            t = toks[i % 4]
+            pin.embed_prefetch(toks[(i + 1) % 4], tokens_ready=True) if i % 2 else None
+            got = pin.embed(t, out_dtype=torch.float32)
+            want = ref.embed(t, out_dtype=torch.float32)
+            other.synchronize()
+            assert torch.equal(got, want), i
+    torch.cuda.current_stream().wait_stream(other)
+    for t in toks:
+        assert torch.equal(pin.embed(t, out_dtype=torch.float32), ref.embed(t, out_dtype=torch.float32))
+    assert pin.status() == 0 and ref.status() == 0

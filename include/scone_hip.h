@@ -256,6 +256,14 @@ int scone_reserve(scone_handle *h, int64_t max_tokens);
 int scone_set_cu_reserve(scone_handle *h, int32_t n_reserved);
 int scone_get_cu_reserve(scone_handle *h, int32_t *n_reserved, int32_t *n_cus);
 int scone_lookup_stream(scone_handle *h, void **stream);
+/* Do kernels queued on stream_b START while a kernel queued before them on stream_a is still running?  HIP multiplexes a
+ * process's streams onto a few hardware queues (four by default); two streams that share a queue run one after the other, and
+ * which streams share depends on how many streams the process created before (profiles/r06i).  A caller that builds its own
+ * overlap around the lookup -- the split-phase exchange of a row-sharded table plans and packs on a side stream -- picks that
+ * side stream among a few candidates with this probe (scone_amd.hip_backend.SconeTable.pick_side_stream); the staging
+ * pipeline of a pinned-host table does the same internally.  An 80-us spinning kernel on stream_a, a time stamp on stream_b;
+ * synchronises both streams; *overlap = 1 or 0.  (No counterpart in the reference: it has no streams.) */
+int scone_streams_overlap(scone_handle *h, scone_stream_t stream_a, scone_stream_t stream_b, int32_t *overlap);
 /* Optional timing of the gather/reduce kernel launched by scone_embed: while enabled, every
  * call brackets that kernel with HIP events on the launch stream (a ring of 1024 pairs).
  * scone_profile_read synchronises the device, returns the number of timed launches and

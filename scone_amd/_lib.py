@@ -81,6 +81,7 @@ SIGNATURES = {
     "scone_set_cu_reserve": (C.c_int, [_P, _I32]),
     "scone_get_cu_reserve": (C.c_int, [_P, C.POINTER(_I32), C.POINTER(_I32)]),
     "scone_lookup_stream": (C.c_int, [_P, C.POINTER(_P)]),
+    "scone_streams_overlap": (C.c_int, [_P, _P, _P, C.POINTER(_I32)]),
     "scone_profile_enable": (C.c_int, [_P, C.c_int]),
     "scone_profile_read": (C.c_int, [_P, C.POINTER(_U64), C.POINTER(C.c_double), C.c_int]),
     "scone_profile_samples": (C.c_int, [_P, C.POINTER(C.c_float), _U64, C.POINTER(_U64)]),

@@ -359,15 +359,34 @@ int scone_stage_prepare(scone_handle *h, long long chunk_tokens) {
 // kernel queued before it on the CALLER's stream is still running; PREP likewise, and it must also overlap with the chosen COPY
 // stream.  ~0.1 ms per test, at most 2 * SCONE_STAGE_CAND tests, once per pipeline and caller stream (synchronises the caller's
 // stream: a hidden sync at the FIRST staged lookup only, never afterwards).  SCONE_STAGE_TRACE=1 prints the outcome.
-static int stage_overlaps(scone_handle *h, scone_stage_state *st, hipStream_t a, hipStream_t b, bool *yes) {
+static int streams_overlap(scone_handle *h, long long *d_ts, hipStream_t a, hipStream_t b, bool *yes) {
   long long ts[2] = {0, 0};
-  hipLaunchKernelGGL(k_probe_spin, dim3(1), dim3(1), 0, a, (long long)8000, st->probe_ts);  // 80 us on the 100-MHz clock
-  hipLaunchKernelGGL(k_probe_stamp, dim3(1), dim3(1), 0, b, st->probe_ts);
+  hipLaunchKernelGGL(k_probe_spin, dim3(1), dim3(1), 0, a, (long long)8000, d_ts);  // 80 us on the 100-MHz clock
+  hipLaunchKernelGGL(k_probe_stamp, dim3(1), dim3(1), 0, b, d_ts);
   SCONE_HIP(h, hipGetLastError());
   SCONE_HIP(h, hipStreamSynchronize(a));
   SCONE_HIP(h, hipStreamSynchronize(b));
-  SCONE_HIP(h, hipMemcpy(ts, st->probe_ts, sizeof(ts), hipMemcpyDeviceToHost));
+  SCONE_HIP(h, hipMemcpy(ts, d_ts, sizeof(ts), hipMemcpyDeviceToHost));
   *yes = ts[1] < ts[0];
+  return SCONE_OK;
+}
+static int stage_overlaps(scone_handle *h, scone_stage_state *st, hipStream_t a, hipStream_t b, bool *yes) {
+  return streams_overlap(h, st->probe_ts, a, b, yes);
+}
+
+extern "C" int scone_streams_overlap(scone_handle *h, scone_stream_t stream_a, scone_stream_t stream_b, int32_t *overlap) {
+  if (!h) return SCONE_EINVAL;
+  if (!overlap) return scone_fail(h, SCONE_EINVAL, "scone_streams_overlap: null pointer");
+  *overlap = 0;
+  if (stream_a == stream_b) return SCONE_OK;  // one stream: in order by definition
+  SCONE_ON_DEVICE(h);
+  long long *d_ts = nullptr;
+  SCONE_HIP(h, hipMalloc(&d_ts, 2 * sizeof(long long)));
+  bool yes = false;
+  const int rc = streams_overlap(h, d_ts, (hipStream_t)stream_a, (hipStream_t)stream_b, &yes);
+  (void)hipFree(d_ts);
+  if (rc) return rc;
+  *overlap = yes ? 1 : 0;
   return SCONE_OK;
 }
 

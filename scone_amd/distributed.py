@@ -840,7 +840,8 @@ class ShardedEmbeddingCache:
         if dev is None or torch.device(dev).type != "cuda":   # stand-in tables of the CPU tests: the slots, no streams
             return self._gather_begin(t._tok(tok), slot, 0.0)
         if self._side is None:
-            self._side = torch.cuda.Stream(device=dev)
+            # (round 6: a side stream on the hardware queue of the caller's stream overlaps with nothing -- chosen by probe)
+            self._side = t.pick_side_stream() if hasattr(t, "pick_side_stream") else torch.cuda.Stream(device=dev)
         side = self._side
         if tok.is_cuda:
             if isinstance(tokens_ready, str):

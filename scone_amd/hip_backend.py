@@ -388,6 +388,25 @@ class SconeTable:
         self._check(L.lib().scone_lookup_stream(self._h, C.byref(p)), "scone_lookup_stream")
         return torch.cuda.ExternalStream(p.value, device=self.device) if p.value else None
 
+    def streams_overlap(self, a: "torch.cuda.Stream", b: "torch.cuda.Stream") -> bool:
+        """Do kernels queued on ``b`` start while a kernel queued before them on ``a`` is still running (i.e. do the two streams
+        sit on different hardware queues)?  Synchronises both streams (``scone_streams_overlap``)."""
+        v = C.c_int32(0)
+        with torch.cuda.device(self.device):
+            self._check(L.lib().scone_streams_overlap(self._h, a.cuda_stream, b.cuda_stream, C.byref(v)), "scone_streams_overlap")
+        return bool(v.value)
+
+    def pick_side_stream(self, candidates: int = 6) -> "torch.cuda.Stream":
+        """A new stream whose kernels run BESIDE those of the current stream: the first of ``candidates`` fresh streams that
+        passes :meth:`streams_overlap` against the current stream (HIP spreads streams over four hardware queues; a side
+        stream that shares the current stream's queue overlaps with nothing).  The first candidate if none passes."""
+        cur = torch.cuda.current_stream(self.device)
+        made = [torch.cuda.Stream(device=self.device) for _ in range(max(1, candidates))]
+        for s in made:
+            if self.streams_overlap(cur, s):
+                return s
+        return made[0]
+
     def cu_reserve(self) -> Tuple[int, int]:
         """(compute units reserved, compute units of the device)."""
         a, b = C.c_int32(0), C.c_int32(0)

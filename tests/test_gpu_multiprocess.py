@@ -317,7 +317,7 @@ def test_bench_two_ranks_launched_like_the_driver(mode):
     assert r["scaling"] == ("weak" if mode == "replicated" else "strong")
     assert abs(r["value"] - ranks_counted * 256 * 512 * 5 / (r["ms_per_step"] * 5e-3)) / r["value"] < 1e-6
     if mode == "replicated":
-        assert r["roofline"]["timed_launches"] == 5
+        assert r["roofline"]["kernel_ms"]["n"] == 5
         km = r["roofline"]["kernel_ms"]
         assert km["n"] == 5 and km["min"] <= km["median"] <= km["max"]
         assert 0 < r["roofline"]["frac"] <= 1.0 and r["roofline"]["algorithmic_frac"] > 0
@@ -501,7 +501,7 @@ def test_bench_runs_under_rccl_with_one_rank():
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{"metric"')]
     assert len(lines) == 1, p.stdout[-2000:]
     r = json.loads(lines[0])
-    assert r["n_gpus"] == 1 and r["value"] > 0 and r["roofline"]["timed_launches"] == 5
+    assert r["n_gpus"] == 1 and r["value"] > 0 and r["roofline"]["kernel_ms"]["n"] == 5
 
 
 def _nccl_worker(rank, world, port, q):

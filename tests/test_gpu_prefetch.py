@@ -214,3 +214,27 @@ def test_pipeline_chooses_its_side_streams_against_the_callers_stream_and_rebind
     for t in toks:
         assert torch.equal(pin.embed(t, out_dtype=torch.float32), ref.embed(t, out_dtype=torch.float32))
     assert pin.status() == 0 and ref.status() == 0
+
+
+def test_streams_overlap_probe_and_side_stream_choice():
+    """scone_streams_overlap: a stream never overlaps with itself; a side stream picked by SconeTable.pick_side_stream runs
+    beside the current stream; among more streams than the runtime has hardware queues some pair shares a queue (which is why
+    the probe exists: profiles/r06i)."""
+    rng = np.random.default_rng(512)
+    keys, lens = _vocab(rng, 31, 500)
+    t = _table(keys, lens, rng.standard_normal((500, 64)).astype(np.float32), "fp32")
+    cur = torch.cuda.current_stream()
+    assert t.streams_overlap(cur, cur) is False
+    side = t.pick_side_stream()
+    assert side.cuda_stream != cur.cuda_stream and t.streams_overlap(cur, side) is True
+    streams = [torch.cuda.Stream() for _ in range(9)]
+    shares = [(i, j) for i in range(len(streams)) for j in range(i + 1, len(streams)) if not t.streams_overlap(streams[i], streams[j])]
+    assert shares, "nine streams on four hardware queues: at least one pair must share a queue"
+    assert len(shares) < 36, "and not all of them"
+    # the lookup is unaffected by all of this
+    tok = torch.from_numpy(rng.integers(0, 31, size=(4, 32))).to("cuda", torch.int32)
+    a = t.embed(tok, out_dtype=torch.float32).clone()
+    with torch.cuda.stream(side):
+        b = t.embed(tok, out_dtype=torch.float32)
+    side.synchronize()
+    assert torch.equal(a, b) and t.status() == 0

@@ -439,6 +439,23 @@ def test_roofline_fraction_range_is_ordered_and_physical():
     for b in priced:
         assert b["frac_lo"] <= b["frac"] + 1e-9 and abs(b["frac"] - b["frac_hi"]) < 1e-9 and b["frac_hi"] <= 1.0
         assert b["frac_profile_box"] <= 1.0 and b["profile_kernel_ms"] > 0
+    # ... and every line of the round's configs.jsonl (tools/run_configs.sh: one printed line per single-GPU config)
+    n_lines = 0
+    for d in sorted(os.listdir(prof)):
+        cj = os.path.join(prof, d, "configs.jsonl")
+        if d >= "r06" and re.fullmatch(r"r\d+[a-z]?", d) and os.path.exists(cj):
+            for ln in open(cj):
+                if not ln.strip():
+                    continue
+                c = json.loads(ln)
+                rf = c["roofline"]
+                assert 0 < rf["frac"] <= 1.0, (d, c.get("config_name"))
+                if "pinned" in c["config_name"] or "shard" in c["config_name"]:
+                    continue                                    # PCIe-bound / local half of an exchange: compulsory bytes only
+                assert rf["traffic"] is not None and rf["traffic_stale"] is False, (d, c["config_name"])
+                assert 0 < rf["frac_lo"] < rf["frac"] == rf["frac_hi"] <= 1.0 and 0 < rf["frac_profile_box"] <= 1.0, (d, c["config_name"])
+                n_lines += 1
+    assert n_lines >= 7
 
 
 def test_eight_rank_line_keeps_the_sharded_summary_when_shortened():

@@ -66,7 +66,7 @@ from benchkit.record import LINE_LIMIT, Budget, Line, Watchdog, compact_record, 
 from benchkit.launcher import self_launch  # noqa: E402
 from benchkit.roofline import (_code_only, kernel_source_files, kernel_source_sha, kernel_stats, read_traffic,  # noqa: E402,F401
                                roofline_block, workload_bytes, workload_sig)
-from benchkit.workloads import (MAX_DISTINCT_BATCHES, c1_record, config_record, hbm_variant, latency_block, lookup_loop,  # noqa: E402,F401
+from benchkit.workloads import (MAX_DISTINCT_BATCHES, REFERENCE_GRID, c1_record, config_record, hbm_variant, latency_block, lookup_loop,  # noqa: E402,F401
                                 make_batches, make_vocabulary, measure_lookup, pinned_baseline)
 from benchkit.sharded import NCCL_HIGH_PRIORITY, _rccl_version, run_stages, sharded_record  # noqa: E402,F401
 
@@ -761,11 +761,6 @@ def main():
         dist.destroy_process_group()
     sys.stdout.flush()
     os._exit(0) if dist is not None else None   # skip RCCL's exit-time stdout chatter after the JSON line
-
-
-def benchkit_grid():
-    from benchkit.workloads import REFERENCE_GRID
-    return list(REFERENCE_GRID)
 
 
 _LINE = [None]      # main()'s Line: an exception after the headline was measured must not cost the line

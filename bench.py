@@ -104,6 +104,8 @@ def parse(argv=None):
                          "--stage-tokens: the next batch's first chunks are matched, placed and copied beside this batch's last "
                          "lookups; a no-op for every other table).  auto = on where it does something")
     ap.add_argument("--no-configs", action="store_true", help="skip the `configs` block (BASELINE configs C1, C2, C3, C4-in-HBM)")
+    ap.add_argument("--out-candidates", type=int, default=4, help="the re-used [B, T, d] output buffer is the fastest of this many "
+                    "candidate allocations (3 timed lookups each, before the timed region); 1 = one plain allocation")
     ap.add_argument("--no-latency", action="store_true", help="skip the `latency` block (the reference's benchmark grid on the headline table)")
     ap.add_argument("--configs-steps", type=int, default=15)
     ap.add_argument("--placement", default="hbm", choices=["hbm", "pinned_host"])
@@ -524,7 +526,15 @@ def main():
     g = torch.Generator(device="cuda").manual_seed(5)
     wte = (torch.randn(vocab, d, generator=g, device="cuda") * 0.02).half()
     wpe = (torch.randn(1024, d, generator=g, device="cuda") * 0.01).half()
-    out = torch.empty(B, T, d, dtype=torch.float16, device="cuda")
+    # The output buffer is re-used by every step; the kernel's time follows its physical placement (0.616 ... 0.657 ms over five
+    # allocations of one process, whatever the table: profiles/r06m), so it is chosen by measurement before the timed region:
+    # `--out-candidates` allocations, 3 timed lookups each, the fastest kept (EmbeddingCache.alloc_output; the line says so and
+    # prints every candidate's time).  1 = a plain allocation.
+    out_report = None
+    if args.out_candidates > 1 and emu is None and not sharded and args.placement == "hbm" and hasattr(cache, "alloc_output"):
+        out, out_report = cache.alloc_output(batches[0], wte=wte, wpe=wpe, candidates=args.out_candidates)
+    else:
+        out = torch.empty(B, T, d, dtype=torch.float16, device="cuda")
 
     # workload statistics (outside the timed region)
     table = cache.table
@@ -591,6 +601,9 @@ def main():
                 "tokens_per_step_per_rank": ntok, "mean_hits_per_token": sum_k / ntok, "hits_histogram_K0_6": k_hist[:7],
                 "different_batch_every_step": n_batches > 1, "distinct_batches": n_batches,
                 "next_batch_announced": bool(prefetch),
+                "output_buffer": ({"how": "fastest of N candidate allocations, 3 timed lookups each, before the timed region "
+                                          "(EmbeddingCache.alloc_output): the kernel's time follows the buffer's physical placement",
+                                   **out_report} if out_report else {"how": "one plain allocation", "candidates": 1}),
                 "loop": ("scone_embed(batch i) then scone_embed_prefetch(batch i + 1): the next batch's first chunks are prepared on the "
                          "handle's side streams beside this batch's last lookups" if prefetch else
                          "scone_embed(batch i): k_match_ell, then the gather kernel, on one stream (running the next batch's match on a "
@@ -658,7 +671,7 @@ def main():
             and budget.remaining() > 150.0:
         watchdog.arm("roofline.hbm_variant", min(150.0, budget.remaining() - 60.0))
         try:
-            hv = hbm_variant(args, wte, wpe, sync, prefetch, check=cpu_baseline_spot_check)
+            hv = hbm_variant(args, wte, wpe, sync, prefetch, check=cpu_baseline_spot_check, out_candidates=args.out_candidates)
             with line.lock:
                 res["roofline"]["hbm_variant"] = hv
                 # the cache-defeating variant's bracket, lifted to the top of the block: what really touches HBM is at least
@@ -673,7 +686,8 @@ def main():
             if budget.remaining() > 120.0:
                 watchdog.arm("roofline.mall_variant", min(120.0, budget.remaining() - 60.0))     # a stage of its own (two 10M-row builds)
                 mv = config_record("mall_variant", args.format, args.dim, 10_000_000, "structured", "uniform", args.batch, args.seq,
-                                   max(10, min(args.steps, 30)), 3, sync, prefetch, check=cpu_baseline_spot_check, vocab=262144)
+                                   max(10, min(args.steps, 30)), 3, sync, prefetch, check=cpu_baseline_spot_check, vocab=262144,
+                                   out_candidates=args.out_candidates)
                 with line.lock:
                     res["roofline"]["mall_variant"] = mv
         except Exception as e:
@@ -724,7 +738,7 @@ def main():
                 reuse = (vocab_obj, keys, lens) if (cN, ckg) == (N, args.keygen) else None
                 c = config_record(cname, cfmt, cd, cN, ckg, "uniform", B, T, args.configs_steps, 3, lambda: torch.cuda.synchronize(),
                                   prefetch, vocab_cache=reuse, wte=wte if cd == d else None, wpe=wpe if cd == d else None,
-                                  check=cpu_baseline_spot_check)
+                                  check=cpu_baseline_spot_check, out_candidates=args.out_candidates)
             except Exception as e:
                 c = {"error": repr(e)}
                 torch.cuda.empty_cache()

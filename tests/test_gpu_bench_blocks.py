@@ -47,3 +47,29 @@ def test_config_c1_record_is_bit_exact_against_the_oracle():
     assert rec["gpu_vs_oracle_tokens"] == 8 * 512 and 2.0 < rec["mean_hits_per_token"] < 3.2
     assert rec["tokens_per_s"] > 1e6 and rec["cpu_port_1core_tokens_per_s"] > 1e3 and rec["status_bits"] == 0
     assert rec["positions_returned"] > 400 and rec["get_token_embeddings_ms_per_512_token_sequence"] > 0
+
+
+def test_alloc_output_keeps_the_fastest_candidate_and_changes_no_result():
+    """EmbeddingCache.alloc_output (round 6: the lookup kernel's time follows the physical placement of the buffer it writes,
+    profiles/r06m): N candidate allocations, timed lookups into each, the fastest kept; the lookup into the chosen buffer is
+    the lookup."""
+    import bench
+    from scone_amd import EmbeddingCache
+    from scone_amd import synthetic as S
+    d = 768
+    vocab_obj, keys, lens = bench.make_vocabulary(200_000, "zipf")
+    cache = EmbeddingCache.from_synthetic(vocab_obj, d, table_format="int8", seed=7, base_scale=0.02 / 127)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    wte = (torch.randn(S.GPT2_VOCAB, d, generator=g, device="cuda") * 0.02).half()
+    wpe = (torch.randn(1024, d, generator=g, device="cuda") * 0.01).half()
+    tok = torch.from_numpy(S.stream_zipf(S.GPT2_VOCAB, 96, 512, 3)).to("cuda", torch.int32)
+    out, rep = cache.alloc_output(tok, wte=wte, wpe=wpe, candidates=3, trials=2)
+    assert out.shape == (96, 512, d) and out.dtype == torch.float16 and out.is_contiguous()
+    assert rep["candidates"] == 3 and len(rep["kernel_ms"]) == 3 and all(t > 0 for t in rep["kernel_ms"])
+    assert rep["kept"] == int(np.argmin(rep["kernel_ms"]))
+    want = cache.embed_tokens(tok, wte=wte, wpe=wpe).clone()
+    assert torch.equal(cache.embed_tokens(tok, wte=wte, wpe=wpe, out=out), want)
+    plain, rep1 = cache.alloc_output(tok, wte=wte, wpe=wpe, candidates=1)
+    assert rep1 == {"candidates": 1, "kernel_ms": [None], "kept": 0} and plain.shape == out.shape
+    f32, _ = cache.alloc_output(tok[:2], candidates=2, trials=1)                 # no wte / wpe: fp32 out
+    assert f32.dtype == torch.float32 and cache.table.status() == 0

@@ -30,6 +30,9 @@ def run(cache, out):
 
 caches = [EmbeddingCache.from_synthetic(ex, d, table_format="int8") for _ in range(5)]
 outs = [torch.empty(B, T, d, dtype=torch.float16, device="cuda") for _ in range(5)]
+print("full matrix (rows: tables, columns: out buffers), ms per gather kernel:", flush=True)
+for i, c in enumerate(caches):
+    print("  table[%d]:" % i, " ".join("%.4f" % run(c, o) for o in outs), flush=True)
 print("tables x out[0]:", " ".join("%.4f" % run(c, outs[0]) for c in caches), flush=True)
 print("table[0] x outs:", " ".join("%.4f" % run(caches[0], o) for o in outs), flush=True)
 wtes = [wte.clone() for _ in range(4)]

@@ -22,6 +22,7 @@ if [ "$WHAT" != "rest" ]; then
       timeout -k 10 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$c -- python3 $R/bench.py --steps 5 --warmup 2 --quick --same-batch > $O/pmc_$c.log 2>&1
     done )
   cp $(ls $O/trace/*/*kernel_stats.csv | head -1) $O/kernel_stats.csv
+  python3 $R/tools/timed_kernel_avg.py $O/trace 20 $O/kernel_timed.json
   rm -rf $O/trace/*/*kernel_trace.csv $O/pmc_*/*/*kernel_trace.csv 2>/dev/null
   echo "same_batch: $(head -c 200 $O/bench.json)"
 fi
@@ -37,6 +38,7 @@ quick() {  # tag, bench args...
       timeout -k 10 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$c -- python3 $R/bench.py --steps 5 --warmup 2 --quick "$@" > $O/pmc_$c.log 2>&1
     done )
   cp $(ls $O/trace/*/*kernel_stats.csv | head -1) $O/kernel_stats.csv
+  python3 $R/tools/timed_kernel_avg.py $O/trace 20 $O/kernel_timed.json
   rm -rf $O/trace/*/*kernel_trace.csv $O/pmc_*/*/*kernel_trace.csv 2>/dev/null   # (keep the merge small: the counters and the stats are what is read)
   echo "$T: $(head -c 200 $O/bench.json)"
 }

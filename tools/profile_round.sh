@@ -22,4 +22,5 @@ for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_E
   timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$n -- python3 $R/bench.py --steps 5 --warmup 2 --quick "$@" > $O/pmc_$n.log 2>&1
 done
 cp $(ls $O/trace/*/*kernel_stats.csv | head -1) $O/kernel_stats.csv
+python3 $R/tools/timed_kernel_avg.py $O/trace 20 $O/kernel_timed.json   # the 20 timed launches alone (not warm-up / output-buffer trials)
 cat $O/bench.json

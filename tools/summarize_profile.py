@@ -55,6 +55,10 @@ def main(tag):
             if kern + "<" in row["Name"] or row["Name"].split("(")[0].endswith(kern):
                 prof_ms = float(row["AverageNs"]) / 1e6
                 break
+        kt = os.path.join(src, "kernel_timed.json")   # the timed launches alone (tools/timed_kernel_avg.py), when the run kept them
+        if os.path.exists(kt):
+            shutil.copy(kt, os.path.join(dst, "kernel_timed.json"))
+            prof_ms = json.load(open(kt))["avg_ns"] / 1e6
         entry = {
             "workload_sig": bench.get("workload_sig"),
             # bench.py quotes the entry only for the code it was measured on: the hash the RUN printed (the tree may have moved on)

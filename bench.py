@@ -104,7 +104,7 @@ def parse(argv=None):
                          "--stage-tokens: the next batch's first chunks are matched, placed and copied beside this batch's last "
                          "lookups; a no-op for every other table).  auto = on where it does something")
     ap.add_argument("--no-configs", action="store_true", help="skip the `configs` block (BASELINE configs C1, C2, C3, C4-in-HBM)")
-    ap.add_argument("--out-candidates", type=int, default=6, help="the re-used [B, T, d] output buffer is the fastest of this many "
+    ap.add_argument("--out-candidates", type=int, default=8, help="the re-used [B, T, d] output buffer is the fastest of this many "
                     "candidate allocations (3 timed lookups each, before the timed region); 1 = one plain allocation")
     ap.add_argument("--no-latency", action="store_true", help="skip the `latency` block (the reference's benchmark grid on the headline table)")
     ap.add_argument("--configs-steps", type=int, default=15)

@@ -327,12 +327,13 @@ class EmbeddingCache:
         self.to_device().embed_prefetch(tok, tokens_ready)
 
     def alloc_output(self, input_ids: torch.Tensor, *, wte: Optional[torch.Tensor] = None, wpe: Optional[torch.Tensor] = None,
-                     out_dtype: Optional[torch.dtype] = None, candidates: int = 4, trials: int = 3):
+                     out_dtype: Optional[torch.dtype] = None, candidates: int = 8, trials: int = 3):
         """An output buffer ``[B, T, d]`` for a loop that re-uses it (a server with a static batch shape; ``bench.py``), chosen by
         MEASUREMENT: the lookup kernel's time follows the physical placement of the buffer it writes -- 0.616 ... 0.657 ms over
         five 1.6-GB allocations of one process on the headline workload, the same whatever the table, stable per allocation,
         not a matter of alignment or of the offset inside an allocation (``profiles/r06m``) -- and nothing the library or
-        the caller can ask the driver for decides it.  So: ``candidates`` allocations, ``trials`` timed lookups of
+        the caller can ask the driver for decides it; the first few allocations of a process tend to be the slow ones.  So:
+        ``candidates`` allocations, ``trials`` timed lookups of
         ``input_ids`` into each (HIP events around the kernel), the fastest is kept, the others go back to the driver.  Returns
         ``(out, report)``, ``report`` = the kernel milliseconds of every candidate and the index kept.  Costs
         ``candidates * (trials + 1)`` lookups and, for a moment, ``candidates`` buffers."""

@@ -423,6 +423,7 @@ int scone_stage_bind(scone_handle *h, hipStream_t caller) {
   if (prep < 0) prep = copy == 0 ? 1 : 0;
   st->copy = st->cand[copy], st->prep = st->cand[prep];
   st->bound = true, st->bound_to = caller, st->other_caller_calls = 0;
+  static_assert(SCONE_STAGE_CAND == 6, "the trace line below prints six flags");
   if (const char *ev = getenv("SCONE_STAGE_TRACE"))
     if (*ev && *ev != '0')
       fprintf(stderr, "scone_stage_bind: %d of %d candidate streams overlap with the caller's stream [%d%d%d%d%d%d]; COPY = #%d, PREP = #%d\n",

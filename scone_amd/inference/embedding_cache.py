@@ -345,7 +345,15 @@ class EmbeddingCache:
         if out_dtype is None:
             out_dtype = wte.dtype if wte is not None else (wpe.dtype if wpe is not None else torch.float32)
         n = max(1, int(candidates))
-        bufs = [torch.empty((B, T, self.embedding_dim), dtype=out_dtype, device=table.device) for _ in range(n)]
+        bufs = []
+        for _ in range(n):
+            try:
+                bufs.append(torch.empty((B, T, self.embedding_dim), dtype=out_dtype, device=table.device))
+            except torch.cuda.OutOfMemoryError:      # fewer candidates than asked for: choose among those that fit
+                if not bufs:
+                    raise
+                break
+        n = len(bufs)
         if n == 1:
             return bufs[0], {"candidates": 1, "kernel_ms": [None], "kept": 0}
         for o in bufs:

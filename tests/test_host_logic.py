@@ -490,3 +490,28 @@ def test_eight_rank_line_keeps_the_sharded_summary_when_shortened():
     assert dp["exchange"] == "rows_slices_only" and dp["tokens_per_s"] > 0
     assert ss["n1_pinned_host_tokens_per_s"] > 0 and ss["hung_stage"].startswith("sharded.exchanges")
     assert line["n_gpus"] == 8 and line["value"] == rec["value"]
+
+
+def test_timed_kernel_average_takes_the_last_launches_of_the_gather_kernel(tmp_path):
+    """tools/timed_kernel_avg.py: from a rocprofv3 kernel trace, the average of the LAST `steps` dispatches of the gather kernel
+    (warm-up launches and the trial lookups of alloc_output come first) -- the figure profiles/hbm_traffic.json stores as
+    `profile_kernel_ms`."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = tmp_path / "trace" / "host"
+    d.mkdir(parents=True)
+    rows = ['"Kind","Kernel_Name","Start_Timestamp","End_Timestamp"']
+    t = 1000
+    for i in range(30):                                   # 30 gather launches: 10 slow ones first, then 20 at 600 us
+        dur = 900_000 if i < 10 else 600_000
+        rows.append(f'"KERNEL_DISPATCH","void (anonymous namespace)::k_match_ell<3>(int)",{t},{t + 40_000}')
+        rows.append(f'"KERNEL_DISPATCH","void scone_gather::k_embed_wave<2, __half, 768, 3, true, false, true>(scone_row_store)",{t + 50_000},{t + 50_000 + dur}')
+        t += 2_000_000
+    (d / "123_kernel_trace.csv").write_text("\n".join(rows) + "\n")
+    out = tmp_path / "kernel_timed.json"
+    subprocess.run([sys.executable, os.path.join(root, "tools", "timed_kernel_avg.py"), str(tmp_path / "trace"), "20", str(out)], check=True)
+    r = json.load(open(out))
+    assert r["timed_launches"] == 20 and r["all_calls"] == 30 and r["avg_ns"] == 600_000 and r["all_calls_avg_ns"] == 700_000
+    assert "k_embed_wave" in r["kernel"]

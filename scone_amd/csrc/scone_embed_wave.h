@@ -133,7 +133,7 @@ template <int FMT, int D> struct wave_geom {
 // to three more waves per SIMD (INT8 d = 768: 7 -> 8, fp16 d = 768: 6 -> 7, INT4 d = 1024: 5 -> 8).  More waves = more
 // row requests in flight per CU, which is what a latency-bound gather converts into bandwidth.  launch_wave takes it
 // whenever the position ids are the default arange(T) (with caller-supplied positions the row is per token: nothing to
-// keep).  Measured against the round-1 kernel, alternating runs on one box (tools/ab_r1.sh, gather kernel, 1M tokens):
+// keep).  Measured against the round-1 kernel, alternating runs on one box (round 2's tools/ab_r1.sh, gather kernel, 1M tokens):
 //   INT4 100M x 1024 0.794 -> 0.742 ms   INT4 1M x 1024 0.814 -> 0.771 ms   fp16 1M x 768 0.792 -> 0.735 ms
 //   INT8 1M x 768 Zipf stream 0.572 -> 0.542 ms   INT8 1M x 768 S_uniform 0.726 -> 0.705 ms   INT8 10M x 1024 0.906 -> 0.908 ms
 // Switches for A/B builds: SCONE_HIOCC_MASK (bit FMT), SCONE_HIOCC_SLACK_CUT (registers taken off the occupancy

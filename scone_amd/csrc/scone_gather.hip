@@ -19,7 +19,7 @@
 
 using namespace scone_gather;
 
-// One-launch limit (scone_handle::fused_max_tokens, default 32768): measured crossover (tools/latency.py) -- 8K tokens
+// One-launch limit (scone_handle::fused_max_tokens, default 32768): measured crossover (round 2's tools/latency.py; now bench.py's `latency` block) -- 8K tokens
 // 15.5 -> 9.9 us, 16K 20.5 -> 16.8, 32K 30.2 -> 29.3, 64K 45.7 -> 53.7: above it the two-kernel form wins (one probe per
 // window, not per covered token).
 

@@ -105,7 +105,7 @@ def parse(argv=None):
                          "lookups; a no-op for every other table).  auto = on where it does something")
     ap.add_argument("--no-configs", action="store_true", help="skip the `configs` block (BASELINE configs C1, C2, C3, C4-in-HBM)")
     ap.add_argument("--out-candidates", type=int, default=8, help="the re-used [B, T, d] output buffer is the fastest of this many "
-                    "candidate allocations (3 timed lookups each, before the timed region); 1 = one plain allocation")
+                    "candidate allocations (5 timed lookups each, before the timed region); 1 = one plain allocation")
     ap.add_argument("--no-latency", action="store_true", help="skip the `latency` block (the reference's benchmark grid on the headline table)")
     ap.add_argument("--configs-steps", type=int, default=15)
     ap.add_argument("--placement", default="hbm", choices=["hbm", "pinned_host"])
@@ -528,7 +528,7 @@ def main():
     wpe = (torch.randn(1024, d, generator=g, device="cuda") * 0.01).half()
     # The output buffer is re-used by every step; the kernel's time follows its physical placement (0.616 ... 0.657 ms over five
     # allocations of one process, whatever the table: profiles/r06m), so it is chosen by measurement before the timed region:
-    # `--out-candidates` allocations, 3 timed lookups each, the fastest kept (EmbeddingCache.alloc_output; the line says so and
+    # `--out-candidates` allocations, 5 timed lookups each, the fastest kept (EmbeddingCache.alloc_output; the line says so and
     # prints every candidate's time).  1 = a plain allocation.
     out_report = None
     if args.out_candidates > 1 and emu is None and not sharded and args.placement == "hbm" and hasattr(cache, "alloc_output"):
@@ -601,7 +601,7 @@ def main():
                 "tokens_per_step_per_rank": ntok, "mean_hits_per_token": sum_k / ntok, "hits_histogram_K0_6": k_hist[:7],
                 "different_batch_every_step": n_batches > 1, "distinct_batches": n_batches,
                 "next_batch_announced": bool(prefetch),
-                "output_buffer": ({"how": "fastest of N candidate allocations, 3 timed lookups each, before the timed region "
+                "output_buffer": ({"how": "fastest of N candidate allocations, 5 timed lookups each, before the timed region "
                                           "(EmbeddingCache.alloc_output): the kernel's time follows the buffer's physical placement",
                                    **out_report} if out_report else {"how": "one plain allocation", "candidates": 1}),
                 "loop": ("scone_embed(batch i) then scone_embed_prefetch(batch i + 1): the next batch's first chunks are prepared on the "

@@ -327,7 +327,7 @@ class EmbeddingCache:
         self.to_device().embed_prefetch(tok, tokens_ready)
 
     def alloc_output(self, input_ids: torch.Tensor, *, wte: Optional[torch.Tensor] = None, wpe: Optional[torch.Tensor] = None,
-                     out_dtype: Optional[torch.dtype] = None, candidates: int = 8, trials: int = 3):
+                     out_dtype: Optional[torch.dtype] = None, candidates: int = 8, trials: int = 5):
         """An output buffer ``[B, T, d]`` for a loop that re-uses it (a server with a static batch shape; ``bench.py``), chosen by
         MEASUREMENT: the lookup kernel's time follows the physical placement of the buffer it writes -- 0.616 ... 0.657 ms over
         five 1.6-GB allocations of one process on the headline workload, the same whatever the table, stable per allocation,

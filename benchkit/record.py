@@ -61,7 +61,7 @@ def compact_record(res, details_path=None):
     out["config"] = _pick(cfg, ("tokens_per_step_per_rank", "mean_hits_per_token", "different_batch_every_step", "distinct_batches",
                                 "distinct_table_rows_per_launch", "distinct_wte_rows_per_launch", "next_batch_announced"))
     if isinstance(cfg.get("output_buffer"), dict):
-        out["config"]["output_buffer"] = _sig(_pick(cfg["output_buffer"], ("candidates", "kernel_ms", "kept")), 4)
+        out["config"]["output_buffer"] = _sig(_pick(cfg["output_buffer"], ("candidates", "kernel_ms", "finalists_kernel_ms", "kept")), 4)
     out["config"]["workload"] = _cut(cfg.get("workload"), 160)
     out["config"]["parallelism"] = _cut(cfg.get("parallelism"), 110)
     left_l2 = rf.get("traffic") is not None

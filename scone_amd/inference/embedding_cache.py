@@ -334,7 +334,8 @@ class EmbeddingCache:
         not a matter of alignment or of the offset inside an allocation (``profiles/r06m``) -- and nothing the library or
         the caller can ask the driver for decides it; the first few allocations of a process tend to be the slow ones.  So:
         ``candidates`` allocations, ``trials`` timed lookups of
-        ``input_ids`` into each (HIP events around the kernel), the fastest is kept, the others go back to the driver.  Returns
+        ``input_ids`` into each (HIP events around the kernel), a re-match of the three fastest, the winner is kept, the others go
+        back to the driver.  Returns
         ``(out, report)``, ``report`` = the kernel milliseconds of every candidate and the index kept.  Costs
         ``candidates * (trials + 1)`` lookups and, for a moment, ``candidates`` buffers."""
         table = self.to_device()
@@ -368,11 +369,25 @@ class EmbeddingCache:
             k, ms = table.profile_read(reset=True)
             table.profile_enable(False)
             times.append(ms / max(k, 1))
-        kept = min(range(n), key=lambda i: times[i])
+        # second look at the three fastest, interleaved (round-robin) so that drift hits them alike: the minimum of `candidates`
+        # noisy averages is biased low, and the buffer that wins a re-match is the one a long loop will see
+        finalists = sorted(range(n), key=lambda i: times[i])[:min(3, n)]
+        again = {i: 0.0 for i in finalists}
+        for _ in range(max(1, trials)):
+            for i in finalists:
+                table.profile_enable(True)
+                table.profile_read(reset=True)
+                table.embed(tok, wte=wte, wpe=wpe, out=bufs[i])
+                k, ms = table.profile_read(reset=True)
+                table.profile_enable(False)
+                again[i] += ms / max(k, 1)
+        again = {i: v / max(1, trials) for i, v in again.items()}
+        kept = min(finalists, key=lambda i: again[i])
         out = bufs[kept]
         del bufs, o
         torch.cuda.empty_cache()                                        # the rejected blocks go back to the driver, not into torch's cache
-        return out, {"candidates": n, "kernel_ms": [float(t) for t in times], "kept": int(kept)}
+        return out, {"candidates": n, "kernel_ms": [float(t) for t in times], "finalists_kernel_ms": {int(i): float(v) for i, v in again.items()},
+                     "kept": int(kept)}
 
     # ------------------------------------------------------------------ native shard format
     NATIVE_MAGIC = "scone_amd.table.v1"          # round 1-2: one uncompressed .npz, whole arrays in host memory
